@@ -1,0 +1,41 @@
+"""Shared builders for the parity tests: synthetic configs, oracle models, product models."""
+from __future__ import annotations
+
+import functools
+
+import torch
+
+from pantomatrix_amd import spec, synthetic
+from pantomatrix_amd.configuration_emage_audio import EmageAudioConfig, EmageVQVAEConvConfig, EmageVAEConvConfig
+
+PARTS = ("face", "upper", "hands", "lower")
+
+
+def cfg_dicts(vae_layer=2, global_layer=4, global_length=240):
+    return (dict(spec.EMAGE_AUDIO_DEFAULTS), {p: spec.default_vq_cfg_dict(p, vae_layer) for p in PARTS},
+            spec.default_global_cfg_dict(global_layer, global_length))
+
+
+@functools.lru_cache(maxsize=4)
+def oracle_models(seed=0, vae_layer=2):
+    from oracle import emage_oracle as orc
+    acfg, vqc, gc = cfg_dicts(vae_layer)
+    cfg = EmageAudioConfig(**acfg)
+    model = orc.AudioModel(synthetic.audio_model_state(cfg, seed), cfg)
+    parts = [orc.VQVAE(synthetic.vqvae_state(EmageVQVAEConvConfig(**vqc[p]), p, seed), EmageVQVAEConvConfig(**vqc[p])) for p in PARTS]
+    vq = orc.VQModel(*parts, orc.VAE(synthetic.vae_state(EmageVAEConvConfig(**gc), seed), EmageVAEConvConfig(**gc)))
+    return model, vq
+
+
+def window_inputs(batch, frames=64, seed=7):
+    """A forward() window: audio, speaker ids, a partly-masked motion window."""
+    from oracle import emage_oracle as orc
+    g = torch.Generator().manual_seed(seed)
+    audio = 0.1 * torch.randn(batch, frames * 533, generator=g)
+    aa = 0.3 * torch.randn(batch, frames, 55, 3, generator=g)
+    motion = torch.cat([orc.axis_angle_to_rotation_6d(aa).reshape(batch, frames, 330),
+                        0.1 * torch.randn(batch, frames, 7, generator=g)], dim=-1)
+    mask = torch.ones(batch, frames, 337)
+    mask[:, :4] = 0
+    mask[:, 20:24, :100] = 0
+    return audio, torch.zeros(batch, 1, dtype=torch.long), motion, mask
