@@ -1,0 +1,170 @@
+/*
+ * emage_hip.h — C ABI of libemage_hip.so, the MI355X (gfx950) kernels behind the EMAGE hot path.
+ *
+ * The reference (PantoMatrix @ 2025-01-17) has no FFI/operator registry for this path: the
+ * arithmetic lives in torch.nn calls made from
+ *   models/emage_audio/modeling_emage_audio.py   (M:)
+ *   models/emage_audio/processing_emage_audio.py (P:)
+ * Each entry point below replaces one ATen op family at the cited call sites (SURVEY.md §2b K1-K11,
+ * §8b last row).  Conventions, all entry points:
+ *   - extern "C", plain device pointers + sizes, no torch types;
+ *   - non-owning: never allocates, frees or synchronises; safe inside hipGraph capture;
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - returns 0 on success, a hipError_t (> 0) from the launch, or a negative EMAGE_E* code for
+ *     an argument the kernels do not support (the host turns non-zero into an exception);
+ *   - activations are (B,T,C) row-major == (rows, C) with a row stride `ld*` in ELEMENTS;
+ *   - `dtype` selects the storage/MFMA operand type of activations and weights:
+ *       EMAGE_F32  : float32 operands, v_mfma_f32_16x16x4_f32  (exact fp32, parity mode)
+ *       EMAGE_BF16 : bfloat16 operands, v_mfma_f32_16x16x32_bf16, fp32 accumulate
+ *     accumulators, biases, LayerNorm statistics, softmax and every index are fp32 / int64 in
+ *     both modes.
+ */
+#ifndef EMAGE_HIP_H
+#define EMAGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMAGE_F32 0
+#define EMAGE_BF16 1
+
+#define EMAGE_EINVAL (-1)   /* unsupported size / alignment / null pointer */
+
+/* Library identification: ABI version (bumped on any signature change) and target arch string. */
+int emage_abi_version(void);
+const char* emage_target_arch(void);
+
+/*
+ * K6 — VQ nearest neighbour.  Replaces Quantizer.map2index / Quantizer.forward's argmin (P:144-164)
+ * and EmageVQVAEConv.decode_from_latent's inline copy (M:60-67):
+ *   d[n][k] = (sum_j z[n][j]^2 + sum_j e[k][j]^2) - 2 * sum_j z[n][j] e[k][j];  idx[n] = argmin_k d[n][k]
+ * fp32 throughout, first minimum wins ties (torch.argmin).  z: (N,D) fp32 row stride ldz;
+ * codebook: (K,D) fp32 contiguous; idx: (N,) int64.  D % 4 == 0, D <= 1024, K <= 4096.
+ */
+int emage_vq_argmin_f32(const float* z, int ldz, const float* codebook, int64_t* idx,
+                        int N, int K, int D, void* stream);
+
+/*
+ * K8 — code selection from classifier logits.  Replaces torch.max(F.log_softmax(x, dim=2), dim=2)[1]
+ * (M:398-401, test_emage_audio.py:39-42): y = (x - max) - log(sum exp(x - max)) in fp32, first maximum.
+ * logits: (N,C) fp32 row stride ld; idx: (N,) int64.  C <= 4096.
+ */
+int emage_argmax_logsoftmax_f32(const float* logits, int ld, int64_t* idx, int N, int C, void* stream);
+
+/*
+ * K7 — codebook / embedding gather.  Replaces Quantizer.get_codebook_entry (P:166-170).
+ * table: (K,D) fp32; idx: (N,) int64; out: (N, ldo) in `dtype`, columns [D, n_store) zero-filled.
+ */
+int emage_gather_rows(const float* table, const int64_t* idx, void* out, int ldo, int n_store,
+                      int N, int K, int D, int dtype, void* stream);
+
+/*
+ * K1/K2/K3 — the one contraction kernel: Linear and Conv1d as (implicit) GEMM with a fused epilogue.
+ * Replaces nn.Linear (M:232-263 call sites, MLP P:316-326), nn.Conv1d k=3 of VQEncoderV5/V6,
+ * VQDecoderV5, ResBlock (P:178-261) and nn.Conv1d k=15 (+ folded eval BatchNorm1d + LeakyReLU +
+ * shortcut add) of BasicBlock (P:263-294).
+ *
+ *   out[m][n] = leaky( sum_{tap,c} A[row(m,tap)][c] * W[n][tap*Cp + c] + bias[n], slope[n] ) + res[m][n]      (res_first = 0)
+ *   out[m][n] = leaky( sum_{tap,c} ...                                + bias[n] + res[m][n], slope[n] )      (res_first = 1,
+ *               BasicBlock's "x += shortcut; act2(x)", P:291-293)
+ *   m = b*Lout + l,  row(m,tap) = b*Lin + l*stride + tap - pad, taken as zeros when
+ *   l*stride + tap - pad is outside [0, Lin)   (taps=1,stride=1,pad=0,Lin=Lout => plain Linear).
+ *
+ * A:     (rows_in, lda) `dtype`; channels [C, Cp) must hold finite values (they meet zero weights).
+ * W:     (N, taps*Cp) `dtype`, Cp % 64 == 0, zero in the padded channels; K = taps*Cp.
+ * bias:  (N) fp32 or NULL.   slope: (N) fp32 or NULL; leaky(v,s) = v > 0 ? v : v*s
+ *        (0 = ReLU, 1 = identity, 0.2 / 0.1 / 0.01 = the reference's LeakyReLU slopes).
+ * res:   (M, ldr) residual, fp32 if res_is_f32 else `dtype`; or NULL.
+ * out:   (M, ldo) `dtype` or NULL; columns [N, n_store) are written as zeros (keeps padded channel
+ *        tails finite for the next contraction).   out_f32: (M, ldf) fp32 or NULL.
+ * out_t: transposed destination or NULL: columns n >= t_col0 go to out_t[(b*(N-t_col0) + n-t_col0)*t_ld + l]
+ *        instead of `out` (b = m / t_rows, l = m % t_rows) — used to emit V^T for emage_attention.
+ */
+int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
+               const void* res, int ldr, int res_is_f32, int res_first,
+               void* out, int ldo, int n_store, float* out_f32, int ldf,
+               void* out_t, int t_col0, int t_rows, int t_ld,
+               int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
+               void* stream);
+
+/*
+ * K1 first layer — WavEncoder block 0 on the raw waveform (Cin = 1), P:301 + P:283-290:
+ *   out[b][l][c] = leaky( sum_k wav[b][l*stride + k - pad] * w[c][k] + bias[c], slope[c] )
+ * wav: (B, L) fp32; w: (C, taps) fp32 (eval BatchNorm folded); out: (B*Lout, ldo) `dtype`.
+ * Computes conv1 and the downsample shortcut (same input, same geometry) in one pass: the host
+ * stacks their filters along C and gives the shortcut channels slope 1.  C % 8 == 0, taps <= 16.
+ */
+int emage_wav_conv_in(int dtype, const float* wav, int L, const float* w, const float* bias, const float* slope,
+                      void* out, int ldo, int B, int Lout, int C, int taps, int stride, int pad, void* stream);
+
+/*
+ * K4 — multi-head attention core, softmax(Q K^T / sqrt(hd)) V, no mask (nn.MultiheadAttention inside
+ * the 15 decoder layers and 1 encoder layer, M:238-250,261).
+ * q:  (B*Tq, ldq) `dtype`, head h at columns [h*hd, (h+1)*hd).
+ * k:  (B*Tk, ldk) `dtype`, same head layout.
+ * vt: V transposed, (B, vt_rows, ldvt) `dtype`: vt[(b*vt_rows + h*hd + d)*ldvt + t], vt_rows >= H*hd (several
+ *     layers' V^T may share one buffer); ldvt % 32 == 0, ldvt >= Tk, columns [Tk, ldvt) must be finite (zero).
+ * out:(B*Tq, ldo) `dtype`, head-concatenated like nn.MultiheadAttention before out_proj.
+ * hd == 192 (768 / 4 heads, the only head size on this path), Tk <= 128.
+ */
+int emage_attention(int dtype, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int vt_rows,
+                    void* out, int ldo, int B, int H, int Tq, int Tk, int hd, void* stream);
+
+/*
+ * K5 — LayerNorm(C, eps) over rows (post-norm of every transformer sub-layer):
+ *   y = (x - mean) * rsqrt(var + eps) * gamma + beta (+ add[m][:])
+ * x: (M, ldx) fp32 (the fp32 residual stream).  add: (M, ldadd) fp32 or NULL (folds the positional /
+ * speaker / skip adds that follow a LayerNorm, M:304-305,312).  y_f32: (M, ldy) fp32 or NULL;
+ * y: (M, ldy) `dtype` or NULL.  C % 64 == 0, C <= 1024.
+ */
+int emage_layernorm(int dtype, const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                    const float* add, int ldadd, float* y_f32, void* y, int ldy, int M, int C, void* stream);
+
+/*
+ * K11 — elementwise glue.
+ * emage_add: out[m] = a[m] + b[m % mod_b] (+ c[m % mod_c]), fp32 inputs with row strides (mod_* = 0: no
+ *   wrap; mod = T broadcasts a (T,C) positional table over the batch, P:341-343), writes fp32 and/or `dtype`.
+ * emage_pack_motion: where(mask == 1, mask_embedding, motion) (M:267-268) -> `dtype`, (M, ldo),
+ *   columns [C, n_store) zero.
+ * emage_cast_pad: fp32 (M,C) -> `dtype` (M, ldo) with zero tail [C, n_store).
+ */
+int emage_add(int dtype, const float* a, int lda, const float* b, int ldb, int mod_b, const float* c, int ldc, int mod_c,
+              float* out_f32, void* out, int ldo, int M, int C, void* stream);
+int emage_pack_motion(int dtype, const float* motion, const float* mask, const float* mask_embedding,
+                      void* out, int ldo, int n_store, int M, int C, void* stream);
+int emage_cast_pad(int dtype, const float* src, int lds, void* out, int ldo, int n_store, int M, int C, void* stream);
+
+/*
+ * K9 — rotation conversions (P:16-104), elementwise over n joints.
+ */
+int emage_rot6d_to_axis_angle(const float* rot6d, float* aa, int n, void* stream);
+int emage_axis_angle_to_rot6d(const float* aa, float* rot6d, int n, void* stream);
+
+/*
+ * K9+K11 — EmageVQModel.decode's merge (M:137-188) in one pass and without host syncs:
+ * part decoder outputs -> rot6d->axis-angle per part joint, scatter into the 55 SMPL-X joints
+ * (recover_from_mask_ts, P:118-132; jaw at joint 22), re-encode to rot6d, append trans/contact.
+ * face: (M, ldface) fp32 [6 jaw rot6d | 100 expression] or NULL (zeros); upper: (M, ldup) 78;
+ * hands: (M, ldh) 180; lower: (M, ldlow) [54 rot6d | 3 trans-vel | 4 contact] or NULL.
+ * Outputs (any may be NULL): axis_angle (M,165), motion (M,337) = [330 rot6d | 7], expression (M,100).
+ */
+int emage_merge_parts(const float* face, int ldface, const float* upper, int ldup, const float* hands, int ldh,
+                      const float* lower, int ldlow, float* axis_angle, float* motion, float* expression,
+                      int M, void* stream);
+
+/*
+ * K10 — velocity2position (P:107-115) for get_global_motion (M:195-205):
+ *   trans[b][0][x|z] = init[b][x|z]; trans[b][t][x|z] = vel[b][t-1][x|z]*dt + trans[b][t-1][x|z]
+ *   trans[b][t][y] = vel[b][t][y]        (sequential fp32, product rounded before the add)
+ * vel: (B*T, ldv) fp32, the 3 velocity channels start at column col0; init: (B,3) fp32.
+ */
+int emage_velocity_to_position(const float* vel, int ldv, int col0, const float* init, float dt,
+                               float* trans, int B, int T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMAGE_HIP_H */

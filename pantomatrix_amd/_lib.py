@@ -1,0 +1,66 @@
+"""ctypes binding of libemage_hip.so (include/emage_hip.h).  There is NO fallback: if the library is
+missing or a symbol is absent, importing the ops fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
+
+F32, BF16 = 0, 1
+ABI_VERSION = 1
+
+_p, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+# name -> argtypes, exactly the prototypes of include/emage_hip.h
+SIGNATURES = {
+    "emage_vq_argmin_f32": [_p, _i, _p, _p, _i, _i, _i, _p],
+    "emage_argmax_logsoftmax_f32": [_p, _i, _p, _i, _i, _p],
+    "emage_gather_rows": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "emage_gemm": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i,
+                   _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "emage_wav_conv_in": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "emage_attention": [_i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
+    "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _i, _p],
+    "emage_pack_motion": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "emage_cast_pad": [_i, _p, _i, _p, _i, _i, _i, _i, _p],
+    "emage_rot6d_to_axis_angle": [_p, _p, _i, _p],
+    "emage_axis_angle_to_rot6d": [_p, _p, _i, _p],
+    "emage_merge_parts": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p],
+    "emage_velocity_to_position": [_p, _i, _i, _p, _f, _p, _i, _i, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). The EMAGE path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.emage_abi_version.restype = _i
+    lib.emage_target_arch.restype = C.c_char_p
+    if lib.emage_abi_version() != ABI_VERSION:
+        raise ImportError(f"libemage_hip.so ABI {lib.emage_abi_version()} != expected {ABI_VERSION}; rebuild")
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.argtypes = args
+        fn.restype = _i
+    _lib = lib
+    return lib
+
+
+class EmageKernelError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str):
+    if code != 0:
+        kind = "unsupported argument (EMAGE_EINVAL)" if code < 0 else f"hipError {code}"
+        raise EmageKernelError(f"{what}: {kind}")

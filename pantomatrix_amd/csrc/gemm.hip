@@ -1,0 +1,229 @@
+// emage_gemm — Linear / Conv1d as implicit GEMM on MFMA, fused bias + LeakyReLU + residual epilogue.
+// One kernel for both operand types: a lane's operand unit is a 16-byte chunk (8 bf16 -> one
+// v_mfma_f32_16x16x32_bf16, or 4 fp32 -> four v_mfma_f32_16x16x4_f32), so the tile geometry in
+// bytes is identical: K-tile = 8 chunks = 128 B per row, LDS rows XOR-swizzled by (row>>1)&7 so a
+// ds_read_b128 lane group touches 16 distinct 16-B slots.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+    const void* A; const void* W; const float* bias; const float* slope;
+    const void* res; void* out; float* out_f32; void* out_t;
+    int lda, ldr, ldo, ldf, res_is_f32, res_first, n_store;
+    int t_col0, t_rows, t_ld;
+    int M, N, K, Cp, taps, stride, pad, Lin, Lout;
+    int tiles_m, tiles_n;
+};
+
+constexpr int NTHREADS = 256;
+constexpr int KCH = 8;   // 16-byte chunks per K-tile row
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = KCH * EPC;            // K elements per tile
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    constexpr int A_PER = BM * KCH / NTHREADS;   // chunks per thread per tile
+    constexpr int B_PER = BN * KCH / NTHREADS;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(A_PER >= 1 && B_PER >= 1, "tile too small");
+
+    __shared__ uint4 sA[2][BM * KCH];
+    __shared__ uint4 sB[2][BN * KCH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give each XCD a
+    // contiguous run of tiles (neighbouring tiles share A rows / W columns in that XCD's L2).
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ W = (const T*)p.W;
+
+    // per-thread load slots: chunk c = tid + 256*i -> (row = c>>3, g = c&7)
+    const int g = tid & 7;
+    long a_off[A_PER]; int a_lpos[A_PER]; bool a_ok[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int b = mm / p.Lout, l = mm - b * p.Lout;
+        a_lpos[i] = l * p.stride - p.pad;
+        a_off[i] = ((long)b * p.Lin + a_lpos[i]) * p.lda + g * EPC;
+    }
+    long b_off[B_PER]; bool b_ok[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        b_ok[i] = n < p.N;
+        b_off[i] = (long)(b_ok[i] ? n : 0) * p.K + g * EPC;
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[A_PER], rb[B_PER];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cp;
+        const int c0 = k0 - tap * p.Cp;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const bool ok = a_ok[i] && (unsigned)(a_lpos[i] + tap) < (unsigned)p.Lin;
+            ra[i] = ok ? *(const uint4*)(A + a_off[i] + (long)tap * p.lda + c0) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i)
+            rb[i] = b_ok[i] ? *(const uint4*)(W + b_off[i] + k0) : zero4;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            sA[buf][row * KCH + (g ^ ((row >> 1) & 7))] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            sB[buf][row * KCH + (g ^ ((row >> 1) & 7))] = rb[i];
+        }
+    };
+
+    const int nk = p.K / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            uint4 af[FM], bf[FN];
+            const int gg = kg * 4 + fg;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = wm * WTM + i * 16 + fr;
+                af[i] = sA[cur][row * KCH + (gg ^ ((row >> 1) & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = wn * WTN + j * 16 + fr;
+                bf[j] = sB[cur][row * KCH + (gg ^ ((row >> 1) & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = Elem<T>::mma(af[i], bf[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds rows (lane>>4)*4 + j, column lane&15 of each 16x16 fragment
+    T* __restrict__ out = (T*)p.out;
+    T* __restrict__ out_t = (T*)p.out_t;
+    const int t_ncols = p.N - p.t_col0;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fr;
+        const bool n_in = n < p.N;
+        const float bv = (n_in && p.bias) ? p.bias[n] : 0.f;
+        const float sv = (n_in && p.slope) ? p.slope[n] : 1.f;
+        const bool to_t = out_t != nullptr && n >= p.t_col0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * WTM + i * 16 + fg * 4 + r;
+                if (m >= p.M) continue;
+                if (n_in) {
+                    float v = acc[i][j][r] + bv;
+                    float rv = 0.f;
+                    if (p.res) {
+                        rv = p.res_is_f32 ? ((const float*)p.res)[(long)m * p.ldr + n]
+                                          : Elem<T>::from(((const T*)p.res)[(long)m * p.ldr + n]);
+                    }
+                    if (p.res_first) v += rv;
+                    v = leaky(v, sv);
+                    if (!p.res_first) v += rv;
+                    if (to_t) {
+                        const int b = m / p.t_rows, l = m - b * p.t_rows;
+                        out_t[((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l] = Elem<T>::to(v);
+                    } else {
+                        if (out) out[(long)m * p.ldo + n] = Elem<T>::to(v);
+                        if (p.out_f32) p.out_f32[(long)m * p.ldf + n] = v;
+                    }
+                } else if (out && n < p.n_store) {
+                    out[(long)m * p.ldo + n] = Elem<T>::to(0.f);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch(GemmArgs& a, hipStream_t s) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    const int ncols = a.n_store > a.N ? a.n_store : a.N;
+    a.tiles_n = (ncols + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(NTHREADS), 0, s, a);
+    return launch_status();
+}
+
+template <typename T>
+int dispatch(GemmArgs& a, hipStream_t s) {
+    const int ncols = a.n_store > a.N ? a.n_store : a.N;
+    const long big = (long)((a.M + 127) / 128) * ((ncols + 127) / 128);
+    if (ncols <= 64) {
+        if ((a.M + 127) / 128 >= 256) return launch<T, 128, 64, 4, 1>(a, s);
+        return launch<T, 64, 64, 2, 2>(a, s);
+    }
+    if (big >= 256) return launch<T, 128, 128, 2, 2>(a, s);
+    if ((long)((a.M + 63) / 64) * ((ncols + 127) / 128) >= 192) return launch<T, 64, 128, 1, 4>(a, s);
+    return launch<T, 64, 64, 2, 2>(a, s);
+}
+
+}  // namespace
+
+extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
+                          const void* res, int ldr, int res_is_f32, int res_first,
+                          void* out, int ldo, int n_store, float* out_f32, int ldf,
+                          void* out_t, int t_col0, int t_rows, int t_ld,
+                          int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
+                          void* stream) {
+    const int epc = dtype == EMAGE_BF16 ? 8 : 4;
+    if (!A || !W || M <= 0 || N <= 0 || taps <= 0 || Cp <= 0 || Cp % 64 != 0) return EMAGE_EINVAL;
+    if (dtype != EMAGE_BF16 && dtype != EMAGE_F32) return EMAGE_EINVAL;
+    if (lda % epc != 0 || lda < Cp) return EMAGE_EINVAL;                 // 16-byte aligned operand rows
+    if (((uintptr_t)A | (uintptr_t)W) & 15) return EMAGE_EINVAL;
+    if (Lout <= 0 || Lin <= 0 || M % Lout != 0 || stride <= 0) return EMAGE_EINVAL;
+    if (!out && !out_f32 && !out_t) return EMAGE_EINVAL;
+    if (out_t && (t_rows <= 0 || M % t_rows != 0 || t_ld < t_rows || t_col0 < 0 || t_col0 > N)) return EMAGE_EINVAL;
+    GemmArgs a;
+    a.A = A; a.W = W; a.bias = bias; a.slope = slope; a.res = res; a.out = out; a.out_f32 = out_f32; a.out_t = out_t;
+    a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.ldf = ldf; a.res_is_f32 = res_is_f32; a.res_first = res_first; a.n_store = out ? n_store : 0;
+    a.t_col0 = out_t ? t_col0 : N; a.t_rows = t_rows > 0 ? t_rows : 1; a.t_ld = t_ld;
+    a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
+    hipStream_t s = (hipStream_t)stream;
+    return dtype == EMAGE_BF16 ? dispatch<bf16_t>(a, s) : dispatch<float>(a, s);
+}

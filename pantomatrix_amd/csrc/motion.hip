@@ -1,0 +1,158 @@
+// SMPL-X motion glue of EmageVQModel.decode: rot-6D <-> axis-angle (K9), the 55-joint merge (K9+K11)
+// and the root-translation scan (K10).  fp32 elementwise math in the reference's operation order
+// (compiled with -ffp-contract=off), no host synchronisation (the reference's boolean-mask indexing and
+// .item() calls force ~60 syncs per decode on a GPU).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float sqrt_pos(float x) { return x > 0.f ? sqrtf(x) : 0.f; }          // P:10-14
+__device__ __forceinline__ float copysign_ref(float a, float b) { return ((a < 0.f) != (b < 0.f)) ? -a : a; }   // P:6-8
+__device__ __forceinline__ float sin_half_over_angle(float angle, float half) {                   // P:35-43, 66-74
+    return fabsf(angle) < 1e-6f ? 0.5f - (angle * angle) / 48.f : sinf(half) / angle;
+}
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {                        // F.normalize, eps 1e-12
+    const float n = fmaxf(sqrtf((x * x + y * y) + z * z), 1e-12f);
+    x /= n; y /= n; z /= n;
+}
+
+// rotation_6d_to_axis_angle, P:50-59 + P:16-44
+__device__ __forceinline__ void rot6d_to_aa(const float* d6, float* aa) {
+    float b1x = d6[0], b1y = d6[1], b1z = d6[2];
+    const float a2x = d6[3], a2y = d6[4], a2z = d6[5];
+    normalize3(b1x, b1y, b1z);
+    const float dot = (b1x * a2x + b1y * a2y) + b1z * a2z;
+    float b2x = a2x - dot * b1x, b2y = a2y - dot * b1y, b2z = a2z - dot * b1z;
+    normalize3(b2x, b2y, b2z);
+    const float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
+    const float m00 = b1x, m01 = b1y, m02 = b1z, m10 = b2x, m11 = b2y, m12 = b2z, m20 = b3x, m21 = b3y, m22 = b3z;
+    const float w = 0.5f * sqrt_pos(((1.f + m00) + m11) + m22);
+    float x = 0.5f * sqrt_pos(((1.f + m00) - m11) - m22);
+    float y = 0.5f * sqrt_pos(((1.f - m00) + m11) - m22);
+    float z = 0.5f * sqrt_pos(((1.f - m00) - m11) + m22);
+    x = copysign_ref(x, m21 - m12);
+    y = copysign_ref(y, m02 - m20);
+    z = copysign_ref(z, m10 - m01);
+    const float nrm = sqrtf((x * x + y * y) + z * z);
+    const float half = atan2f(nrm, w);
+    const float s = sin_half_over_angle(2.f * half, half);
+    aa[0] = x / s; aa[1] = y / s; aa[2] = z / s;
+}
+
+// axis_angle_to_rotation_6d, P:64-104
+__device__ __forceinline__ void aa_to_rot6d(const float* aa, float* d6) {
+    const float ax = aa[0], ay = aa[1], az = aa[2];
+    const float angle = sqrtf((ax * ax + ay * ay) + az * az);
+    const float half = 0.5f * angle;
+    const float s = sin_half_over_angle(angle, half);
+    const float r = cosf(half), i = ax * s, j = ay * s, k = az * s;
+    const float two_s = 2.0f / (((r * r + i * i) + j * j) + k * k);
+    d6[0] = 1.f - two_s * (j * j + k * k);
+    d6[1] = two_s * (i * j - k * r);
+    d6[2] = two_s * (i * k + j * r);
+    d6[3] = two_s * (i * j + k * r);
+    d6[4] = 1.f - two_s * (i * i + k * k);
+    d6[5] = two_s * (j * k - i * r);
+}
+
+__global__ void rot6d_to_aa_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d6[6], aa[3];
+    for (int c = 0; c < 6; ++c) d6[c] = in[(long)i * 6 + c];
+    rot6d_to_aa(d6, aa);
+    for (int c = 0; c < 3; ++c) out[(long)i * 3 + c] = aa[c];
+}
+__global__ void aa_to_rot6d_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float d6[6], aa[3];
+    for (int c = 0; c < 3; ++c) aa[c] = in[(long)i * 3 + c];
+    aa_to_rot6d(aa, d6);
+    for (int c = 0; c < 6; ++c) out[(long)i * 6 + c] = d6[c];
+}
+
+// joint -> (part, slot) with part 0 none, 1 upper, 2 hands, 3 lower, 4 jaw  (M:75-90,181,185)
+__constant__ signed char c_part[55] = {
+    3, 3, 3, 1, 3, 3, 1, 3, 3, 1, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 4, 0, 0,
+    2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2};
+__constant__ signed char c_slot[55] = {
+    0, 1, 2, 0, 3, 4, 1, 5, 6, 2, 7, 8, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 0, 0, 0,
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29};
+
+// block = one frame (row m): threads 0..54 joints, 64..70 trans/contact, 96..195 expression
+__global__ __launch_bounds__(256) void merge_parts_kernel(const float* __restrict__ face, int ldface, const float* __restrict__ upper, int ldup,
+                                                          const float* __restrict__ hands, int ldh, const float* __restrict__ lower, int ldlow,
+                                                          float* __restrict__ aa_out, float* __restrict__ motion, float* __restrict__ expr, int M) {
+    const int m = blockIdx.x, t = threadIdx.x;
+    if (t < 55) {
+        const int part = c_part[t], slot = c_slot[t];
+        const float* src = nullptr;
+        if (part == 1 && upper) src = upper + (long)m * ldup + slot * 6;
+        else if (part == 2 && hands) src = hands + (long)m * ldh + slot * 6;
+        else if (part == 3 && lower) src = lower + (long)m * ldlow + slot * 6;
+        else if (part == 4 && face) src = face + (long)m * ldface;
+        float aa[3] = {0.f, 0.f, 0.f}, d6[6];
+        if (src) {
+            for (int c = 0; c < 6; ++c) d6[c] = src[c];
+            rot6d_to_aa(d6, aa);
+        }
+        if (aa_out) for (int c = 0; c < 3; ++c) aa_out[(long)m * 165 + t * 3 + c] = aa[c];
+        if (motion) {
+            aa_to_rot6d(aa, d6);
+            for (int c = 0; c < 6; ++c) motion[(long)m * 337 + t * 6 + c] = d6[c];
+        }
+    } else if (t >= 64 && t < 71) {
+        if (motion) motion[(long)m * 337 + 330 + (t - 64)] = lower ? lower[(long)m * ldlow + 54 + (t - 64)] : 0.f;
+    } else if (t >= 96 && t < 196) {
+        if (expr) expr[(long)m * 100 + (t - 96)] = face ? face[(long)m * ldface + 6 + (t - 96)] : 0.f;
+    }
+}
+
+// one thread per (batch, axis): x and z integrate, y copies  (P:107-115, M:195-205)
+__global__ void velocity_scan_kernel(const float* __restrict__ vel, int ldv, int col0, const float* __restrict__ init, float dt,
+                                     float* __restrict__ trans, int B, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 3) return;
+    const int b = i / 3, ax = i - b * 3;
+    const float* v = vel + (long)b * T * ldv + col0 + ax;
+    float* o = trans + (long)b * T * 3 + ax;
+    if (ax == 1) {
+        for (int t = 0; t < T; ++t) o[(long)t * 3] = v[(long)t * ldv];
+    } else {
+        float pos = init[b * 3 + ax];
+        o[0] = pos;
+        for (int t = 1; t < T; ++t) {
+            pos = __fadd_rn(__fmul_rn(v[(long)(t - 1) * ldv], dt), pos);
+            o[(long)t * 3] = pos;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int emage_rot6d_to_axis_angle(const float* rot6d, float* aa, int n, void* stream) {
+    if (!rot6d || !aa || n <= 0) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(rot6d_to_aa_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rot6d, aa, n);
+    return launch_status();
+}
+extern "C" int emage_axis_angle_to_rot6d(const float* aa, float* rot6d, int n, void* stream) {
+    if (!rot6d || !aa || n <= 0) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(aa_to_rot6d_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, aa, rot6d, n);
+    return launch_status();
+}
+extern "C" int emage_merge_parts(const float* face, int ldface, const float* upper, int ldup, const float* hands, int ldh,
+                                 const float* lower, int ldlow, float* axis_angle, float* motion, float* expression,
+                                 int M, void* stream) {
+    if (M <= 0 || (!axis_angle && !motion && !expression)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(merge_parts_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, face, ldface, upper, ldup, hands, ldh, lower, ldlow,
+                       axis_angle, motion, expression, M);
+    return launch_status();
+}
+extern "C" int emage_velocity_to_position(const float* vel, int ldv, int col0, const float* init, float dt,
+                                          float* trans, int B, int T, void* stream) {
+    if (!vel || !init || !trans || B <= 0 || T <= 0) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(velocity_scan_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, (hipStream_t)stream, vel, ldv, col0, init, dt, trans, B, T);
+    return launch_status();
+}

@@ -1,0 +1,829 @@
+"""MI355X-native EMAGE model classes — the host side of the drop-in boundary.
+
+Same public surface as /root/reference/models/emage_audio/modeling_emage_audio.py:
+
+* ``EmageVAEConv`` (M:19-32), ``EmageVQVAEConv`` (M:34-70), ``EmageVQModel`` (M:72-205),
+  ``EmageAudioModel`` with ``forward`` (M:265-341) and ``inference`` (M:343-490);
+* same state-dict keys (``pantomatrix_amd/spec.py``), same (B,T,C) fp32 tensors at the API,
+  int64 indices, float 0/1 masks with 1 = masked.
+
+Nothing here computes on the CPU: every arithmetic op is a launch into libemage_hip.so
+(``pantomatrix_amd/ops.py`` -> ``include/emage_hip.h``); torch supplies device memory, the
+current HIP stream and small index/shape plumbing.  There is no fallback path — tensors must be on
+a ROCm device and the library must be built, otherwise calls raise.
+
+Precision: ``set_precision("bf16")`` (default; bf16 MFMA operands, fp32 accumulate / residual
+stream / LayerNorm / softmax / arg-min) or ``set_precision("fp32")`` (exact-fp32 MFMA everywhere,
+the parity mode that reproduces the reference's fp32 results).
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import OrderedDict
+
+import torch
+
+from . import ops, spec, synthetic
+from ._lib import BF16, F32
+from .configuration_emage_audio import EmageAudioConfig, EmageVAEConvConfig, EmageVQVAEConvConfig
+
+OUT_KEYS = ("rec_face", "rec_upper", "rec_hands", "rec_lower", "cls_face", "cls_upper", "cls_hands", "cls_lower")
+_PRECISIONS = {"bf16": BF16, "fp32": F32}
+_WAV_TAPS = spec.WAV_KERNEL
+
+
+def _rup(x, m=64):
+    return (x + m - 1) // m * m
+
+
+# ======================================================================================
+# parameter container with the HuggingFace-style persistence the reference gets from
+# transformers.PreTrainedModel (config.json + model.safetensors / pytorch_model.bin)
+# ======================================================================================
+class _EmageModule:
+    config_class = None
+    _spec_fn = None
+
+    def __init__(self, config):
+        self.config = config
+        self.cfg = config                      # the reference exposes `.cfg` (M:214, test_emage_audio.py:34-42)
+        self.training = False
+        self._device = torch.device("cpu")
+        self._dt = BF16
+        self._packed = None
+        self._spec = type(self)._spec_fn(config)
+        self._params = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
+                                                      prefix=type(self).__name__ + "/")
+
+    # ---- nn.Module-like surface -------------------------------------------------------
+    @property
+    def device(self):
+        return self._device
+
+    def state_dict(self):
+        return OrderedDict((k, v) for k, v in self._params.items())
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing = [k for k in self._spec if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._spec]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing {missing[:5]}, unexpected {unexpected[:5]}")
+        for k, (shape, _role) in self._spec.items():
+            if k in state_dict:
+                v = state_dict[k]
+                if tuple(v.shape) != tuple(shape):
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(shape)}")
+                self._params[k] = v.detach().to(device=self._device, dtype=self._params[k].dtype).clone()
+        self._packed = None
+        return self
+
+    def parameters(self):
+        return (v for k, v in self._params.items() if self._spec[k][1] not in ("bn_mean", "bn_var", "bn_count", "ppe"))
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device != self._device:
+            self._params = OrderedDict((k, v.to(device)) for k, v in self._params.items())
+            self._device = device
+            self._packed = None
+        return self
+
+    def cuda(self, index=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if index is None else index))
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("training through the HIP path is not built yet (SURVEY.md §8f row 1); "
+                                      "the accelerated modules run eval-mode inference only")
+        return self.eval()
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def set_precision(self, precision: str):
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        if _PRECISIONS[precision] != self._dt:
+            self._dt = _PRECISIONS[precision]
+            self._packed = None
+        return self
+
+    @property
+    def precision(self):
+        return "bf16" if self._dt == BF16 else "fp32"
+
+    # ---- persistence ---------------------------------------------------------------
+    def save_pretrained(self, save_directory):
+        from safetensors.torch import save_file
+        self.config.save_pretrained(save_directory)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self._params.items()},
+                  os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, **_unused):
+        """Load a HuggingFace-format directory (config.json + model.safetensors | pytorch_model.bin).  A hub
+        repo id is resolved through huggingface_hub when it is not a local directory (needs network)."""
+        root = path
+        if not os.path.isdir(root):
+            from huggingface_hub import snapshot_download
+            root = snapshot_download(path)
+        d = os.path.join(root, subfolder) if subfolder else root
+        with open(os.path.join(d, "config.json")) as f:
+            cfg = json.load(f)
+        for k in ("model_type", "architectures", "transformers_version", "torch_dtype", "dtype"):
+            cfg.pop(k, None)
+        model = cls(cls.config_class(**cfg))
+        st = os.path.join(d, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu")
+        model.load_state_dict(sd, strict=True)
+        return model
+
+    # ---- engine plumbing -------------------------------------------------------------
+    def _engine(self):
+        if self._device.type != "cuda":
+            raise RuntimeError(f"{type(self).__name__} runs only on an MI355X device: call .to('cuda') first "
+                               "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests only)")
+        if self._packed is None:
+            self._packed = _Packed(self._params, self._device, self._dt)
+            self._pack(self._packed)
+        return self._packed
+
+    def _pack(self, pk):
+        raise NotImplementedError
+
+
+# ======================================================================================
+# packed weights: MFMA-operand dtype, K-contiguous rows, taps flattened, BatchNorm folded
+# ======================================================================================
+class _Packed:
+    def __init__(self, params, device, dt):
+        self.p, self.device, self.dt = params, device, dt
+        self.tdt = ops.TORCH_DTYPE[dt]
+        self.w = {}
+        self._slopes = {}
+
+    def slope(self, value, n):
+        key = (float(value), n)
+        if key not in self._slopes:
+            self._slopes[key] = torch.full((n,), float(value), dtype=torch.float32, device=self.device)
+        return self._slopes[key]
+
+    def f32(self, name):
+        return self.p[name].to(torch.float32).contiguous()
+
+    def _pack_mat(self, w2d):
+        n, k = w2d.shape
+        kp = _rup(k)
+        if kp != k:
+            w2d = torch.nn.functional.pad(w2d, (0, kp - k))
+        return w2d.to(self.tdt).contiguous(), kp
+
+    def linear(self, key, names, rows=None):
+        """Stack nn.Linear weights along N (optionally row-slices `rows[i]` of each) -> entry `key`."""
+        ws, bs = [], []
+        for i, nm in enumerate(names):
+            w, b = self.p[nm + ".weight"], self.p[nm + ".bias"]
+            if rows is not None:
+                w, b = w[rows[i]], b[rows[i]]
+            ws.append(w)
+            bs.append(b)
+        w, kp = self._pack_mat(torch.cat(ws, 0).float())
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1)
+
+    def in_proj(self, key, names, parts):
+        """Row blocks of packed in_proj weights: parts e.g. "qkv", "q", "kv"; several layers stack as
+        [K_0..K_n | V_0..V_n] so that one GEMM emits every layer's K and V^T (V columns last)."""
+        d = self.p[names[0] + ".in_proj_weight"].shape[1]
+        sl = {"q": slice(0, d), "k": slice(d, 2 * d), "v": slice(2 * d, 3 * d)}
+        ws, bs = [], []
+        for part in parts:
+            for nm in names:
+                ws.append(self.p[nm + ".in_proj_weight"][sl[part]])
+                bs.append(self.p[nm + ".in_proj_bias"][sl[part]])
+        w, kp = self._pack_mat(torch.cat(ws, 0).float())
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1)
+
+    def folded(self, cname, bn=None):
+        """Raw Conv1d (weight (Cout,Cin,k), bias) with an eval-mode BatchNorm1d folded in:
+        W' = W*g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps)+beta (eps 1e-5)."""
+        w, b = self.p[cname + ".weight"].float(), self.p[cname + ".bias"].float()
+        if bn is not None:
+            s = self.p[bn + ".weight"].float() / torch.sqrt(self.p[bn + ".running_var"].float() + 1e-5)
+            w = w * s[:, None, None]
+            b = (b - self.p[bn + ".running_mean"].float()) * s + self.p[bn + ".bias"].float()
+        return w, b
+
+    def conv(self, key, name, fold_bn=None, extra=None):
+        """Conv1d weight (Cout,Cin,k) -> (Cout, k*Cp), taps major, channels zero-padded to Cp; `extra`
+        = (conv, bn) stacks a second conv (the downsample shortcut) along Cout."""
+        w, b = self.folded(name, fold_bn)
+        if extra is not None:
+            w2, b2 = self.folded(*extra)
+            w, b = torch.cat([w, w2], 0), torch.cat([b, b2])
+        cout, cin, k = w.shape
+        cp = _rup(cin)
+        w = w.permute(0, 2, 1)                                   # (Cout, k, Cin)
+        if cp != cin:
+            w = torch.nn.functional.pad(w, (0, cp - cin))
+        self.w[key] = dict(w=w.reshape(cout, k * cp).to(self.tdt).contiguous(), b=b.contiguous(), n=cout, cp=cp, taps=k)
+
+    def norm(self, key, name):
+        self.w[key] = dict(g=self.f32(name + ".weight"), b=self.f32(name + ".bias"))
+
+
+# ======================================================================================
+# kernel-call helpers shared by the model classes
+# ======================================================================================
+class _Ctx:
+    """One forward's launch context: packed weights + dtype + allocation helpers."""
+
+    def __init__(self, pk: _Packed):
+        self.pk, self.dt, self.tdt, self.dev = pk, pk.dt, pk.tdt, pk.device
+
+    def lo(self, m, n):
+        return torch.empty(m, n, dtype=self.tdt, device=self.dev)
+
+    def f32(self, m, n):
+        return torch.empty(m, n, dtype=torch.float32, device=self.dev)
+
+    def gemm(self, a, key, *, slope=None, res=None, res_first=False, out=None, out_f32=None, want="lo", n_store=0,
+             out_t=None, t_col0=0, t_rows=0, conv=None, m=None, dt=None, w=None):
+        """Run one contraction.  want: "lo", "f32", "both" allocate the outputs when not passed in.
+        conv = (stride, pad, lin, lout) turns it into the implicit-GEMM Conv1d with the entry's tap count."""
+        e = w if w is not None else self.pk.w[key]
+        dt = self.dt if dt is None else dt
+        m = a.shape[0] if m is None else m
+        n = e["n"]
+        if out is None and out_t is None and want in ("lo", "both"):
+            out = torch.empty(m, max(n, n_store), dtype=ops.TORCH_DTYPE[dt], device=self.dev)
+        if out_f32 is None and want in ("f32", "both"):
+            out_f32 = self.f32(m, n)
+        sl = None if slope is None else self.pk.slope(slope, n) if not torch.is_tensor(slope) else slope
+        kw = {}
+        if conv is not None:
+            stride, pad, lin, lout = conv
+            kw = dict(taps=e["taps"], stride=stride, pad=pad, lin=lin, lout=lout)
+        ops.gemm(dt, a, e["w"], e["b"], sl, res, out, out_f32, out_t, n=n, cp=e["cp"], n_store=n_store,
+                 t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, **kw)
+        return out, out_f32
+
+    def conv3(self, a, key, t, **kw):
+        return self.gemm(a, key, conv=(1, 1, t, t), **kw)
+
+    def vt_buffer(self, b, rows, tk):
+        tp = _rup(tk, 32)
+        alloc = torch.empty if tp == tk else torch.zeros      # padded key columns must stay finite
+        return alloc(b, rows, tp, dtype=self.tdt, device=self.dev)
+
+
+def _conv_encoder(cx: _Ctx, prefix, x_lo, t, n_layer, length, want_f32):
+    """VQEncoderV5 / V6 (P:189-235) on a (M, Cp) operand; returns (lo (M,Cp(length)), f32 (M,length)|None)."""
+    lp = _rup(length)
+    h, hf = x_lo, None
+    for i in range(n_layer):
+        h, _ = cx.conv3(h, f"{prefix}.main.{3 * i}", t, slope=0.2, n_store=lp)
+        r, _ = cx.conv3(h, f"{prefix}.main.{3 * i + 2}.model.0", t, slope=0.2, n_store=lp)
+        last = i == n_layer - 1
+        h, hf = cx.conv3(r, f"{prefix}.main.{3 * i + 2}.model.2", t, res=h, n_store=lp,
+                         want="both" if (last and want_f32) else "lo")
+    return h, hf
+
+
+def _conv_decoder(cx: _Ctx, prefix, z_lo, t, n_layer, length, out_dim):
+    """VQDecoderV5 (P:237-261): (M, Cp(length)) -> fp32 (M, out_dim)."""
+    lp, dp = _rup(length), _rup(out_dim)
+    h = z_lo
+    for i in range(2):
+        r, _ = cx.conv3(h, f"{prefix}.main.{i}.model.0", t, slope=0.2, n_store=lp)
+        h, _ = cx.conv3(r, f"{prefix}.main.{i}.model.2", t, res=h, n_store=lp)
+    for i in range(n_layer):
+        h, _ = cx.conv3(h, f"{prefix}.main.{2 + 2 * i}", t, slope=0.2, n_store=dp if i == n_layer - 1 else lp)
+    _, out = cx.conv3(h, f"{prefix}.main.{2 + 2 * n_layer}", t, want="f32")
+    return out
+
+
+def _pack_conv_encoder(pk, prefix, n_layer):
+    for i in range(n_layer):
+        pk.conv(f"{prefix}.main.{3 * i}", f"{prefix}.main.{3 * i}")
+        pk.conv(f"{prefix}.main.{3 * i + 2}.model.0", f"{prefix}.main.{3 * i + 2}.model.0")
+        pk.conv(f"{prefix}.main.{3 * i + 2}.model.2", f"{prefix}.main.{3 * i + 2}.model.2")
+
+
+def _pack_conv_decoder(pk, prefix, n_layer):
+    for i in range(2):
+        pk.conv(f"{prefix}.main.{i}.model.0", f"{prefix}.main.{i}.model.0")
+        pk.conv(f"{prefix}.main.{i}.model.2", f"{prefix}.main.{i}.model.2")
+    for i in range(n_layer + 1):
+        pk.conv(f"{prefix}.main.{2 + 2 * i}", f"{prefix}.main.{2 + 2 * i}")
+
+
+# ======================================================================================
+# EmageVAEConv / EmageVQVAEConv  (M:19-70)
+# ======================================================================================
+class EmageVAEConv(_EmageModule):
+    config_class = EmageVAEConvConfig
+    base_model_prefix = "emage_vaeconv"
+    _spec_fn = staticmethod(spec.vae_spec)
+
+    def _pack(self, pk):
+        _pack_conv_encoder(pk, "encoder", self.config.vae_layer)
+        _pack_conv_decoder(pk, "decoder", self.config.vae_layer)
+
+    def forward(self, inputs):
+        c = self.config
+        cx = _Ctx(self._engine())
+        b, t, d = inputs.shape
+        x = ops.cast_pad(cx.dt, inputs.reshape(b * t, d).float().contiguous(), _rup(d))
+        h, _ = _conv_encoder(cx, "encoder", x, t, c.vae_layer, c.vae_length, False)
+        rec = _conv_decoder(cx, "decoder", h, t, c.vae_layer, c.vae_length, c.vae_test_dim)
+        return {"rec_pose": rec.view(b, t, c.vae_test_dim)}
+
+    __call__ = forward
+
+
+class EmageVQVAEConv(_EmageModule):
+    config_class = EmageVQVAEConvConfig
+    base_model_prefix = "emage_vqvaeconv"
+    _spec_fn = staticmethod(spec.vqvae_spec)
+
+    def _pack(self, pk):
+        _pack_conv_encoder(pk, "encoder", self.config.vae_layer)
+        _pack_conv_decoder(pk, "decoder", self.config.vae_layer)
+        pk.w["codebook"] = pk.f32("quantizer.embedding.weight")
+
+    # -- pieces --------------------------------------------------------------------------
+    def _encode(self, cx, inputs):
+        c = self.config
+        b, t, d = inputs.shape
+        x = ops.cast_pad(cx.dt, inputs.reshape(b * t, d).float().contiguous(), _rup(d))
+        _, pre = _conv_encoder(cx, "encoder", x, t, c.vae_layer, c.vae_length, True)
+        return pre                                                  # fp32 (B*T, vae_length)
+
+    def _nearest(self, cx, z2d):
+        assert z2d.shape[-1] == self.config.vae_length               # P:145,159
+        return ops.vq_argmin(z2d, cx.pk.w["codebook"])
+
+    def _decode_idx(self, cx, idx_flat, b, t):
+        c = self.config
+        zq = ops.gather_rows(cx.pk.w["codebook"], idx_flat, cx.dt, _rup(c.vae_length))
+        return _conv_decoder(cx, "decoder", zq, t, c.vae_layer, c.vae_length, c.vae_test_dim)   # fp32 (B*T, dim)
+
+    # -- reference API ---------------------------------------------------------------------
+    def map2index(self, inputs):                                     # M:47-50
+        cx = _Ctx(self._engine())
+        return self._nearest(cx, self._encode(cx, inputs)).view(inputs.shape[0], -1)
+
+    def map2latent(self, inputs):                                    # M:51-55
+        cx = _Ctx(self._engine())
+        idx = self._nearest(cx, self._encode(cx, inputs))
+        return ops.gather_rows(cx.pk.w["codebook"], idx, F32).view(inputs.shape[0], inputs.shape[1], -1)
+
+    def decode(self, index):                                         # M:56-59
+        cx = _Ctx(self._engine())
+        b, t = index.shape
+        return self._decode_idx(cx, index.reshape(-1), b, t).view(b, t, -1)
+
+    def decode_from_latent(self, latent):                            # M:60-70
+        cx = _Ctx(self._engine())
+        b, t, d = latent.shape
+        idx = self._nearest(cx, latent.reshape(b * t, d).float().contiguous())
+        return self._decode_idx(cx, idx, b, t).view(b, t, -1)
+
+    def forward(self, inputs):                                       # M:42-46 (values; eval mode)
+        cx = _Ctx(self._engine())
+        b, t, _ = inputs.shape
+        pre = self._encode(cx, inputs)
+        idx = self._nearest(cx, pre)
+        zq = ops.gather_rows(cx.pk.w["codebook"], idx, F32)
+        # Quantizer.forward's scalars (P:151,154-155) are training diagnostics: tiny reductions, done with torch
+        diff = torch.mean((zq - pre) ** 2)
+        loss = diff + self.config.vae_quantizer_lambda * diff
+        e_mean = torch.bincount(idx, minlength=self.config.vae_codebook_size).float() / idx.numel()
+        perplexity = torch.exp(-torch.sum(e_mean * torch.log(e_mean + 1e-10)))
+        rec = self._decode_idx(cx, idx, b, t)
+        return {"poses_feat": zq.view(b, t, -1), "embedding_loss": loss, "perplexity": perplexity,
+                "rec_pose": rec.view(b, t, -1)}
+
+    __call__ = forward
+
+
+# ======================================================================================
+# EmageVQModel  (M:72-205)
+# ======================================================================================
+class EmageVQModel:
+    def __init__(self, face_model, upper_model, hands_model, lower_model, global_model):
+        # joint partition of the 55 SMPL-X joints, M:75-90 (boolean masks in the reference)
+        self.joint_mask_upper = [j in (3, 6, 9, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21) for j in range(55)]
+        self.joint_mask_lower = [j in (0, 1, 2, 4, 5, 7, 8, 10, 11) for j in range(55)]
+        self.vq_model_face = face_model
+        self.vq_model_upper = upper_model
+        self.vq_model_hands = hands_model
+        self.vq_model_lower = lower_model
+        self.global_motion = global_model
+
+    def _models(self):
+        return (self.vq_model_face, self.vq_model_upper, self.vq_model_hands, self.vq_model_lower, self.global_motion)
+
+    def to(self, device):
+        for m in self._models():
+            m.to(device)
+        return self
+
+    def eval(self):
+        return self
+
+    def set_precision(self, precision):
+        for m in self._models():
+            m.set_precision(precision)
+        return self
+
+    def spilt_inputs(self, smplx_body_rot6d, expression, tar_contact=None, tar_trans=None):     # (sic) M:97-108
+        bs, t, j6 = smplx_body_rot6d.shape
+        r = smplx_body_rot6d.reshape(bs, t, j6 // 6, 6)
+        up = [j for j in range(55) if self.joint_mask_upper[j]]
+        lo = [j for j in range(55) if self.joint_mask_lower[j]]
+        dev = smplx_body_rot6d.device
+        face = torch.cat([r[:, :, 22], expression], dim=2)
+        upper = r[:, :, up].reshape(bs, t, 78)
+        hands = r[:, :, 25:55].reshape(bs, t, 180)
+        lower = r[:, :, lo].reshape(bs, t, 54)
+        tar_contact = torch.zeros(bs, t, 4, device=dev) if tar_contact is None else tar_contact
+        tar_trans = torch.zeros(bs, t, 3, device=dev) if tar_trans is None else tar_trans
+        return dict(face=face, upper=upper, hands=hands, lower=torch.cat([lower, tar_trans, tar_contact], dim=2))
+
+    def map2index(self, smplx_body_rot6d, expression, tar_contact=None, tar_trans=None):        # M:110-116
+        x = self.spilt_inputs(smplx_body_rot6d, expression, tar_contact, tar_trans)
+        return {p: getattr(self, f"vq_model_{p}").map2index(x[p]) for p in ("face", "upper", "hands", "lower")}
+
+    def map2latent(self, smplx_body_rot6d, expression, tar_contact=None, tar_trans=None):       # M:118-124
+        x = self.spilt_inputs(smplx_body_rot6d, expression, tar_contact, tar_trans)
+        return {p: getattr(self, f"vq_model_{p}").map2latent(x[p]) for p in ("face", "upper", "hands", "lower")}
+
+    def decode(self, face_index=None, upper_index=None, hands_index=None, lower_index=None,
+               face_latent=None, upper_latent=None, hands_latent=None, lower_latent=None,
+               get_global_motion=False, ref_trans=None):                                         # M:126-193
+        bs = t = None
+        for x in (face_index, upper_index, hands_index, lower_index, face_latent, upper_latent, hands_latent, lower_latent):
+            if x is not None:
+                bs, t = x.shape[:2]
+                break
+        m = bs * t
+        parts = {}
+        for name, index, latent in (("face", face_index, face_latent), ("upper", upper_index, upper_latent),
+                                    ("hands", hands_index, hands_latent), ("lower", lower_index, lower_latent)):
+            model = getattr(self, f"vq_model_{name}")
+            if index is not None:
+                cx = _Ctx(model._engine())
+                parts[name] = model._decode_idx(cx, index.reshape(-1).contiguous(), bs, t)
+            elif latent is not None:
+                cx = _Ctx(model._engine())
+                idx = model._nearest(cx, latent.reshape(m, -1).float().contiguous())
+                parts[name] = model._decode_idx(cx, idx, bs, t)
+            else:
+                parts[name] = None
+        dev = self.vq_model_face.device
+        aa, motion, expr = ops.merge_parts(parts["face"], parts["upper"], parts["hands"], parts["lower"], m, dev)
+        trans = None
+        if get_global_motion:
+            lower_mix = parts["lower"]
+            if lower_mix is None:   # zeros pose: identity rot6d + zero trans/contact (M:174-177)
+                lower_mix = torch.tensor([1.0, 0, 0, 0, 1, 0] * 9 + [0.0] * 7, device=dev).repeat(m, 1)
+            trans = self.get_global_motion(lower_mix.view(bs, t, -1), ref_trans)
+        return dict(expression=expr.view(bs, t, 100), all_motion4inference=motion.view(bs, t, 337),
+                    motion_axis_angle=aa.view(bs, t, 165), trans=trans)
+
+    def get_global_motion(self, lower_body, ref_trans):                                          # M:195-205
+        bs, t, _ = lower_body.shape
+        rec = self.global_motion.forward(lower_body)["rec_pose"]                                 # (B,T,61) fp32
+        if ref_trans.dim() == 2:
+            ref_trans = ref_trans.unsqueeze(0).repeat(bs, 1, 1)
+        init = ref_trans[:, 0, :].to(device=rec.device, dtype=torch.float32).contiguous()
+        return ops.velocity_to_position(rec.view(bs * t, -1), 54, init, 1 / 30, bs, t)
+
+
+# ======================================================================================
+# EmageAudioModel  (M:207-490)
+# ======================================================================================
+class EmageAudioModel(_EmageModule):
+    config_class = EmageAudioConfig
+    base_model_prefix = "emage_audio"
+    _spec_fn = staticmethod(spec.audio_model_spec)
+
+    # ---- weight packing ----------------------------------------------------------------
+    def _pack(self, pk):
+        c = self.config
+        _pack_conv_encoder(pk, "motion_encoder", spec.MOTION_ENC_LAYERS)
+        pk.linear("bodyhints.fc1", ["bodyhints_face.fc1", "bodyhints_body.fc1"])
+        pk.linear("bodyhints_face.fc2", ["bodyhints_face.fc2"])
+        pk.linear("bodyhints_body.fc2", ["bodyhints_body.fc2"])
+        for nm in ("audio_body_motion_proj", "moton_proj", "audio_face_motion_proj", "face_out_proj"):
+            pk.linear(nm, [nm])
+        parts = ("upper", "hands", "lower")
+        pk.linear("motion2latent.fc1", [f"motion2latent_{p}.fc1" for p in parts])
+        for p in parts:
+            pk.linear(f"motion2latent_{p}.fc2", [f"motion2latent_{p}.fc2"])
+            pk.linear(f"motion_out_proj_{p}", [f"motion_out_proj_{p}"])
+            pk.linear(f"motion_cls_{p}.fc1", [f"motion_cls_{p}.fc1"])
+            pk.linear(f"motion_cls_{p}.fc2", [f"motion_cls_{p}.fc2"])
+        pk.linear("face_cls.fc1", ["face_cls.fc1"])
+        pk.linear("face_cls.fc2", ["face_cls.fc2"])
+        # transformer layers
+        self._pack_layer(pk, "motion_self_encoder.layers.0", cross=False)
+        cross = [f"audio_motion_cross_attn.layers.{i}" for i in range(spec.N_CROSS_LAYERS)]
+        face = [f"face_motion_decoder.layers.{i}" for i in range(spec.N_FACE_LAYERS)]
+        for nm in cross + face + [f"body_motion_decoder_{p}.layers.0" for p in parts]:
+            self._pack_layer(pk, nm, cross=True)
+        pk.in_proj("cross.kv_all", [n + ".multihead_attn" for n in cross], "kv")
+        pk.in_proj("face.kv_all", [n + ".multihead_attn" for n in face], "kv")
+        # audio encoders: block 0 of both encoders shares one first-layer launch
+        w0, b0, s0 = [], [], []
+        for enc in ("audio_encoder_face", "audio_encoder_body"):
+            blocks = spec.wav_encoder_blocks(c.audio_f)
+            for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
+                base = f"{enc}.feat_extractor.{i}"
+                if i == 0:
+                    for conv, bn, sl in ((base + ".conv1", base + ".bn1", 0.01), (base + ".downsample.0", base + ".downsample.1", 1.0)):
+                        w, b = pk.folded(conv, bn)
+                        w0.append(w.reshape(cout, _WAV_TAPS))
+                        b0.append(b)
+                        s0.append(torch.full((cout,), sl, device=pk.device))
+                else:
+                    pk.conv(base + ".conv1", base + ".conv1", fold_bn=base + ".bn1",
+                            extra=(base + ".downsample.0", base + ".downsample.1") if ds else None)
+                    n1 = cout * (2 if ds else 1)
+                    pk.w[base + ".conv1"]["slope"] = torch.cat([torch.full((cout,), 0.01, device=pk.device),
+                                                                torch.ones(n1 - cout, device=pk.device)]).contiguous()
+                pk.conv(base + ".conv2", base + ".conv2", fold_bn=base + ".bn2")
+        pk.w["wav_in"] = dict(w=torch.cat(w0, 0).float().contiguous(), b=torch.cat(b0).float().contiguous(),
+                              slope=torch.cat(s0).float().contiguous())
+        pk.w["pe"] = pk.f32("position_embeddings.pe")[0].contiguous()                 # (2*pose_length, d)
+        pk.w["spk_body"] = pk.f32("speaker_embedding_body.weight")
+        pk.w["spk_face"] = pk.f32("speaker_embedding_face.weight")
+        pk.w["mask_emb"] = pk.f32("mask_embedding").reshape(-1).contiguous()
+
+    @staticmethod
+    def _pack_layer(pk, name, cross):
+        pk.in_proj(name + ".sa.qkv", [name + ".self_attn"], "qkv")
+        pk.linear(name + ".sa.out", [name + ".self_attn.out_proj"])
+        pk.norm(name + ".norm1", name + ".norm1")
+        pk.norm(name + ".norm2", name + ".norm2")
+        if cross:
+            pk.in_proj(name + ".ca.q", [name + ".multihead_attn"], "q")
+            pk.in_proj(name + ".ca.kv", [name + ".multihead_attn"], "kv")
+            pk.linear(name + ".ca.out", [name + ".multihead_attn.out_proj"])
+            pk.norm(name + ".norm3", name + ".norm3")
+        pk.linear(name + ".ff1", [name + ".linear1"])
+        pk.linear(name + ".ff2", [name + ".linear2"])
+
+    # ---- building blocks -----------------------------------------------------------------
+    def _self_attn(self, cx, name, x_f, x_lo, b, t):
+        d, h = self.config.hidden_size, spec.N_HEAD
+        m = b * t
+        qk = cx.lo(m, 2 * d)
+        vt = cx.vt_buffer(b, d, t)
+        cx.gemm(x_lo, name + ".sa.qkv", out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
+        att = cx.lo(m, d)
+        ops.attention(cx.dt, qk[:, :d], qk[:, d:], vt, d, att, b, h, t, t, d // h)
+        _, s = cx.gemm(att, name + ".sa.out", res=x_f, want="f32")
+        return s
+
+    def _ln(self, cx, key, s, add=None, want_f32=True):
+        n = cx.pk.w[key]
+        y_f = cx.f32(*s.shape) if want_f32 else None
+        y_lo = cx.lo(*s.shape)
+        ops.layernorm(cx.dt, s, n["g"], n["b"], 1e-5, add, y_f, y_lo)
+        return y_f, y_lo
+
+    def _ffn(self, cx, name, x_f, x_lo):
+        f, _ = cx.gemm(x_lo, name + ".ff1", slope=0.0)
+        _, s = cx.gemm(f, name + ".ff2", res=x_f, want="f32")
+        return s
+
+    def _decoder_layer(self, cx, name, x_f, x_lo, b, t, mem_k, mem_vt, vt_rows, tk, post_add=None):
+        """nn.TransformerDecoderLayer, post-norm, ReLU, no masks.  mem_k: (B*Tk, ld) view of this
+        layer's projected memory keys; mem_vt: view at this layer's first row of a (B, vt_rows, Tp) V^T buffer."""
+        d, h = self.config.hidden_size, spec.N_HEAD
+        x_f, x_lo = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x_f, x_lo, b, t))
+        q, _ = cx.gemm(x_lo, name + ".ca.q")
+        att = cx.lo(b * t, d)
+        ops.attention(cx.dt, q, mem_k, mem_vt, vt_rows, att, b, h, t, tk, d // h)
+        _, s = cx.gemm(att, name + ".ca.out", res=x_f, want="f32")
+        x_f, x_lo = self._ln(cx, name + ".norm2", s)
+        return self._ln(cx, name + ".norm3", self._ffn(cx, name, x_f, x_lo), add=post_add)
+
+    def _memory_kv(self, cx, key, mem_lo, b, tk, n_layers):
+        """Project a cross-attention memory for `n_layers` layers at once: K (B*Tk, n_layers*d) and
+        V^T (B, n_layers*d, Tp)."""
+        d = self.config.hidden_size
+        k = cx.lo(b * tk, n_layers * d)
+        vt = cx.vt_buffer(b, n_layers * d, tk)
+        cx.gemm(mem_lo, key, out=k, out_t=vt, t_col0=n_layers * d, t_rows=tk)
+        return k, vt
+
+    def _wav_encoders(self, cx, audio, face_out, body_out):
+        """Both WavEncoders (P:296-314).  Returns T' (frames emitted); writes (B*T', 256) into the given
+        2-D destinations when their row count matches, else returns fresh tensors."""
+        c = self.config
+        b, l = audio.shape
+        blocks = spec.wav_encoder_blocks(c.audio_f)
+        k = _WAV_TAPS
+        lens = []
+        cur = l
+        for (_ci, _co, stride, pad, _ds) in blocks:
+            cur = (cur + 2 * pad - k) // stride + 1
+            lens.append(cur)
+        if min(lens) <= 0:
+            raise RuntimeError(f"audio window of {l} samples is too short for the WavEncoder")
+        w_in = cx.pk.w["wav_in"]
+        q = blocks[0][1]
+        y0 = cx.lo(b * lens[0], 4 * q)
+        ops.wav_conv_in(cx.dt, audio, w_in["w"], w_in["b"], w_in["slope"], y0, lens[0], blocks[0][2], blocks[0][3])
+        outs = []
+        for e, enc in enumerate(("audio_encoder_face", "audio_encoder_body")):
+            dest = (face_out, body_out)[e]
+            x, lin = None, None
+            for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
+                base = f"{enc}.feat_extractor.{i}"
+                lout = lens[i]
+                if i == 0:
+                    y1, sc = y0[:, e * 2 * q: e * 2 * q + q], y0[:, e * 2 * q + q: (e + 1) * 2 * q]
+                else:
+                    ent = cx.pk.w[base + ".conv1"]
+                    y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout)
+                    y1, sc = (y[:, :cout], y[:, cout:]) if ds else (y, x)
+                last = i == len(blocks) - 1
+                out = dest if (last and dest is not None and dest.shape[0] == b * lout) else None
+                x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
+                               m=b * lout, out=out)
+                lin = lout
+            outs.append(x)
+        return lens[-1], outs[0], outs[1]
+
+    # ---- forward -------------------------------------------------------------------------
+    def forward(self, audio, speaker_id, masked_motion, mask, use_audio=True):
+        """EmageAudioModel.forward (M:265-341), eval mode.  audio (B,L) fp32, speaker_id (B,1) int64,
+        masked_motion / mask (B,T,337) fp32 -> dict of 8 (B,T,256) fp32 tensors."""
+        c = self.config
+        cx = _Ctx(self._engine())
+        pk = cx.pk
+        dev = cx.dev
+        b, t, cm = masked_motion.shape
+        m = b * t
+        d, mf, af = c.hidden_size, c.motion_f, c.audio_f
+        if t > pk.w["pe"].shape[0]:
+            raise RuntimeError(f"sequence of {t} frames exceeds the positional table ({pk.w['pe'].shape[0]})")
+        audio = audio.to(device=dev, dtype=torch.float32).contiguous()
+        motion2d = masked_motion.to(device=dev, dtype=torch.float32).reshape(m, cm).contiguous()
+        mask2d = mask.to(device=dev, dtype=torch.float32).reshape(m, cm).contiguous()
+
+        # masked motion -> spatial hints (M:267-273)
+        x0 = ops.pack_motion(cx.dt, motion2d, mask2d, pk.w["mask_emb"], _rup(cm))
+        hint, _ = _conv_encoder(cx, "motion_encoder", x0, t, spec.MOTION_ENC_LAYERS, mf, False)
+        hh, _ = cx.gemm(hint, "bodyhints.fc1", slope=0.1)                       # [face | body] hidden, (M, 2d)
+        memcat = cx.lo(m, af + mf)                                              # [audio2face | body_hint_face] (M:288)
+        cx.gemm(hh[:, :d], "bodyhints_face.fc2", out=memcat[:, af:])
+        hint_body, _ = cx.gemm(hh[:, d:], "bodyhints_body.fc2")
+
+        # audio encoders (M:275-281)
+        ta, a_face, a_body = self._wav_encoders(cx, audio, memcat[:, :af], None)
+        if ta < t:
+            raise RuntimeError(f"Sizes of tensors must match: audio features {ta} frames vs motion {t} frames")
+        if ta > t:      # tail windows: face features trimmed to T, body features keep T' = T+1 (M:278-281, sic)
+            memcat[:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)
+
+        # speaker / positional tables (M:285-286, P:341-343)
+        sid = speaker_id.to(dev).reshape(b, 1).expand(b, t).reshape(-1).contiguous()
+        spk_body = ops.gather_rows(pk.w["spk_body"], sid, F32)                  # (M,d) fp32
+        spk_face = ops.gather_rows(pk.w["spk_face"], sid, F32)
+        pe = pk.w["pe"][:t]
+        face_f, face_lo = cx.f32(m, d), cx.lo(m, d)
+        ops.add(cx.dt, spk_face, pe, out_f32=face_f, out=face_lo, mod_b=t)       # position_embeddings(speaker_face)
+        pos_spk = cx.f32(m, d)
+        ops.add(cx.dt, spk_body, pe, out_f32=pos_spk, mod_b=t)                   # speaker_body + pe, reused twice
+
+        # face branch (M:288-294)
+        mem_face, _ = cx.gemm(memcat, "audio_face_motion_proj")
+        nf = spec.N_FACE_LAYERS
+        fk, fvt = self._memory_kv(cx, "face.kv_all", mem_face, b, t, nf)
+        for i in range(nf):
+            face_f, face_lo = self._decoder_layer(cx, f"face_motion_decoder.layers.{i}", face_f, face_lo, b, t,
+                                                  fk[:, i * d:(i + 1) * d], fvt[:, i * d:], nf * d, t)
+        out = {}
+        rec_lo, out["rec_face"] = cx.gemm(face_lo, "face_out_proj", want="both")
+        hc, _ = cx.gemm(rec_lo, "face_cls.fc1", slope=0.1)
+        _, out["cls_face"] = cx.gemm(hc, "face_cls.fc2", want="f32")
+
+        # body branch: temporal self-attention (M:297-300)
+        x_lo, x_f = cx.gemm(hint_body, "moton_proj", res=pos_spk, want="both")
+        name = "motion_self_encoder.layers.0"
+        x_f, x_lo = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x_f, x_lo, b, t))
+        x_f, x_lo = self._ln(cx, name + ".norm2", self._ffn(cx, name, x_f, x_lo), add=pos_spk)   # + speaker + pe (M:304-305)
+        # audio cross-attention stack (M:303-312)
+        if use_audio:
+            mem_body, _ = cx.gemm(a_body, "audio_body_motion_proj")
+            nc = spec.N_CROSS_LAYERS
+            bk, bvt = self._memory_kv(cx, "cross.kv_all", mem_body, b, ta, nc)
+            base_f = x_f
+            for i in range(nc):
+                x_f, x_lo = self._decoder_layer(cx, f"audio_motion_cross_attn.layers.{i}", x_f, x_lo, b, t,
+                                                bk[:, i * d:(i + 1) * d], bvt[:, i * d:], nc * d, ta,
+                                                post_add=base_f if i == nc - 1 else None)   # motion_fea + cross
+        # part latents + refinement (M:315-330)
+        parts = ("upper", "hands", "lower")
+        hl, _ = cx.gemm(x_lo, "motion2latent.fc1", slope=0.1)                    # (M, 3d)
+        lat = {}
+        for i, p in enumerate(parts):
+            _, lat[p] = cx.gemm(hl[:, i * d:(i + 1) * d], f"motion2latent_{p}.fc2", want="f32")
+        others = {"upper": ("hands", "lower"), "hands": ("upper", "lower"), "lower": ("upper", "hands")}
+        for p in parts:
+            tgt_f, tgt_lo, mem_lo = cx.f32(m, d), cx.lo(m, d), cx.lo(m, d)
+            ops.add(cx.dt, lat[p], spk_body, out_f32=tgt_f, out=tgt_lo)
+            ops.add(cx.dt, lat[others[p][0]], lat[others[p][1]], out=mem_lo)
+            name = f"body_motion_decoder_{p}.layers.0"
+            k1, vt1 = self._memory_kv(cx, name + ".ca.kv", mem_lo, b, t, 1)
+            ref_f, _ = self._decoder_layer(cx, name, tgt_f, tgt_lo, b, t, k1, vt1, d, t)
+            sum_lo = cx.lo(m, d)
+            ops.add(cx.dt, lat[p], ref_f, out=sum_lo)
+            rec_lo, out[f"rec_{p}"] = cx.gemm(sum_lo, f"motion_out_proj_{p}", want="both")
+            hc, _ = cx.gemm(rec_lo, f"motion_cls_{p}.fc1", slope=0.1)
+            _, out[f"cls_{p}"] = cx.gemm(hc, f"motion_cls_{p}.fc2", want="f32")
+        return {k: out[k].view(b, t, -1) for k in OUT_KEYS}
+
+    __call__ = forward
+
+    # ---- inference -----------------------------------------------------------------------
+    def _select_codes(self, net_out):
+        """Latent-vs-index routing (M:398-410; test_emage_audio.py:34-42): argmax(log_softmax(cls)) when the
+        part is classified (c* > 0), the regressed latent when only l* > 0."""
+        c = self.config
+        kw = {}
+        for p, l_, c_ in (("face", c.lf, c.cf), ("upper", c.lu, c.cu), ("hands", c.lh, c.ch), ("lower", c.ll, c.cl)):
+            kw[f"{p}_latent"] = net_out[f"rec_{p}"] if (l_ > 0 and c_ == 0) else None
+            if c_ > 0:
+                logits = net_out[f"cls_{p}"]
+                bsz, t, k = logits.shape
+                kw[f"{p}_index"] = ops.argmax_logsoftmax(logits.reshape(bsz * t, k)).view(bsz, t)
+            else:
+                kw[f"{p}_index"] = None
+        return kw
+
+    def inference(self, audio, speaker_id, vq_model, masked_motion=None, mask=None):
+        """EmageAudioModel.inference (M:343-490): sliding 64-frame windows with 4 seed frames carried over
+        through the VQ decode of the previous window; full windows drop their last 4 frames, an optional tail
+        window of 4+remain frames is kept whole."""
+        c = self.config
+        dev = self._device
+        audio = audio.to(device=dev, dtype=torch.float32)
+        bs = audio.shape[0]
+        length = audio.shape[1] * 30 // 16000                                                   # M:345
+        motion = torch.zeros(bs, length, c.pose_dims + 7, device=dev)
+        motion[:, :, 0:c.pose_dims:6] = 1.0          # identity rot6d [1,0,0,0,1,0] per joint (M:347-351)
+        motion[:, :, 4:c.pose_dims:6] = 1.0
+        if masked_motion is not None:
+            motion[:, :masked_motion.shape[1]] = masked_motion.to(dev)
+        full_mask = torch.ones_like(motion)
+        if mask is not None:
+            full_mask[:, :mask.shape[1]] = mask.to(dev)
+        window, pre = c.pose_length, c.seed_frames
+        rounds, remain = (length - pre) // (window - pre), (length - pre) % (window - pre)       # M:364-368
+        spf = 16000 // 30
+        chunks = {k: [] for k in OUT_KEYS}
+        last = motion[:, :pre]
+
+        def run_window(start, end, need_decode):
+            w_mask = full_mask[:, start:end].clone()
+            w_motion = motion[:, start:end].clone()
+            w_motion[:, :pre] = torch.where(w_mask[:, :pre] == 0, motion[:, start:start + pre], last)   # M:386-390
+            w_mask[:, :pre] = 0
+            a = audio[:, start * spf:start * spf + (end - start) * spf]                          # M:393-394
+            net = self.forward(a, speaker_id, w_motion, w_mask, use_audio=True)
+            dec = vq_model.decode(**self._select_codes(net)) if need_decode else None
+            return net, dec
+
+        tail = remain > pre
+        for i in range(rounds):                                                                  # M:380-426
+            start = i * (window - pre)
+            # the decode only feeds the next window's seed: the reference also runs it after the last window
+            # where its result is discarded; skipping that one changes no output
+            net, dec = run_window(start, start + window, need_decode=(i + 1 < rounds) or tail)
+            if dec is not None:
+                last = dec["all_motion4inference"][:, -pre:]
+            for k in OUT_KEYS:
+                chunks[k].append(net[k][:, :-pre])
+        if tail:                                                                                 # M:428-470
+            start = rounds * (window - pre)
+            net, _ = run_window(start, start + pre + remain, need_decode=False)
+            for k in OUT_KEYS:
+                chunks[k].append(net[k])
+        return {k: torch.cat(chunks[k], dim=1) for k in OUT_KEYS}

@@ -1,0 +1,167 @@
+"""Tensor-level wrappers over the C ABI: pointer/stride extraction, output allocation, stream selection.
+PyTorch is plumbing here (device memory + the current HIP stream); every kernel is in libemage_hip.so.
+All tensors must live on a ROCm device; nothing here runs on CPU."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, check
+
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise RuntimeError("pantomatrix_amd kernels need tensors on an MI355X device (no CPU fallback)")
+
+
+def _ld(t):
+    """Row stride (elements) of a 2-D view (rows, C) with unit inner stride."""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.stride(0)
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def vq_argmin(z2d, codebook):
+    """z2d (N,D) fp32, codebook (K,D) fp32 contiguous -> (N,) int64."""
+    _dev(z2d)
+    assert z2d.dtype == torch.float32 and codebook.dtype == torch.float32 and codebook.is_contiguous()
+    n, d = z2d.shape
+    idx = torch.empty(n, dtype=torch.int64, device=z2d.device)
+    check(_lib.load().emage_vq_argmin_f32(_ptr(z2d), _ld(z2d), _ptr(codebook), _ptr(idx), n, codebook.shape[0], d, _stream()), "vq_argmin")
+    return idx
+
+
+def argmax_logsoftmax(logits2d):
+    _dev(logits2d)
+    assert logits2d.dtype == torch.float32
+    n, c = logits2d.shape
+    idx = torch.empty(n, dtype=torch.int64, device=logits2d.device)
+    check(_lib.load().emage_argmax_logsoftmax_f32(_ptr(logits2d), _ld(logits2d), _ptr(idx), n, c, _stream()), "argmax_logsoftmax")
+    return idx
+
+
+def gather_rows(table, idx, dtype, n_store=None):
+    _dev(table)
+    k, d = table.shape
+    n_store = d if n_store is None else n_store
+    idx = idx.reshape(-1).contiguous()
+    out = torch.empty(idx.numel(), n_store, dtype=TORCH_DTYPE[dtype], device=table.device)
+    check(_lib.load().emage_gather_rows(_ptr(table), _ptr(idx), _ptr(out), n_store, n_store, idx.numel(), k, d, dtype, _stream()), "gather_rows")
+    return out
+
+
+def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
+         n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None):
+    """See include/emage_hip.h:emage_gemm.  `a` (rows, lda) and `w` (n, taps*cp) are in `dtype`."""
+    _dev(a)
+    m = a.shape[0] if m is None else m
+    lin = m if lin is None else lin
+    lout = m if lout is None else lout
+    res_f32 = 1 if (res is not None and res.dtype == torch.float32) else 0
+    t_ld = out_t.shape[-1] if out_t is not None else 0
+    check(_lib.load().emage_gemm(dtype, _ptr(a), _ld(a), _ptr(w), _ptr(bias), _ptr(slope),
+                                 _ptr(res), _ld(res) if res is not None else 0, res_f32, 1 if res_first else 0,
+                                 _ptr(out), _ld(out) if out is not None else 0, n_store,
+                                 _ptr(out_f32), _ld(out_f32) if out_f32 is not None else 0,
+                                 _ptr(out_t), t_col0, t_rows, t_ld,
+                                 m, n, cp, taps, stride, pad, lin, lout, _stream()), "gemm")
+
+
+def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad):
+    _dev(wav)
+    b, l = wav.shape
+    c, taps = w.shape
+    check(_lib.load().emage_wav_conv_in(dtype, _ptr(wav), l, _ptr(w), _ptr(bias), _ptr(slope), _ptr(out), _ld(out),
+                                        b, lout, c, taps, stride, pad, _stream()), "wav_conv_in")
+
+
+def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
+    """q (B*Tq, ldq), k (B*Tk, ldk) 2-D views; vt a view into a (B, vt_rows, ldvt) buffer starting at this
+    layer's first row; out (B*Tq, ldo)."""
+    _dev(q)
+    check(_lib.load().emage_attention(dtype, _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(vt), vt.shape[-1], vt_rows, _ptr(out), _ld(out),
+                                      b, h, tq, tk, hd, _stream()), "attention")
+
+
+def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
+    _dev(x)
+    m, c = x.shape
+    ldy = _ld(y_f32) if y_f32 is not None else _ld(y)
+    if y_f32 is not None and y is not None:
+        assert _ld(y) == _ld(y_f32)
+    check(_lib.load().emage_layernorm(dtype, _ptr(x), _ld(x), _ptr(gamma), _ptr(beta), eps, _ptr(add), _ld(add) if add is not None else 0,
+                                      _ptr(y_f32), _ptr(y), ldy, m, c, _stream()), "layernorm")
+
+
+def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
+    _dev(a)
+    m, n = a.shape
+    ldo = _ld(out_f32) if out_f32 is not None else _ld(out)
+    if out_f32 is not None and out is not None:
+        assert _ld(out) == _ld(out_f32)
+    check(_lib.load().emage_add(dtype, _ptr(a), _ld(a), _ptr(b), _ld(b), mod_b, _ptr(c), _ld(c) if c is not None else 0, mod_c,
+                                _ptr(out_f32), _ptr(out), ldo, m, n, _stream()), "add")
+
+
+def pack_motion(dtype, motion2d, mask2d, emb, n_store):
+    _dev(motion2d)
+    m, c = motion2d.shape
+    assert motion2d.is_contiguous() and mask2d.is_contiguous()
+    out = torch.empty(m, n_store, dtype=TORCH_DTYPE[dtype], device=motion2d.device)
+    check(_lib.load().emage_pack_motion(dtype, _ptr(motion2d), _ptr(mask2d), _ptr(emb), _ptr(out), n_store, n_store, m, c, _stream()), "pack_motion")
+    return out
+
+
+def cast_pad(dtype, src2d, n_store):
+    _dev(src2d)
+    m, c = src2d.shape
+    out = torch.empty(m, n_store, dtype=TORCH_DTYPE[dtype], device=src2d.device)
+    check(_lib.load().emage_cast_pad(dtype, _ptr(src2d), _ld(src2d), _ptr(out), n_store, n_store, m, c, _stream()), "cast_pad")
+    return out
+
+
+def rot6d_to_axis_angle(rot6d):
+    _dev(rot6d)
+    x = rot6d.contiguous().float()
+    out = torch.empty(x.shape[:-1] + (3,), dtype=torch.float32, device=x.device)
+    check(_lib.load().emage_rot6d_to_axis_angle(_ptr(x), _ptr(out), x.numel() // 6, _stream()), "rot6d_to_axis_angle")
+    return out
+
+
+def axis_angle_to_rot6d(aa):
+    _dev(aa)
+    x = aa.contiguous().float()
+    out = torch.empty(x.shape[:-1] + (6,), dtype=torch.float32, device=x.device)
+    check(_lib.load().emage_axis_angle_to_rot6d(_ptr(x), _ptr(out), x.numel() // 3, _stream()), "axis_angle_to_rot6d")
+    return out
+
+
+def merge_parts(face, upper, hands, lower, m, device, want_motion=True):
+    """2-D fp32 part tensors (M, ld) or None -> (axis_angle (M,165), motion (M,337), expression (M,100))."""
+    aa = torch.empty(m, 165, dtype=torch.float32, device=device)
+    motion = torch.empty(m, 337, dtype=torch.float32, device=device) if want_motion else None
+    expr = torch.empty(m, 100, dtype=torch.float32, device=device)
+    ld = lambda t: _ld(t) if t is not None else 0
+    check(_lib.load().emage_merge_parts(_ptr(face), ld(face), _ptr(upper), ld(upper), _ptr(hands), ld(hands), _ptr(lower), ld(lower),
+                                        _ptr(aa), _ptr(motion), _ptr(expr), m, _stream()), "merge_parts")
+    return aa, motion, expr
+
+
+def velocity_to_position(vel2d, col0, init, dt, b, t):
+    _dev(vel2d)
+    trans = torch.empty(b, t, 3, dtype=torch.float32, device=vel2d.device)
+    check(_lib.load().emage_velocity_to_position(_ptr(vel2d), _ld(vel2d), col0, _ptr(init), dt, _ptr(trans), b, t, _stream()), "velocity_to_position")
+    return trans

@@ -88,10 +88,14 @@ def vae_state(cfg, seed: int = 0):
 
 
 def synthetic_audio(batch: int, n_samples: int, seed: int = 1234) -> torch.Tensor:
-    """0.1*N(0,1) 16 kHz audio, the BASELINE.md §3 input (seed 1234)."""
-    g = torch.Generator(device="cpu")
-    g.manual_seed(seed)
-    return 0.1 * torch.randn(batch, n_samples, generator=g, dtype=torch.float32)
+    """0.1*N(0,1) 16 kHz audio, the BASELINE.md §3 input (seed 1234).  Each clip has its own generator
+    (seed, clip index), so clip i is the same waveform whatever the batch size."""
+    rows = []
+    for i in range(batch):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed * 1_000_003 + i)
+        rows.append(0.1 * torch.randn(n_samples, generator=g, dtype=torch.float32))
+    return torch.stack(rows)
 
 
 def samples_for_frames(frames: int, sr: int = 16000, fps: int = 30) -> int:

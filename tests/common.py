@@ -39,3 +39,38 @@ def window_inputs(batch, frames=64, seed=7):
     mask[:, :4] = 0
     mask[:, 20:24, :100] = 0
     return audio, torch.zeros(batch, 1, dtype=torch.long), motion, mask
+
+
+def product_models(seed=0, vae_layer=2, precision="fp32", device="cpu"):
+    """pantomatrix_amd model objects loaded with the same synthetic weights as `oracle_models`."""
+    import pantomatrix_amd as pa
+    acfg, vqc, gc = cfg_dicts(vae_layer)
+    cfg = pa.EmageAudioConfig(**acfg)
+    model = pa.EmageAudioModel(cfg)
+    model.load_state_dict(synthetic.audio_model_state(cfg, seed))
+    parts = {}
+    for p in PARTS:
+        c = pa.EmageVQVAEConvConfig(**vqc[p])
+        parts[p] = pa.EmageVQVAEConv(c)
+        parts[p].load_state_dict(synthetic.vqvae_state(c, p, seed))
+    g = pa.EmageVAEConv(pa.EmageVAEConvConfig(**gc))
+    g.load_state_dict(synthetic.vae_state(pa.EmageVAEConvConfig(**gc), seed))
+    vq = pa.EmageVQModel(face_model=parts["face"], upper_model=parts["upper"], hands_model=parts["hands"],
+                         lower_model=parts["lower"], global_model=g)
+    model.set_precision(precision)
+    vq.set_precision(precision)
+    if device != "cpu":
+        model.to(device)
+        vq.to(device)
+    return model.eval(), vq.eval()
+
+
+def product_infer_clip(model, vq, audio, speaker_id=None):
+    """test_emage_audio.py:16-53 against the product classes; returns numpy (poses, expressions, trans)."""
+    bs = audio.shape[0]
+    dev = model.device
+    if speaker_id is None:
+        speaker_id = torch.zeros(bs, 1, dtype=torch.long, device=dev)
+    lat = model.inference(audio.to(dev), speaker_id, vq)
+    pred = vq.decode(**model._select_codes(lat), get_global_motion=True, ref_trans=torch.zeros(1, 3, device=dev))
+    return (pred["motion_axis_angle"].cpu().numpy(), pred["expression"].cpu().numpy(), pred["trans"].cpu().numpy()), lat

@@ -1,0 +1,227 @@
+"""TEST-ONLY stand-in for pantomatrix_amd.ops: each C-ABI entry point of include/emage_hip.h restated with
+torch on the CPU, operating on the SAME tensor views / strides / packed weights the real wrappers receive.
+
+Purpose: exercise the HOST logic (weight packing, buffer views, launch sequence, window schedule) of
+pantomatrix_amd against the oracle in the `-m "not gpu"` suite, where no MI355X exists.  It is installed by
+monkeypatching inside tests only; the product has no switch that reaches this file and no CPU fallback.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+
+import torch
+
+from pantomatrix_amd import modeling_emage_audio as M
+from pantomatrix_amd import ops
+from pantomatrix_amd._lib import BF16, F32
+
+TD = {F32: torch.float32, BF16: torch.bfloat16}
+CALLS = []
+
+
+def _leaky(v, s):
+    return torch.where(v > 0, v, v * s)
+
+
+def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
+         n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None):
+    CALLS.append("gemm")
+    m = a.shape[0] if m is None else m
+    lin = m if lin is None else lin
+    lout = m if lout is None else lout
+    assert a.dtype == TD[dtype] and w.dtype == TD[dtype] and w.shape == (n, taps * cp), (a.dtype, w.shape, n, taps, cp)
+    assert a.stride(1) == 1 and a.stride(0) >= cp and m % lout == 0 and cp % 64 == 0
+    assert a.data_ptr() % 16 == 0 and (a.stride(0) * a.element_size()) % 16 == 0
+    nb = m // lout
+    assert a.shape[0] >= nb * lin, (a.shape, nb, lin)
+    # read exactly what the kernel reads: cp columns from the row start, even beyond a.shape[1]
+    af = torch.as_strided(a, (nb * lin, cp), (a.stride(0), 1)).float()
+    assert torch.isfinite(af).all(), "padded channels of A must be finite"
+    rows = torch.arange(m)
+    b_, l_ = rows // lout, rows % lout
+    cols = []
+    for tap in range(taps):
+        pos = l_ * stride + tap - pad
+        valid = (pos >= 0) & (pos < lin)
+        r = (b_ * lin + pos.clamp(0, lin - 1))
+        cols.append(af[r] * valid[:, None].float())
+    x = torch.cat(cols, dim=1)                                   # (M, taps*cp)
+    v = x @ w.float().t()
+    if bias is not None:
+        v = v + bias
+    rv = 0.0
+    if res is not None:
+        assert res.stride(1) == 1
+        rv = torch.as_strided(res, (m, n), (res.stride(0), 1)).float()
+    if res_first:
+        v = v + rv
+    if slope is not None:
+        assert slope.shape == (n,)
+        v = _leaky(v, slope)
+    if not res_first:
+        v = v + rv
+    ncol_n = n if out_t is None else t_col0
+    if out is not None:
+        assert out.dtype == TD[dtype]
+        o = torch.as_strided(out, (m, max(ncol_n, n_store)), (out.stride(0), 1))
+        o[:, :ncol_n] = v[:, :ncol_n].to(TD[dtype])
+        if n_store > n:
+            o[:, n:n_store] = 0
+    if out_f32 is not None:
+        torch.as_strided(out_f32, (m, ncol_n), (out_f32.stride(0), 1))[:] = v[:, :ncol_n]
+    if out_t is not None:
+        nt = n - t_col0
+        tp = out_t.shape[-1]
+        assert m % t_rows == 0
+        nb_t = m // t_rows
+        o = torch.as_strided(out_t, (nb_t, nt, tp), (nt * tp, tp, 1))
+        o[:, :, :t_rows] = v[:, t_col0:].reshape(nb_t, t_rows, nt).permute(0, 2, 1).to(TD[dtype])
+
+
+def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
+    CALLS.append("attention")
+    tp = vt.shape[-1]
+    assert tp % 32 == 0 and tp >= tk and tk <= 128 and hd == 192
+    qf = torch.as_strided(q, (b * tq, h * hd), (q.stride(0), 1)).float().view(b, tq, h, hd).transpose(1, 2)
+    kf = torch.as_strided(k, (b * tk, h * hd), (k.stride(0), 1)).float().view(b, tk, h, hd).transpose(1, 2)
+    v_all = torch.as_strided(vt, (b, h * hd, tp), (vt_rows * tp, tp, 1)).float()
+    assert torch.isfinite(v_all).all(), "V^T padding must be finite"
+    vf = v_all[:, :, :tk].reshape(b, h, hd, tk).transpose(2, 3)
+    p = torch.softmax((qf @ kf.transpose(-1, -2)) * (1.0 / math.sqrt(hd)), dim=-1)
+    if dtype == BF16:
+        p = p.to(torch.bfloat16).float()
+    o = (p @ vf).transpose(1, 2).reshape(b * tq, h * hd)
+    torch.as_strided(out, (b * tq, h * hd), (out.stride(0), 1))[:] = o.to(TD[dtype])
+
+
+def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
+    CALLS.append("layernorm")
+    v = torch.nn.functional.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps)
+    if add is not None:
+        v = v + add
+    if y_f32 is not None:
+        y_f32[:] = v
+    if y is not None:
+        y[:] = v.to(TD[dtype])
+
+
+def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
+    CALLS.append("add")
+    m = a.shape[0]
+    r = torch.arange(m)
+    v = a + b[r % mod_b if mod_b else r]
+    if c is not None:
+        v = v + c[r % mod_c if mod_c else r]
+    if out_f32 is not None:
+        out_f32[:] = v
+    if out is not None:
+        out[:] = v.to(TD[dtype])
+
+
+def pack_motion(dtype, motion2d, mask2d, emb, n_store):
+    CALLS.append("pack_motion")
+    m, c = motion2d.shape
+    out = torch.zeros(m, n_store, dtype=TD[dtype])
+    out[:, :c] = torch.where(mask2d == 1, emb.expand_as(motion2d), motion2d).to(TD[dtype])
+    return out
+
+
+def cast_pad(dtype, src2d, n_store):
+    CALLS.append("cast_pad")
+    m, c = src2d.shape
+    out = torch.zeros(m, n_store, dtype=TD[dtype])
+    out[:, :c] = src2d.to(TD[dtype])
+    return out
+
+
+def gather_rows(table, idx, dtype, n_store=None):
+    CALLS.append("gather_rows")
+    k, d = table.shape
+    n_store = d if n_store is None else n_store
+    out = torch.zeros(idx.numel(), n_store, dtype=TD[dtype])
+    out[:, :d] = table[idx.reshape(-1)].to(TD[dtype])
+    return out
+
+
+def vq_argmin(z2d, codebook):
+    CALLS.append("vq_argmin")
+    d = (torch.sum(z2d ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1)) - 2 * (z2d @ codebook.t())
+    return torch.argmin(d, dim=1)
+
+
+def argmax_logsoftmax(logits2d):
+    CALLS.append("argmax_logsoftmax")
+    return torch.max(torch.log_softmax(logits2d, dim=1), dim=1)[1]
+
+
+def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad):
+    CALLS.append("wav_conv_in")
+    y = torch.nn.functional.conv1d(wav.unsqueeze(1), w.unsqueeze(1), bias, stride=stride, padding=pad)   # (B,C,Lout)
+    assert y.shape[2] == lout
+    y = _leaky(y, slope.view(1, -1, 1)).permute(0, 2, 1).reshape(-1, w.shape[0])
+    out[:] = y.to(TD[dtype])
+
+
+def merge_parts(face, upper, hands, lower, m, device, want_motion=True):
+    CALLS.append("merge_parts")
+    from oracle import emage_oracle as orc
+    z = lambda n: torch.zeros(m, n)
+    to_aa = lambda r6: orc.rotation_6d_to_axis_angle(r6.reshape(m, -1, 6)).reshape(m, -1)
+    jaw = to_aa(face[:, :6]) if face is not None else z(3)
+    expr = face[:, 6:106].clone() if face is not None else z(100)
+    up = to_aa(upper[:, :78]) if upper is not None else z(39)
+    ha = to_aa(hands[:, :180]) if hands is not None else z(90)
+    lo = to_aa(lower[:, :54]) if lower is not None else z(27)
+    tf = lower[:, 54:61] if lower is not None else z(7)
+    aa = orc.scatter_joints(up, orc.UPPER_JOINTS) + orc.scatter_joints(ha, orc.HANDS_JOINTS) + orc.scatter_joints(lo, orc.LOWER_JOINTS)
+    aa[:, 66:69] = jaw
+    motion = torch.cat([orc.axis_angle_to_rotation_6d(aa.reshape(m, 55, 3)).reshape(m, 330), tf], dim=1)
+    return aa, motion, expr
+
+
+def velocity_to_position(vel2d, col0, init, dt, b, t):
+    CALLS.append("velocity_to_position")
+    from oracle import emage_oracle as orc
+    v = torch.as_strided(vel2d, (b * t, 3), (vel2d.stride(0), 1), vel2d.storage_offset() + col0).reshape(b, t, 3)
+    x = orc.velocity2position(v[:, :, 0:1], dt, init[:, 0:1])
+    zz = orc.velocity2position(v[:, :, 2:3], dt, init[:, 2:3])
+    return torch.cat([x, v[:, :, 1:2], zz], dim=-1)
+
+
+def rot6d_to_axis_angle(x):
+    from oracle import emage_oracle as orc
+    return orc.rotation_6d_to_axis_angle(x)
+
+
+def axis_angle_to_rot6d(x):
+    from oracle import emage_oracle as orc
+    return orc.axis_angle_to_rotation_6d(x)
+
+
+_NAMES = ["gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+          "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
+
+
+@contextlib.contextmanager
+def installed():
+    """Patch pantomatrix_amd.ops with the CPU restatements and lift the device check, for the duration of a test."""
+    saved = {n: getattr(ops, n) for n in _NAMES}
+    saved_engine = M._EmageModule._engine
+
+    def _engine(self):
+        if self._packed is None:
+            self._packed = M._Packed(self._params, self._device, self._dt)
+            self._pack(self._packed)
+        return self._packed
+
+    try:
+        for n in _NAMES:
+            setattr(ops, n, globals()[n])
+        M._EmageModule._engine = _engine
+        CALLS.clear()
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(ops, n, f)
+        M._EmageModule._engine = saved_engine

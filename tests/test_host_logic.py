@@ -1,0 +1,120 @@
+"""Host-side logic of pantomatrix_amd (weight packing, buffer views, launch sequence, window schedule) checked
+on CPU against the oracle, with every C-ABI call replaced by its torch restatement (tests/fake_ops.py).
+This is NOT a parity claim for the kernels — those are the `-m gpu` tests — it proves the host drives them with
+the right operands."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+import fake_ops
+from oracle import emage_oracle as orc
+from pantomatrix_amd import synthetic
+
+
+def test_forward_window_fp32_host_logic(golden_dir):
+    model, _ = common.product_models(precision="fp32")
+    omodel, _ = common.oracle_models()
+    audio, spk, motion, mask = common.window_inputs(2)
+    with fake_ops.installed(), torch.no_grad():
+        out = model.forward(audio, spk, motion, mask)
+        out_na = model.forward(audio, spk, motion, mask, use_audio=False)
+        ref = omodel.forward(audio, spk, motion, mask)
+        ref_na = omodel.forward(audio, spk, motion, mask, use_audio=False)
+    for k in orc.OUT_KEYS:
+        assert out[k].shape == (2, 64, 256)
+        assert float((out[k] - ref[k]).abs().max()) < 2e-4, k
+        assert float((out_na[k] - ref_na[k]).abs().max()) < 2e-4, k
+    g = np.load(os.path.join(golden_dir, "forward_b1.npz"))
+    audio, spk, motion, mask = common.window_inputs(1)
+    with fake_ops.installed(), torch.no_grad():
+        out1 = model.forward(audio, spk, motion, mask)
+    for k in orc.OUT_KEYS:
+        np.testing.assert_allclose(out1[k].numpy(), g[k], atol=3e-4, rtol=0)
+
+
+def test_forward_window_bf16_host_logic():
+    """bf16 storage only perturbs the result (~0.7 % on latents); catches dtype plumbing errors."""
+    model, _ = common.product_models(precision="bf16")
+    omodel, _ = common.oracle_models()
+    audio, spk, motion, mask = common.window_inputs(1)
+    with fake_ops.installed(), torch.no_grad():
+        out = model.forward(audio, spk, motion, mask)
+        ref = omodel.forward(audio, spk, motion, mask)
+    for k in orc.OUT_KEYS:
+        rel = float((out[k] - ref[k]).norm() / ref[k].norm())
+        assert rel < 0.05, (k, rel)
+
+
+@pytest.mark.parametrize("frames,batch", [(128, 2), (70, 1), (129, 1)])
+def test_inference_and_decode_host_logic(golden_dir, frames, batch):
+    """Whole clip: window schedule, seed carry-over through the VQ decode, tail windows with T+1 audio
+    frames, final decode with global translation — against the REFERENCE's golden outputs."""
+    g = np.load(os.path.join(golden_dir, f"infer_{frames}f_b{batch}.npz"))
+    model, vq = common.product_models(precision="fp32")
+    audio = synthetic.synthetic_audio(batch, synthetic.samples_for_frames(frames))
+    with fake_ops.installed(), torch.no_grad():
+        (poses, expr, trans), lat = common.product_infer_clip(model, vq, audio)
+        sel = model._select_codes(lat)
+    assert poses.shape == g["poses"].shape
+    for p in ("upper", "hands", "lower"):
+        assert np.array_equal(sel[f"{p}_index"].numpy(), g[f"index_{p}"]), p
+    np.testing.assert_allclose(lat["rec_face"].numpy(), g["rec_face"], atol=3e-4, rtol=0)
+    np.testing.assert_allclose(poses, g["poses"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(expr, g["expressions"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(trans, g["trans"], atol=1e-3, rtol=0)
+
+
+@pytest.mark.parametrize("layer", [2, 3])
+def test_vq_api_host_logic(golden_dir, layer):
+    import pantomatrix_amd as pa
+    g = np.load(os.path.join(golden_dir, f"vq_layer{layer}.npz"))
+    _, vqc, gc = common.cfg_dicts(vae_layer=layer, global_layer=4 if layer == 2 else 3)
+    gen = torch.Generator().manual_seed(11)
+    with fake_ops.installed(), torch.no_grad():
+        for p in common.PARTS:
+            cfg = pa.EmageVQVAEConvConfig(**vqc[p])
+            m = pa.EmageVQVAEConv(cfg).set_precision("fp32")
+            m.load_state_dict(synthetic.vqvae_state(cfg, p, 0))
+            x = torch.randn(2, 40, cfg.vae_test_dim, generator=gen)
+            idx = torch.randint(0, 256, (2, 40), generator=gen)
+            z = torch.randn(2, 40, 256, generator=gen)
+            assert np.array_equal(m.map2index(x).numpy(), g[f"{p}_map2index"])
+            np.testing.assert_allclose(m.decode(idx).numpy(), g[f"{p}_decode"], atol=2e-4, rtol=0)
+            np.testing.assert_allclose(m.decode_from_latent(z).numpy(), g[f"{p}_decode_from_latent"], atol=2e-4, rtol=0)
+            lat = m.map2latent(x)
+            assert lat.shape == (2, 40, 256)
+            f = m.forward(x)
+            assert set(f) == {"poses_feat", "embedding_loss", "perplexity", "rec_pose"} and f["rec_pose"].shape == x.shape
+        gcfg = pa.EmageVAEConvConfig(**gc)
+        ae = pa.EmageVAEConv(gcfg).set_precision("fp32")
+        ae.load_state_dict(synthetic.vae_state(gcfg, 0))
+        x = torch.randn(2, 40, 61, generator=gen)
+        np.testing.assert_allclose(ae.forward(x)["rec_pose"].numpy(), g["global_rec_pose"], atol=2e-4, rtol=0)
+
+
+def test_no_cpu_fallback():
+    """Outside the test patch the product refuses to run without a device."""
+    model, vq = common.product_models(precision="fp32")
+    audio, spk, motion, mask = common.window_inputs(1)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        model.forward(audio, spk, motion, mask)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        vq.vq_model_upper.decode(torch.zeros(1, 8, dtype=torch.long))
+
+
+def test_checkpoint_round_trip(tmp_path):
+    import pantomatrix_amd as pa
+    _, vqc, _ = common.cfg_dicts()
+    cfg = pa.EmageVQVAEConvConfig(**vqc["face"])
+    m = pa.EmageVQVAEConv(cfg)
+    m.load_state_dict(synthetic.vqvae_state(cfg, "face", 3))
+    m.save_pretrained(str(tmp_path / "emage_vq" / "face"))
+    m2 = pa.EmageVQVAEConv.from_pretrained(str(tmp_path), subfolder="emage_vq/face")
+    assert m2.config.vae_test_dim == 106 and list(m2.state_dict()) == list(m.state_dict())
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict({"bogus": torch.zeros(1)})

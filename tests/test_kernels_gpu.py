@@ -1,0 +1,221 @@
+"""Per-kernel parity: every C-ABI entry point of libemage_hip.so, called through pantomatrix_amd.ops on the
+MI355X, against its CPU restatement (tests/fake_ops.py == the oracle's arithmetic) on the same seeded inputs.
+Tolerances are written per test; index outputs are compared exactly."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import fake_ops as F
+from oracle import emage_oracle as orc
+from pantomatrix_amd import ops
+from pantomatrix_amd._lib import BF16, F32
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TD = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _cmp(name, got, ref, atol, rtol=0.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = int((err > tol).sum())
+    assert bad == 0, f"{name}: {bad}/{err.numel()} outside tol, max err {float(err.max()):.3e}, ref max {float(ref.abs().max()):.3e}"
+
+
+GEMM_CASES = [
+    # name, M-structure (nb, lin, lout), cin, n, taps, stride, pad, flags
+    ("linear_small", (1, 300, 300), 128, 200, 1, 1, 0, dict(bias=True, slope=0.1)),
+    ("linear_768x2304", (4, 64, 64), 768, 2304, 1, 1, 0, dict(bias=True)),
+    ("linear_res_f32", (3, 50, 50), 1536, 768, 1, 1, 0, dict(bias=True, res="f32", want="f32")),
+    ("linear_n64", (2, 700, 700), 64, 64, 1, 1, 0, dict(bias=True, slope=0.0)),
+    ("linear_vt", (3, 40, 40), 768, 2304, 1, 1, 0, dict(bias=True, vt=1536)),
+    ("conv3_337", (3, 37, 37), 337, 256, 3, 1, 1, dict(bias=True, slope=0.2, n_store=256)),
+    ("conv3_res", (2, 64, 64), 256, 256, 3, 1, 1, dict(bias=True, res="lo", n_store=256)),
+    ("conv3_out106", (2, 29, 29), 256, 106, 3, 1, 1, dict(bias=True, slope=0.2, n_store=128)),
+    ("conv15_s6", (2, 1241, 205), 64, 256, 15, 6, 0, dict(bias=True, slope_vec=True)),
+    ("conv15_s1_resfirst", (2, 300, 300), 64, 64, 15, 1, 7, dict(bias=True, slope=0.01, res="lo", res_first=True)),
+    ("conv15_s3", (3, 205, 64), 128, 512, 15, 3, 0, dict(bias=True)),
+    ("big_m", (64, 64, 64), 768, 768, 1, 1, 0, dict(bias=True, res="f32", want="both")),
+]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
+def test_gemm(case, dtype):
+    name, (nb, lin, lout), cin, n, taps, stride, pad, fl = case
+    g = _g(hash(name) % 1000)
+    td = TD[dtype]
+    cp = ops.round_up(cin, 64)
+    m = nb * lout
+    a = torch.zeros(nb * lin, cp)
+    a[:, :cin] = torch.randn(nb * lin, cin, generator=g)
+    w = torch.zeros(n, taps, cp)
+    w[:, :, :cin] = torch.randn(n, taps, cin, generator=g) / math.sqrt(cin * taps)
+    a, w = a.to(td), w.reshape(n, taps * cp).to(td)
+    bias = torch.randn(n, generator=g) * 0.1 if fl.get("bias") else None
+    slope = None
+    if "slope" in fl:
+        slope = torch.full((n,), float(fl["slope"]))
+    if fl.get("slope_vec"):
+        slope = torch.cat([torch.full((n // 2,), 0.01), torch.ones(n - n // 2)])
+    res = None
+    if fl.get("res") == "f32":
+        res = torch.randn(m, n, generator=g)
+    elif fl.get("res") == "lo":
+        res = torch.randn(m, n + 64, generator=g).to(td)[:, 32:32 + n]      # strided, offset view
+    n_store = fl.get("n_store", 0)
+    want = fl.get("want", "lo")
+    vt0 = fl.get("vt")
+    ncol = vt0 if vt0 else n
+
+    def run(mod, dev):
+        mv = lambda t: None if t is None else t.to(dev)
+        res_d = res.to(dev) if fl.get("res") == "f32" else None
+        if fl.get("res") == "lo":
+            base = torch.zeros(m, n + 64, dtype=td)
+            base[:, 32:32 + n] = res
+            res_d = base.to(dev)[:, 32:32 + n]
+        out = torch.full((m, max(ncol, n_store)), 7.0, dtype=td, device=dev) if want in ("lo", "both") else None
+        out_f = torch.full((m, ncol), 7.0, device=dev) if want in ("f32", "both") else None
+        out_t = None
+        if vt0:
+            tp = ops.round_up(lout, 32)
+            out_t = torch.zeros(nb, n - vt0, tp, dtype=td, device=dev)
+        mod.gemm(dtype, mv(a), mv(w), mv(bias), mv(slope), res_d, out, out_f, out_t, n=n, cp=cp, n_store=n_store,
+                 t_col0=vt0 or 0, t_rows=lout if vt0 else 0, res_first=fl.get("res_first", False),
+                 taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m)
+        return out, out_f, out_t
+
+    got = run(ops, DEV)
+    torch.cuda.synchronize()
+    ref = run(F, "cpu")
+    # operands are identical (bf16-rounded where bf16); only the fp32 accumulation order differs
+    atol = 2e-4 if dtype == F32 else 2e-2
+    for nm, gt, rf in zip(("out", "out_f32", "out_t"), got, ref):
+        if gt is not None:
+            _cmp(f"{name}.{nm}", gt, rf, atol=atol if (nm != "out_f32") else 2e-4, rtol=1e-2 if dtype == BF16 and nm != "out_f32" else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("b,tq,tk", [(3, 64, 64), (2, 10, 11), (2, 24, 25), (1, 64, 128), (2, 60, 60), (5, 33, 33)])
+def test_attention(dtype, b, tq, tk):
+    g = _g(b * 1000 + tq * 10 + tk)
+    td, h, hd, d = TD[dtype], 4, 192, 768
+    q = torch.randn(b * tq, 2 * d, generator=g).to(td)[:, :d]            # ld = 2d views, like the qk buffer
+    k = torch.randn(b * tk, 2 * d, generator=g).to(td)[:, d:]
+    tp = ops.round_up(tk, 32)
+    vt_all = torch.zeros(b, 2 * d, tp, dtype=td)
+    vt_all[:, :, :tk] = torch.randn(b, 2 * d, tk, generator=g).to(td)
+    out_c = torch.zeros(b * tq, d, dtype=td)
+    F.attention(dtype, q, k, vt_all[:, d:], 2 * d, out_c, b, h, tq, tk, hd)
+    qb = torch.zeros(b * tq, 2 * d, dtype=td); qb[:, :d] = q
+    kb = torch.zeros(b * tk, 2 * d, dtype=td); kb[:, d:] = k
+    qd, kd, vd = qb.to(DEV)[:, :d], kb.to(DEV)[:, d:], vt_all.to(DEV)
+    out_d = torch.zeros(b * tq, d, dtype=td, device=DEV)
+    ops.attention(dtype, qd, kd, vd[:, d:], 2 * d, out_d, b, h, tq, tk, hd)
+    _cmp("attention", out_d, out_c, atol=2e-5 if dtype == F32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16], ids=["fp32", "bf16"])
+def test_layernorm_add_pack_cast_gather(dtype):
+    g = _g(3)
+    td = TD[dtype]
+    x = torch.randn(1000, 768, generator=g) * 3 + 0.5
+    gamma, beta, addt = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g), torch.randn(1000, 768, generator=g)
+    for add in (None, addt):
+        yf_c, y_c = torch.zeros(1000, 768), torch.zeros(1000, 768, dtype=td)
+        F.layernorm(dtype, x, gamma, beta, 1e-5, add, yf_c, y_c)
+        yf, y = torch.zeros(1000, 768, device=DEV), torch.zeros(1000, 768, dtype=td, device=DEV)
+        ops.layernorm(dtype, x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, None if add is None else add.to(DEV), yf, y)
+        _cmp("layernorm.f32", yf, yf_c, atol=2e-5)
+        _cmp("layernorm.lo", y, y_c, atol=1e-6 if dtype == F32 else 4e-2)
+    a, b2, c = torch.randn(640, 768, generator=g), torch.randn(64, 768, generator=g), torch.randn(640, 768, generator=g)
+    of_c, o_c = torch.zeros(640, 768), torch.zeros(640, 768, dtype=td)
+    F.add(dtype, a, b2, c, of_c, o_c, mod_b=64)
+    of, o = torch.zeros(640, 768, device=DEV), torch.zeros(640, 768, dtype=td, device=DEV)
+    ops.add(dtype, a.to(DEV), b2.to(DEV), c.to(DEV), of, o, mod_b=64)
+    assert torch.equal(of.cpu(), of_c) and torch.equal(o.cpu(), o_c)
+    motion, mask, emb = torch.randn(130, 337, generator=g), (torch.rand(130, 337, generator=g) > 0.5).float(), torch.randn(337, generator=g)
+    assert torch.equal(ops.pack_motion(dtype, motion.to(DEV), mask.to(DEV), emb.to(DEV), 384).cpu(), F.pack_motion(dtype, motion, mask, emb, 384))
+    src = torch.randn(77, 106, generator=g)
+    assert torch.equal(ops.cast_pad(dtype, src.to(DEV), 128).cpu(), F.cast_pad(dtype, src, 128))
+    table, idx = torch.randn(256, 256, generator=g), torch.randint(0, 256, (513,), generator=g)
+    assert torch.equal(ops.gather_rows(table.to(DEV), idx.to(DEV), dtype, 256).cpu(), F.gather_rows(table, idx, dtype, 256))
+
+
+@pytest.mark.parametrize("n,k,d", [(4096, 256, 256), (7680, 256, 256), (33, 256, 256), (500, 100, 64), (200, 37, 240)])
+def test_vq_argmin_indices_exact(n, k, d):
+    g = _g(n + k)
+    z, cb = torch.randn(n, d, generator=g), torch.randn(k, d, generator=g)
+    ref = orc.vq_nearest(z.unsqueeze(0), cb).reshape(-1)
+    got = ops.vq_argmin(z.to(DEV), cb.to(DEV)).cpu()
+    assert got.dtype == torch.int64
+    if not torch.equal(got, ref):
+        dist = orc.vq_distances(z, cb)
+        bad = (got != ref).nonzero().reshape(-1)
+        gap = (dist[bad, got[bad]] - dist[bad, ref[bad]]).abs()
+        raise AssertionError(f"{bad.numel()} / {n} indices differ; distance gaps {gap[:8].tolist()}")
+    # invariant: every codebook row maps to itself; exact ties pick the first index
+    assert torch.equal(ops.vq_argmin(cb.to(DEV), cb.to(DEV)).cpu(), torch.arange(k))
+    cb2 = torch.cat([cb, cb], 0)[: min(2 * k, 4096)]
+    assert torch.equal(ops.vq_argmin(z[:64].to(DEV), cb2.to(DEV)).cpu(), ref[:64])
+
+
+def test_argmax_logsoftmax_exact():
+    g = _g(9)
+    x = torch.randn(4096, 256, generator=g) * 3
+    x[5, 17] = x[5, 200] = 50.0                   # exact tie -> first index
+    ref = torch.max(torch.log_softmax(x, dim=1), dim=1)[1]
+    got = ops.argmax_logsoftmax(x.to(DEV)).cpu()
+    assert torch.equal(got, ref) and int(got[5]) == 17
+
+
+def test_wav_conv_in():
+    g = _g(4)
+    wav = 0.1 * torch.randn(3, 34112, generator=g)
+    w, bias = torch.randn(256, 15, generator=g) / 4, torch.randn(256, generator=g) * 0.1
+    slope = torch.cat([torch.full((64,), 0.01), torch.ones(64)] * 2)
+    for dtype in (F32, BF16):
+        out_c = torch.zeros(3 * 7460, 256, dtype=TD[dtype])
+        F.wav_conv_in(dtype, wav, w, bias, slope, out_c, 7460, 5, 1600)
+        out = torch.zeros(3 * 7460, 256, dtype=TD[dtype], device=DEV)
+        ops.wav_conv_in(dtype, wav.to(DEV), w.to(DEV), bias.to(DEV), slope.to(DEV), out, 7460, 5, 1600)
+        _cmp("wav_conv_in", out, out_c, atol=1e-5 if dtype == F32 else 1e-2)
+
+
+def test_rotations_merge_scan(golden_dir):
+    import os
+    g = _g(5)
+    gold = np.load(os.path.join(golden_dir, "rotations.npz"))
+    d6 = torch.randn(4, 50, 6, generator=g)
+    aa = torch.randn(4, 50, 3, generator=g) * torch.tensor([1.0, 0.3, 1e-4, 0.0]).view(4, 1, 1)
+    np.testing.assert_allclose(ops.rot6d_to_axis_angle(d6.to(DEV)).cpu().numpy(), gold["rot6d_to_aa"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(ops.axis_angle_to_rot6d(aa.to(DEV)).cpu().numpy(), gold["aa_to_rot6d"], atol=2e-6, rtol=0)
+    assert torch.equal(ops.axis_angle_to_rot6d(torch.zeros(2, 3, device=DEV)).cpu(), torch.tensor([[1.0, 0, 0, 0, 1, 0]] * 2))
+    m = 300
+    face, upper, hands, lower = (torch.randn(m, c, generator=g) for c in (106, 78, 180, 61))
+    for parts in ((face, upper, hands, lower), (None, upper, None, lower), (face, None, hands, None)):
+        ref = F.merge_parts(*parts, m, "cpu")
+        got = ops.merge_parts(*[None if p is None else p.to(DEV) for p in parts], m, DEV)
+        for nm, gt, rf in zip(("aa", "motion", "expr"), got, ref):
+            _cmp("merge." + nm, gt, rf, atol=3e-5)
+    vel = torch.randn(5 * 120, 61, generator=g)
+    init = torch.randn(5, 3, generator=g)
+    ref = F.velocity_to_position(vel, 54, init, 1 / 30, 5, 120)
+    got = ops.velocity_to_position(vel.to(DEV), 54, init.to(DEV), 1 / 30, 5, 120)
+    assert torch.equal(got.cpu(), ref), float((got.cpu() - ref).abs().max())
+
+
+def test_bad_arguments_raise():
+    from pantomatrix_amd._lib import EmageKernelError
+    with pytest.raises(EmageKernelError):
+        ops.vq_argmin(torch.zeros(4, 6, device=DEV), torch.zeros(3, 6, device=DEV))       # D % 4 != 0
+    with pytest.raises(RuntimeError):
+        ops.vq_argmin(torch.zeros(4, 8), torch.zeros(3, 8))                                 # CPU tensors: no fallback
