@@ -28,6 +28,10 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def build_models(precision, device):
     import common
     return common.product_models(precision=precision, device=device)
@@ -112,12 +116,15 @@ def cpu_baseline(frames, seconds_budget=20.0):
     import common
     from oracle import emage_oracle as orc
     from pantomatrix_amd import synthetic
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # torch's default intra-op thread count (it honours the container's CPU affinity / quota); forcing
+    # os.cpu_count() threads oversubscribes a cgroup-limited box and measures the scheduler, not the code
     omodel, ovq = common.oracle_models()
-    bs = 8
+    t0 = time.time()
+    orc.infer_clip(omodel, ovq, synthetic.synthetic_audio(1, synthetic.samples_for_frames(frames)))   # warm-up
+    t_one = time.time() - t0
+    log(f"cpu_baseline: warm-up clip took {t_one:.2f}s with {torch.get_num_threads()} threads")
+    bs = 8 if t_one < 1.0 else (2 if t_one < 4.0 else 1)
     audio = synthetic.synthetic_audio(bs, synthetic.samples_for_frames(frames))
-    orc.infer_clip(omodel, ovq, audio[:1])                      # warm-up
     times, out_frames, t_start = [], 0, time.time()
     while True:
         t0 = time.time()
@@ -171,8 +178,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"models built on {dev}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
         poses, _, _ = one_step(model, vq, audio, spk, zeros_trans)
+    log("timed region")
     frames_per_step = poses.shape[0] * poses.shape[1] if args.warmup else None
     barrier()
     t0 = time.perf_counter()
@@ -186,6 +195,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert np.isfinite(poses.numpy()).all()
+    log(f"timed: {1e3 * elapsed / args.steps:.2f} ms/step")
 
     result = {
         "metric": "motion-frames/sec (30fps SMPL-X) EMAGE infer, 128-frame clips",

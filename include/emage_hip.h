@@ -38,6 +38,12 @@ int emage_abi_version(void);
 const char* emage_target_arch(void);
 
 /*
+ * Tuning hook for tests and tools (never needed for correctness): key 0 = force emage_gemm's tile
+ * configuration id (value -1 restores the built-in heuristic).  Returns EMAGE_EINVAL for unknown keys.
+ */
+int emage_set_tuning(int key, int value);
+
+/*
  * K6 — VQ nearest neighbour.  Replaces Quantizer.map2index / Quantizer.forward's argmin (P:144-164)
  * and EmageVQVAEConv.decode_from_latent's inline copy (M:60-67):
  *   d[n][k] = (sum_j z[n][j]^2 + sum_j e[k][j]^2) - 2 * sum_j z[n][j] e[k][j];  idx[n] = argmin_k d[n][k]

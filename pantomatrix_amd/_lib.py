@@ -15,6 +15,7 @@ _p, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 # name -> argtypes, exactly the prototypes of include/emage_hip.h
 SIGNATURES = {
+    "emage_set_tuning": [_i, _i],
     "emage_vq_argmin_f32": [_p, _i, _p, _p, _i, _i, _i, _p],
     "emage_argmax_logsoftmax_f32": [_p, _i, _p, _i, _i, _p],
     "emage_gather_rows": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -7,6 +7,8 @@
 
 namespace {
 
+int g_force_config = -1;   // tuning knob (tests / tools): -1 = heuristic, else a fixed configuration id
+
 struct GemmArgs {
     const void* A; const void* W; const float* bias; const float* slope;
     const void* res; void* out; float* out_f32; void* out_t;
@@ -18,6 +20,50 @@ struct GemmArgs {
 
 constexpr int NTHREADS = 256;
 constexpr int KCH = 8;   // 16-byte chunks per K-tile row
+
+// epilogue shared by both kernels: lane holds rows (lane>>4)*4 + r, column lane&15 of each 16x16 fragment
+template <typename T, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[FM][FN], int mw, int nw, int fr, int fg) {
+    T* __restrict__ out = (T*)p.out;
+    T* __restrict__ out_t = (T*)p.out_t;
+    const int t_ncols = p.N - p.t_col0;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = nw + j * 16 + fr;
+        const bool n_in = n < p.N;
+        const float bv = (n_in && p.bias) ? p.bias[n] : 0.f;
+        const float sv = (n_in && p.slope) ? p.slope[n] : 1.f;
+        const bool to_t = out_t != nullptr && n >= p.t_col0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mw + i * 16 + fg * 4 + r;
+                if (m >= p.M) continue;
+                if (n_in) {
+                    float v = acc[i][j][r] + bv;
+                    float rv = 0.f;
+                    if (p.res) {
+                        rv = p.res_is_f32 ? ((const float*)p.res)[(long)m * p.ldr + n]
+                                          : Elem<T>::from(((const T*)p.res)[(long)m * p.ldr + n]);
+                    }
+                    if (p.res_first) v += rv;
+                    v = leaky(v, sv);
+                    if (!p.res_first) v += rv;
+                    if (to_t) {
+                        const int b = m / p.t_rows, l = m - b * p.t_rows;
+                        out_t[((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l] = Elem<T>::to(v);
+                    } else {
+                        if (out) out[(long)m * p.ldo + n] = Elem<T>::to(v);
+                        if (p.out_f32) p.out_f32[(long)m * p.ldf + n] = v;
+                    }
+                } else if (out && n < p.n_store) {
+                    out[(long)m * p.ldo + n] = Elem<T>::to(0.f);
+                }
+            }
+        }
+    }
+}
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
@@ -139,46 +185,295 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // epilogue: lane holds rows (lane>>4)*4 + j, column lane&15 of each 16x16 fragment
+    gemm_epilogue<T, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg);
+}
+
+// Row-contiguous store of a staged fp32 tile Cs[BM][CLD]: thread -> (row, 4 consecutive columns); 16-byte
+// vector loads/stores when the leading dimensions allow, scalar otherwise.  Columns >= t_col0 (V^T region)
+// are stored column-contiguous along the sequence axis instead.
+template <typename T> struct Pack4;
+template <> struct Pack4<float> {
+    __device__ static __forceinline__ void store(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+};
+template <> struct Pack4<bf16_t> {
+    __device__ static __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+        uint2 t;
+        t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *(uint2*)p = t;
+    }
+    __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+        const uint2 t = *(const uint2*)p;
+        v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+        v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+    }
+};
+
+template <typename T, int BM, int BN, int CLD>
+__device__ __forceinline__ void staged_store(const GemmArgs& p, const float* Cs, int m0, int n0, int tid) {
     T* __restrict__ out = (T*)p.out;
     T* __restrict__ out_t = (T*)p.out_t;
-    const int t_ncols = p.N - p.t_col0;
+    const int ncol_n = p.out_t ? p.t_col0 : p.N;        // columns below this go to out / out_f32
+    // vector path needs every touched row/column group 16-byte (fp32) / 8-byte (bf16) aligned
+    const bool vec = (p.N % 4 == 0) && (ncol_n % 4 == 0) && (p.n_store % 4 == 0) &&
+                     (!out || (p.ldo % 4 == 0 && ((uintptr_t)out & 15) == 0)) &&
+                     (!p.out_f32 || (p.ldf % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
+                     (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+                     (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.slope || ((uintptr_t)p.slope & 15) == 0);
+    constexpr int GPR = BN / 4;                         // 4-column groups per row
+    if (n0 < ncol_n || (out && n0 < p.n_store)) {
+#pragma unroll 2
+        for (int gid = tid; gid < BM * GPR; gid += NTHREADS) {
+            const int row = gid / GPR, cg = gid - row * GPR;
+            const int m = m0 + row, n = n0 + cg * 4;
+            if (m >= p.M) continue;
+            float v[4];
+            { const float4 c = *(const float4*)(Cs + row * CLD + cg * 4); v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w; }
+            if (vec && n + 3 < ncol_n) {
+                float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) Pack4<float>::load(p.bias + n, bv);
+                if (p.slope) Pack4<float>::load(p.slope + n, sv);
+                if (p.res) {
+                    if (p.res_is_f32) Pack4<float>::load((const float*)p.res + (long)m * p.ldr + n, rv);
+                    else Pack4<T>::load((const T*)p.res + (long)m * p.ldr + n, rv);
+                }
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * WTN + j * 16 + fr;
-        const bool n_in = n < p.N;
-        const float bv = (n_in && p.bias) ? p.bias[n] : 0.f;
-        const float sv = (n_in && p.slope) ? p.slope[n] : 1.f;
-        const bool to_t = out_t != nullptr && n >= p.t_col0;
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e] + bv[e];
+                    if (p.res_first) x += rv[e];
+                    x = leaky(x, sv[e]);
+                    if (!p.res_first) x += rv[e];
+                    v[e] = x;
+                }
+                if (out) Pack4<T>::store(out + (long)m * p.ldo + n, v);
+                if (p.out_f32) Pack4<float>::store(p.out_f32 + (long)m * p.ldf + n, v);
+            } else {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * WTM + i * 16 + fg * 4 + r;
-                if (m >= p.M) continue;
-                if (n_in) {
-                    float v = acc[i][j][r] + bv;
-                    float rv = 0.f;
-                    if (p.res) {
-                        rv = p.res_is_f32 ? ((const float*)p.res)[(long)m * p.ldr + n]
-                                          : Elem<T>::from(((const T*)p.res)[(long)m * p.ldr + n]);
+                for (int e = 0; e < 4; ++e) {
+                    const int nn = n + e;
+                    if (nn < ncol_n) {
+                        float x = v[e] + (p.bias ? p.bias[nn] : 0.f);
+                        float r = 0.f;
+                        if (p.res) r = p.res_is_f32 ? ((const float*)p.res)[(long)m * p.ldr + nn]
+                                                    : Elem<T>::from(((const T*)p.res)[(long)m * p.ldr + nn]);
+                        if (p.res_first) x += r;
+                        x = leaky(x, p.slope ? p.slope[nn] : 1.f);
+                        if (!p.res_first) x += r;
+                        if (out) out[(long)m * p.ldo + nn] = Elem<T>::to(x);
+                        if (p.out_f32) p.out_f32[(long)m * p.ldf + nn] = x;
+                    } else if (out && nn >= p.N && nn < p.n_store) {
+                        out[(long)m * p.ldo + nn] = Elem<T>::to(0.f);
                     }
-                    if (p.res_first) v += rv;
-                    v = leaky(v, sv);
-                    if (!p.res_first) v += rv;
-                    if (to_t) {
-                        const int b = m / p.t_rows, l = m - b * p.t_rows;
-                        out_t[((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l] = Elem<T>::to(v);
-                    } else {
-                        if (out) out[(long)m * p.ldo + n] = Elem<T>::to(v);
-                        if (p.out_f32) p.out_f32[(long)m * p.ldf + n] = v;
-                    }
-                } else if (out && n < p.n_store) {
-                    out[(long)m * p.ldo + n] = Elem<T>::to(0.f);
                 }
             }
         }
     }
+    if (out_t && n0 + BN > p.t_col0) {
+        const int t_ncols = p.N - p.t_col0;
+        constexpr int RG = BM / 4;                      // 4-row groups per column
+        const bool tvec = (p.t_rows % 4 == 0) && (p.t_ld % 4 == 0) && (((uintptr_t)out_t & 15) == 0);
+        for (int gid = tid; gid < BN * RG; gid += NTHREADS) {
+            const int col = gid / RG, rg = gid - col * RG;
+            const int n = n0 + col, m = m0 + rg * 4;
+            if (n < p.t_col0 || n >= p.N || m >= p.M) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f, sv = p.slope ? p.slope[n] : 1.f;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = leaky(Cs[(rg * 4 + e) * CLD + col] + bv, sv);
+            const int b = m / p.t_rows, l = m - b * p.t_rows;
+            T* dst = out_t + ((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l;
+            if (tvec && m + 3 < p.M) {
+                Pack4<T>::store(dst, v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int mm = m + e;
+                    if (mm < p.M) {
+                        const int bb = mm / p.t_rows, ll = mm - bb * p.t_rows;
+                        out_t[((long)bb * t_ncols + (n - p.t_col0)) * p.t_ld + ll] = Elem<T>::to(v[e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined variant: global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), an NS-deep
+// ring of K-tiles kept in flight across ONE raw s_barrier per K-tile with counted s_waitcnt vmcnt(N),
+// fragment reads as inline-asm ds_read_b128 (hipcc would otherwise drain every in-flight LDS-DMA before a
+// compiler-visible LDS read of the same array).  Same LDS image as the kernel above: row-major 128-B rows,
+// 16-B slot s of row r holds K-chunk s ^ ((r>>1)&7); the DMA writes LDS linearly in lane order, so the
+// swizzle is applied to each lane's SOURCE chunk.  Rows outside M / N / the conv's valid span read a
+// 16-byte zero block instead.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __attribute__((aligned(16))) const unsigned g_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(GemmArgs p) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = KCH * EPC;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 16, FN = WTN / 16;
+    constexpr int GA = BM / 32, GB = BN / 32;        // 1-KiB DMA instructions per wave per tile (8 rows each)
+    constexpr int G = GA + GB;
+    constexpr int STAGE = (BM + BN) * 128;           // bytes per ring slot: A rows then W rows
+    static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
+    static_assert(NS >= 2 && NS <= 4, "ring depth");
+
+    constexpr int CLD = BN + 4;                      // fp32 row stride of the epilogue staging tile
+    constexpr int CBYTES = BM * CLD * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE > CBYTES ? NS * STAGE : CBYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ W = (const T*)p.W;
+    const T* zero_src = (const T*)g_zero_chunk;
+
+    // DMA slots of this lane: instruction j of this wave fills rows (wave + 4j)*8 .. +7 of the A (or W) tile;
+    // lane -> row offset lane>>3, LDS slot lane&7, source chunk (lane&7) ^ ((row>>1)&7)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    long a_off[GA]; int a_lpos[GA]; bool a_ok[GA];
+#pragma unroll
+    for (int j = 0; j < GA; ++j) {
+        const int row = (wave + 4 * j) * 8 + lrow;
+        const int m = m0 + row;
+        a_ok[j] = m < p.M;
+        const int mm = a_ok[j] ? m : 0;
+        const int b = mm / p.Lout, l = mm - b * p.Lout;
+        a_lpos[j] = l * p.stride - p.pad;
+        a_off[j] = ((long)b * p.Lin + a_lpos[j]) * p.lda + (lslot ^ ((row >> 1) & 7)) * EPC;
+    }
+    long b_off[GB]; bool b_ok[GB];
+#pragma unroll
+    for (int j = 0; j < GB; ++j) {
+        const int row = (wave + 4 * j) * 8 + lrow;
+        const int n = n0 + row;
+        b_ok[j] = n < p.N;
+        b_off[j] = (long)(b_ok[j] ? n : 0) * p.K + (lslot ^ ((row >> 1) & 7)) * EPC;
+    }
+
+    auto issue = [&](int kt, int slot) {
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cp;
+        const int c0 = k0 - tap * p.Cp;
+        unsigned char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int j = 0; j < GA; ++j) {
+            const bool ok = a_ok[j] && (unsigned)(a_lpos[j] + tap) < (unsigned)p.Lin;
+            const T* src = ok ? A + a_off[j] + (long)tap * p.lda + c0 : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            const T* src = b_ok[j] ? W + b_off[j] + k0 : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + (wave + 4 * j) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    // fragment addresses inside a ring slot (bytes): row * 128 + swizzled 16-B slot; the k-group (0/1) flips bit 2
+    const int fr = lane & 15, fg = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned a_addr[FM], b_addr[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = wm * WTM + i * 16 + fr;
+        a_addr[i] = row * 128 + ((fg ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int row = wn * WTN + j * 16 + fr;
+        b_addr[j] = BM * 128 + row * 128 + ((fg ^ ((row >> 1) & 7)) << 4);
+    }
+
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed; tiles issued after it (at most NS-2) may stay in flight
+        const int newer = nk - 1 - kt;
+        if (NS >= 4 && newer >= 2) wait_vmcnt<2 * G>();
+        else if (NS >= 3 && newer >= 1) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) {
+            int ns = slot + NS - 1; if (ns >= NS) ns -= NS;
+            issue(kt + NS - 1, ns);
+        }
+        const unsigned sb = lds0 + slot * STAGE;
+        u32x4 af0[FM], bf0[FN], af1[FM], bf1[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af0[i] = lds_read128(sb + a_addr[i]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf0[j] = lds_read128(sb + b_addr[j]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af1[i] = lds_read128(sb + (a_addr[i] ^ 64u));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf1[j] = lds_read128(sb + (b_addr[j] ^ 64u));
+        wait_lgkmcnt<FM + FN>();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, af0[i]), __builtin_bit_cast(uint4, bf0[j]), acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, af1[i]), __builtin_bit_cast(uint4, bf1[j]), acc[i][j]);
+        if (++slot == NS) slot = 0;
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32 tile) -> row-contiguous 4-wide groups -> global ----
+    __syncthreads();                                  // every wave is done reading the ring
+    float* Cs = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[(wm * WTM + i * 16 + fg * 4 + r) * CLD + wn * WTN + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    staged_store<T, BM, BN, CLD>(p, Cs, m0, n0, tid);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -190,17 +485,45 @@ int launch(GemmArgs& a, hipStream_t s) {
     return launch_status();
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+int launch_pipe(GemmArgs& a, hipStream_t s) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    const int ncols = a.n_store > a.N ? a.n_store : a.N;
+    a.tiles_n = (ncols + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS>), dim3(a.tiles_m * a.tiles_n), dim3(NTHREADS), 0, s, a);
+    return launch_status();
+}
+
+template <typename T>
+int run_config(int cfg, GemmArgs& a, hipStream_t s) {
+    switch (cfg) {
+        case 0: return launch<T, 128, 128, 2, 2>(a, s);          // register-staged, 2 LDS buffers
+        case 1: return launch<T, 64, 128, 1, 4>(a, s);
+        case 2: return launch<T, 128, 64, 4, 1>(a, s);
+        case 3: return launch<T, 64, 64, 2, 2>(a, s);
+        case 10: return launch_pipe<T, 128, 128, 2, 2, 3>(a, s);  // LDS-DMA ring
+        case 11: return launch_pipe<T, 64, 128, 2, 2, 3>(a, s);
+        case 12: return launch_pipe<T, 64, 128, 2, 2, 4>(a, s);
+        case 13: return launch_pipe<T, 128, 64, 2, 2, 3>(a, s);
+        case 14: return launch_pipe<T, 128, 64, 4, 1, 4>(a, s);
+        case 15: return launch_pipe<T, 64, 64, 2, 2, 4>(a, s);
+        case 16: return launch_pipe<T, 256, 64, 4, 1, 3>(a, s);
+        case 17: return launch_pipe<T, 64, 128, 1, 4, 3>(a, s);
+        case 18: return launch_pipe<T, 128, 128, 2, 2, 2>(a, s);
+        case 19: return launch_pipe<T, 64, 64, 2, 2, 3>(a, s);
+        default: return EMAGE_EINVAL;
+    }
+}
+
 template <typename T>
 int dispatch(GemmArgs& a, hipStream_t s) {
+    if (g_force_config >= 0) return run_config<T>(g_force_config, a, s);
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
-    const long big = (long)((a.M + 127) / 128) * ((ncols + 127) / 128);
-    if (ncols <= 64) {
-        if ((a.M + 127) / 128 >= 256) return launch<T, 128, 64, 4, 1>(a, s);
-        return launch<T, 64, 64, 2, 2>(a, s);
-    }
-    if (big >= 256) return launch<T, 128, 128, 2, 2>(a, s);
-    if ((long)((a.M + 63) / 64) * ((ncols + 127) / 128) >= 192) return launch<T, 64, 128, 1, 4>(a, s);
-    return launch<T, 64, 64, 2, 2>(a, s);
+    const long t128 = (long)((a.M + 127) / 128) * ((ncols + 127) / 128);
+    if (ncols <= 64) return run_config<T>((a.M + 127) / 128 >= 512 ? 14 : 15, a, s);
+    if (t128 >= 256) return run_config<T>(10, a, s);
+    if ((long)((a.M + 63) / 64) * ((ncols + 127) / 128) >= 192) return run_config<T>(11, a, s);
+    return run_config<T>(15, a, s);
 }
 
 }  // namespace
@@ -226,4 +549,9 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
     hipStream_t s = (hipStream_t)stream;
     return dtype == EMAGE_BF16 ? dispatch<bf16_t>(a, s) : dispatch<float>(a, s);
+}
+
+extern "C" int emage_set_tuning(int key, int value) {
+    if (key == 0) { g_force_config = value; return 0; }
+    return EMAGE_EINVAL;
 }

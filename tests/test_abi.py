@@ -1,0 +1,41 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/emage_hip.h declares, with the
+prototypes pantomatrix_amd/_lib.py binds."""
+import os
+import re
+
+from pantomatrix_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "emage_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(?:int|const char\*)\s+(emage_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        protos[m.group(1)] = args
+    return protos
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    protos = _declared()
+    assert len(protos) >= 17
+    for name, args in protos.items():
+        assert hasattr(lib, name), f"{name} declared in emage_hip.h but not exported"
+        if name in ("emage_abi_version", "emage_target_arch"):
+            continue
+        assert name in _lib.SIGNATURES, f"{name} not bound in _lib.py"
+        assert len(_lib.SIGNATURES[name]) == len(args), (name, len(_lib.SIGNATURES[name]), len(args))
+    assert set(_lib.SIGNATURES) <= set(protos)
+    assert lib.emage_abi_version() == _lib.ABI_VERSION and lib.emage_target_arch() == b"gfx950"
+
+
+def test_argument_validation_without_gpu():
+    """Invalid arguments are rejected before any launch (EMAGE_EINVAL = -1), so this runs without a device."""
+    lib = _lib.load()
+    assert lib.emage_vq_argmin_f32(None, 0, None, None, 0, 0, 0, None) == -1
+    assert lib.emage_gemm(1, None, 0, None, None, None, None, 0, 0, 0, None, 0, 0, None, 0, None, 0, 0, 0,
+                          0, 0, 0, 0, 0, 0, 0, 0, None) == -1
+    assert lib.emage_set_tuning(99, 0) == -1
