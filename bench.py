@@ -37,16 +37,18 @@ def build_models(precision, device):
     return common.product_models(precision=precision, device=device)
 
 
-def one_step(model, vq, audio, spk, zeros_trans):
-    lat = model.inference(audio, spk, vq)
-    pred = vq.decode(**model._select_codes(lat), get_global_motion=True, ref_trans=zeros_trans)
-    poses = pred["motion_axis_angle"].cpu()
-    expr = pred["expression"].cpu()
-    trans = pred["trans"].cpu()
-    return poses, expr, trans
+def one_step(runner, audio):
+    """The timed unit: audio (already in HBM) -> runner (hipGraph replay of inference + final decode) -> poses /
+    expressions / trans on the host."""
+    return runner(audio)
 
 
 def profile_kernels(model, vq, audio, spk, zeros_trans):
+    def eager_step():
+        lat = model.inference(audio, spk, vq)
+        pred = vq.decode(**model._select_codes(lat), get_global_motion=True, ref_trans=zeros_trans)
+        return pred["motion_axis_angle"].cpu()
+
     """One extra, untimed step with a HIP-event pair around every kernel launch (same stream the kernels run
     on).  Returns {family: [count, total_ms, algorithmic flops, algorithmic bytes]}."""
     from pantomatrix_amd import ops
@@ -95,7 +97,7 @@ def profile_kernels(model, vq, audio, spk, zeros_trans):
         for nm, cost in table.items():
             saved[nm] = getattr(ops, nm)
             setattr(ops, nm, wrap(nm, saved[nm], cost))
-        one_step(model, vq, audio, spk, zeros_trans)
+        eager_step()
         torch.cuda.synchronize()
     finally:
         for nm, fn in saved.items():
@@ -148,6 +150,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,15 +181,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"models built on {dev}; warm-up x{args.warmup}")
+    from pantomatrix_amd.runtime import ClipRunner
+    log(f"models built on {dev}; capturing the clip graph")
+    runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph)
+    log(f"warm-up x{args.warmup}")
     for _ in range(args.warmup):
-        poses, _, _ = one_step(model, vq, audio, spk, zeros_trans)
+        poses, _, _ = one_step(runner, audio)
     log("timed region")
     frames_per_step = poses.shape[0] * poses.shape[1] if args.warmup else None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        poses, expr, trans = one_step(model, vq, audio, spk, zeros_trans)
+        poses, expr, trans = one_step(runner, audio)
     barrier()
     elapsed = time.perf_counter() - t0
     frames_per_step = poses.shape[0] * poses.shape[1]
@@ -194,7 +200,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert np.isfinite(poses.numpy()).all()
+    assert np.isfinite(poses).all()
     log(f"timed: {1e3 * elapsed / args.steps:.2f} ms/step")
 
     result = {
@@ -209,7 +215,8 @@ def main():
                                f"(BASELINE configs[1]): 2 windows of 64 frames + final VQ decode with global motion, "
                                f"{frames_per_step // args.batch} frames out per clip; synthetic seeded weights",
                    "clips_per_gpu": args.batch, "frames_in": args.frames, "frames_out_per_clip": frames_per_step // args.batch,
-                   "parallelism": f"replicas x{world} (clip-sharded, no collective)"},
+                   "parallelism": f"replicas x{world} (clip-sharded, no collective)",
+                   "launch": "eager" if args.no_graph else "hipGraph replay"},
     }
     if rank == 0 and not args.no_roofline:
         fam = profile_kernels(model, vq, audio, spk, zeros_trans)

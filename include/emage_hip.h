@@ -122,23 +122,25 @@ int emage_attention(int dtype, const void* q, int ldq, const void* k, int ldk, c
 /*
  * K5 — LayerNorm(C, eps) over rows (post-norm of every transformer sub-layer):
  *   y = (x - mean) * rsqrt(var + eps) * gamma + beta (+ add[m][:])
- * x: (M, ldx) fp32 (the fp32 residual stream).  add: (M, ldadd) fp32 or NULL (folds the positional /
+ * x: (M, ldx) `dtype` — the residual stream is stored in the compute dtype (fp32 in parity mode, bf16 in bf16
+ * mode); statistics and the affine map are fp32.  add: (M, ldadd) `dtype` or NULL (folds the positional /
  * speaker / skip adds that follow a LayerNorm, M:304-305,312).  y_f32: (M, ldy) fp32 or NULL;
  * y: (M, ldy) `dtype` or NULL.  C % 64 == 0, C <= 1024.
  */
-int emage_layernorm(int dtype, const float* x, int ldx, const float* gamma, const float* beta, float eps,
-                    const float* add, int ldadd, float* y_f32, void* y, int ldy, int M, int C, void* stream);
+int emage_layernorm(int dtype, const void* x, int ldx, const float* gamma, const float* beta, float eps,
+                    const void* add, int ldadd, float* y_f32, void* y, int ldy, int M, int C, void* stream);
 
 /*
  * K11 — elementwise glue.
- * emage_add: out[m] = a[m] + b[m % mod_b] (+ c[m % mod_c]), fp32 inputs with row strides (mod_* = 0: no
- *   wrap; mod = T broadcasts a (T,C) positional table over the batch, P:341-343), writes fp32 and/or `dtype`.
+ * emage_add: out[m] = a[m] + b[m % mod_b] (+ c[m % mod_c]); operand k (a=0,b=1,c=2) is fp32 when bit k of
+ *   f32_mask is set, else `dtype` (mod_* = 0: no wrap; mod = T broadcasts a (T,C) positional table over the
+ *   batch, P:341-343); writes fp32 and/or `dtype`.  C % 4 == 0.
  * emage_pack_motion: where(mask == 1, mask_embedding, motion) (M:267-268) -> `dtype`, (M, ldo),
  *   columns [C, n_store) zero.
  * emage_cast_pad: fp32 (M,C) -> `dtype` (M, ldo) with zero tail [C, n_store).
  */
-int emage_add(int dtype, const float* a, int lda, const float* b, int ldb, int mod_b, const float* c, int ldc, int mod_c,
-              float* out_f32, void* out, int ldo, int M, int C, void* stream);
+int emage_add(int dtype, const void* a, int lda, const void* b, int ldb, int mod_b, const void* c, int ldc, int mod_c,
+              int f32_mask, float* out_f32, void* out, int ldo, int M, int C, void* stream);
 int emage_pack_motion(int dtype, const float* motion, const float* mask, const float* mask_embedding,
                       void* out, int ldo, int n_store, int M, int C, void* stream);
 int emage_cast_pad(int dtype, const float* src, int lds, void* out, int ldo, int n_store, int M, int C, void* stream);

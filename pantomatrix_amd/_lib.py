@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p, _i, _f = C.c_void_p, C.c_int, C.c_float
 
@@ -24,7 +24,7 @@ SIGNATURES = {
     "emage_wav_conv_in": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "emage_attention": [_i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
-    "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _i, _p],
+    "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p],
     "emage_pack_motion": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "emage_cast_pad": [_i, _p, _i, _p, _i, _i, _i, _i, _p],
     "emage_rot6d_to_axis_angle": [_p, _p, _i, _p],

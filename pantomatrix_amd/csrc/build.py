@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "attention.hip", "vq.hip", "elementwise.hip", "motion.hip", "wavconv.hip", "version.hip"]
 LIB = os.path.join(HERE, "libemage_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 
 def _hipcc():

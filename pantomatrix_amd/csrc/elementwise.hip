@@ -5,23 +5,44 @@
 
 namespace {
 
-// One wave per row, C = 64*NV*4?  Generic: each lane owns float4 groups j = lane + 64*i (C % 4 == 0).
+// 4 consecutive elements of T as floats (16-byte fp32 / 8-byte bf16 access)
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    __device__ static __forceinline__ float4 load(const float* p) { return *(const float4*)p; }
+    __device__ static __forceinline__ void store(float* p, float4 v) { *(float4*)p = v; }
+};
+template <> struct Vec4<bf16_t> {
+    __device__ static __forceinline__ float4 load(const bf16_t* p) {
+        const uint2 t = *(const uint2*)p;
+        return make_float4(__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
+                           __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u));
+    }
+    __device__ static __forceinline__ void store(bf16_t* p, float4 v) {
+        uint2 t;
+        t.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+        t.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+        *(uint2*)p = t;
+    }
+};
+
+// LayerNorm: one wave per row; each lane owns 4-element groups j = lane + 64*i (C % 4 == 0).  The row (the
+// residual stream, stored in the compute dtype) is read once, statistics and the affine map are fp32.
 template <typename T, int MAXV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                        const float* __restrict__ add, int ldadd,
+                                                        const T* __restrict__ add, int ldadd,
                                                         float* __restrict__ yf, T* __restrict__ y, int ldy, int M, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
-    const int nv = C >> 2;   // float4 groups per row
-    const float4* xp = (const float4*)(x + (long)row * ldx);
+    const int nv = C >> 2;
+    const T* xp = x + (long)row * ldx;
     float4 v[MAXV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int j = lane + 64 * i;
-        v[i] = j < nv ? xp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = j < nv ? Vec4<T>::load(xp + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
@@ -39,7 +60,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = 1.0f / sqrtf(q / (float)C + eps);
     const float4* gp = (const float4*)gamma;
     const float4* bp = (const float4*)beta;
-    const float4* ap = add ? (const float4*)(add + (long)row * ldadd) : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int j = lane + 64 * i;
@@ -50,27 +70,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z;
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            if (ap) { const float4 a = ap[j]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+            if (add) { const float4 a = Vec4<T>::load(add + (long)row * ldadd + 4 * j); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
             if (yf) ((float4*)(yf + (long)row * ldy))[j] = o;
-            if (y) {
-                T* yp = y + (long)row * ldy + 4 * j;
-                yp[0] = Elem<T>::to(o.x); yp[1] = Elem<T>::to(o.y); yp[2] = Elem<T>::to(o.z); yp[3] = Elem<T>::to(o.w);
-            }
+            if (y) Vec4<T>::store(y + (long)row * ldy + 4 * j, o);
         }
     }
 }
 
+// out[m] = a[m] + b[m % mod_b] (+ c[m % mod_c]); operand k is fp32 when bit k of f32_mask is set, else T
 template <typename T>
-__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int mod_b,
-                                                  const float* __restrict__ c, int ldc, int mod_c, float* __restrict__ of, T* __restrict__ o, int ldo,
-                                                  int M, int C) {
-    const long total = (long)M * C;
+__global__ __launch_bounds__(256) void add_kernel(const void* __restrict__ a, int lda, const void* __restrict__ b, int ldb, int mod_b,
+                                                  const void* __restrict__ c, int ldc, int mod_c, int f32_mask,
+                                                  float* __restrict__ of, T* __restrict__ o, int ldo, int M, int C) {
+    const int nv = C >> 2;
+    const long total = (long)M * nv;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(i / C), n = (int)(i - (long)m * C);
-        float v = a[(long)m * lda + n] + b[(long)(mod_b ? m % mod_b : m) * ldb + n];
-        if (c) v += c[(long)(mod_c ? m % mod_c : m) * ldc + n];
-        if (of) of[(long)m * ldo + n] = v;
-        if (o) o[(long)m * ldo + n] = Elem<T>::to(v);
+        const int m = (int)(i / nv), n = 4 * (int)(i - (long)m * nv);
+        auto ld = [&](const void* p, int ldp, int mod, int bit) {
+            const long r = mod ? m % mod : m;
+            return (f32_mask >> bit) & 1 ? Vec4<float>::load((const float*)p + r * ldp + n) : Vec4<T>::load((const T*)p + r * ldp + n);
+        };
+        float4 v = ld(a, lda, 0, 0);
+        const float4 w = ld(b, ldb, mod_b, 1);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        if (c) { const float4 u = ld(c, ldc, mod_c, 2); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        if (of) Vec4<float>::store(of + (long)m * ldo + n, v);
+        if (o) Vec4<T>::store(o + (long)m * ldo + n, v);
     }
 }
 
@@ -103,26 +128,27 @@ inline int grid_for(long total) {
 
 }  // namespace
 
-extern "C" int emage_layernorm(int dtype, const float* x, int ldx, const float* gamma, const float* beta, float eps,
-                               const float* add, int ldadd, float* y_f32, void* y, int ldy, int M, int C, void* stream) {
+extern "C" int emage_layernorm(int dtype, const void* x, int ldx, const float* gamma, const float* beta, float eps,
+                               const void* add, int ldadd, float* y_f32, void* y, int ldy, int M, int C, void* stream) {
     if (!x || !gamma || !beta || (!y_f32 && !y) || M <= 0 || C <= 0 || C % 64 || C > 1024) return EMAGE_EINVAL;
     if (ldx % 4 || ldy % 4 || (add && ldadd % 4)) return EMAGE_EINVAL;
-    if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)add | (uintptr_t)y_f32) & 15) return EMAGE_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)add | (uintptr_t)y_f32 | (uintptr_t)y) & 15) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((M + 3) / 4), block(256);
-    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, 4>), grid, block, 0, s, x, ldx, gamma, beta, eps, add, ldadd, y_f32, (bf16_t*)y, ldy, M, C);
-    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, s, x, ldx, gamma, beta, eps, add, ldadd, y_f32, (float*)y, ldy, M, C);
+    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, 4>), grid, block, 0, s, (const bf16_t*)x, ldx, gamma, beta, eps, (const bf16_t*)add, ldadd, y_f32, (bf16_t*)y, ldy, M, C);
+    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, eps, (const float*)add, ldadd, y_f32, (float*)y, ldy, M, C);
     else return EMAGE_EINVAL;
     return launch_status();
 }
 
-extern "C" int emage_add(int dtype, const float* a, int lda, const float* b, int ldb, int mod_b, const float* c, int ldc, int mod_c,
-                         float* out_f32, void* out, int ldo, int M, int C, void* stream) {
-    if (!a || !b || (!out_f32 && !out) || M <= 0 || C <= 0) return EMAGE_EINVAL;
+extern "C" int emage_add(int dtype, const void* a, int lda, const void* b, int ldb, int mod_b, const void* c, int ldc, int mod_c,
+                         int f32_mask, float* out_f32, void* out, int ldo, int M, int C, void* stream) {
+    if (!a || !b || (!out_f32 && !out) || M <= 0 || C <= 0 || C % 4 || lda % 4 || ldb % 4 || ldo % 4 || (c && ldc % 4)) return EMAGE_EINVAL;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out_f32 | (uintptr_t)out) & 7) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(grid_for((long)M * C)), block(256);
-    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((add_kernel<bf16_t>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, out_f32, (bf16_t*)out, ldo, M, C);
-    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((add_kernel<float>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, out_f32, (float*)out, ldo, M, C);
+    const dim3 grid(grid_for((long)M * C / 4)), block(256);
+    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((add_kernel<bf16_t>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask, out_f32, (bf16_t*)out, ldo, M, C);
+    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((add_kernel<float>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask | 7, out_f32, (float*)out, ldo, M, C);
     else return EMAGE_EINVAL;
     return launch_status();
 }

@@ -4,10 +4,12 @@
 // bytes is identical: K-tile = 8 chunks = 128 B per row, LDS rows XOR-swizzled by (row>>1)&7 so a
 // ds_read_b128 lane group touches 16 distinct 16-B slots.
 #include "common.h"
+#include <utility>
 
 namespace {
 
 int g_force_config = -1;   // tuning knob (tests / tools): -1 = heuristic, else a fixed configuration id
+int g_debug_skip = 0;      // diagnostics (tools/bench_gemm.py --ablate): 1 = no operand DMA, 2 = no LDS reads/MFMA, 4 = no epilogue
 
 struct GemmArgs {
     const void* A; const void* W; const float* bias; const float* slope;
@@ -16,6 +18,7 @@ struct GemmArgs {
     int t_col0, t_rows, t_ld;
     int M, N, K, Cp, taps, stride, pad, Lin, Lout;
     int tiles_m, tiles_n;
+    int dbg;
 };
 
 constexpr int NTHREADS = 256;
@@ -211,88 +214,30 @@ template <> struct Pack4<bf16_t> {
 };
 
 template <typename T, int BM, int BN, int CLD>
-__device__ __forceinline__ void staged_store(const GemmArgs& p, const float* Cs, int m0, int n0, int tid) {
-    T* __restrict__ out = (T*)p.out;
+__device__ __forceinline__ void transposed_store(const GemmArgs& p, const float* Cs, int m0, int n0, int tid) {
     T* __restrict__ out_t = (T*)p.out_t;
-    const int ncol_n = p.out_t ? p.t_col0 : p.N;        // columns below this go to out / out_f32
-    // vector path needs every touched row/column group 16-byte (fp32) / 8-byte (bf16) aligned
-    const bool vec = (p.N % 4 == 0) && (ncol_n % 4 == 0) && (p.n_store % 4 == 0) &&
-                     (!out || (p.ldo % 4 == 0 && ((uintptr_t)out & 15) == 0)) &&
-                     (!p.out_f32 || (p.ldf % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
-                     (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
-                     (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.slope || ((uintptr_t)p.slope & 15) == 0);
-    constexpr int GPR = BN / 4;                         // 4-column groups per row
-    if (n0 < ncol_n || (out && n0 < p.n_store)) {
-#pragma unroll 2
-        for (int gid = tid; gid < BM * GPR; gid += NTHREADS) {
-            const int row = gid / GPR, cg = gid - row * GPR;
-            const int m = m0 + row, n = n0 + cg * 4;
-            if (m >= p.M) continue;
-            float v[4];
-            { const float4 c = *(const float4*)(Cs + row * CLD + cg * 4); v[0] = c.x; v[1] = c.y; v[2] = c.z; v[3] = c.w; }
-            if (vec && n + 3 < ncol_n) {
-                float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) Pack4<float>::load(p.bias + n, bv);
-                if (p.slope) Pack4<float>::load(p.slope + n, sv);
-                if (p.res) {
-                    if (p.res_is_f32) Pack4<float>::load((const float*)p.res + (long)m * p.ldr + n, rv);
-                    else Pack4<T>::load((const T*)p.res + (long)m * p.ldr + n, rv);
-                }
+    const int t_ncols = p.N - p.t_col0;
+    constexpr int RG = BM / 4;                          // 4-row groups per column
+    const bool tvec = (p.t_rows % 4 == 0) && (p.t_ld % 4 == 0) && (((uintptr_t)out_t & 15) == 0);
+    for (int gid = tid; gid < BN * RG; gid += NTHREADS) {
+        const int col = gid / RG, rg = gid - col * RG;
+        const int n = n0 + col, m = m0 + rg * 4;
+        if (n < p.t_col0 || n >= p.N || m >= p.M) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f, sv = p.slope ? p.slope[n] : 1.f;
+        float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[e] + bv[e];
-                    if (p.res_first) x += rv[e];
-                    x = leaky(x, sv[e]);
-                    if (!p.res_first) x += rv[e];
-                    v[e] = x;
-                }
-                if (out) Pack4<T>::store(out + (long)m * p.ldo + n, v);
-                if (p.out_f32) Pack4<float>::store(p.out_f32 + (long)m * p.ldf + n, v);
-            } else {
+        for (int e = 0; e < 4; ++e) v[e] = leaky(Cs[(rg * 4 + e) * CLD + col] + bv, sv);
+        const int b = m / p.t_rows, l = m - b * p.t_rows;
+        T* dst = out_t + ((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l;
+        if (tvec && m + 3 < p.M) {
+            Pack4<T>::store(dst, v);
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int nn = n + e;
-                    if (nn < ncol_n) {
-                        float x = v[e] + (p.bias ? p.bias[nn] : 0.f);
-                        float r = 0.f;
-                        if (p.res) r = p.res_is_f32 ? ((const float*)p.res)[(long)m * p.ldr + nn]
-                                                    : Elem<T>::from(((const T*)p.res)[(long)m * p.ldr + nn]);
-                        if (p.res_first) x += r;
-                        x = leaky(x, p.slope ? p.slope[nn] : 1.f);
-                        if (!p.res_first) x += r;
-                        if (out) out[(long)m * p.ldo + nn] = Elem<T>::to(x);
-                        if (p.out_f32) p.out_f32[(long)m * p.ldf + nn] = x;
-                    } else if (out && nn >= p.N && nn < p.n_store) {
-                        out[(long)m * p.ldo + nn] = Elem<T>::to(0.f);
-                    }
-                }
-            }
-        }
-    }
-    if (out_t && n0 + BN > p.t_col0) {
-        const int t_ncols = p.N - p.t_col0;
-        constexpr int RG = BM / 4;                      // 4-row groups per column
-        const bool tvec = (p.t_rows % 4 == 0) && (p.t_ld % 4 == 0) && (((uintptr_t)out_t & 15) == 0);
-        for (int gid = tid; gid < BN * RG; gid += NTHREADS) {
-            const int col = gid / RG, rg = gid - col * RG;
-            const int n = n0 + col, m = m0 + rg * 4;
-            if (n < p.t_col0 || n >= p.N || m >= p.M) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f, sv = p.slope ? p.slope[n] : 1.f;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = leaky(Cs[(rg * 4 + e) * CLD + col] + bv, sv);
-            const int b = m / p.t_rows, l = m - b * p.t_rows;
-            T* dst = out_t + ((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l;
-            if (tvec && m + 3 < p.M) {
-                Pack4<T>::store(dst, v);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int mm = m + e;
-                    if (mm < p.M) {
-                        const int bb = mm / p.t_rows, ll = mm - bb * p.t_rows;
-                        out_t[((long)bb * t_ncols + (n - p.t_col0)) * p.t_ld + ll] = Elem<T>::to(v[e]);
-                    }
+            for (int e = 0; e < 4; ++e) {
+                const int mm = m + e;
+                if (mm < p.M) {
+                    const int bb = mm / p.t_rows, ll = mm - bb * p.t_rows;
+                    out_t[((long)bb * t_ncols + (n - p.t_col0)) * p.t_ld + ll] = Elem<T>::to(v[e]);
                 }
             }
         }
@@ -319,20 +264,48 @@ __device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+// LDS image per ring slot: rows of KC 16-byte chunks (KC = 8: 128-B rows, two MFMA k-groups per tile;
+// KC = 4: 64-B rows, one k-group).  16-B slot of chunk g in row r: g ^ swz(r), chosen so that each 16-lane
+// service group of ds_read_b128 hits 16 distinct slots of the 256-B bank row:
+//   KC = 8: swz = (r>>1)&7        KC = 4: swz = (-(r>>2))&3        (both invariant under r += 16)
+template <int KC> __device__ __forceinline__ int swz(int row) { return KC == 8 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3); }
+
+template <int OFF> __device__ __forceinline__ u32x4 lds_read128_off(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
+// The kernel is instruction-issue bound at these sizes (rocprof: MFMA is <20 % of active wave cycles in a
+// naive loop), so the K-loop carries no per-tile vector address math: operands stream through
+// buffer_load_dwordx4 ... lds with a per-lane byte offset fixed at kernel start and the K-tile advance in the
+// scalar offset; rows outside M / N and conv halo rows get an out-of-range offset, for which the buffer unit
+// returns zeros.  MFMA operands are SWAPPED (A-operand = W rows, B-operand = activation rows) so that a lane
+// ends up with 4 consecutive output COLUMNS of one row: the epilogue is direct 16-byte (fp32) / 8-byte (bf16)
+// vector loads/stores, no LDS staging.  Only V^T tiles (column-contiguous along the sequence) stage through LDS.
+constexpr unsigned OOB = 0x80000000u;    // > any num_records we create (buffers are < 2 GiB)
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, int KC>
 __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(GemmArgs p) {
     constexpr int EPC = Elem<T>::EPC;
-    constexpr int BK = KCH * EPC;
+    constexpr int ES = 16 / EPC;                     // element size in bytes
+    constexpr int BK = KC * EPC;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int FM = WTM / 16, FN = WTN / 16;
-    constexpr int GA = BM / 32, GB = BN / 32;        // 1-KiB DMA instructions per wave per tile (8 rows each)
+    constexpr int RB = KC * 16;                      // bytes per tile row
+    constexpr int RPI = 1024 / RB;                   // rows filled by one 1-KiB DMA wave-instruction
+    constexpr int GA = BM / (4 * RPI), GB = BN / (4 * RPI);   // DMA instructions per wave per tile
     constexpr int G = GA + GB;
-    constexpr int STAGE = (BM + BN) * 128;           // bytes per ring slot: A rows then W rows
-    static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
-    static_assert(NS >= 2 && NS <= 4, "ring depth");
+    constexpr int STAGE = (BM + BN) * RB;            // bytes per ring slot: A rows then W rows
+    constexpr int NKG = KC / 4;                      // MFMA k-groups per tile
+    static_assert(WM * WN == 4 && BM % (4 * RPI) == 0 && BN % (4 * RPI) == 0, "tile shape");
+    static_assert(NS >= 2 && NS <= 4 && (KC == 4 || KC == 8), "ring depth / row width");
 
-    constexpr int CLD = BN + 4;                      // fp32 row stride of the epilogue staging tile
-    constexpr int CBYTES = BM * CLD * 4;
+    constexpr int CLD = BN + 4;                      // fp32 row stride of the V^T staging tile
+    constexpr int EP = (BM * CLD * 4 <= NS * STAGE) ? 1 : 2;   // staging passes (row halves) so it fits the ring
+    constexpr int HB = BM / EP;
+    constexpr int CBYTES = HB * CLD * 4;
+    static_assert(HB % 16 == 0, "staging half must hold whole fragments");
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE > CBYTES ? NS * STAGE : CBYTES];
 
     const int tid = threadIdx.x;
@@ -349,51 +322,66 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(GemmArgs p) {
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const T* __restrict__ A = (const T*)p.A;
-    const T* __restrict__ W = (const T*)p.W;
-    const T* zero_src = (const T*)g_zero_chunk;
+    // buffer descriptors (wave-uniform): raw buffers, byte offsets, out-of-range reads return 0
+    const int nbatch = p.M / p.Lout;
+    // A's descriptor starts `pad` rows BEFORE the tensor so that every per-lane offset is non-negative (the range
+    // check is on the unsigned offset); rows in front of / behind a clip are masked explicitly per tap below
+    const unsigned a_shift = (unsigned)p.pad * (unsigned)(p.lda * ES);
+    const unsigned a_bytes = (unsigned)((((long)nbatch * p.Lin - 1) * p.lda + p.Cp) * ES) + a_shift;
+    const unsigned w_bytes = (unsigned)((long)p.N * p.K * ES);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
 
-    // DMA slots of this lane: instruction j of this wave fills rows (wave + 4j)*8 .. +7 of the A (or W) tile;
-    // lane -> row offset lane>>3, LDS slot lane&7, source chunk (lane&7) ^ ((row>>1)&7)
-    const int lrow = lane >> 3, lslot = lane & 7;
-    long a_off[GA]; int a_lpos[GA]; bool a_ok[GA];
+    // DMA slots of this lane: instruction j of this wave fills rows (wave + 4j)*RPI .. +RPI-1 of the A (or W)
+    // tile; lane -> row offset lane / KC, LDS slot lane % KC, source chunk slot ^ swz(row)
+    const int lrow = lane / KC, lslot = lane % KC;
+    const bool is_conv = p.taps > 1;
+    unsigned a_voff[GA]; int a_lpos[GA];
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
-        const int row = (wave + 4 * j) * 8 + lrow;
+        const int row = (wave + 4 * j) * RPI + lrow;
         const int m = m0 + row;
-        a_ok[j] = m < p.M;
-        const int mm = a_ok[j] ? m : 0;
-        const int b = mm / p.Lout, l = mm - b * p.Lout;
-        a_lpos[j] = l * p.stride - p.pad;
-        a_off[j] = ((long)b * p.Lin + a_lpos[j]) * p.lda + (lslot ^ ((row >> 1) & 7)) * EPC;
+        const unsigned chunk = (unsigned)((lslot ^ swz<KC>(row)) * 16);
+        if (!is_conv) {
+            a_lpos[j] = 0;
+            a_voff[j] = m < p.M ? (unsigned)m * (unsigned)(p.lda * ES) + chunk : OOB;
+        } else {
+            const int mm = m < p.M ? m : 0;
+            const int b = mm / p.Lout, l = mm - b * p.Lout;
+            a_lpos[j] = m < p.M ? l * p.stride - p.pad : -0x40000000;      // invalid rows fail every tap's range test
+            a_voff[j] = (unsigned)(((long)b * p.Lin + l * p.stride) * p.lda * ES) + chunk;   // relative to the shifted base
+        }
     }
-    long b_off[GB]; bool b_ok[GB];
+    unsigned b_voff[GB];
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
-        const int row = (wave + 4 * j) * 8 + lrow;
+        const int row = (wave + 4 * j) * RPI + lrow;
         const int n = n0 + row;
-        b_ok[j] = n < p.N;
-        b_off[j] = (long)(b_ok[j] ? n : 0) * p.K + (lslot ^ ((row >> 1) & 7)) * EPC;
+        b_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.K * ES) + (unsigned)((lslot ^ swz<KC>(row)) * 16) : OOB;
     }
 
-    auto issue = [&](int kt, int slot) {
-        const int k0 = kt * BK;
-        const int tap = k0 / p.Cp;
-        const int c0 = k0 - tap * p.Cp;
-        unsigned char* base = smem + slot * STAGE;
+    // running position of the next tile to issue: tap, channel offset, scalar byte offsets
+    int is_tap = 0, is_c0 = 0, is_slot = 0;
+    unsigned soff_a = 0, soff_w = 0;
+    const unsigned tap_step = (unsigned)(p.lda - p.Cp + BK) * ES;            // soff_a jump when the tap advances
+    auto issue = [&]() {
+        if (p.dbg & 1) return;
+        unsigned char* base = smem + is_slot * STAGE;
 #pragma unroll
         for (int j = 0; j < GA; ++j) {
-            const bool ok = a_ok[j] && (unsigned)(a_lpos[j] + tap) < (unsigned)p.Lin;
-            const T* src = ok ? A + a_off[j] + (long)tap * p.lda + c0 : zero_src;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 1024), 16, 0, 0);
+            unsigned vo = a_voff[j];
+            if (is_conv) vo = (unsigned)(a_lpos[j] + is_tap) < (unsigned)p.Lin ? vo : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 1024),
+                                                     16, (int)vo, (int)soff_a, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < GB; ++j) {
-            const T* src = b_ok[j] ? W + b_off[j] + k0 : zero_src;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + (wave + 4 * j) * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < GB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + BM * RB + (wave + 4 * j) * 1024),
+                                                     16, (int)b_voff[j], (int)soff_w, 0, 0);
+        soff_w += BK * ES;
+        is_c0 += BK;
+        if (is_c0 == p.Cp) { is_c0 = 0; ++is_tap; soff_a += tap_step; } else { soff_a += BK * ES; }
+        if (++is_slot == NS) is_slot = 0;
     };
 
     f32x4 acc[FM][FN];
@@ -405,24 +393,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(GemmArgs p) {
     const int nk = p.K / BK;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue(s, s);
+        if (s < nk) issue();
 
-    // fragment addresses inside a ring slot (bytes): row * 128 + swizzled 16-B slot; the k-group (0/1) flips bit 2
+    // fragment read addresses inside a ring slot (bytes): row * RB + swizzled 16-B slot; fragment i adds the
+    // immediate i*16*RB (the swizzle is invariant under +16 rows); k-group 1 flips slot bit 2
     const int fr = lane & 15, fg = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    unsigned a_addr[FM], b_addr[FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int row = wm * WTM + i * 16 + fr;
-        a_addr[i] = row * 128 + ((fg ^ ((row >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int row = wn * WTN + j * 16 + fr;
-        b_addr[j] = BM * 128 + row * 128 + ((fg ^ ((row >> 1) & 7)) << 4);
-    }
+    const int arow = wm * WTM + fr, brow = wn * WTN + fr;
+    const unsigned a_rd0 = lds0 + arow * RB + ((fg ^ swz<KC>(arow)) << 4);
+    const unsigned b_rd0 = lds0 + BM * RB + brow * RB + ((fg ^ swz<KC>(brow)) << 4);
+    const unsigned a_rd1 = a_rd0 ^ 64u, b_rd1 = b_rd0 ^ 64u;   // lds0 is 128-B aligned, so the xor acts on the slot bit
 
-    int slot = 0;
+    unsigned sb = 0;                                  // byte offset of the slot being consumed
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed; tiles issued after it (at most NS-2) may stay in flight
         const int newer = nk - 1 - kt;
@@ -430,50 +412,132 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(GemmArgs p) {
         else if (NS >= 3 && newer >= 1) wait_vmcnt<G>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) {
-            int ns = slot + NS - 1; if (ns >= NS) ns -= NS;
-            issue(kt + NS - 1, ns);
+        if (kt + NS - 1 < nk) issue();
+        if (p.dbg & 2) continue;
+        u32x4 af0[FM], bf0[FN];
+        const unsigned a0 = a_rd0 + sb, b0 = b_rd0 + sb;
+        [&]<int... I>(std::integer_sequence<int, I...>) { ((af0[I] = lds_read128_off<I * 16 * RB>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
+        [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<J * 16 * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
+        if constexpr (NKG == 2) {
+            u32x4 af1[FM], bf1[FN];
+            const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<J * 16 * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
+            wait_lgkmcnt<FM + FN>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf1[j]), __builtin_bit_cast(uint4, af1[i]), acc[i][j]);
+        } else {
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
         }
-        const unsigned sb = lds0 + slot * STAGE;
-        u32x4 af0[FM], bf0[FN], af1[FM], bf1[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af0[i] = lds_read128(sb + a_addr[i]);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf0[j] = lds_read128(sb + b_addr[j]);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af1[i] = lds_read128(sb + (a_addr[i] ^ 64u));
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf1[j] = lds_read128(sb + (b_addr[j] ^ 64u));
-        wait_lgkmcnt<FM + FN>();
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, af0[i]), __builtin_bit_cast(uint4, bf0[j]), acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_lgkmcnt<0>();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, af1[i]), __builtin_bit_cast(uint4, bf1[j]), acc[i][j]);
-        if (++slot == NS) slot = 0;
+        sb += STAGE;
+        if (sb == NS * STAGE) sb = 0;
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32 tile) -> row-contiguous 4-wide groups -> global ----
-    __syncthreads();                                  // every wave is done reading the ring
-    float* Cs = (float*)smem;
+    // ---- epilogue.  acc[i][j][r] = out[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + j*16 + fg*4 + r] ----
+    if (p.dbg & 4) {                                  // diagnostics: keep the accumulators live, store nothing
+        if (acc[0][0][0] == 123.456f) ((float*)p.out_f32)[0] = 0.f;
+        return;
+    }
+    const int ncol_n = p.out_t ? p.t_col0 : p.N;     // columns below this go to out / out_f32
+    T* __restrict__ out = (T*)p.out;
+    if (n0 < ncol_n || (out && n0 < p.n_store)) {
+        const bool vec = (p.N % 4 == 0) && (ncol_n % 4 == 0) && (p.n_store % 4 == 0) &&
+                         (!out || (p.ldo % 4 == 0 && ((uintptr_t)out & 15) == 0)) &&
+                         (!p.out_f32 || (p.ldf % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
+                         (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+                         (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.slope || ((uintptr_t)p.slope & 15) == 0);
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + fg * 4;
+            if (vec && n + 3 < ncol_n) {
+                float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p.bias) Pack4<float>::load(p.bias + n, bv);
+                if (p.slope) Pack4<float>::load(p.slope + n, sv);
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+                for (int i = 0; i < FM; ++i) {
+                    const int m = m0 + wm * WTM + i * 16 + fr;
+                    if (m >= p.M) continue;
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
+                    if (p.res) {
+                        if (p.res_is_f32) Pack4<float>::load((const float*)p.res + (long)m * p.ldr + n, rv);
+                        else Pack4<T>::load((const T*)p.res + (long)m * p.ldr + n, rv);
+                    }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Cs[(wm * WTM + i * 16 + fg * 4 + r) * CLD + wn * WTN + j * 16 + fr] = acc[i][j][r];
-    __syncthreads();
-    staged_store<T, BM, BN, CLD>(p, Cs, m0, n0, tid);
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][e] + bv[e];
+                        if (p.res_first) x += rv[e];
+                        x = leaky(x, sv[e]);
+                        if (!p.res_first) x += rv[e];
+                        v[e] = x;
+                    }
+                    if (out) Pack4<T>::store(out + (long)m * p.ldo + n, v);
+                    if (p.out_f32) Pack4<float>::store(p.out_f32 + (long)m * p.ldf + n, v);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int m = m0 + wm * WTM + i * 16 + fr;
+                    if (m >= p.M) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int nn = n + e;
+                        if (nn < ncol_n) {
+                            float x = acc[i][j][e] + (p.bias ? p.bias[nn] : 0.f);
+                            float r = 0.f;
+                            if (p.res) r = p.res_is_f32 ? ((const float*)p.res)[(long)m * p.ldr + nn]
+                                                        : Elem<T>::from(((const T*)p.res)[(long)m * p.ldr + nn]);
+                            if (p.res_first) x += r;
+                            x = leaky(x, p.slope ? p.slope[nn] : 1.f);
+                            if (!p.res_first) x += r;
+                            if (out) out[(long)m * p.ldo + nn] = Elem<T>::to(x);
+                            if (p.out_f32) p.out_f32[(long)m * p.ldf + nn] = x;
+                        } else if (out && nn >= p.N && nn < p.n_store) {
+                            out[(long)m * p.ldo + nn] = Elem<T>::to(0.f);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // V^T columns: stage the tile in LDS (row-major fp32) and store it column-contiguous along the sequence
+    if (p.out_t && n0 + BN > p.t_col0) {
+        float* Cs = (float*)smem;
+#pragma unroll
+        for (int h = 0; h < EP; ++h) {
+            __syncthreads();                          // ring (or previous half) no longer being read
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int rb = wm * WTM + i * 16;
+                if (rb / HB == h) {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        *(float4*)(Cs + (rb - h * HB + fr) * CLD + wn * WTN + j * 16 + fg * 4) =
+                            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                }
+            }
+            __syncthreads();
+            transposed_store<T, HB, BN, CLD>(p, Cs, m0 + h * HB, n0, tid);
+        }
+    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -485,12 +549,12 @@ int launch(GemmArgs& a, hipStream_t s) {
     return launch_status();
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int KC = 8>
 int launch_pipe(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M + BM - 1) / BM;
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     a.tiles_n = (ncols + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS>), dim3(a.tiles_m * a.tiles_n), dim3(NTHREADS), 0, s, a);
+    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS, KC>), dim3(a.tiles_m * a.tiles_n), dim3(NTHREADS), 0, s, a);
     return launch_status();
 }
 
@@ -511,6 +575,13 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 17: return launch_pipe<T, 64, 128, 1, 4, 3>(a, s);
         case 18: return launch_pipe<T, 128, 128, 2, 2, 2>(a, s);
         case 19: return launch_pipe<T, 64, 64, 2, 2, 3>(a, s);
+        case 20: return launch_pipe<T, 128, 128, 2, 2, 3, 4>(a, s);   // 64-B rows (K-tile of 4 chunks): 3 blocks/CU
+        case 21: return launch_pipe<T, 128, 128, 2, 2, 4, 4>(a, s);
+        case 22: return launch_pipe<T, 64, 128, 2, 2, 4, 4>(a, s);
+        case 23: return launch_pipe<T, 128, 64, 2, 2, 4, 4>(a, s);
+        case 24: return launch_pipe<T, 64, 64, 2, 2, 4, 4>(a, s);
+        case 25: return launch_pipe<T, 64, 64, 2, 2, 2>(a, s);
+        case 26: return launch_pipe<T, 128, 128, 2, 2, 2, 4>(a, s);
         default: return EMAGE_EINVAL;
     }
 }
@@ -520,10 +591,10 @@ int dispatch(GemmArgs& a, hipStream_t s) {
     if (g_force_config >= 0) return run_config<T>(g_force_config, a, s);
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     const long t128 = (long)((a.M + 127) / 128) * ((ncols + 127) / 128);
-    if (ncols <= 64) return run_config<T>((a.M + 127) / 128 >= 512 ? 14 : 15, a, s);
-    if (t128 >= 256) return run_config<T>(10, a, s);
-    if ((long)((a.M + 63) / 64) * ((ncols + 127) / 128) >= 192) return run_config<T>(11, a, s);
-    return run_config<T>(15, a, s);
+    // measured on MI355X (tools/bench_gemm.py): with M = 4096 the operand stream, not MFMA, bounds these
+    // launches, and many small resident blocks (64x64, 5 per CU) beat large tiles except on very wide outputs
+    if (t128 >= 1024) return run_config<T>(20, a, s);
+    return run_config<T>(25, a, s);
 }
 
 }  // namespace
@@ -546,6 +617,7 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
     a.A = A; a.W = W; a.bias = bias; a.slope = slope; a.res = res; a.out = out; a.out_f32 = out_f32; a.out_t = out_t;
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.ldf = ldf; a.res_is_f32 = res_is_f32; a.res_first = res_first; a.n_store = out ? n_store : 0;
     a.t_col0 = out_t ? t_col0 : N; a.t_rows = t_rows > 0 ? t_rows : 1; a.t_ld = t_ld;
+    a.dbg = g_debug_skip;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
     hipStream_t s = (hipStream_t)stream;
     return dtype == EMAGE_BF16 ? dispatch<bf16_t>(a, s) : dispatch<float>(a, s);
@@ -553,5 +625,6 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
 
 extern "C" int emage_set_tuning(int key, int value) {
     if (key == 0) { g_force_config = value; return 0; }
+    if (key == 1) { g_debug_skip = value; return 0; }
     return EMAGE_EINVAL;
 }

@@ -25,6 +25,7 @@ from collections import OrderedDict
 import torch
 
 from . import ops, spec, synthetic
+from .streams import Fork
 from ._lib import BF16, F32
 from .configuration_emage_audio import EmageAudioConfig, EmageVAEConvConfig, EmageVQVAEConvConfig
 
@@ -52,6 +53,7 @@ class _EmageModule:
         self._device = torch.device("cpu")
         self._dt = BF16
         self._packed = None
+        self.concurrent = True                 # issue independent launch chains on side streams (streams.py)
         self._spec = type(self)._spec_fn(config)
         self._params = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
                                                       prefix=type(self).__name__ + "/")
@@ -171,13 +173,12 @@ class _Packed:
         self.p, self.device, self.dt = params, device, dt
         self.tdt = ops.TORCH_DTYPE[dt]
         self.w = {}
-        self._slopes = {}
+        # per-column LeakyReLU slope vectors, built once here (before any stream fork can race on them):
+        # 0 = ReLU, 0.01 / 0.1 / 0.2 = the reference's LeakyReLU slopes
+        self._slopes = {v: torch.full((4096,), v, dtype=torch.float32, device=device) for v in (0.0, 0.01, 0.1, 0.2)}
 
     def slope(self, value, n):
-        key = (float(value), n)
-        if key not in self._slopes:
-            self._slopes[key] = torch.full((n,), float(value), dtype=torch.float32, device=self.device)
-        return self._slopes[key]
+        return self._slopes[float(value)][:n]
 
     def f32(self, name):
         return self.p[name].to(torch.float32).contiguous()
@@ -480,26 +481,31 @@ class EmageVQModel:
                 break
         m = bs * t
         parts = {}
-        for name, index, latent in (("face", face_index, face_latent), ("upper", upper_index, upper_latent),
-                                    ("hands", hands_index, hands_latent), ("lower", lower_index, lower_latent)):
-            model = getattr(self, f"vq_model_{name}")
-            if index is not None:
-                cx = _Ctx(model._engine())
-                parts[name] = model._decode_idx(cx, index.reshape(-1).contiguous(), bs, t)
-            elif latent is not None:
-                cx = _Ctx(model._engine())
-                idx = model._nearest(cx, latent.reshape(m, -1).float().contiguous())
-                parts[name] = model._decode_idx(cx, idx, bs, t)
-            else:
-                parts[name] = None
         dev = self.vq_model_face.device
-        aa, motion, expr = ops.merge_parts(parts["face"], parts["upper"], parts["hands"], parts["lower"], m, dev)
+        todo = (("lower", lower_index, lower_latent), ("hands", hands_index, hands_latent),
+                ("upper", upper_index, upper_latent), ("face", face_index, face_latent))
         trans = None
-        if get_global_motion:
-            lower_mix = parts["lower"]
-            if lower_mix is None:   # zeros pose: identity rot6d + zero trans/contact (M:174-177)
-                lower_mix = torch.tensor([1.0, 0, 0, 0, 1, 0] * 9 + [0.0] * 7, device=dev).repeat(m, 1)
-            trans = self.get_global_motion(lower_mix.view(bs, t, -1), ref_trans)
+        # the four part decoders are independent chains: one stream lane each; the global-translation AE only
+        # needs the lower stream, so it follows it on lane 0
+        with Fork(dev, 4, getattr(self.vq_model_face, "concurrent", True)) as fk:
+            for lane, (name, index, latent) in enumerate(todo):
+                model = getattr(self, f"vq_model_{name}")
+                with fk.lane(lane):
+                    if index is not None:
+                        cx = _Ctx(model._engine())
+                        parts[name] = model._decode_idx(cx, index.reshape(-1).contiguous(), bs, t)
+                    elif latent is not None:
+                        cx = _Ctx(model._engine())
+                        idx = model._nearest(cx, latent.reshape(m, -1).float().contiguous())
+                        parts[name] = model._decode_idx(cx, idx, bs, t)
+                    else:
+                        parts[name] = None
+                    if name == "lower" and get_global_motion:
+                        lower_mix = parts["lower"]
+                        if lower_mix is None:   # zeros pose: identity rot6d + zero trans/contact (M:174-177)
+                            lower_mix = torch.tensor([1.0, 0, 0, 0, 1, 0] * 9 + [0.0] * 7, device=dev).repeat(m, 1)
+                        trans = self.get_global_motion(lower_mix.view(bs, t, -1), ref_trans)
+        aa, motion, expr = ops.merge_parts(parts["face"], parts["upper"], parts["hands"], parts["lower"], m, dev)
         return dict(expression=expr.view(bs, t, 100), all_motion4inference=motion.view(bs, t, 337),
                     motion_axis_angle=aa.view(bs, t, 165), trans=trans)
 
@@ -587,40 +593,41 @@ class EmageAudioModel(_EmageModule):
         pk.linear(name + ".ff2", [name + ".linear2"])
 
     # ---- building blocks -----------------------------------------------------------------
-    def _self_attn(self, cx, name, x_f, x_lo, b, t):
+    # The residual stream x is stored in the compute dtype (fp32 in parity mode, bf16 in bf16 mode): each
+    # sub-layer's GEMM epilogue adds the residual and writes the pre-norm sum once, LayerNorm reads it once.
+    def _self_attn(self, cx, name, x, b, t):
         d, h = self.config.hidden_size, spec.N_HEAD
         m = b * t
         qk = cx.lo(m, 2 * d)
         vt = cx.vt_buffer(b, d, t)
-        cx.gemm(x_lo, name + ".sa.qkv", out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
+        cx.gemm(x, name + ".sa.qkv", out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
         att = cx.lo(m, d)
         ops.attention(cx.dt, qk[:, :d], qk[:, d:], vt, d, att, b, h, t, t, d // h)
-        _, s = cx.gemm(att, name + ".sa.out", res=x_f, want="f32")
+        s, _ = cx.gemm(att, name + ".sa.out", res=x)
         return s
 
-    def _ln(self, cx, key, s, add=None, want_f32=True):
+    def _ln(self, cx, key, s, add=None):
         n = cx.pk.w[key]
-        y_f = cx.f32(*s.shape) if want_f32 else None
-        y_lo = cx.lo(*s.shape)
-        ops.layernorm(cx.dt, s, n["g"], n["b"], 1e-5, add, y_f, y_lo)
-        return y_f, y_lo
+        y = cx.lo(*s.shape)
+        ops.layernorm(cx.dt, s, n["g"], n["b"], 1e-5, add, None, y)
+        return y
 
-    def _ffn(self, cx, name, x_f, x_lo):
-        f, _ = cx.gemm(x_lo, name + ".ff1", slope=0.0)
-        _, s = cx.gemm(f, name + ".ff2", res=x_f, want="f32")
+    def _ffn(self, cx, name, x):
+        f, _ = cx.gemm(x, name + ".ff1", slope=0.0)
+        s, _ = cx.gemm(f, name + ".ff2", res=x)
         return s
 
-    def _decoder_layer(self, cx, name, x_f, x_lo, b, t, mem_k, mem_vt, vt_rows, tk, post_add=None):
+    def _decoder_layer(self, cx, name, x, b, t, mem_k, mem_vt, vt_rows, tk, post_add=None):
         """nn.TransformerDecoderLayer, post-norm, ReLU, no masks.  mem_k: (B*Tk, ld) view of this
         layer's projected memory keys; mem_vt: view at this layer's first row of a (B, vt_rows, Tp) V^T buffer."""
         d, h = self.config.hidden_size, spec.N_HEAD
-        x_f, x_lo = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x_f, x_lo, b, t))
-        q, _ = cx.gemm(x_lo, name + ".ca.q")
+        x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
+        q, _ = cx.gemm(x, name + ".ca.q")
         att = cx.lo(b * t, d)
         ops.attention(cx.dt, q, mem_k, mem_vt, vt_rows, att, b, h, t, tk, d // h)
-        _, s = cx.gemm(att, name + ".ca.out", res=x_f, want="f32")
-        x_f, x_lo = self._ln(cx, name + ".norm2", s)
-        return self._ln(cx, name + ".norm3", self._ffn(cx, name, x_f, x_lo), add=post_add)
+        s, _ = cx.gemm(att, name + ".ca.out", res=x)
+        x = self._ln(cx, name + ".norm2", s)
+        return self._ln(cx, name + ".norm3", self._ffn(cx, name, x), add=post_add)
 
     def _memory_kv(self, cx, key, mem_lo, b, tk, n_layers):
         """Project a cross-attention memory for `n_layers` layers at once: K (B*Tk, n_layers*d) and
@@ -631,44 +638,46 @@ class EmageAudioModel(_EmageModule):
         cx.gemm(mem_lo, key, out=k, out_t=vt, t_col0=n_layers * d, t_rows=tk)
         return k, vt
 
-    def _wav_encoders(self, cx, audio, face_out, body_out):
-        """Both WavEncoders (P:296-314).  Returns T' (frames emitted); writes (B*T', 256) into the given
-        2-D destinations when their row count matches, else returns fresh tensors."""
-        c = self.config
-        b, l = audio.shape
-        blocks = spec.wav_encoder_blocks(c.audio_f)
-        k = _WAV_TAPS
-        lens = []
-        cur = l
-        for (_ci, _co, stride, pad, _ds) in blocks:
-            cur = (cur + 2 * pad - k) // stride + 1
+    def _wav_lengths(self, l):
+        """Frame counts after each of the 6 BasicBlocks (P:301-306) for an l-sample window."""
+        lens, cur = [], l
+        for (_ci, _co, stride, pad, _ds) in spec.wav_encoder_blocks(self.config.audio_f):
+            cur = (cur + 2 * pad - _WAV_TAPS) // stride + 1
             lens.append(cur)
         if min(lens) <= 0:
             raise RuntimeError(f"audio window of {l} samples is too short for the WavEncoder")
+        return lens
+
+    def _wav_first_layer(self, cx, audio, lens):
+        """Block 0's conv1 and downsample shortcut of BOTH encoders in one launch: (B*L0, 4q) =
+        [face conv1 | face shortcut | body conv1 | body shortcut]."""
+        blocks = spec.wav_encoder_blocks(self.config.audio_f)
         w_in = cx.pk.w["wav_in"]
-        q = blocks[0][1]
-        y0 = cx.lo(b * lens[0], 4 * q)
+        y0 = cx.lo(audio.shape[0] * lens[0], 4 * blocks[0][1])
         ops.wav_conv_in(cx.dt, audio, w_in["w"], w_in["b"], w_in["slope"], y0, lens[0], blocks[0][2], blocks[0][3])
-        outs = []
-        for e, enc in enumerate(("audio_encoder_face", "audio_encoder_body")):
-            dest = (face_out, body_out)[e]
-            x, lin = None, None
-            for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
-                base = f"{enc}.feat_extractor.{i}"
-                lout = lens[i]
-                if i == 0:
-                    y1, sc = y0[:, e * 2 * q: e * 2 * q + q], y0[:, e * 2 * q + q: (e + 1) * 2 * q]
-                else:
-                    ent = cx.pk.w[base + ".conv1"]
-                    y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout)
-                    y1, sc = (y[:, :cout], y[:, cout:]) if ds else (y, x)
-                last = i == len(blocks) - 1
-                out = dest if (last and dest is not None and dest.shape[0] == b * lout) else None
-                x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
-                               m=b * lout, out=out)
-                lin = lout
-            outs.append(x)
-        return lens[-1], outs[0], outs[1]
+        return y0
+
+    def _wav_encoder_chain(self, cx, enc, e, y0, b, lens, dest=None):
+        """Blocks 0..5 of one WavEncoder (P:283-314) after the shared first layer.  Returns (B*T', 256); written
+        straight into `dest` (a 2-D view) when its row count matches."""
+        blocks = spec.wav_encoder_blocks(self.config.audio_f)
+        k, q = _WAV_TAPS, blocks[0][1]
+        x, lin = None, None
+        for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
+            base = f"{enc}.feat_extractor.{i}"
+            lout = lens[i]
+            if i == 0:
+                y1, sc = y0[:, e * 2 * q: e * 2 * q + q], y0[:, e * 2 * q + q: (e + 1) * 2 * q]
+            else:
+                ent = cx.pk.w[base + ".conv1"]
+                y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout)
+                y1, sc = (y[:, :cout], y[:, cout:]) if ds else (y, x)
+            last = i == len(blocks) - 1
+            out = dest if (last and dest is not None and dest.shape[0] == b * lout) else None
+            x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
+                           m=b * lout, out=out)
+            lin = lout
+        return x
 
     # ---- forward -------------------------------------------------------------------------
     def forward(self, audio, speaker_id, masked_motion, mask, use_audio=True):
@@ -687,77 +696,101 @@ class EmageAudioModel(_EmageModule):
         motion2d = masked_motion.to(device=dev, dtype=torch.float32).reshape(m, cm).contiguous()
         mask2d = mask.to(device=dev, dtype=torch.float32).reshape(m, cm).contiguous()
 
-        # masked motion -> spatial hints (M:267-273)
-        x0 = ops.pack_motion(cx.dt, motion2d, mask2d, pk.w["mask_emb"], _rup(cm))
-        hint, _ = _conv_encoder(cx, "motion_encoder", x0, t, spec.MOTION_ENC_LAYERS, mf, False)
-        hh, _ = cx.gemm(hint, "bodyhints.fc1", slope=0.1)                       # [face | body] hidden, (M, 2d)
-        memcat = cx.lo(m, af + mf)                                              # [audio2face | body_hint_face] (M:288)
-        cx.gemm(hh[:, :d], "bodyhints_face.fc2", out=memcat[:, af:])
-        hint_body, _ = cx.gemm(hh[:, d:], "bodyhints_body.fc2")
-
-        # audio encoders (M:275-281)
-        ta, a_face, a_body = self._wav_encoders(cx, audio, memcat[:, :af], None)
+        lens = self._wav_lengths(audio.shape[1])
+        ta = lens[-1]
         if ta < t:
             raise RuntimeError(f"Sizes of tensors must match: audio features {ta} frames vs motion {t} frames")
-        if ta > t:      # tail windows: face features trimmed to T, body features keep T' = T+1 (M:278-281, sic)
-            memcat[:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)
-
-        # speaker / positional tables (M:285-286, P:341-343)
-        sid = speaker_id.to(dev).reshape(b, 1).expand(b, t).reshape(-1).contiguous()
-        spk_body = ops.gather_rows(pk.w["spk_body"], sid, F32)                  # (M,d) fp32
-        spk_face = ops.gather_rows(pk.w["spk_face"], sid, F32)
-        pe = pk.w["pe"][:t]
-        face_f, face_lo = cx.f32(m, d), cx.lo(m, d)
-        ops.add(cx.dt, spk_face, pe, out_f32=face_f, out=face_lo, mod_b=t)       # position_embeddings(speaker_face)
-        pos_spk = cx.f32(m, d)
-        ops.add(cx.dt, spk_body, pe, out_f32=pos_spk, mod_b=t)                   # speaker_body + pe, reused twice
-
-        # face branch (M:288-294)
-        mem_face, _ = cx.gemm(memcat, "audio_face_motion_proj")
-        nf = spec.N_FACE_LAYERS
-        fk, fvt = self._memory_kv(cx, "face.kv_all", mem_face, b, t, nf)
-        for i in range(nf):
-            face_f, face_lo = self._decoder_layer(cx, f"face_motion_decoder.layers.{i}", face_f, face_lo, b, t,
-                                                  fk[:, i * d:(i + 1) * d], fvt[:, i * d:], nf * d, t)
+        memcat = cx.lo(m, af + mf)                                              # [audio2face | body_hint_face] (M:288)
         out = {}
-        rec_lo, out["rec_face"] = cx.gemm(face_lo, "face_out_proj", want="both")
-        hc, _ = cx.gemm(rec_lo, "face_cls.fc1", slope=0.1)
-        _, out["cls_face"] = cx.gemm(hc, "face_cls.fc2", want="f32")
-
-        # body branch: temporal self-attention (M:297-300)
-        x_lo, x_f = cx.gemm(hint_body, "moton_proj", res=pos_spk, want="both")
-        name = "motion_self_encoder.layers.0"
-        x_f, x_lo = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x_f, x_lo, b, t))
-        x_f, x_lo = self._ln(cx, name + ".norm2", self._ffn(cx, name, x_f, x_lo), add=pos_spk)   # + speaker + pe (M:304-305)
-        # audio cross-attention stack (M:303-312)
-        if use_audio:
-            mem_body, _ = cx.gemm(a_body, "audio_body_motion_proj")
-            nc = spec.N_CROSS_LAYERS
-            bk, bvt = self._memory_kv(cx, "cross.kv_all", mem_body, b, ta, nc)
-            base_f = x_f
-            for i in range(nc):
-                x_f, x_lo = self._decoder_layer(cx, f"audio_motion_cross_attn.layers.{i}", x_f, x_lo, b, t,
-                                                bk[:, i * d:(i + 1) * d], bvt[:, i * d:], nc * d, ta,
-                                                post_add=base_f if i == nc - 1 else None)   # motion_fea + cross
-        # part latents + refinement (M:315-330)
         parts = ("upper", "hands", "lower")
-        hl, _ = cx.gemm(x_lo, "motion2latent.fc1", slope=0.1)                    # (M, 3d)
-        lat = {}
-        for i, p in enumerate(parts):
-            _, lat[p] = cx.gemm(hl[:, i * d:(i + 1) * d], f"motion2latent_{p}.fc2", want="f32")
         others = {"upper": ("hands", "lower"), "hands": ("upper", "lower"), "lower": ("upper", "hands")}
-        for p in parts:
-            tgt_f, tgt_lo, mem_lo = cx.f32(m, d), cx.lo(m, d), cx.lo(m, d)
-            ops.add(cx.dt, lat[p], spk_body, out_f32=tgt_f, out=tgt_lo)
-            ops.add(cx.dt, lat[others[p][0]], lat[others[p][1]], out=mem_lo)
-            name = f"body_motion_decoder_{p}.layers.0"
-            k1, vt1 = self._memory_kv(cx, name + ".ca.kv", mem_lo, b, t, 1)
-            ref_f, _ = self._decoder_layer(cx, name, tgt_f, tgt_lo, b, t, k1, vt1, d, t)
-            sum_lo = cx.lo(m, d)
-            ops.add(cx.dt, lat[p], ref_f, out=sum_lo)
-            rec_lo, out[f"rec_{p}"] = cx.gemm(sum_lo, f"motion_out_proj_{p}", want="both")
-            hc, _ = cx.gemm(rec_lo, f"motion_cls_{p}.fc1", slope=0.1)
-            _, out[f"cls_{p}"] = cx.gemm(hc, f"motion_cls_{p}.fc2", want="f32")
+        nf, nc = spec.N_FACE_LAYERS, spec.N_CROSS_LAYERS
+
+        # Independent chains run on separate streams (pantomatrix_amd/streams.py).  lane 0: motion hints -> body
+        # stack; lane 1: face WavEncoder -> face decoder; lane 2: body WavEncoder -> cross-attention memory.
+        with Fork(dev, 3, self.concurrent) as fk:
+            with fk.lane(1):
+                y0 = self._wav_first_layer(cx, audio, lens)
+            fk.after(2, 1)
+            with fk.lane(1):
+                a_face = self._wav_encoder_chain(cx, "audio_encoder_face", 0, y0, b, lens, dest=memcat[:, :af])
+                if ta > t:  # tail windows: face features trimmed to T, body features keep T' = T+1 (M:278-281, sic)
+                    memcat[:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)
+            with fk.lane(2):
+                a_body = self._wav_encoder_chain(cx, "audio_encoder_body", 1, y0, b, lens)
+                if use_audio:
+                    mem_body, _ = cx.gemm(a_body, "audio_body_motion_proj")                 # M:303
+                    bk, bvt = self._memory_kv(cx, "cross.kv_all", mem_body, b, ta, nc)
+
+            with fk.lane(0):
+                # masked motion -> spatial hints (M:267-273)
+                x0 = ops.pack_motion(cx.dt, motion2d, mask2d, pk.w["mask_emb"], _rup(cm))
+                hint, _ = _conv_encoder(cx, "motion_encoder", x0, t, spec.MOTION_ENC_LAYERS, mf, False)
+                hh, _ = cx.gemm(hint, "bodyhints.fc1", slope=0.1)               # [face | body] hidden, (M, 2d)
+                cx.gemm(hh[:, :d], "bodyhints_face.fc2", out=memcat[:, af:])
+                hint_body, _ = cx.gemm(hh[:, d:], "bodyhints_body.fc2")
+                # speaker / positional tables (M:285-286, P:341-343)
+                sid = speaker_id.to(dev).reshape(b, 1).expand(b, t).reshape(-1).contiguous()
+                spk_body = ops.gather_rows(pk.w["spk_body"], sid, F32)          # (M,d) fp32
+                spk_face = ops.gather_rows(pk.w["spk_face"], sid, F32)
+                pe = pk.w["pe"][:t]
+                face0 = cx.lo(m, d)                              # kept alive to the join: lane 1 reads it
+                ops.add(cx.dt, spk_face, pe, out=face0, mod_b=t)                     # position_embeddings(speaker_face)
+                pos_spk = cx.lo(m, d)
+                ops.add(cx.dt, spk_body, pe, out=pos_spk, mod_b=t)                   # speaker_body + pe, reused twice
+
+            # face branch (M:288-294) on lane 1, once the hints (lane 0) are there
+            fk.after(1, 0)
+            with fk.lane(1):
+                mem_face, _ = cx.gemm(memcat, "audio_face_motion_proj")
+                fkk, fvt = self._memory_kv(cx, "face.kv_all", mem_face, b, t, nf)
+                face = face0
+                for i in range(nf):
+                    face = self._decoder_layer(cx, f"face_motion_decoder.layers.{i}", face, b, t,
+                                               fkk[:, i * d:(i + 1) * d], fvt[:, i * d:], nf * d, t)
+                rec_lo, out["rec_face"] = cx.gemm(face, "face_out_proj", want="both")
+                hc, _ = cx.gemm(rec_lo, "face_cls.fc1", slope=0.1)
+                _, out["cls_face"] = cx.gemm(hc, "face_cls.fc2", want="f32")
+
+            with fk.lane(0):
+                # body branch: temporal self-attention (M:297-300)
+                x, _ = cx.gemm(hint_body, "moton_proj", res=pos_spk)
+                name = "motion_self_encoder.layers.0"
+                x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
+                x = self._ln(cx, name + ".norm2", self._ffn(cx, name, x), add=pos_spk)   # + speaker + pe (M:304-305)
+            # audio cross-attention stack (M:303-312) needs lane 2's projected memory
+            if use_audio:
+                fk.after(0, 2)
+                with fk.lane(0):
+                    base = x
+                    for i in range(nc):
+                        x = self._decoder_layer(cx, f"audio_motion_cross_attn.layers.{i}", x, b, t,
+                                                bk[:, i * d:(i + 1) * d], bvt[:, i * d:], nc * d, ta,
+                                                post_add=base if i == nc - 1 else None)             # motion_fea + cross
+            with fk.lane(0):
+                # part latents (M:315-317)
+                hl, _ = cx.gemm(x, "motion2latent.fc1", slope=0.1)               # (M, 3d)
+                lat = {}
+                for i, p in enumerate(parts):
+                    lat[p], _ = cx.gemm(hl[:, i * d:(i + 1) * d], f"motion2latent_{p}.fc2")
+            # refinement + heads (M:320-330): three independent chains; "upper" stays on lane 0, "lower" takes
+            # lane 2 (idle by now), "hands" queues behind the face decoder on lane 1
+            lane_of = {"upper": 0, "hands": 1, "lower": 2}
+            fk.after(1, 0)
+            fk.after(2, 0)
+            for p in parts:
+                with fk.lane(lane_of[p]):
+                    tgt, mem_lo = cx.lo(m, d), cx.lo(m, d)
+                    ops.add(cx.dt, lat[p], spk_body, out=tgt)
+                    ops.add(cx.dt, lat[others[p][0]], lat[others[p][1]], out=mem_lo)
+                    name = f"body_motion_decoder_{p}.layers.0"
+                    k1, vt1 = self._memory_kv(cx, name + ".ca.kv", mem_lo, b, t, 1)
+                    ref = self._decoder_layer(cx, name, tgt, b, t, k1, vt1, d, t)
+                    sum_lo = cx.lo(m, d)
+                    ops.add(cx.dt, lat[p], ref, out=sum_lo)
+                    rec_lo, out[f"rec_{p}"] = cx.gemm(sum_lo, f"motion_out_proj_{p}", want="both")
+                    hc, _ = cx.gemm(rec_lo, f"motion_cls_{p}.fc1", slope=0.1)
+                    _, out[f"cls_{p}"] = cx.gemm(hc, f"motion_cls_{p}.fc2", want="f32")
         return {k: out[k].view(b, t, -1) for k in OUT_KEYS}
 
     __call__ = forward

@@ -97,8 +97,10 @@ def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
 
 
 def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
+    """x / add / y are in `dtype` (the residual stream's storage type)."""
     _dev(x)
     m, c = x.shape
+    assert x.dtype == TORCH_DTYPE[dtype] and (add is None or add.dtype == x.dtype)
     ldy = _ld(y_f32) if y_f32 is not None else _ld(y)
     if y_f32 is not None and y is not None:
         assert _ld(y) == _ld(y_f32)
@@ -107,13 +109,19 @@ def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
 
 
 def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
+    """out = a + b[m % mod_b] (+ c); each operand may be fp32 or `dtype` (detected from the tensor)."""
     _dev(a)
     m, n = a.shape
+    mask = 0
+    for bit, t in enumerate((a, b, c)):
+        if t is not None:
+            assert t.dtype in (torch.float32, TORCH_DTYPE[dtype])
+            mask |= (1 << bit) if t.dtype == torch.float32 else 0
     ldo = _ld(out_f32) if out_f32 is not None else _ld(out)
     if out_f32 is not None and out is not None:
         assert _ld(out) == _ld(out_f32)
     check(_lib.load().emage_add(dtype, _ptr(a), _ld(a), _ptr(b), _ld(b), mod_b, _ptr(c), _ld(c) if c is not None else 0, mod_c,
-                                _ptr(out_f32), _ptr(out), ldo, m, n, _stream()), "add")
+                                mask, _ptr(out_f32), _ptr(out), ldo, m, n, _stream()), "add")
 
 
 def pack_motion(dtype, motion2d, mask2d, emb, n_store):

@@ -97,9 +97,10 @@ def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
 
 def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
     CALLS.append("layernorm")
+    assert x.dtype == TD[dtype] and (add is None or add.dtype == TD[dtype])
     v = torch.nn.functional.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps)
     if add is not None:
-        v = v + add
+        v = v + add.float()
     if y_f32 is not None:
         y_f32[:] = v
     if y is not None:
@@ -110,9 +111,9 @@ def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
     CALLS.append("add")
     m = a.shape[0]
     r = torch.arange(m)
-    v = a + b[r % mod_b if mod_b else r]
+    v = a.float() + b.float()[r % mod_b if mod_b else r]
     if c is not None:
-        v = v + c[r % mod_c if mod_c else r]
+        v = v + c.float()[r % mod_c if mod_c else r]
     if out_f32 is not None:
         out_f32[:] = v
     if out is not None:

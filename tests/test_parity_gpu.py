@@ -126,3 +126,22 @@ def test_vq_round_trip_properties(fp32_models):
         assert m.decode(idx).shape == (64, 120, m.config.vae_test_dim)
         assert torch.equal(m.map2latent(m.decode(idx[:2])) , cb[m.map2index(m.decode(idx[:2]))])
         assert m.decode_from_latent(lat).shape == (4, 64, m.config.vae_test_dim)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_clip_runner_graph_equals_eager(precision):
+    """The hipGraph-captured batch (pantomatrix_amd.runtime.ClipRunner) reproduces the eager launch sequence
+    bit for bit, replay after replay, and for new audio."""
+    from pantomatrix_amd.runtime import ClipRunner
+    model, vq = common.product_models(precision=precision, device=DEV)
+    n = synthetic.samples_for_frames(128)
+    a1 = synthetic.synthetic_audio(4, n).to(DEV)
+    a2 = synthetic.synthetic_audio(4, n, seed=77).to(DEV)
+    eager = ClipRunner(model, vq, 4, n, use_graph=False)
+    graphed = ClipRunner(model, vq, 4, n, use_graph=True)
+    for a in (a1, a2, a1):
+        e = [x.copy() for x in eager(a)]
+        g = [x.copy() for x in graphed(a)]
+        for x, y in zip(e, g):
+            assert x.shape == y.shape and np.array_equal(x, y)
+    assert e[0].shape == (4, 120, 165)

@@ -33,18 +33,23 @@ SHAPES = [
     ("wav b5.conv1+ds 128->512 s3", (64, 205, 64), 128, 512, 15, 3, 0, dict()),
     ("wav b5.conv2 256->256", (64, 64, 64), 256, 256, 15, 1, 7, dict()),
 ]
-CONFIGS = [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 16, 17, 19]
+CONFIGS = [10, 11, 13, 15, 18, 19, 20, 21, 22, 23, 24, 25, 26]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--ablate", action="store_true", help="time each config with DMA / MFMA / epilogue removed (diagnostic)")
+    ap.add_argument("--configs", default="")
     args = ap.parse_args()
     dt = BF16 if args.dtype == "bf16" else F32
     td = ops.TORCH_DTYPE[dt]
     lib = _lib.load()
     dev = "cuda"
+    global CONFIGS
+    if args.configs:
+        CONFIGS = [int(c) for c in args.configs.split(",")]
     g = torch.Generator().manual_seed(0)
     print(f"{'shape':32s} GF  | " + " ".join(f"c{c:<6d}" for c in CONFIGS) + " | best")
     for name, (nb, lin, lout), cin, n, taps, stride, pad, ex in SHAPES:
@@ -71,14 +76,31 @@ def main():
                                     t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m)
             call()
             torch.cuda.synchronize()
+            # replay a captured graph of `iters` launches so the host launch cost (~8 us/op from Python) is excluded
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(args.iters):
+                    call()
+            gr.replay()
+            torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(args.iters):
-                call()
+            gr.replay()
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / args.iters * 1e3, out, out_f, out_t
 
+        if args.ablate:
+            row = []
+            for cfg in CONFIGS:
+                cell = []
+                for dbg in (0, 1, 2, 4, 7):
+                    lib.emage_set_tuning(1, dbg)
+                    cell.append(run(cfg)[0])
+                lib.emage_set_tuning(1, 0)
+                row.append(f"c{cfg}: full {cell[0]:.1f} noDMA {cell[1]:.1f} noMFMA {cell[2]:.1f} noEpi {cell[3]:.1f} none {cell[4]:.1f}")
+            print(f"{name:30s} " + " | ".join(row))
+            continue
         ref = None
         cells, best = [], (1e9, None)
         for cfg in CONFIGS:
