@@ -28,6 +28,17 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 
 
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -71,7 +82,8 @@ def profile_kernels(model, vq, audio, spk, zeros_trans):
         n, cp, taps = k["n"], k["cp"], k.get("taps", 1)
         m = k.get("m") or A.shape[0]
         es = 2 if dtype == BF16 else 4
-        flops = 2.0 * m * n * taps * cp
+        kk = k.get("k_real") or taps * cp                    # unpadded contraction length
+        flops = 2.0 * m * n * kk
         byts = (m * cp * es) + n * taps * cp * es + m * n * es
         return ("gemm_bf16" if dtype == BF16 else "gemm_f32", flops, byts)
 
@@ -118,8 +130,9 @@ def cpu_baseline(frames, seconds_budget=20.0):
     import common
     from oracle import emage_oracle as orc
     from pantomatrix_amd import synthetic
-    # torch's default intra-op thread count (it honours the container's CPU affinity / quota); forcing
-    # os.cpu_count() threads oversubscribes a cgroup-limited box and measures the scheduler, not the code
+    # use the cores this container may actually run on (affinity AND cgroup CPU quota): forcing os.cpu_count()
+    # threads on a quota-limited box measures the scheduler, not the code
+    torch.set_num_threads(usable_cores())
     omodel, ovq = common.oracle_models()
     t0 = time.time()
     orc.infer_clip(omodel, ovq, synthetic.synthetic_audio(1, synthetic.samples_for_frames(frames)))   # warm-up
@@ -150,6 +163,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sub-batches", type=int, default=1, help="independent clip groups issued on parallel stream lanes")
+    ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
+    ap.add_argument("--no-concurrent", action="store_true", help="A/B: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -160,16 +176,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" == RCCL on ROCm; used for barriers/timing only
+    from pantomatrix_amd import dist as pdist
+    dist = pdist.init("nccl", dev) if world > 1 else None          # "nccl" == RCCL on ROCm; barriers / timing only
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from pantomatrix_amd import synthetic
     model, vq = build_models(args.precision, dev)
+    model.hoist_audio = not args.no_hoist
+    model.concurrent = not args.no_concurrent
+    for part in (vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
+        part.concurrent = not args.no_concurrent
     n_samples = synthetic.samples_for_frames(args.frames)
     # clip i of the global batch lives on rank i % world; every rank gets `batch` clips
     audio = synthetic.synthetic_audio(args.batch, n_samples, seed=1234 + rank).to(dev)
@@ -177,13 +194,12 @@ def main():
     zeros_trans = torch.zeros(1, 3, device=dev)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        pdist.barrier()
         torch.cuda.synchronize()
 
     from pantomatrix_amd.runtime import ClipRunner
     log(f"models built on {dev}; capturing the clip graph")
-    runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph)
+    runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph, sub_batches=args.sub_batches)
     log(f"warm-up x{args.warmup}")
     for _ in range(args.warmup):
         poses, _, _ = one_step(runner, audio)
@@ -196,10 +212,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     frames_per_step = poses.shape[0] * poses.shape[1]
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pdist.max_over_ranks(elapsed, dev)
     assert np.isfinite(poses).all()
     log(f"timed: {1e3 * elapsed / args.steps:.2f} ms/step")
 
@@ -216,7 +229,7 @@ def main():
                                f"{frames_per_step // args.batch} frames out per clip; synthetic seeded weights",
                    "clips_per_gpu": args.batch, "frames_in": args.frames, "frames_out_per_clip": frames_per_step // args.batch,
                    "parallelism": f"replicas x{world} (clip-sharded, no collective)",
-                   "launch": "eager" if args.no_graph else "hipGraph replay"},
+                   "launch": "eager" if args.no_graph else "hipGraph replay", "sub_batches": args.sub_batches},
     }
     if rank == 0 and not args.no_roofline:
         fam = profile_kernels(model, vq, audio, spk, zeros_trans)
@@ -230,7 +243,12 @@ def main():
         else:
             ach = byts / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-        roof.update({"traffic": None, "kernel": name, "launches_per_step": cnt, "avg_launch_us": 1e3 * ms / cnt,
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f).get(name)
+        roof.update({"traffic": traffic, "kernel": name, "launches_per_step": cnt, "avg_launch_us": 1e3 * ms / cnt,
                      "algorithmic_gflop_per_launch": flops / cnt / 1e9,
                      "share_of_kernel_time": ms / total_ms if total_ms else None,
                      "kernel_time_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
@@ -240,9 +258,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args.frames)
     if rank == 0:
         print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    pdist.finalize()
 
 
 if __name__ == "__main__":

@@ -44,19 +44,59 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) qf[s] = *(const uint4*)(qp + s * 4 * EPC);
 
-    // scores S^T[key][q]
+    // scores S^T[key][q].  The whole problem is latency-bound (72 KB per (b,h), one wave per 16 queries), so for
+    // Tk <= 64 every K chunk is requested before the first MFMA instead of tile by tile.
     f32x4 sc[NT];
+    if constexpr (NT <= 4) {
+        uint4 kf[NT][NSTEP];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int krow = min(nt * 16 + fr, p.Tk - 1);
-        const T* kp = K + ((long)b * p.Tk + krow) * p.ldk + h * HD + fg * EPC;
-        uint4 kf[NSTEP];
+        for (int nt = 0; nt < NT; ++nt) {
+            const int krow = min(nt * 16 + fr, p.Tk - 1);
+            const T* kp = K + ((long)b * p.Tk + krow) * p.ldk + h * HD + fg * EPC;
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) kf[s] = *(const uint4*)(kp + s * 4 * EPC);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < NSTEP; ++s) kf[nt][s] = *(const uint4*)(kp + s * 4 * EPC);
+        }
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) acc = Elem<T>::mma(kf[s], qf[s], acc);
-        sc[nt] = acc;
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) acc = Elem<T>::mma(kf[nt][s], qf[s], acc);
+            sc[nt] = acc;
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int krow = min(nt * 16 + fr, p.Tk - 1);
+            const T* kp = K + ((long)b * p.Tk + krow) * p.ldk + h * HD + fg * EPC;
+            uint4 kf[NSTEP];
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) kf[s] = *(const uint4*)(kp + s * 4 * EPC);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) acc = Elem<T>::mma(kf[s], qf[s], acc);
+            sc[nt] = acc;
+        }
+    }
+
+    // V^T chunks are requested now (independent of the softmax below), consumed by the P V product afterwards
+    constexpr int NPC = (EPC == 8) ? (NT + 1) / 2 : NT;
+    constexpr bool PREV = NT <= 4;
+    uint4 vpre[PREV ? NDT : 1][PREV ? NPC : 1];
+    if constexpr (PREV) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const T* vp = VT + ((long)b * p.vt_rows + h * HD + dt * 16 + fr) * p.ldvt + fg * 4;
+#pragma unroll
+            for (int c = 0; c < NPC; ++c) {
+                if constexpr (EPC == 8) {
+                    const uint2 lo = *(const uint2*)(vp + c * 32);
+                    const uint2 hi = *(const uint2*)(vp + c * 32 + 16);
+                    vpre[dt][c] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                } else {
+                    vpre[dt][c] = *(const uint4*)(vp + c * 16);
+                }
+            }
+        }
     }
 
     // softmax over keys for query column fr
@@ -89,7 +129,6 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) sc[nt][r] = sc[nt][r] / sum;
 
     // P chunks (A operand: row i = query fr, contraction = keys)
-    constexpr int NPC = (EPC == 8) ? (NT + 1) / 2 : NT;
     uint4 pc[NPC];
     if constexpr (EPC == 8) {
 #pragma unroll
@@ -116,7 +155,9 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int c = 0; c < NPC; ++c) {
             uint4 vf;
-            if constexpr (EPC == 8) {
+            if constexpr (PREV) {
+                vf = vpre[dt][c];
+            } else if constexpr (EPC == 8) {
                 const uint2 lo = *(const uint2*)(vp + c * 32);        // keys 32c + 4g .. +3
                 const uint2 hi = *(const uint2*)(vp + c * 32 + 16);   // keys 32c + 16 + 4g .. +3
                 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);

@@ -285,8 +285,20 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_read128_off(unsigned add
 // vector loads/stores, no LDS staging.  Only V^T tiles (column-contiguous along the sequence) stage through LDS.
 constexpr unsigned OOB = 0x80000000u;    // > any num_records we create (buffers are < 2 GiB)
 
+// blocks per CU the LDS footprint admits (capped at 3): used as the launch-bounds occupancy target so the register
+// allocator does not cost a resident block
+template <int BM, int BN, int NS, int KC>
+constexpr int lds_blocks() {
+    const int ring = NS * (BM + BN) * KC * 16;
+    const int stage_full = BM * (BN + 4) * 4;
+    const int stage = stage_full <= ring ? stage_full : stage_full / 2;
+    const int bytes = ring > stage ? ring : stage;
+    const int n = 160 * 1024 / bytes;
+    return n >= 3 ? 3 : (n >= 2 ? 2 : 1);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NS, int KC>
-__global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(GemmArgs p) {
+__global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm_pipe_kernel(GemmArgs p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = 16 / EPC;                     // element size in bytes
     constexpr int BK = KC * EPC;
@@ -384,6 +396,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(GemmArgs p) {
         if (++is_slot == NS) is_slot = 0;
     };
 
+    // Epilogue operands (residual rows, bias, slope) are fetched NOW, ahead of the operand DMA: they are the
+    // oldest entries of this wave's memory queue, so the first counted vmcnt wait of the K-loop retires them and
+    // the epilogue does not start with an exposed HBM round trip.  (Vector path only; the scalar fallback for
+    // odd widths loads in the epilogue.)
+    const int fr = lane & 15, fg = lane >> 4;
+    const int ncol_n = p.out_t ? p.t_col0 : p.N;     // columns below this go to out / out_f32
+    T* __restrict__ out = (T*)p.out;
+    auto vec_ok = [&]() {
+        return (p.N % 4 == 0) && (ncol_n % 4 == 0) && (p.n_store % 4 == 0) &&
+               (!out || (p.ldo % 4 == 0 && ((uintptr_t)out & 15) == 0)) &&
+               (!p.out_f32 || (p.ldf % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
+               (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+               (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.slope || ((uintptr_t)p.slope & 15) == 0);
+    };
+    constexpr bool PRE = FM * FN <= 4;               // small tiles only: the prefetch costs 4 VGPRs per fragment
+    constexpr int PM = PRE ? FM : 1, PN = PRE ? FN : 1;
+    float pre_b[PN][4], pre_s[PN][4], pre_r[PM][PN][4];
+    bool vec = false;
+    if constexpr (PRE) vec = vec_ok();
+#pragma unroll
+    for (int j = 0; j < (PRE ? PN : 0); ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fg * 4;
+        const bool on = PRE && vec && n + 3 < ncol_n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pre_b[j][e] = 0.f; pre_s[j][e] = 1.f; }
+        if (on && p.bias) Pack4<float>::load(p.bias + n, pre_b[j]);
+        if (on && p.slope) Pack4<float>::load(p.slope + n, pre_s[j]);
+#pragma unroll
+        for (int i = 0; i < PM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pre_r[i][j][e] = 0.f;
+            if (on && p.res && m < p.M) {
+                if (p.res_is_f32) Pack4<float>::load((const float*)p.res + (long)m * p.ldr + n, pre_r[i][j]);
+                else Pack4<T>::load((const T*)p.res + (long)m * p.ldr + n, pre_r[i][j]);
+            }
+        }
+    }
+
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -397,7 +448,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(GemmArgs p) {
 
     // fragment read addresses inside a ring slot (bytes): row * RB + swizzled 16-B slot; fragment i adds the
     // immediate i*16*RB (the swizzle is invariant under +16 rows); k-group 1 flips slot bit 2
-    const int fr = lane & 15, fg = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int arow = wm * WTM + fr, brow = wn * WTN + fr;
     const unsigned a_rd0 = lds0 + arow * RB + ((fg ^ swz<KC>(arow)) << 4);
@@ -457,27 +507,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_pipe_kernel(GemmArgs p) {
         if (acc[0][0][0] == 123.456f) ((float*)p.out_f32)[0] = 0.f;
         return;
     }
-    const int ncol_n = p.out_t ? p.t_col0 : p.N;     // columns below this go to out / out_f32
-    T* __restrict__ out = (T*)p.out;
     if (n0 < ncol_n || (out && n0 < p.n_store)) {
-        const bool vec = (p.N % 4 == 0) && (ncol_n % 4 == 0) && (p.n_store % 4 == 0) &&
-                         (!out || (p.ldo % 4 == 0 && ((uintptr_t)out & 15) == 0)) &&
-                         (!p.out_f32 || (p.ldf % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
-                         (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
-                         (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.slope || ((uintptr_t)p.slope & 15) == 0);
+        if constexpr (!PRE) vec = vec_ok();
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = n0 + wn * WTN + j * 16 + fg * 4;
             if (vec && n + 3 < ncol_n) {
                 float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
-                if (p.bias) Pack4<float>::load(p.bias + n, bv);
-                if (p.slope) Pack4<float>::load(p.slope + n, sv);
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = pre_b[j % PN][e]; sv[e] = pre_s[j % PN][e]; }
+                } else {
+                    if (p.bias) Pack4<float>::load(p.bias + n, bv);
+                    if (p.slope) Pack4<float>::load(p.slope + n, sv);
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int m = m0 + wm * WTM + i * 16 + fr;
                     if (m >= p.M) continue;
                     float rv[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
-                    if (p.res) {
+                    if constexpr (PRE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rv[e] = pre_r[i % PM][j % PN][e];
+                    } else if (p.res) {
                         if (p.res_is_f32) Pack4<float>::load((const float*)p.res + (long)m * p.ldr + n, rv);
                         else Pack4<T>::load((const T*)p.res + (long)m * p.ldr + n, rv);
                     }
@@ -593,7 +645,7 @@ int dispatch(GemmArgs& a, hipStream_t s) {
     const long t128 = (long)((a.M + 127) / 128) * ((ncols + 127) / 128);
     // measured on MI355X (tools/bench_gemm.py): with M = 4096 the operand stream, not MFMA, bounds these
     // launches, and many small resident blocks (64x64, 5 per CU) beat large tiles except on very wide outputs
-    if (t128 >= 1024) return run_config<T>(20, a, s);
+    if (ncols > 64 && t128 >= 1024) return run_config<T>(20, a, s);     // very wide outputs (batched K/V projections)
     return run_config<T>(25, a, s);
 }
 

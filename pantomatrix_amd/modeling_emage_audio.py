@@ -54,6 +54,7 @@ class _EmageModule:
         self._dt = BF16
         self._packed = None
         self.concurrent = True                 # issue independent launch chains on side streams (streams.py)
+        self.hoist_audio = True                # inference(): waveform-only features of all full windows in one pass
         self._spec = type(self)._spec_fn(config)
         self._params = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
                                                       prefix=type(self).__name__ + "/")
@@ -199,8 +200,9 @@ class _Packed:
                 w, b = w[rows[i]], b[rows[i]]
             ws.append(w)
             bs.append(b)
+        k_real = ws[0].shape[1]
         w, kp = self._pack_mat(torch.cat(ws, 0).float())
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1)
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real)
 
     def in_proj(self, key, names, parts):
         """Row blocks of packed in_proj weights: parts e.g. "qkv", "q", "kv"; several layers stack as
@@ -212,8 +214,9 @@ class _Packed:
             for nm in names:
                 ws.append(self.p[nm + ".in_proj_weight"][sl[part]])
                 bs.append(self.p[nm + ".in_proj_bias"][sl[part]])
+        k_real = ws[0].shape[1]
         w, kp = self._pack_mat(torch.cat(ws, 0).float())
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1)
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real)
 
     def folded(self, cname, bn=None):
         """Raw Conv1d (weight (Cout,Cin,k), bias) with an eval-mode BatchNorm1d folded in:
@@ -237,7 +240,8 @@ class _Packed:
         w = w.permute(0, 2, 1)                                   # (Cout, k, Cin)
         if cp != cin:
             w = torch.nn.functional.pad(w, (0, cp - cin))
-        self.w[key] = dict(w=w.reshape(cout, k * cp).to(self.tdt).contiguous(), b=b.contiguous(), n=cout, cp=cp, taps=k)
+        self.w[key] = dict(w=w.reshape(cout, k * cp).to(self.tdt).contiguous(), b=b.contiguous(), n=cout, cp=cp, taps=k,
+                           k_real=k * cin)
 
     def norm(self, key, name):
         self.w[key] = dict(g=self.f32(name + ".weight"), b=self.f32(name + ".bias"))
@@ -276,7 +280,7 @@ class _Ctx:
             stride, pad, lin, lout = conv
             kw = dict(taps=e["taps"], stride=stride, pad=pad, lin=lin, lout=lout)
         ops.gemm(dt, a, e["w"], e["b"], sl, res, out, out_f32, out_t, n=n, cp=e["cp"], n_store=n_store,
-                 t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, **kw)
+                 t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, k_real=e.get("k_real"), **kw)
         return out, out_f32
 
     def conv3(self, a, key, t, **kw):
@@ -680,9 +684,38 @@ class EmageAudioModel(_EmageModule):
         return x
 
     # ---- forward -------------------------------------------------------------------------
-    def forward(self, audio, speaker_id, masked_motion, mask, use_audio=True):
+    def _audio_features(self, cx, audio, b, t, use_audio, fk, lane_face, lane_body):
+        """Everything that depends on the waveform only (M:275-281, 303 and the cross-attention K/V projections):
+        both WavEncoders, `audio_body_motion_proj` and the 8 layers' memory K / V^T.  Returns a dict
+        {memcat (B*T, audio_f+motion_f) with the face features in its first audio_f columns, bk, bvt, ta}.
+        Runs on two stream lanes of `fk`; `inference()` calls it once for ALL full windows of a batch."""
+        c = self.config
+        af, mf, nc = c.audio_f, c.motion_f, spec.N_CROSS_LAYERS
+        lens = self._wav_lengths(audio.shape[1])
+        ta = lens[-1]
+        if ta < t:
+            raise RuntimeError(f"Sizes of tensors must match: audio features {ta} frames vs motion {t} frames")
+        m = b * t
+        feats = dict(memcat=cx.lo(m, af + mf), bk=None, bvt=None, ta=ta)            # [audio2face | body_hint_face] (M:288)
+        with fk.lane(lane_face):
+            y0 = self._wav_first_layer(cx, audio, lens)
+        fk.after(lane_body, lane_face)
+        with fk.lane(lane_face):
+            a_face = self._wav_encoder_chain(cx, "audio_encoder_face", 0, y0, b, lens, dest=feats["memcat"][:, :af])
+            if ta > t:  # tail windows: face features trimmed to T, body features keep T' = T+1 (M:278-281, sic)
+                feats["memcat"][:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)
+        with fk.lane(lane_body):
+            a_body = self._wav_encoder_chain(cx, "audio_encoder_body", 1, y0, b, lens)
+            if use_audio:
+                mem_body, _ = cx.gemm(a_body, "audio_body_motion_proj")                 # M:303
+                feats["bk"], feats["bvt"] = self._memory_kv(cx, "cross.kv_all", mem_body, b, ta, nc)
+        feats["_keep"] = (y0, a_face, a_body)       # cross-lane operands stay alive until the caller's join
+        return feats
+
+    def forward(self, audio, speaker_id, masked_motion, mask, use_audio=True, _audio_feats=None):
         """EmageAudioModel.forward (M:265-341), eval mode.  audio (B,L) fp32, speaker_id (B,1) int64,
-        masked_motion / mask (B,T,337) fp32 -> dict of 8 (B,T,256) fp32 tensors."""
+        masked_motion / mask (B,T,337) fp32 -> dict of 8 (B,T,256) fp32 tensors.
+        `_audio_feats` (internal): waveform-only features already computed by `inference()` for this window."""
         c = self.config
         cx = _Ctx(self._engine())
         pk = cx.pk
@@ -696,11 +729,6 @@ class EmageAudioModel(_EmageModule):
         motion2d = masked_motion.to(device=dev, dtype=torch.float32).reshape(m, cm).contiguous()
         mask2d = mask.to(device=dev, dtype=torch.float32).reshape(m, cm).contiguous()
 
-        lens = self._wav_lengths(audio.shape[1])
-        ta = lens[-1]
-        if ta < t:
-            raise RuntimeError(f"Sizes of tensors must match: audio features {ta} frames vs motion {t} frames")
-        memcat = cx.lo(m, af + mf)                                              # [audio2face | body_hint_face] (M:288)
         out = {}
         parts = ("upper", "hands", "lower")
         others = {"upper": ("hands", "lower"), "hands": ("upper", "lower"), "lower": ("upper", "hands")}
@@ -709,18 +737,8 @@ class EmageAudioModel(_EmageModule):
         # Independent chains run on separate streams (pantomatrix_amd/streams.py).  lane 0: motion hints -> body
         # stack; lane 1: face WavEncoder -> face decoder; lane 2: body WavEncoder -> cross-attention memory.
         with Fork(dev, 3, self.concurrent) as fk:
-            with fk.lane(1):
-                y0 = self._wav_first_layer(cx, audio, lens)
-            fk.after(2, 1)
-            with fk.lane(1):
-                a_face = self._wav_encoder_chain(cx, "audio_encoder_face", 0, y0, b, lens, dest=memcat[:, :af])
-                if ta > t:  # tail windows: face features trimmed to T, body features keep T' = T+1 (M:278-281, sic)
-                    memcat[:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)
-            with fk.lane(2):
-                a_body = self._wav_encoder_chain(cx, "audio_encoder_body", 1, y0, b, lens)
-                if use_audio:
-                    mem_body, _ = cx.gemm(a_body, "audio_body_motion_proj")                 # M:303
-                    bk, bvt = self._memory_kv(cx, "cross.kv_all", mem_body, b, ta, nc)
+            feats = _audio_feats if _audio_feats is not None else self._audio_features(cx, audio, b, t, use_audio, fk, 1, 2)
+            memcat, bk, bvt, ta = feats["memcat"], feats["bk"], feats["bvt"], feats["ta"]
 
             with fk.lane(0):
                 # masked motion -> spatial hints (M:267-273)
@@ -834,13 +852,39 @@ class EmageAudioModel(_EmageModule):
         chunks = {k: [] for k in OUT_KEYS}
         last = motion[:, :pre]
 
-        def run_window(start, end, need_decode):
+        # The waveform-only part of every full window (WavEncoders, audio projection, cross-attention K/V) does not
+        # depend on the autoregressive motion state: compute it for all `rounds` windows in one set of launches
+        # (rows = rounds*B clips) before the sequential loop.
+        hoisted = None
+        if rounds > 0 and self.hoist_audio:
+            cx = _Ctx(self._engine())
+            d, af = c.hidden_size, c.audio_f
+            wins = torch.stack([audio[:, i * (window - pre) * spf: i * (window - pre) * spf + window * spf]
+                                for i in range(rounds)]).reshape(rounds * bs, window * spf).contiguous()   # M:393-394
+            # Issued on the side streams the first window's forward() will use for its own lanes 1 and 2 and NOT
+            # joined here: window 0's motion path (lane 0) starts at once, its face decoder and cross-attention
+            # queue behind this work by stream order, and forward()'s join closes the fork.
+            fk = Fork(dev, 3, self.concurrent)
+            fk.__enter__()
+            hoisted = self._audio_features(cx, wins, rounds * bs, window, True, fk, 1, 2)
+            if hoisted["ta"] != window:
+                fk.__exit__(None, None, None)
+                hoisted = None
+
+        def window_feats(i):
+            if hoisted is None:
+                return None
+            ta, mrows = hoisted["ta"], bs * window
+            return dict(memcat=hoisted["memcat"][i * mrows:(i + 1) * mrows], ta=ta,
+                        bk=hoisted["bk"][i * bs * ta:(i + 1) * bs * ta], bvt=hoisted["bvt"][i * bs:(i + 1) * bs])
+
+        def run_window(start, end, need_decode, feats=None):
             w_mask = full_mask[:, start:end].clone()
             w_motion = motion[:, start:end].clone()
             w_motion[:, :pre] = torch.where(w_mask[:, :pre] == 0, motion[:, start:start + pre], last)   # M:386-390
             w_mask[:, :pre] = 0
             a = audio[:, start * spf:start * spf + (end - start) * spf]                          # M:393-394
-            net = self.forward(a, speaker_id, w_motion, w_mask, use_audio=True)
+            net = self.forward(a, speaker_id, w_motion, w_mask, use_audio=True, _audio_feats=feats)
             dec = vq_model.decode(**self._select_codes(net)) if need_decode else None
             return net, dec
 
@@ -849,7 +893,7 @@ class EmageAudioModel(_EmageModule):
             start = i * (window - pre)
             # the decode only feeds the next window's seed: the reference also runs it after the last window
             # where its result is discarded; skipping that one changes no output
-            net, dec = run_window(start, start + window, need_decode=(i + 1 < rounds) or tail)
+            net, dec = run_window(start, start + window, need_decode=(i + 1 < rounds) or tail, feats=window_feats(i))
             if dec is not None:
                 last = dec["all_motion4inference"][:, -pre:]
             for k in OUT_KEYS:

@@ -64,8 +64,10 @@ def gather_rows(table, idx, dtype, n_store=None):
 
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
-         n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None):
-    """See include/emage_hip.h:emage_gemm.  `a` (rows, lda) and `w` (n, taps*cp) are in `dtype`."""
+         n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
+         k_real=None):
+    """See include/emage_hip.h:emage_gemm.  `a` (rows, lda) and `w` (n, taps*cp) are in `dtype`.  `k_real` (the
+    unpadded contraction length) is bookkeeping for bench.py's algorithmic-flop count; the kernel ignores it."""
     _dev(a)
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin

@@ -7,6 +7,10 @@ static — it depends only on (batch, audio length, precision) — so it is capt
 launches are captured like any other) and replayed per batch: `inference()` (sequential 64-frame windows, seed
 frames carried through the VQ decode) + the final `EmageVQModel.decode(get_global_motion=True)`.
 Outputs land in pinned host buffers with one synchronisation.
+
+`sub_batches = k` splits the batch into k independent groups of clips, each with its own captured graph, replayed
+on k streams at once: the launch chain of one window is ~300 dependent kernels of a few microseconds each, and a
+second independent chain fills the ramp / drain gaps of the first.
 """
 from __future__ import annotations
 
@@ -14,12 +18,24 @@ import torch
 
 
 class ClipRunner:
-    def __init__(self, model, vq_model, batch: int, n_samples: int, use_graph: bool = True, warmup: int = 2):
+    def __init__(self, model, vq_model, batch: int, n_samples: int, use_graph: bool = True, warmup: int = 2,
+                 sub_batches: int = 1):
         self.model, self.vq = model, vq_model
         dev = model.device
         if dev.type != "cuda":
             raise RuntimeError("ClipRunner needs the models on an MI355X device")
-        self.device = dev
+        if batch % sub_batches:
+            raise ValueError("batch must be divisible by sub_batches")
+        self.device, self.batch, self.sub = dev, batch, sub_batches
+        self.children, self.streams = [], []
+        if sub_batches > 1:
+            self.children = [ClipRunner(model, vq_model, batch // sub_batches, n_samples, use_graph, warmup, 1)
+                             for _ in range(sub_batches)]
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(sub_batches)]
+            self.frames_out = self.children[0].frames_out
+            self.host = tuple(torch.empty((batch,) + tuple(h.shape[1:]), dtype=h.dtype, pin_memory=True)
+                              for h in self.children[0].host)
+            return
         self.audio = torch.zeros(batch, n_samples, dtype=torch.float32, device=dev)
         self.speaker_id = torch.zeros(batch, 1, dtype=torch.long, device=dev)
         self.ref_trans = torch.zeros(1, 3, device=dev)
@@ -41,8 +57,9 @@ class ClipRunner:
         return pred["motion_axis_angle"], pred["expression"], pred["trans"]
 
     def run_device(self, audio=None, speaker_id=None):
-        """Launch one batch; returns device tensors (poses (B,T,165), expressions (B,T,100), trans (B,T,3)) that are
-        overwritten by the next call."""
+        """Launch one batch on the current stream; returns device tensors (poses (B,T,165), expressions (B,T,100),
+        trans (B,T,3)) that are overwritten by the next call."""
+        assert self.sub == 1
         if audio is not None:
             self.audio.copy_(audio, non_blocking=True)
         if speaker_id is not None:
@@ -53,10 +70,27 @@ class ClipRunner:
             self.out = self._step()
         return self.out
 
+    def _to_host(self, host_views):
+        for h, d in zip(host_views, self.out):
+            h.copy_(d, non_blocking=True)
+
     def __call__(self, audio=None, speaker_id=None):
         """One batch end to end, results as numpy arrays on the host (the arrays `beat_format_save` receives)."""
-        out = self.run_device(audio, speaker_id)
-        for h, d in zip(self.host, out):
-            h.copy_(d, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        if self.sub == 1:
+            self.run_device(audio, speaker_id)
+            self._to_host(self.host)
+            torch.cuda.current_stream(self.device).synchronize()
+            return tuple(h.numpy() for h in self.host)
+        main = torch.cuda.current_stream(self.device)
+        start = torch.cuda.Event()
+        start.record(main)
+        n = self.batch // self.sub
+        for i, (child, s) in enumerate(zip(self.children, self.streams)):
+            s.wait_event(start)
+            with torch.cuda.stream(s):
+                child.run_device(None if audio is None else audio[i * n:(i + 1) * n],
+                                 None if speaker_id is None else speaker_id[i * n:(i + 1) * n])
+                child._to_host(tuple(h[i * n:(i + 1) * n] for h in self.host))
+        for s in self.streams:
+            s.synchronize()
         return tuple(h.numpy() for h in self.host)

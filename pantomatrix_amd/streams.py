@@ -14,8 +14,10 @@ import torch
 _POOLS = {}
 
 
-def _side_streams(device, n):
-    pool = _POOLS.setdefault(device, [])
+def _side_streams(device, n, parent):
+    """Side streams owned by `parent` (keyed by its handle): nested forks issued from different lanes get
+    different streams, so two concurrent sub-graphs never queue behind each other by accident."""
+    pool = _POOLS.setdefault((device, parent.cuda_stream), [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
@@ -31,7 +33,7 @@ class Fork:
         self.lanes = lanes
         if self.cuda:
             self.main = torch.cuda.current_stream(device)
-            self.side = _side_streams(torch.device(device), lanes - 1)
+            self.side = _side_streams(torch.device(device), lanes - 1, self.main)
 
     def __enter__(self):
         if self.cuda:

@@ -25,7 +25,8 @@ def _leaky(v, s):
 
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
-         n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None):
+         n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
+         k_real=None):
     CALLS.append("gemm")
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin

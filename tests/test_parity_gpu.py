@@ -145,3 +145,15 @@ def test_clip_runner_graph_equals_eager(precision):
         for x, y in zip(e, g):
             assert x.shape == y.shape and np.array_equal(x, y)
     assert e[0].shape == (4, 120, 165)
+
+
+def test_clip_runner_sub_batches_match():
+    """Splitting the batch into stream-parallel groups changes scheduling only: results equal the single-group run."""
+    from pantomatrix_amd.runtime import ClipRunner
+    model, vq = common.product_models(precision="bf16", device=DEV)
+    n = synthetic.samples_for_frames(128)
+    a = synthetic.synthetic_audio(8, n).to(DEV)
+    one = [x.copy() for x in ClipRunner(model, vq, 8, n, use_graph=True)(a)]
+    two = [x.copy() for x in ClipRunner(model, vq, 8, n, use_graph=True, sub_batches=2)(a)]
+    for x, y in zip(one, two):
+        assert np.array_equal(x, y)
