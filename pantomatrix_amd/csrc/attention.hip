@@ -19,11 +19,32 @@ struct AttnArgs {
     float scale;
 };
 
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint4 bload128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 bload64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_uint2(v.x, v.y);
+}
+// probabilities are in [0,1]: plain round-to-nearest-even, no NaN path
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
 template <typename T, int HD, int NT>
 __global__ __launch_bounds__(64) void attn_kernel(AttnArgs p) {
     constexpr int EPC = Elem<T>::EPC;
+    constexpr int ES = 16 / EPC;
     constexpr int NSTEP = HD / (4 * EPC);     // contraction steps over head_dim (4 chunks per step)
     constexpr int NDT = HD / 16;              // output d tiles
+    constexpr int NPC = (EPC == 8) ? (NT + 1) / 2 : NT;   // P chunks (A/B operand units along the key axis)
     const int lane = threadIdx.x;
     const int fr = lane & 15, fg = lane >> 4;
     const int qtiles = (p.Tq + 15) >> 4;
@@ -33,70 +54,65 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs p) {
     const int b = bid / p.H;
     const int q0 = qt * 16;
 
-    const T* __restrict__ Q = (const T*)p.q;
-    const T* __restrict__ K = (const T*)p.k;
-    const T* __restrict__ VT = (const T*)p.vt;
+    // The kernel is a single wave per SIMD with ~50 MFMAs of work: instruction count and exposed latency are what
+    // it costs.  Operands therefore come through buffer descriptors (one VGPR offset per row, the walk along the
+    // head dimension / key axis / d tiles in scalar or immediate offsets), and ALL of Q, K and V^T are requested
+    // before the first MFMA (this wave owns its SIMD's register file).
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)p.q, 0, (unsigned)((long)p.B * p.Tq * p.ldq * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, (unsigned)((long)p.B * p.Tk * p.ldk * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)p.vt, 0, (unsigned)((long)p.B * p.vt_rows * p.ldvt * ES), 0x00020000);
 
-    // Q fragments (B operand: column j = query)
     const int qrow = min(q0 + fr, p.Tq - 1);
-    const T* qp = Q + ((long)b * p.Tq + qrow) * p.ldq + h * HD + fg * EPC;
+    const int qoff = ((b * p.Tq + qrow) * p.ldq + h * HD + fg * EPC) * ES;
     uint4 qf[NSTEP];
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) qf[s] = *(const uint4*)(qp + s * 4 * EPC);
+    for (int s = 0; s < NSTEP; ++s) qf[s] = bload128(rq, qoff, s * 64);
 
-    // scores S^T[key][q].  The whole problem is latency-bound (72 KB per (b,h), one wave per 16 queries), so for
-    // Tk <= 64 every K chunk is requested before the first MFMA instead of tile by tile.
-    f32x4 sc[NT];
-    if constexpr (NT <= 4) {
-        uint4 kf[NT][NSTEP];
+    constexpr bool PRE = NT <= 4;             // Tk <= 64 (every inference window): everything in flight at once
+    constexpr int KT = PRE ? NT : 1;
+    uint4 kf[KT][NSTEP];
+    auto load_k = [&](int nt, uint4 (&dst)[NSTEP]) {
+        const int krow = min(nt * 16 + fr, p.Tk - 1);
+        const int koff = ((b * p.Tk + krow) * p.ldk + h * HD + fg * EPC) * ES;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int krow = min(nt * 16 + fr, p.Tk - 1);
-            const T* kp = K + ((long)b * p.Tk + krow) * p.ldk + h * HD + fg * EPC;
+        for (int s = 0; s < NSTEP; ++s) dst[s] = bload128(rk, koff, s * 64);
+    };
+    if constexpr (PRE) {
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) kf[nt][s] = *(const uint4*)(kp + s * 4 * EPC);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < NSTEP; ++s) acc = Elem<T>::mma(kf[nt][s], qf[s], acc);
-            sc[nt] = acc;
-        }
-    } else {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int krow = min(nt * 16 + fr, p.Tk - 1);
-            const T* kp = K + ((long)b * p.Tk + krow) * p.ldk + h * HD + fg * EPC;
-            uint4 kf[NSTEP];
-#pragma unroll
-            for (int s = 0; s < NSTEP; ++s) kf[s] = *(const uint4*)(kp + s * 4 * EPC);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < NSTEP; ++s) acc = Elem<T>::mma(kf[s], qf[s], acc);
-            sc[nt] = acc;
-        }
+        for (int nt = 0; nt < NT; ++nt) load_k(nt, kf[nt]);
     }
-
-    // V^T chunks are requested now (independent of the softmax below), consumed by the P V product afterwards
-    constexpr int NPC = (EPC == 8) ? (NT + 1) / 2 : NT;
-    constexpr bool PREV = NT <= 4;
-    uint4 vpre[PREV ? NDT : 1][PREV ? NPC : 1];
-    if constexpr (PREV) {
+    // V^T chunk c of d-tile dt: keys {32c + 4g + r} U {32c + 16 + 4g + r} (bf16) / {16c + 4g + r} (fp32), r = 0..3
+    const int voff = ((b * p.vt_rows + h * HD + fr) * p.ldvt + fg * 4) * ES;
+    const int vstep = 16 * p.ldvt * ES;
+    constexpr int VT_ = PRE ? NDT : 1;
+    uint4 vf[VT_][NPC];
+    auto load_v = [&](int dt, uint4 (&dst)[NPC]) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const T* vp = VT + ((long)b * p.vt_rows + h * HD + dt * 16 + fr) * p.ldvt + fg * 4;
-#pragma unroll
-            for (int c = 0; c < NPC; ++c) {
-                if constexpr (EPC == 8) {
-                    const uint2 lo = *(const uint2*)(vp + c * 32);
-                    const uint2 hi = *(const uint2*)(vp + c * 32 + 16);
-                    vpre[dt][c] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                } else {
-                    vpre[dt][c] = *(const uint4*)(vp + c * 16);
-                }
+        for (int c = 0; c < NPC; ++c) {
+            if constexpr (EPC == 8) {
+                const uint2 lo = bload64(rv, voff, dt * vstep + c * 64);
+                const uint2 hi = bload64(rv, voff, dt * vstep + c * 64 + 32);
+                dst[c] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                dst[c] = bload128(rv, voff, dt * vstep + c * 64);
             }
         }
+    };
+    if constexpr (PRE) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) load_v(dt, vf[dt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // scores S^T[key][q] = K Q^T: lane holds keys {16nt + 4g + r} of query column fr
+    f32x4 sc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!PRE) load_k(nt, kf[0]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) acc = Elem<T>::mma(kf[PRE ? nt : 0][s], qf[s], acc);
+        sc[nt] = acc;
     }
 
     // softmax over keys for query column fr
@@ -123,12 +139,9 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs p) {
         }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sc[nt][r] = sc[nt][r] / sum;
+    const float inv = 1.0f / sum;
 
-    // P chunks (A operand: row i = query fr, contraction = keys)
+    // P chunks (contraction = keys), normalised
     uint4 pc[NPC];
     if constexpr (EPC == 8) {
 #pragma unroll
@@ -136,40 +149,39 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs p) {
             const f32x4 lo = sc[2 * c];
             f32x4 hi = {0.f, 0.f, 0.f, 0.f};
             if (2 * c + 1 < NT) hi = sc[2 * c + 1];
-            pc[c].x = (unsigned)f32_to_bf16(lo[0]) | ((unsigned)f32_to_bf16(lo[1]) << 16);
-            pc[c].y = (unsigned)f32_to_bf16(lo[2]) | ((unsigned)f32_to_bf16(lo[3]) << 16);
-            pc[c].z = (unsigned)f32_to_bf16(hi[0]) | ((unsigned)f32_to_bf16(hi[1]) << 16);
-            pc[c].w = (unsigned)f32_to_bf16(hi[2]) | ((unsigned)f32_to_bf16(hi[3]) << 16);
+            pc[c].x = pack_bf16x2(lo[0] * inv, lo[1] * inv);
+            pc[c].y = pack_bf16x2(lo[2] * inv, lo[3] * inv);
+            pc[c].z = pack_bf16x2(hi[0] * inv, hi[1] * inv);
+            pc[c].w = pack_bf16x2(hi[2] * inv, hi[3] * inv);
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < NPC; ++c) pc[c] = __builtin_bit_cast(uint4, sc[c]);
+        for (int c = 0; c < NPC; ++c) {
+            const f32x4 v = sc[c];
+            pc[c] = __builtin_bit_cast(uint4, f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv});
+        }
     }
 
-    // O = P V, one 16-wide d tile at a time
+    // O^T = V^T P^T (operands swapped): lane holds O[q = q0 + fr][d = 16dt + 4g + r], 4 consecutive d -> one
+    // 8-byte (bf16) / 16-byte (fp32) store per d tile
     T* __restrict__ O = (T*)p.out;
+    const int qq = q0 + fr;
+    T* orow = O + ((long)b * p.Tq + qq) * p.ldo + h * HD + fg * 4;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-        const T* vp = VT + ((long)b * p.vt_rows + h * HD + dt * 16 + fr) * p.ldvt + fg * 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!PRE) load_v(dt, vf[0]);
 #pragma unroll
-        for (int c = 0; c < NPC; ++c) {
-            uint4 vf;
-            if constexpr (PREV) {
-                vf = vpre[dt][c];
-            } else if constexpr (EPC == 8) {
-                const uint2 lo = *(const uint2*)(vp + c * 32);        // keys 32c + 4g .. +3
-                const uint2 hi = *(const uint2*)(vp + c * 32 + 16);   // keys 32c + 16 + 4g .. +3
-                vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        for (int c = 0; c < NPC; ++c) acc = Elem<T>::mma(vf[PRE ? dt : 0][c], pc[c], acc);
+        if (qq < p.Tq) {
+            if constexpr (EPC == 8) {
+                uint2 t;
+                t.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
+                t.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+                *(uint2*)(orow + dt * 16) = t;
             } else {
-                vf = *(const uint4*)(vp + c * 16);                    // keys 16c + 4g .. +3
+                *(float4*)(orow + dt * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
-            acc = Elem<T>::mma(pc[c], vf, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qq = q0 + fg * 4 + r;
-            if (qq < p.Tq) O[((long)b * p.Tq + qq) * p.ldo + h * HD + dt * 16 + fr] = Elem<T>::to(acc[r]);
         }
     }
 }
@@ -191,8 +203,9 @@ extern "C" int emage_attention(int dtype, const void* q, int ldq, const void* k,
     if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || Tk > 128 || vt_rows < H * hd) return EMAGE_EINVAL;
     if (dtype != EMAGE_BF16 && dtype != EMAGE_F32) return EMAGE_EINVAL;
     const int epc = dtype == EMAGE_BF16 ? 8 : 4;
-    if (ldq % epc || ldk % epc || ldvt % 32 || ldvt < ((Tk + 31) / 32) * 32) return EMAGE_EINVAL;
-    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) return EMAGE_EINVAL;
+    if (ldq % epc || ldk % epc || ldo % 4 || ldvt % 32 || ldvt < ((Tk + 31) / 32) * 32) return EMAGE_EINVAL;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) return EMAGE_EINVAL;
+    if ((long)B * Tq * ldq * 4 >= (1L << 31) || (long)B * Tk * ldk * 4 >= (1L << 31) || (long)B * vt_rows * ldvt * 4 >= (1L << 31)) return EMAGE_EINVAL;
     AttnArgs a{q, k, vt, out, ldq, ldk, ldvt, vt_rows, ldo, B, H, Tq, Tk, 1.0f / sqrtf((float)hd)};
     hipStream_t s = (hipStream_t)stream;
     return dtype == EMAGE_BF16 ? dispatch<bf16_t>(a, hd, s) : dispatch<float>(a, hd, s);

@@ -645,7 +645,7 @@ int dispatch(GemmArgs& a, hipStream_t s) {
     const long t128 = (long)((a.M + 127) / 128) * ((ncols + 127) / 128);
     // measured on MI355X (tools/bench_gemm.py): with M = 4096 the operand stream, not MFMA, bounds these
     // launches, and many small resident blocks (64x64, 5 per CU) beat large tiles except on very wide outputs
-    if (ncols > 64 && t128 >= 1024) return run_config<T>(20, a, s);     // very wide outputs (batched K/V projections)
+    if (ncols > 64 && t128 >= 512) return run_config<T>(26, a, s);      // wide outputs (QKV, batched K/V projections)
     return run_config<T>(25, a, s);
 }
 

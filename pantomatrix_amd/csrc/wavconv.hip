@@ -9,6 +9,14 @@ namespace {
 constexpr int ROWS = 64;      // output positions per block
 constexpr int MAXTAPS = 16;
 
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+    uint2 t;
+    t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *(uint2*)p = t;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void wav_conv_in_kernel(const float* __restrict__ wav, int L, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const float* __restrict__ slope,
@@ -48,8 +56,10 @@ __global__ __launch_bounds__(256) void wav_conv_in_kernel(const float* __restric
                 }
             }
             T* op = out + ((long)b * Lout + l) * ldo + cg * 4;
+            float v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) op[c] = Elem<T>::to(leaky(acc[c] + bv[c], sv[c]));
+            for (int c = 0; c < 4; ++c) v[c] = leaky(acc[c] + bv[c], sv[c]);
+            store4(op, v);                               // one 8-byte (bf16) / 16-byte (fp32) store per thread
         }
     }
 }
@@ -59,7 +69,7 @@ __global__ __launch_bounds__(256) void wav_conv_in_kernel(const float* __restric
 extern "C" int emage_wav_conv_in(int dtype, const float* wav, int L, const float* w, const float* bias, const float* slope,
                                  void* out, int ldo, int B, int Lout, int C, int taps, int stride, int pad, void* stream) {
     if (!wav || !w || !out || B <= 0 || Lout <= 0 || C <= 0 || C % 8 || taps <= 0 || taps > MAXTAPS || stride <= 0 || ldo < C) return EMAGE_EINVAL;
-    if (256 % (C / 4) != 0 || C / 4 > 256) return EMAGE_EINVAL;
+    if (256 % (C / 4) != 0 || C / 4 > 256 || ldo % 4 != 0 || ((uintptr_t)out & 15)) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((Lout + ROWS - 1) / ROWS, B), block(256);
     const size_t lds = ((ROWS - 1) * stride + taps) * sizeof(float);

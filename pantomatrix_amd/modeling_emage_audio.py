@@ -55,6 +55,7 @@ class _EmageModule:
         self._packed = None
         self.concurrent = True                 # issue independent launch chains on side streams (streams.py)
         self.hoist_audio = True                # inference(): waveform-only features of all full windows in one pass
+        self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
         self._spec = type(self)._spec_fn(config)
         self._params = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
                                                       prefix=type(self).__name__ + "/")
@@ -833,6 +834,36 @@ class EmageAudioModel(_EmageModule):
         """EmageAudioModel.inference (M:343-490): sliding 64-frame windows with 4 seed frames carried over
         through the VQ decode of the previous window; full windows drop their last 4 frames, an optional tail
         window of 4+remain frames is kept whole."""
+        chunks = {k: [] for k in OUT_KEYS}
+        for net, keep in self._windows(audio, speaker_id, vq_model, masked_motion, mask):
+            for k in OUT_KEYS:
+                chunks[k].append(net[k][:, :keep])
+        return {k: torch.cat(chunks[k], dim=1) for k in OUT_KEYS}
+
+    def infer_codes(self, audio, speaker_id, vq_model, masked_motion=None, mask=None):
+        """The same window loop, returning what `EmageVQModel.decode` consumes (the keyword arguments built at
+        test_emage_audio.py:34-47) instead of the eight full-length tensors: per-window code indices / latents are
+        sliced and concatenated directly — identical values (arg-max is per frame), without materialising and
+        re-scanning (B,T,256) logits.  Used by `runtime.ClipRunner`."""
+        sel = {}
+        for net, keep in self._windows(audio, speaker_id, vq_model, masked_motion, mask, want_codes=True):
+            for k, v in net["_codes"].items():
+                if v is not None:
+                    sel.setdefault(k, []).append(v[:, :keep])
+        out = {k: None for k in ("face_latent", "upper_latent", "hands_latent", "lower_latent",
+                                 "face_index", "upper_index", "hands_index", "lower_index")}
+        out.update({k: torch.cat(v, dim=1) for k, v in sel.items()})
+        return out
+
+    def _seed_decode_frames(self, vq_model, t):
+        """Frames the seed decode must cover: the decoder stack is 2 ResBlocks (4 convs) + vae_layer convs + 1 conv of
+        kernel 3, so output frame i depends on inputs i-R..i+R with R = 5 + vae_layer; decoding the last
+        seed_frames + R frames reproduces the last seed_frames outputs of the full decode exactly."""
+        r = 5 + max(int(getattr(vq_model, f"vq_model_{p}").config.vae_layer) for p in ("face", "upper", "hands", "lower"))
+        return min(t, self.config.seed_frames + r)
+
+    def _windows(self, audio, speaker_id, vq_model, masked_motion=None, mask=None, want_codes=False):
+        """Generator over the autoregressive windows of M:343-470; yields (forward outputs, frames to keep)."""
         c = self.config
         dev = self._device
         audio = audio.to(device=dev, dtype=torch.float32)
@@ -849,16 +880,14 @@ class EmageAudioModel(_EmageModule):
         window, pre = c.pose_length, c.seed_frames
         rounds, remain = (length - pre) // (window - pre), (length - pre) % (window - pre)       # M:364-368
         spf = 16000 // 30
-        chunks = {k: [] for k in OUT_KEYS}
         last = motion[:, :pre]
 
         # The waveform-only part of every full window (WavEncoders, audio projection, cross-attention K/V) does not
         # depend on the autoregressive motion state: compute it for all `rounds` windows in one set of launches
-        # (rows = rounds*B clips) before the sequential loop.
+        # (rows = rounds*B clips) ahead of the sequential loop.
         hoisted = None
         if rounds > 0 and self.hoist_audio:
             cx = _Ctx(self._engine())
-            d, af = c.hidden_size, c.audio_f
             wins = torch.stack([audio[:, i * (window - pre) * spf: i * (window - pre) * spf + window * spf]
                                 for i in range(rounds)]).reshape(rounds * bs, window * spf).contiguous()   # M:393-394
             # Issued on the side streams the first window's forward() will use for its own lanes 1 and 2 and NOT
@@ -878,29 +907,34 @@ class EmageAudioModel(_EmageModule):
             return dict(memcat=hoisted["memcat"][i * mrows:(i + 1) * mrows], ta=ta,
                         bk=hoisted["bk"][i * bs * ta:(i + 1) * bs * ta], bvt=hoisted["bvt"][i * bs:(i + 1) * bs])
 
-        def run_window(start, end, need_decode, feats=None):
+        def run_window(start, end, need_seed, feats=None):
             w_mask = full_mask[:, start:end].clone()
             w_motion = motion[:, start:end].clone()
             w_motion[:, :pre] = torch.where(w_mask[:, :pre] == 0, motion[:, start:start + pre], last)   # M:386-390
             w_mask[:, :pre] = 0
             a = audio[:, start * spf:start * spf + (end - start) * spf]                          # M:393-394
             net = self.forward(a, speaker_id, w_motion, w_mask, use_audio=True, _audio_feats=feats)
-            dec = vq_model.decode(**self._select_codes(net)) if need_decode else None
-            return net, dec
+            codes = self._select_codes(net) if (need_seed or want_codes) else None
+            net["_codes"] = codes
+            seed = None
+            if need_seed:
+                # only the last `seed_frames` of the decode feed the next window (M:418): decode just the frames
+                # that can influence them (exact, see _seed_decode_frames)
+                ts = self._seed_decode_frames(vq_model, end - start) if self.seed_only_decode else end - start
+                tail = {k: (None if v is None else v[:, -ts:].contiguous()) for k, v in codes.items()}
+                seed = vq_model.decode(**tail)["all_motion4inference"][:, -pre:]
+            return net, seed
 
         tail = remain > pre
         for i in range(rounds):                                                                  # M:380-426
             start = i * (window - pre)
             # the decode only feeds the next window's seed: the reference also runs it after the last window
             # where its result is discarded; skipping that one changes no output
-            net, dec = run_window(start, start + window, need_decode=(i + 1 < rounds) or tail, feats=window_feats(i))
-            if dec is not None:
-                last = dec["all_motion4inference"][:, -pre:]
-            for k in OUT_KEYS:
-                chunks[k].append(net[k][:, :-pre])
+            net, seed = run_window(start, start + window, need_seed=(i + 1 < rounds) or tail, feats=window_feats(i))
+            if seed is not None:
+                last = seed
+            yield net, window - pre
         if tail:                                                                                 # M:428-470
             start = rounds * (window - pre)
-            net, _ = run_window(start, start + pre + remain, need_decode=False)
-            for k in OUT_KEYS:
-                chunks[k].append(net[k])
-        return {k: torch.cat(chunks[k], dim=1) for k in OUT_KEYS}
+            net, _ = run_window(start, start + pre + remain, need_seed=False)
+            yield net, pre + remain

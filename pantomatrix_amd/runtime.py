@@ -52,8 +52,8 @@ class ClipRunner:
         self.frames_out = int(out[0].shape[1])
 
     def _step(self):
-        lat = self.model.inference(self.audio, self.speaker_id, self.vq)
-        pred = self.vq.decode(**self.model._select_codes(lat), get_global_motion=True, ref_trans=self.ref_trans)
+        codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
+        pred = self.vq.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
         return pred["motion_axis_angle"], pred["expression"], pred["trans"]
 
     def run_device(self, audio=None, speaker_id=None):

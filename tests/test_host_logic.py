@@ -118,3 +118,23 @@ def test_checkpoint_round_trip(tmp_path):
         assert torch.equal(v, m2.state_dict()[k])
     with pytest.raises(RuntimeError):
         m2.load_state_dict({"bogus": torch.zeros(1)})
+
+
+def test_infer_codes_equals_inference_path(golden_dir):
+    """The lean code path (per-window indices, seed-only decode) produces the reference's codes and motion."""
+    g = np.load(os.path.join(golden_dir, "infer_129f_b1.npz"))
+    model, vq = common.product_models(precision="fp32")
+    audio = synthetic.synthetic_audio(1, synthetic.samples_for_frames(129))
+    with fake_ops.installed(), torch.no_grad():
+        codes = model.infer_codes(audio, torch.zeros(1, 1, dtype=torch.long), vq)
+        pred = vq.decode(**codes, get_global_motion=True, ref_trans=torch.zeros(1, 3))
+        model.seed_only_decode = False
+        codes_full = model.infer_codes(audio, torch.zeros(1, 1, dtype=torch.long), vq)
+    for p in ("upper", "hands", "lower"):
+        assert np.array_equal(codes[f"{p}_index"].numpy(), g[f"index_{p}"])
+        assert torch.equal(codes[f"{p}_index"], codes_full[f"{p}_index"])
+    assert codes["face_index"] is None and codes["face_latent"].shape == (1, 129, 256)
+    # seed-only decode is exact in exact arithmetic; the CPU BLAS behind the fake ops blocks differently per M
+    assert float((codes["face_latent"] - codes_full["face_latent"]).abs().max()) < 1e-4
+    np.testing.assert_allclose(pred["motion_axis_angle"].numpy(), g["poses"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(pred["trans"].numpy(), g["trans"], atol=1e-3, rtol=0)

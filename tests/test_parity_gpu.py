@@ -157,3 +157,21 @@ def test_clip_runner_sub_batches_match():
     two = [x.copy() for x in ClipRunner(model, vq, 8, n, use_graph=True, sub_batches=2)(a)]
     for x, y in zip(one, two):
         assert np.array_equal(x, y)
+
+
+def test_lean_code_path_is_exact_on_device(fp32_models):
+    """infer_codes (per-window indices, seed-only decode) == the inference() + select route, bit for bit: on the
+    device every row's arithmetic is independent of how many rows a launch carries."""
+    model, vq = fp32_models
+    audio = synthetic.synthetic_audio(2, synthetic.samples_for_frames(129)).to(DEV)
+    spk = torch.zeros(2, 1, dtype=torch.long, device=DEV)
+    codes = model.infer_codes(audio, spk, vq)
+    model.seed_only_decode = False
+    try:
+        ref = model._select_codes(model.inference(audio, spk, vq))
+    finally:
+        model.seed_only_decode = True
+    for k, v in ref.items():
+        assert (v is None) == (codes[k] is None)
+        if v is not None:
+            assert torch.equal(v, codes[k]), k
