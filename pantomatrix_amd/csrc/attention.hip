@@ -38,20 +38,24 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return (a >> 16) | (b & 0xffff0000u);
 }
 
+constexpr int QW = 4;    // query tiles (waves) per workgroup: the waves of one (batch, head) share K / V^T through the CU's L1
+
 template <typename T, int HD, int NT>
-__global__ __launch_bounds__(64) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * QW, 1) void attn_kernel(AttnArgs p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = 16 / EPC;
     constexpr int NSTEP = HD / (4 * EPC);     // contraction steps over head_dim (4 chunks per step)
     constexpr int NDT = HD / 16;              // output d tiles
     constexpr int NPC = (EPC == 8) ? (NT + 1) / 2 : NT;   // P chunks (A/B operand units along the key axis)
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int fr = lane & 15, fg = lane >> 4;
     const int qtiles = (p.Tq + 15) >> 4;
+    const int qgroups = (qtiles + QW - 1) / QW;
     int bid = blockIdx.x;
-    const int qt = bid % qtiles; bid /= qtiles;
+    const int qt = (bid % qgroups) * QW + (int)(threadIdx.x >> 6); bid /= qgroups;
     const int h = bid % p.H;
     const int b = bid / p.H;
+    if (qt >= qtiles) return;                 // no barriers below: surplus waves simply leave
     const int q0 = qt * 16;
 
     // The kernel is a single wave per SIMD with ~50 MFMAs of work: instruction count and exposed latency are what
@@ -189,10 +193,11 @@ __global__ __launch_bounds__(64) void attn_kernel(AttnArgs p) {
 template <typename T>
 int dispatch(AttnArgs& a, int hd, hipStream_t s) {
     if (hd != 192) return EMAGE_EINVAL;
-    const int grid = a.B * a.H * ((a.Tq + 15) / 16);
-    if (a.Tk <= 32) hipLaunchKernelGGL((attn_kernel<T, 192, 2>), dim3(grid), dim3(64), 0, s, a);
-    else if (a.Tk <= 64) hipLaunchKernelGGL((attn_kernel<T, 192, 4>), dim3(grid), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<T, 192, 8>), dim3(grid), dim3(64), 0, s, a);
+    const int qtiles = (a.Tq + 15) / 16;
+    const int grid = a.B * a.H * ((qtiles + QW - 1) / QW);
+    if (a.Tk <= 32) hipLaunchKernelGGL((attn_kernel<T, 192, 2>), dim3(grid), dim3(64 * QW), 0, s, a);
+    else if (a.Tk <= 64) hipLaunchKernelGGL((attn_kernel<T, 192, 4>), dim3(grid), dim3(64 * QW), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<T, 192, 8>), dim3(grid), dim3(64 * QW), 0, s, a);
     return launch_status();
 }
 

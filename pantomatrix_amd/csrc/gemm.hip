@@ -213,6 +213,33 @@ template <> struct Pack4<bf16_t> {
     }
 };
 
+// 8 consecutive elements: two 16-byte accesses (fp32) or one (bf16)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const uint4 t = *(const uint4*)p;
+    v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+    v[4] = __builtin_bit_cast(float, t.z << 16); v[5] = __builtin_bit_cast(float, t.z & 0xffff0000u);
+    v[6] = __builtin_bit_cast(float, t.w << 16); v[7] = __builtin_bit_cast(float, t.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    uint4 t;
+    t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    t.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+    t.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    *(uint4*)p = t;
+}
+
 template <typename T, int BM, int BN, int CLD>
 __device__ __forceinline__ void transposed_store(const GemmArgs& p, const float* Cs, int m0, int n0, int tid) {
     T* __restrict__ out_t = (T*)p.out_t;
@@ -269,6 +296,13 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("
 // service group of ds_read_b128 hits 16 distinct slots of the 256-B bank row:
 //   KC = 8: swz = (r>>1)&7        KC = 4: swz = (-(r>>2))&3        (both invariant under r += 16)
 template <int KC> __device__ __forceinline__ int swz(int row) { return KC == 8 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3); }
+// The W tile is read with a PERMUTED row order (see the kernel): lane fr of fragment j fetches W row
+// (j>>1)*32 + (j&1)*4 + 8*(fr>>2) + (fr&3), so a 16-lane group covers rows {0-3, 8-11, 16-19, 24-27}.  Its slot
+// swizzle is chosen for that pattern (distinct (row parity, slot) per ds_read_b128 service group):
+//   KC = 8: swzW = ((r>>1)&1) | (((r>>3)&3)<<1)      KC = 4: swzW = (-(r>>3))&3     (both invariant under r += 4, 32)
+template <int KC> __device__ __forceinline__ int swzW(int row) {
+    return KC == 8 ? (((row >> 1) & 1) | (((row >> 3) & 3) << 1)) : ((-(row >> 3)) & 3);
+}
 
 template <int OFF> __device__ __forceinline__ u32x4 lds_read128_off(unsigned addr) {
     u32x4 v;
@@ -283,6 +317,8 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_read128_off(unsigned add
 // returns zeros.  MFMA operands are SWAPPED (A-operand = W rows, B-operand = activation rows) so that a lane
 // ends up with 4 consecutive output COLUMNS of one row: the epilogue is direct 16-byte (fp32) / 8-byte (bf16)
 // vector loads/stores, no LDS staging.  Only V^T tiles (column-contiguous along the sequence) stage through LDS.
+// On top of that the W rows are fed to MFMA in a permuted order, so that the two fragments of a pair give a lane
+// EIGHT consecutive output columns: 16-byte bf16 stores, 64 contiguous bytes per row per store instruction.
 constexpr unsigned OOB = 0x80000000u;    // > any num_records we create (buffers are < 2 GiB)
 
 // blocks per CU the LDS footprint admits (capped at 3): used as the launch-bounds occupancy target so the register
@@ -311,6 +347,8 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
     constexpr int STAGE = (BM + BN) * RB;            // bytes per ring slot: A rows then W rows
     constexpr int NKG = KC / 4;                      // MFMA k-groups per tile
     static_assert(WM * WN == 4 && BM % (4 * RPI) == 0 && BN % (4 * RPI) == 0, "tile shape");
+    static_assert(FN % 2 == 0, "fragments pair up along N");
+    constexpr int FP = FN / 2;                       // fragment pairs = 8-column groups per lane per M fragment
     static_assert(NS >= 2 && NS <= 4 && (KC == 4 || KC == 8), "ring depth / row width");
 
     constexpr int CLD = BN + 4;                      // fp32 row stride of the V^T staging tile
@@ -369,7 +407,7 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
     for (int j = 0; j < GB; ++j) {
         const int row = (wave + 4 * j) * RPI + lrow;
         const int n = n0 + row;
-        b_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.K * ES) + (unsigned)((lslot ^ swz<KC>(row)) * 16) : OOB;
+        b_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.K * ES) + (unsigned)((lslot ^ swzW<KC>(row)) * 16) : OOB;
     }
 
     // running position of the next tile to issue: tap, channel offset, scalar byte offsets
@@ -404,33 +442,33 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
     const int ncol_n = p.out_t ? p.t_col0 : p.N;     // columns below this go to out / out_f32
     T* __restrict__ out = (T*)p.out;
     auto vec_ok = [&]() {
-        return (p.N % 4 == 0) && (ncol_n % 4 == 0) && (p.n_store % 4 == 0) &&
-               (!out || (p.ldo % 4 == 0 && ((uintptr_t)out & 15) == 0)) &&
+        return (p.N % 8 == 0) && (ncol_n % 8 == 0) && (p.n_store % 8 == 0) &&
+               (!out || (p.ldo % 8 == 0 && ((uintptr_t)out & 15) == 0)) &&
                (!p.out_f32 || (p.ldf % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
-               (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+               (!p.res || (p.ldr % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
                (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.slope || ((uintptr_t)p.slope & 15) == 0);
     };
     constexpr bool PRE = FM * FN <= 4;               // small tiles only: the prefetch costs 4 VGPRs per fragment
-    constexpr int PM = PRE ? FM : 1, PN = PRE ? FN : 1;
-    float pre_b[PN][4], pre_s[PN][4], pre_r[PM][PN][4];
+    constexpr int PM = PRE ? FM : 1, PP = PRE ? FP : 1;
+    float pre_b[PP][8], pre_s[PP][8], pre_r[PM][PP][8];
     bool vec = false;
     if constexpr (PRE) vec = vec_ok();
 #pragma unroll
-    for (int j = 0; j < (PRE ? PN : 0); ++j) {
-        const int n = n0 + wn * WTN + j * 16 + fg * 4;
-        const bool on = PRE && vec && n + 3 < ncol_n;
+    for (int jp = 0; jp < (PRE ? PP : 0); ++jp) {
+        const int n = n0 + wn * WTN + jp * 32 + fg * 8;
+        const bool on = PRE && vec && n + 7 < ncol_n;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { pre_b[j][e] = 0.f; pre_s[j][e] = 1.f; }
-        if (on && p.bias) Pack4<float>::load(p.bias + n, pre_b[j]);
-        if (on && p.slope) Pack4<float>::load(p.slope + n, pre_s[j]);
+        for (int e = 0; e < 8; ++e) { pre_b[jp][e] = 0.f; pre_s[jp][e] = 1.f; }
+        if (on && p.bias) load8<float>(p.bias + n, pre_b[jp]);
+        if (on && p.slope) load8<float>(p.slope + n, pre_s[jp]);
 #pragma unroll
         for (int i = 0; i < PM; ++i) {
             const int m = m0 + wm * WTM + i * 16 + fr;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pre_r[i][j][e] = 0.f;
+            for (int e = 0; e < 8; ++e) pre_r[i][jp][e] = 0.f;
             if (on && p.res && m < p.M) {
-                if (p.res_is_f32) Pack4<float>::load((const float*)p.res + (long)m * p.ldr + n, pre_r[i][j]);
-                else Pack4<T>::load((const T*)p.res + (long)m * p.ldr + n, pre_r[i][j]);
+                if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, pre_r[i][jp]);
+                else load8<T>((const T*)p.res + (long)m * p.ldr + n, pre_r[i][jp]);
             }
         }
     }
@@ -449,9 +487,9 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
     // fragment read addresses inside a ring slot (bytes): row * RB + swizzled 16-B slot; fragment i adds the
     // immediate i*16*RB (the swizzle is invariant under +16 rows); k-group 1 flips slot bit 2
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int arow = wm * WTM + fr, brow = wn * WTN + fr;
+    const int arow = wm * WTM + fr, brow = wn * WTN + 8 * (fr >> 2) + (fr & 3);
     const unsigned a_rd0 = lds0 + arow * RB + ((fg ^ swz<KC>(arow)) << 4);
-    const unsigned b_rd0 = lds0 + BM * RB + brow * RB + ((fg ^ swz<KC>(brow)) << 4);
+    const unsigned b_rd0 = lds0 + BM * RB + brow * RB + ((fg ^ swzW<KC>(brow)) << 4);
     const unsigned a_rd1 = a_rd0 ^ 64u, b_rd1 = b_rd0 ^ 64u;   // lds0 is 128-B aligned, so the xor acts on the slot bit
 
     unsigned sb = 0;                                  // byte offset of the slot being consumed
@@ -467,12 +505,12 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
         u32x4 af0[FM], bf0[FN];
         const unsigned a0 = a_rd0 + sb, b0 = b_rd0 + sb;
         [&]<int... I>(std::integer_sequence<int, I...>) { ((af0[I] = lds_read128_off<I * 16 * RB>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
-        [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<J * 16 * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
+        [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
         if constexpr (NKG == 2) {
             u32x4 af1[FM], bf1[FN];
             const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
             [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
-            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<J * 16 * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
             wait_lgkmcnt<FM + FN>();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -502,7 +540,9 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
         if (sb == NS * STAGE) sb = 0;
     }
 
-    // ---- epilogue.  acc[i][j][r] = out[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + j*16 + fg*4 + r] ----
+    // ---- epilogue.  With the permuted W rows, lane (fr, fg) holds for M fragment i and fragment pair jp the 8
+    // consecutive columns  out[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + jp*32 + fg*8 + e],
+    // e = 0..3 from acc[i][2jp], e = 4..7 from acc[i][2jp+1]. ----
     if (p.dbg & 4) {                                  // diagnostics: keep the accumulators live, store nothing
         if (acc[0][0][0] == 123.456f) ((float*)p.out_f32)[0] = 0.f;
         return;
@@ -510,39 +550,43 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
     if (n0 < ncol_n || (out && n0 < p.n_store)) {
         if constexpr (!PRE) vec = vec_ok();
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + fg * 4;
-            if (vec && n + 3 < ncol_n) {
-                float bv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {1.f, 1.f, 1.f, 1.f};
+        for (int jp = 0; jp < FP; ++jp) {
+            const int n = n0 + wn * WTN + jp * 32 + fg * 8;
+            if (vec && n + 7 < ncol_n) {
+                float bv[8], sv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bv[e] = 0.f; sv[e] = 1.f; }
                 if constexpr (PRE) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { bv[e] = pre_b[j % PN][e]; sv[e] = pre_s[j % PN][e]; }
+                    for (int e = 0; e < 8; ++e) { bv[e] = pre_b[jp % PP][e]; sv[e] = pre_s[jp % PP][e]; }
                 } else {
-                    if (p.bias) Pack4<float>::load(p.bias + n, bv);
-                    if (p.slope) Pack4<float>::load(p.slope + n, sv);
+                    if (p.bias) load8<float>(p.bias + n, bv);
+                    if (p.slope) load8<float>(p.slope + n, sv);
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int m = m0 + wm * WTM + i * 16 + fr;
                     if (m >= p.M) continue;
-                    float rv[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
+                    float rv[8], v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] = 0.f;
                     if constexpr (PRE) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) rv[e] = pre_r[i % PM][j % PN][e];
+                        for (int e = 0; e < 8; ++e) rv[e] = pre_r[i % PM][jp % PP][e];
                     } else if (p.res) {
-                        if (p.res_is_f32) Pack4<float>::load((const float*)p.res + (long)m * p.ldr + n, rv);
-                        else Pack4<T>::load((const T*)p.res + (long)m * p.ldr + n, rv);
+                        if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, rv);
+                        else load8<T>((const T*)p.res + (long)m * p.ldr + n, rv);
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = acc[i][j][e] + bv[e];
+                    for (int e = 0; e < 8; ++e) {
+                        float x = (e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4]) + bv[e];
                         if (p.res_first) x += rv[e];
                         x = leaky(x, sv[e]);
                         if (!p.res_first) x += rv[e];
                         v[e] = x;
                     }
-                    if (out) Pack4<T>::store(out + (long)m * p.ldo + n, v);
-                    if (p.out_f32) Pack4<float>::store(p.out_f32 + (long)m * p.ldf + n, v);
+                    if (out) store8<T>(out + (long)m * p.ldo + n, v);
+                    if (p.out_f32) store8<float>(p.out_f32 + (long)m * p.ldf + n, v);
                 }
             } else {
 #pragma unroll
@@ -550,10 +594,10 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
                     const int m = m0 + wm * WTM + i * 16 + fr;
                     if (m >= p.M) continue;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < 8; ++e) {
                         const int nn = n + e;
                         if (nn < ncol_n) {
-                            float x = acc[i][j][e] + (p.bias ? p.bias[nn] : 0.f);
+                            float x = (e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4]) + (p.bias ? p.bias[nn] : 0.f);
                             float r = 0.f;
                             if (p.res) r = p.res_is_f32 ? ((const float*)p.res)[(long)m * p.ldr + nn]
                                                         : Elem<T>::from(((const T*)p.res)[(long)m * p.ldr + nn]);
@@ -581,9 +625,11 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
                 const int rb = wm * WTM + i * 16;
                 if (rb / HB == h) {
 #pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        *(float4*)(Cs + (rb - h * HB + fr) * CLD + wn * WTN + j * 16 + fg * 4) =
-                            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    for (int jp = 0; jp < FP; ++jp) {
+                        float* dst = Cs + (rb - h * HB + fr) * CLD + wn * WTN + jp * 32 + fg * 8;
+                        *(float4*)dst = make_float4(acc[i][2 * jp][0], acc[i][2 * jp][1], acc[i][2 * jp][2], acc[i][2 * jp][3]);
+                        *(float4*)(dst + 4) = make_float4(acc[i][2 * jp + 1][0], acc[i][2 * jp + 1][1], acc[i][2 * jp + 1][2], acc[i][2 * jp + 1][3]);
+                    }
                 }
             }
             __syncthreads();
