@@ -177,7 +177,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from pantomatrix_amd import dist as pdist
-    dist = pdist.init("nccl", dev) if world > 1 else None          # "nccl" == RCCL on ROCm; barriers / timing only
+    dist = pdist.init("nccl", dev)      # "nccl" == RCCL on ROCm; barriers / timing only; None without a launcher
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 

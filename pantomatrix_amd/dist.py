@@ -17,7 +17,7 @@ def env_world():
 def init(backend: str, device=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's env)."""
     rank, _local, world = env_world()
-    if world == 1:
+    if world == 1 and "RANK" not in os.environ:      # plain `python bench.py`: no process group at all
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
