@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sub-batches", type=int, default=1, help="independent clip groups issued on parallel stream lanes")
+    ap.add_argument("--pipeline", type=int, default=1, help="batches in flight (PipelinedRunner depth); 1 = one batch at a time")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
@@ -229,7 +230,7 @@ def main():
                                f"{frames_per_step // args.batch} frames out per clip; synthetic seeded weights",
                    "clips_per_gpu": args.batch, "frames_in": args.frames, "frames_out_per_clip": frames_per_step // args.batch,
                    "parallelism": f"replicas x{world} (clip-sharded, no collective)",
-                   "launch": "eager" if args.no_graph else "hipGraph replay", "sub_batches": args.sub_batches},
+                   "launch": "eager" if args.no_graph else "hipGraph replay", "sub_batches": args.sub_batches, "batches_in_flight": args.pipeline},
     }
     if rank == 0 and not args.no_roofline:
         fam = profile_kernels(model, vq, audio, spk, zeros_trans)

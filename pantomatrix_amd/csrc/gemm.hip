@@ -5,11 +5,13 @@
 // ds_read_b128 lane group touches 16 distinct 16-B slots.
 #include "common.h"
 #include <utility>
+#include <cstdlib>
 
 namespace {
 
 int g_force_config = -1;   // tuning knob (tests / tools): -1 = heuristic, else a fixed configuration id
-int g_debug_skip = 0;      // diagnostics (tools/bench_gemm.py --ablate): 1 = no operand DMA, 2 = no LDS reads/MFMA, 4 = no epilogue
+int g_debug_skip = 0;
+int g_persist_per_cu = 0;  // tuning: >0 caps the pipelined kernel's grid at this many blocks per CU; blocks then loop over tiles      // diagnostics (tools/bench_gemm.py --ablate): 1 = no operand DMA, 2 = no LDS reads/MFMA, 4 = no epilogue
 
 struct GemmArgs {
     const void* A; const void* W; const float* bias; const float* slope;
@@ -363,278 +365,285 @@ __global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
+    // Persistent form: a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8 or
+    // the whole tile count, so a block's tiles stay on one XCD).  With a grid smaller than the tile count blocks
+    // drift out of lock-step (one block's epilogue overlaps its neighbour's K-loop) and leave LDS for a second
+    // kernel to co-reside; with grid == tile count this is the plain one-tile-per-block launch.
     const int nblk = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // buffer descriptors (wave-uniform): raw buffers, byte offsets, out-of-range reads return 0
-    const int nbatch = p.M / p.Lout;
-    // A's descriptor starts `pad` rows BEFORE the tensor so that every per-lane offset is non-negative (the range
-    // check is on the unsigned offset); rows in front of / behind a clip are masked explicitly per tap below
-    const unsigned a_shift = (unsigned)p.pad * (unsigned)(p.lda * ES);
-    const unsigned a_bytes = (unsigned)((((long)nbatch * p.Lin - 1) * p.lda + p.Cp) * ES) + a_shift;
-    const unsigned w_bytes = (unsigned)((long)p.N * p.K * ES);
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
-
-    // DMA slots of this lane: instruction j of this wave fills rows (wave + 4j)*RPI .. +RPI-1 of the A (or W)
-    // tile; lane -> row offset lane / KC, LDS slot lane % KC, source chunk slot ^ swz(row)
-    const int lrow = lane / KC, lslot = lane % KC;
-    const bool is_conv = p.taps > 1;
-    unsigned a_voff[GA]; int a_lpos[GA];
-#pragma unroll
-    for (int j = 0; j < GA; ++j) {
-        const int row = (wave + 4 * j) * RPI + lrow;
-        const int m = m0 + row;
-        const unsigned chunk = (unsigned)((lslot ^ swz<KC>(row)) * 16);
-        if (!is_conv) {
-            a_lpos[j] = 0;
-            a_voff[j] = m < p.M ? (unsigned)m * (unsigned)(p.lda * ES) + chunk : OOB;
-        } else {
-            const int mm = m < p.M ? m : 0;
-            const int b = mm / p.Lout, l = mm - b * p.Lout;
-            a_lpos[j] = m < p.M ? l * p.stride - p.pad : -0x40000000;      // invalid rows fail every tap's range test
-            a_voff[j] = (unsigned)(((long)b * p.Lin + l * p.stride) * p.lda * ES) + chunk;   // relative to the shifted base
+    for (int tile = blockIdx.x; tile < nblk; tile += gridDim.x) {
+        int bid = tile;
+        {
+            const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
-    }
-    unsigned b_voff[GB];
-#pragma unroll
-    for (int j = 0; j < GB; ++j) {
-        const int row = (wave + 4 * j) * RPI + lrow;
-        const int n = n0 + row;
-        b_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.K * ES) + (unsigned)((lslot ^ swzW<KC>(row)) * 16) : OOB;
-    }
+        const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // running position of the next tile to issue: tap, channel offset, scalar byte offsets
-    int is_tap = 0, is_c0 = 0, is_slot = 0;
-    unsigned soff_a = 0, soff_w = 0;
-    const unsigned tap_step = (unsigned)(p.lda - p.Cp + BK) * ES;            // soff_a jump when the tap advances
-    auto issue = [&]() {
-        if (p.dbg & 1) return;
-        unsigned char* base = smem + is_slot * STAGE;
-#pragma unroll
+        // buffer descriptors (wave-uniform): raw buffers, byte offsets, out-of-range reads return 0
+        const int nbatch = p.M / p.Lout;
+        // A's descriptor starts `pad` rows BEFORE the tensor so that every per-lane offset is non-negative (the range
+        // check is on the unsigned offset); rows in front of / behind a clip are masked explicitly per tap below
+        const unsigned a_shift = (unsigned)p.pad * (unsigned)(p.lda * ES);
+        const unsigned a_bytes = (unsigned)((((long)nbatch * p.Lin - 1) * p.lda + p.Cp) * ES) + a_shift;
+        const unsigned w_bytes = (unsigned)((long)p.N * p.K * ES);
+        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+
+        // DMA slots of this lane: instruction j of this wave fills rows (wave + 4j)*RPI .. +RPI-1 of the A (or W)
+        // tile; lane -> row offset lane / KC, LDS slot lane % KC, source chunk slot ^ swz(row)
+        const int lrow = lane / KC, lslot = lane % KC;
+        const bool is_conv = p.taps > 1;
+        unsigned a_voff[GA]; int a_lpos[GA];
+    #pragma unroll
         for (int j = 0; j < GA; ++j) {
-            unsigned vo = a_voff[j];
-            if (is_conv) vo = (unsigned)(a_lpos[j] + is_tap) < (unsigned)p.Lin ? vo : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 1024),
-                                                     16, (int)vo, (int)soff_a, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < GB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + BM * RB + (wave + 4 * j) * 1024),
-                                                     16, (int)b_voff[j], (int)soff_w, 0, 0);
-        soff_w += BK * ES;
-        is_c0 += BK;
-        if (is_c0 == p.Cp) { is_c0 = 0; ++is_tap; soff_a += tap_step; } else { soff_a += BK * ES; }
-        if (++is_slot == NS) is_slot = 0;
-    };
-
-    // Epilogue operands (residual rows, bias, slope) are fetched NOW, ahead of the operand DMA: they are the
-    // oldest entries of this wave's memory queue, so the first counted vmcnt wait of the K-loop retires them and
-    // the epilogue does not start with an exposed HBM round trip.  (Vector path only; the scalar fallback for
-    // odd widths loads in the epilogue.)
-    const int fr = lane & 15, fg = lane >> 4;
-    const int ncol_n = p.out_t ? p.t_col0 : p.N;     // columns below this go to out / out_f32
-    T* __restrict__ out = (T*)p.out;
-    auto vec_ok = [&]() {
-        return (p.N % 8 == 0) && (ncol_n % 8 == 0) && (p.n_store % 8 == 0) &&
-               (!out || (p.ldo % 8 == 0 && ((uintptr_t)out & 15) == 0)) &&
-               (!p.out_f32 || (p.ldf % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
-               (!p.res || (p.ldr % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
-               (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.slope || ((uintptr_t)p.slope & 15) == 0);
-    };
-    constexpr bool PRE = FM * FN <= 4;               // small tiles only: the prefetch costs 4 VGPRs per fragment
-    constexpr int PM = PRE ? FM : 1, PP = PRE ? FP : 1;
-    float pre_b[PP][8], pre_s[PP][8], pre_r[PM][PP][8];
-    bool vec = false;
-    if constexpr (PRE) vec = vec_ok();
-#pragma unroll
-    for (int jp = 0; jp < (PRE ? PP : 0); ++jp) {
-        const int n = n0 + wn * WTN + jp * 32 + fg * 8;
-        const bool on = PRE && vec && n + 7 < ncol_n;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { pre_b[jp][e] = 0.f; pre_s[jp][e] = 1.f; }
-        if (on && p.bias) load8<float>(p.bias + n, pre_b[jp]);
-        if (on && p.slope) load8<float>(p.slope + n, pre_s[jp]);
-#pragma unroll
-        for (int i = 0; i < PM; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + fr;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pre_r[i][jp][e] = 0.f;
-            if (on && p.res && m < p.M) {
-                if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, pre_r[i][jp]);
-                else load8<T>((const T*)p.res + (long)m * p.ldr + n, pre_r[i][jp]);
+            const int row = (wave + 4 * j) * RPI + lrow;
+            const int m = m0 + row;
+            const unsigned chunk = (unsigned)((lslot ^ swz<KC>(row)) * 16);
+            if (!is_conv) {
+                a_lpos[j] = 0;
+                a_voff[j] = m < p.M ? (unsigned)m * (unsigned)(p.lda * ES) + chunk : OOB;
+            } else {
+                const int mm = m < p.M ? m : 0;
+                const int b = mm / p.Lout, l = mm - b * p.Lout;
+                a_lpos[j] = m < p.M ? l * p.stride - p.pad : -0x40000000;      // invalid rows fail every tap's range test
+                a_voff[j] = (unsigned)(((long)b * p.Lin + l * p.stride) * p.lda * ES) + chunk;   // relative to the shifted base
             }
         }
-    }
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue();
-
-    // fragment read addresses inside a ring slot (bytes): row * RB + swizzled 16-B slot; fragment i adds the
-    // immediate i*16*RB (the swizzle is invariant under +16 rows); k-group 1 flips slot bit 2
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int arow = wm * WTM + fr, brow = wn * WTN + 8 * (fr >> 2) + (fr & 3);
-    const unsigned a_rd0 = lds0 + arow * RB + ((fg ^ swz<KC>(arow)) << 4);
-    const unsigned b_rd0 = lds0 + BM * RB + brow * RB + ((fg ^ swzW<KC>(brow)) << 4);
-    const unsigned a_rd1 = a_rd0 ^ 64u, b_rd1 = b_rd0 ^ 64u;   // lds0 is 128-B aligned, so the xor acts on the slot bit
-
-    unsigned sb = 0;                                  // byte offset of the slot being consumed
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed; tiles issued after it (at most NS-2) may stay in flight
-        const int newer = nk - 1 - kt;
-        if (NS >= 4 && newer >= 2) wait_vmcnt<2 * G>();
-        else if (NS >= 3 && newer >= 1) wait_vmcnt<G>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) issue();
-        if (p.dbg & 2) continue;
-        u32x4 af0[FM], bf0[FN];
-        const unsigned a0 = a_rd0 + sb, b0 = b_rd0 + sb;
-        [&]<int... I>(std::integer_sequence<int, I...>) { ((af0[I] = lds_read128_off<I * 16 * RB>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
-        [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
-        if constexpr (NKG == 2) {
-            u32x4 af1[FM], bf1[FN];
-            const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
-            [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
-            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
-            wait_lgkmcnt<FM + FN>();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            wait_lgkmcnt<0>();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf1[j]), __builtin_bit_cast(uint4, af1[i]), acc[i][j]);
-        } else {
-            wait_lgkmcnt<0>();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
+        unsigned b_voff[GB];
+    #pragma unroll
+        for (int j = 0; j < GB; ++j) {
+            const int row = (wave + 4 * j) * RPI + lrow;
+            const int n = n0 + row;
+            b_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.K * ES) + (unsigned)((lslot ^ swzW<KC>(row)) * 16) : OOB;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        sb += STAGE;
-        if (sb == NS * STAGE) sb = 0;
-    }
 
-    // ---- epilogue.  With the permuted W rows, lane (fr, fg) holds for M fragment i and fragment pair jp the 8
-    // consecutive columns  out[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + jp*32 + fg*8 + e],
-    // e = 0..3 from acc[i][2jp], e = 4..7 from acc[i][2jp+1]. ----
-    if (p.dbg & 4) {                                  // diagnostics: keep the accumulators live, store nothing
-        if (acc[0][0][0] == 123.456f) ((float*)p.out_f32)[0] = 0.f;
-        return;
-    }
-    if (n0 < ncol_n || (out && n0 < p.n_store)) {
-        if constexpr (!PRE) vec = vec_ok();
-#pragma unroll
-        for (int jp = 0; jp < FP; ++jp) {
+        // running position of the next tile to issue: tap, channel offset, scalar byte offsets
+        int is_tap = 0, is_c0 = 0, is_slot = 0;
+        unsigned soff_a = 0, soff_w = 0;
+        const unsigned tap_step = (unsigned)(p.lda - p.Cp + BK) * ES;            // soff_a jump when the tap advances
+        auto issue = [&]() {
+            if (p.dbg & 1) return;
+            unsigned char* base = smem + is_slot * STAGE;
+    #pragma unroll
+            for (int j = 0; j < GA; ++j) {
+                unsigned vo = a_voff[j];
+                if (is_conv) vo = (unsigned)(a_lpos[j] + is_tap) < (unsigned)p.Lin ? vo : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 1024),
+                                                         16, (int)vo, (int)soff_a, 0, 0);
+            }
+    #pragma unroll
+            for (int j = 0; j < GB; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + BM * RB + (wave + 4 * j) * 1024),
+                                                         16, (int)b_voff[j], (int)soff_w, 0, 0);
+            soff_w += BK * ES;
+            is_c0 += BK;
+            if (is_c0 == p.Cp) { is_c0 = 0; ++is_tap; soff_a += tap_step; } else { soff_a += BK * ES; }
+            if (++is_slot == NS) is_slot = 0;
+        };
+
+        // Epilogue operands (residual rows, bias, slope) are fetched NOW, ahead of the operand DMA: they are the
+        // oldest entries of this wave's memory queue, so the first counted vmcnt wait of the K-loop retires them and
+        // the epilogue does not start with an exposed HBM round trip.  (Vector path only; the scalar fallback for
+        // odd widths loads in the epilogue.)
+        const int fr = lane & 15, fg = lane >> 4;
+        const int ncol_n = p.out_t ? p.t_col0 : p.N;     // columns below this go to out / out_f32
+        T* __restrict__ out = (T*)p.out;
+        auto vec_ok = [&]() {
+            return (p.N % 8 == 0) && (ncol_n % 8 == 0) && (p.n_store % 8 == 0) &&
+                   (!out || (p.ldo % 8 == 0 && ((uintptr_t)out & 15) == 0)) &&
+                   (!p.out_f32 || (p.ldf % 4 == 0 && ((uintptr_t)p.out_f32 & 15) == 0)) &&
+                   (!p.res || (p.ldr % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+                   (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.slope || ((uintptr_t)p.slope & 15) == 0);
+        };
+        constexpr bool PRE = FM * FN <= 4;               // small tiles only: the prefetch costs 4 VGPRs per fragment
+        constexpr int PM = PRE ? FM : 1, PP = PRE ? FP : 1;
+        float pre_b[PP][8], pre_s[PP][8], pre_r[PM][PP][8];
+        bool vec = false;
+        if constexpr (PRE) vec = vec_ok();
+    #pragma unroll
+        for (int jp = 0; jp < (PRE ? PP : 0); ++jp) {
             const int n = n0 + wn * WTN + jp * 32 + fg * 8;
-            if (vec && n + 7 < ncol_n) {
-                float bv[8], sv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { bv[e] = 0.f; sv[e] = 1.f; }
-                if constexpr (PRE) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { bv[e] = pre_b[jp % PP][e]; sv[e] = pre_s[jp % PP][e]; }
-                } else {
-                    if (p.bias) load8<float>(p.bias + n, bv);
-                    if (p.slope) load8<float>(p.slope + n, sv);
+            const bool on = PRE && vec && n + 7 < ncol_n;
+    #pragma unroll
+            for (int e = 0; e < 8; ++e) { pre_b[jp][e] = 0.f; pre_s[jp][e] = 1.f; }
+            if (on && p.bias) load8<float>(p.bias + n, pre_b[jp]);
+            if (on && p.slope) load8<float>(p.slope + n, pre_s[jp]);
+    #pragma unroll
+            for (int i = 0; i < PM; ++i) {
+                const int m = m0 + wm * WTM + i * 16 + fr;
+    #pragma unroll
+                for (int e = 0; e < 8; ++e) pre_r[i][jp][e] = 0.f;
+                if (on && p.res && m < p.M) {
+                    if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, pre_r[i][jp]);
+                    else load8<T>((const T*)p.res + (long)m * p.ldr + n, pre_r[i][jp]);
                 }
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int m = m0 + wm * WTM + i * 16 + fr;
-                    if (m >= p.M) continue;
-                    float rv[8], v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) rv[e] = 0.f;
-                    if constexpr (PRE) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) rv[e] = pre_r[i % PM][jp % PP][e];
-                    } else if (p.res) {
-                        if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, rv);
-                        else load8<T>((const T*)p.res + (long)m * p.ldr + n, rv);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float x = (e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4]) + bv[e];
-                        if (p.res_first) x += rv[e];
-                        x = leaky(x, sv[e]);
-                        if (!p.res_first) x += rv[e];
-                        v[e] = x;
-                    }
-                    if (out) store8<T>(out + (long)m * p.ldo + n, v);
-                    if (p.out_f32) store8<float>(p.out_f32 + (long)m * p.ldf + n, v);
-                }
+            }
+        }
+
+        f32x4 acc[FM][FN];
+    #pragma unroll
+        for (int i = 0; i < FM; ++i)
+    #pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const int nk = p.K / BK;
+    #pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nk) issue();
+
+        // fragment read addresses inside a ring slot (bytes): row * RB + swizzled 16-B slot; fragment i adds the
+        // immediate i*16*RB (the swizzle is invariant under +16 rows); k-group 1 flips slot bit 2
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        const int arow = wm * WTM + fr, brow = wn * WTN + 8 * (fr >> 2) + (fr & 3);
+        const unsigned a_rd0 = lds0 + arow * RB + ((fg ^ swz<KC>(arow)) << 4);
+        const unsigned b_rd0 = lds0 + BM * RB + brow * RB + ((fg ^ swzW<KC>(brow)) << 4);
+        const unsigned a_rd1 = a_rd0 ^ 64u, b_rd1 = b_rd0 ^ 64u;   // lds0 is 128-B aligned, so the xor acts on the slot bit
+
+        unsigned sb = 0;                                  // byte offset of the slot being consumed
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt must have landed; tiles issued after it (at most NS-2) may stay in flight
+            const int newer = nk - 1 - kt;
+            if (NS >= 4 && newer >= 2) wait_vmcnt<2 * G>();
+            else if (NS >= 3 && newer >= 1) wait_vmcnt<G>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + NS - 1 < nk) issue();
+            if (p.dbg & 2) continue;
+            u32x4 af0[FM], bf0[FN];
+            const unsigned a0 = a_rd0 + sb, b0 = b_rd0 + sb;
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((af0[I] = lds_read128_off<I * 16 * RB>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
+            if constexpr (NKG == 2) {
+                u32x4 af1[FM], bf1[FN];
+                const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
+                [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
+                [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
+                wait_lgkmcnt<FM + FN>();
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int i = 0; i < FM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int i = 0; i < FM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf1[j]), __builtin_bit_cast(uint4, af1[i]), acc[i][j]);
             } else {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int m = m0 + wm * WTM + i * 16 + fr;
-                    if (m >= p.M) continue;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int nn = n + e;
-                        if (nn < ncol_n) {
-                            float x = (e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4]) + (p.bias ? p.bias[nn] : 0.f);
-                            float r = 0.f;
-                            if (p.res) r = p.res_is_f32 ? ((const float*)p.res)[(long)m * p.ldr + nn]
-                                                        : Elem<T>::from(((const T*)p.res)[(long)m * p.ldr + nn]);
-                            if (p.res_first) x += r;
-                            x = leaky(x, p.slope ? p.slope[nn] : 1.f);
-                            if (!p.res_first) x += r;
-                            if (out) out[(long)m * p.ldo + nn] = Elem<T>::to(x);
-                            if (p.out_f32) p.out_f32[(long)m * p.ldf + nn] = x;
-                        } else if (out && nn >= p.N && nn < p.n_store) {
-                            out[(long)m * p.ldo + nn] = Elem<T>::to(0.f);
+                wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int i = 0; i < FM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sb += STAGE;
+            if (sb == NS * STAGE) sb = 0;
+        }
+
+        // ---- epilogue.  With the permuted W rows, lane (fr, fg) holds for M fragment i and fragment pair jp the 8
+        // consecutive columns  out[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + jp*32 + fg*8 + e],
+        // e = 0..3 from acc[i][2jp], e = 4..7 from acc[i][2jp+1]. ----
+        if (p.dbg & 4) {                                  // diagnostics: keep the accumulators live, store nothing
+            if (acc[0][0][0] == 123.456f) ((float*)p.out_f32)[0] = 0.f;
+            continue;
+        }
+        if (n0 < ncol_n || (out && n0 < p.n_store)) {
+            if constexpr (!PRE) vec = vec_ok();
+    #pragma unroll
+            for (int jp = 0; jp < FP; ++jp) {
+                const int n = n0 + wn * WTN + jp * 32 + fg * 8;
+                if (vec && n + 7 < ncol_n) {
+                    float bv[8], sv[8];
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) { bv[e] = 0.f; sv[e] = 1.f; }
+                    if constexpr (PRE) {
+    #pragma unroll
+                        for (int e = 0; e < 8; ++e) { bv[e] = pre_b[jp % PP][e]; sv[e] = pre_s[jp % PP][e]; }
+                    } else {
+                        if (p.bias) load8<float>(p.bias + n, bv);
+                        if (p.slope) load8<float>(p.slope + n, sv);
+                    }
+    #pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const int m = m0 + wm * WTM + i * 16 + fr;
+                        if (m >= p.M) continue;
+                        float rv[8], v[8];
+    #pragma unroll
+                        for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+                        if constexpr (PRE) {
+    #pragma unroll
+                            for (int e = 0; e < 8; ++e) rv[e] = pre_r[i % PM][jp % PP][e];
+                        } else if (p.res) {
+                            if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, rv);
+                            else load8<T>((const T*)p.res + (long)m * p.ldr + n, rv);
+                        }
+    #pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float x = (e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4]) + bv[e];
+                            if (p.res_first) x += rv[e];
+                            x = leaky(x, sv[e]);
+                            if (!p.res_first) x += rv[e];
+                            v[e] = x;
+                        }
+                        if (out) store8<T>(out + (long)m * p.ldo + n, v);
+                        if (p.out_f32) store8<float>(p.out_f32 + (long)m * p.ldf + n, v);
+                    }
+                } else {
+    #pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const int m = m0 + wm * WTM + i * 16 + fr;
+                        if (m >= p.M) continue;
+    #pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int nn = n + e;
+                            if (nn < ncol_n) {
+                                float x = (e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4]) + (p.bias ? p.bias[nn] : 0.f);
+                                float r = 0.f;
+                                if (p.res) r = p.res_is_f32 ? ((const float*)p.res)[(long)m * p.ldr + nn]
+                                                            : Elem<T>::from(((const T*)p.res)[(long)m * p.ldr + nn]);
+                                if (p.res_first) x += r;
+                                x = leaky(x, p.slope ? p.slope[nn] : 1.f);
+                                if (!p.res_first) x += r;
+                                if (out) out[(long)m * p.ldo + nn] = Elem<T>::to(x);
+                                if (p.out_f32) p.out_f32[(long)m * p.ldf + nn] = x;
+                            } else if (out && nn >= p.N && nn < p.n_store) {
+                                out[(long)m * p.ldo + nn] = Elem<T>::to(0.f);
+                            }
                         }
                     }
                 }
             }
         }
-    }
-    // V^T columns: stage the tile in LDS (row-major fp32) and store it column-contiguous along the sequence
-    if (p.out_t && n0 + BN > p.t_col0) {
-        float* Cs = (float*)smem;
-#pragma unroll
-        for (int h = 0; h < EP; ++h) {
-            __syncthreads();                          // ring (or previous half) no longer being read
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int rb = wm * WTM + i * 16;
-                if (rb / HB == h) {
-#pragma unroll
-                    for (int jp = 0; jp < FP; ++jp) {
-                        float* dst = Cs + (rb - h * HB + fr) * CLD + wn * WTN + jp * 32 + fg * 8;
-                        *(float4*)dst = make_float4(acc[i][2 * jp][0], acc[i][2 * jp][1], acc[i][2 * jp][2], acc[i][2 * jp][3]);
-                        *(float4*)(dst + 4) = make_float4(acc[i][2 * jp + 1][0], acc[i][2 * jp + 1][1], acc[i][2 * jp + 1][2], acc[i][2 * jp + 1][3]);
+        // V^T columns: stage the tile in LDS (row-major fp32) and store it column-contiguous along the sequence
+        if (p.out_t && n0 + BN > p.t_col0) {
+            float* Cs = (float*)smem;
+    #pragma unroll
+            for (int h = 0; h < EP; ++h) {
+                __syncthreads();                          // ring (or previous half) no longer being read
+    #pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int rb = wm * WTM + i * 16;
+                    if (rb / HB == h) {
+    #pragma unroll
+                        for (int jp = 0; jp < FP; ++jp) {
+                            float* dst = Cs + (rb - h * HB + fr) * CLD + wn * WTN + jp * 32 + fg * 8;
+                            *(float4*)dst = make_float4(acc[i][2 * jp][0], acc[i][2 * jp][1], acc[i][2 * jp][2], acc[i][2 * jp][3]);
+                            *(float4*)(dst + 4) = make_float4(acc[i][2 * jp + 1][0], acc[i][2 * jp + 1][1], acc[i][2 * jp + 1][2], acc[i][2 * jp + 1][3]);
+                        }
                     }
                 }
+                __syncthreads();
+                transposed_store<T, HB, BN, CLD>(p, Cs, m0 + h * HB, n0, tid);
             }
-            __syncthreads();
-            transposed_store<T, HB, BN, CLD>(p, Cs, m0 + h * HB, n0, tid);
         }
+        __syncthreads();                              // the next tile re-uses the ring / staging LDS
     }
 }
 
@@ -652,7 +661,11 @@ int launch_pipe(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M + BM - 1) / BM;
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     a.tiles_n = (ncols + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS, KC>), dim3(a.tiles_m * a.tiles_n), dim3(NTHREADS), 0, s, a);
+    int grid = a.tiles_m * a.tiles_n;
+    static const int env_persist = [] { const char* e = getenv("EMAGE_GEMM_PERSIST"); return e ? atoi(e) : -1; }();
+    const int per_cu = env_persist >= 0 ? env_persist : g_persist_per_cu;
+    if (per_cu > 0 && grid > per_cu * 256) grid = per_cu * 256;   // 256 CUs; a multiple of the 8 XCDs
+    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS, KC>), dim3(grid), dim3(NTHREADS), 0, s, a);
     return launch_status();
 }
 
@@ -680,6 +693,9 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 24: return launch_pipe<T, 64, 64, 2, 2, 4, 4>(a, s);
         case 25: return launch_pipe<T, 64, 64, 2, 2, 2>(a, s);
         case 26: return launch_pipe<T, 128, 128, 2, 2, 2, 4>(a, s);
+        case 27: return launch_pipe<T, 64, 192, 2, 2, 2, 8>(a, s);    // one (clip, head) per block at T = 64, hd = 192
+        case 28: return launch_pipe<T, 64, 192, 2, 2, 3, 4>(a, s);
+        case 29: return launch_pipe<T, 64, 192, 2, 2, 3, 8>(a, s);
         default: return EMAGE_EINVAL;
     }
 }
@@ -692,6 +708,7 @@ int dispatch(GemmArgs& a, hipStream_t s) {
     // measured on MI355X (tools/bench_gemm.py): with M = 4096 the operand stream, not MFMA, bounds these
     // launches, and many small resident blocks (64x64, 5 per CU) beat large tiles except on very wide outputs
     if (ncols > 64 && t128 >= 512) return run_config<T>(26, a, s);      // wide outputs (QKV, batched K/V projections)
+    if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T>(27, a, s);   // FFN up-projection: exactly 2 blocks per CU
     return run_config<T>(25, a, s);
 }
 
@@ -724,5 +741,6 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
 extern "C" int emage_set_tuning(int key, int value) {
     if (key == 0) { g_force_config = value; return 0; }
     if (key == 1) { g_debug_skip = value; return 0; }
+    if (key == 2) { g_persist_per_cu = value; return 0; }
     return EMAGE_EINVAL;
 }

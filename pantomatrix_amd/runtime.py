@@ -94,3 +94,48 @@ class ClipRunner:
         for s in self.streams:
             s.synchronize()
         return tuple(h.numpy() for h in self.host)
+
+
+class PipelinedRunner:
+    """`depth` independent ClipRunners (own graph, own static buffers), used round-robin on `depth` streams:
+    batch i+1 is launched while batch i is still executing, so the tail of one batch (one small kernel at a time
+    in the 8-layer cross-attention stack) overlaps the head of the next.  `submit()` enqueues a batch and returns
+    the results of the batch submitted `depth` calls earlier (None while the pipe fills); `drain()` returns the rest.
+    Results are numpy views of pinned buffers that stay valid until that slot is reused."""
+
+    def __init__(self, model, vq_model, batch: int, n_samples: int, depth: int = 2, use_graph: bool = True):
+        self.runners = [ClipRunner(model, vq_model, batch, n_samples, use_graph=use_graph) for _ in range(depth)]
+        self.streams = [torch.cuda.Stream(device=model.device) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.i = 0
+        self.frames_out = self.runners[0].frames_out
+
+    def _collect(self, slot):
+        if self.pending[slot] is None:
+            return None
+        self.pending[slot].synchronize()
+        self.pending[slot] = None
+        return tuple(h.numpy() for h in self.runners[slot].host)
+
+    def submit(self, audio, speaker_id=None):
+        slot = self.i % len(self.runners)
+        self.i += 1
+        done = self._collect(slot)
+        r, s = self.runners[slot], self.streams[slot]
+        s.wait_stream(torch.cuda.current_stream(r.device))
+        with torch.cuda.stream(s):
+            r.run_device(audio, speaker_id)
+            r._to_host(r.host)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        self.pending[slot] = ev
+        return done
+
+    def drain(self):
+        out = []
+        for k in range(len(self.runners)):
+            slot = (self.i + k) % len(self.runners)
+            d = self._collect(slot)
+            if d is not None:
+                out.append(d)
+        return out

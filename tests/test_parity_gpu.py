@@ -175,3 +175,55 @@ def test_lean_code_path_is_exact_on_device(fp32_models):
         assert (v is None) == (codes[k] is None)
         if v is not None:
             assert torch.equal(v, codes[k]), k
+
+
+def test_long_clip_and_seeded_motion_fp32(fp32_models):
+    """A 20 s clip (600 frames: 9 full windows + a 60-frame tail) with a user-provided motion seed / mask and a
+    3-D ref_trans, against the oracle run here on the host CPU."""
+    model, vq = fp32_models
+    omodel, ovq = common.oracle_models()
+    frames = 600
+    audio = synthetic.synthetic_audio(1, synthetic.samples_for_frames(frames), seed=5)
+    g = torch.Generator().manual_seed(17)
+    aa = 0.2 * torch.randn(1, 8, 55, 3, generator=g)
+    seed_motion = torch.cat([orc.axis_angle_to_rotation_6d(aa).reshape(1, 8, 330), 0.05 * torch.randn(1, 8, 7, generator=g)], dim=-1)
+    seed_mask = torch.zeros(1, 8, 337)
+    spk = torch.zeros(1, 1, dtype=torch.long)
+    with torch.no_grad():
+        ref = omodel.inference(audio, spk, ovq, masked_motion=seed_motion, mask=seed_mask)
+        rdec = ovq.decode(**omodel.select_codes(ref), get_global_motion=True, ref_trans=torch.full((1, 4, 3), 0.25))
+    out = model.inference(audio.to(DEV), spk.to(DEV), vq, masked_motion=seed_motion.to(DEV), mask=seed_mask.to(DEV))
+    dec = vq.decode(**model._select_codes(out), get_global_motion=True, ref_trans=torch.full((1, 4, 3), 0.25, device=DEV))
+    assert out["rec_face"].shape == (1, frames, 256)
+    sel_r, sel_o = omodel.select_codes(ref), model._select_codes(out)
+    for p in ("upper", "hands", "lower"):
+        assert torch.equal(sel_o[f"{p}_index"].cpu(), sel_r[f"{p}_index"]), p
+    for k in ("motion_axis_angle", "expression", "trans"):
+        err = float((dec[k].cpu() - rdec[k]).abs().max())
+        assert err < TOL, (k, err)
+    assert abs(float(dec["trans"][0, 0, 0]) - 0.25) < 1e-6     # x starts at ref_trans, y is the decoded height
+
+
+def test_deeper_vq_stacks_on_device(golden_dir):
+    """vae_layer is a checkpoint parameter (SURVEY §8a note): the 3-layer VQ-VAE / AE stacks against the reference."""
+    import pantomatrix_amd as pa
+    g = np.load(os.path.join(golden_dir, "vq_layer3.npz"))
+    _, vqc, gc = common.cfg_dicts(vae_layer=3, global_layer=3)
+    gen = torch.Generator().manual_seed(11)
+    for p in common.PARTS:
+        cfg = pa.EmageVQVAEConvConfig(**vqc[p])
+        m = pa.EmageVQVAEConv(cfg).set_precision("fp32")
+        m.load_state_dict(synthetic.vqvae_state(cfg, p, 0))
+        m.to(DEV)
+        x = torch.randn(2, 40, cfg.vae_test_dim, generator=gen)
+        idx = torch.randint(0, 256, (2, 40), generator=gen)
+        z = torch.randn(2, 40, 256, generator=gen)
+        assert np.array_equal(m.map2index(x.to(DEV)).cpu().numpy(), g[f"{p}_map2index"])
+        assert np.abs(m.decode(idx.to(DEV)).cpu().numpy() - g[f"{p}_decode"]).max() < 2e-4
+        assert np.abs(m.decode_from_latent(z.to(DEV)).cpu().numpy() - g[f"{p}_decode_from_latent"]).max() < 2e-4
+    gcfg = pa.EmageVAEConvConfig(**gc)
+    ae = pa.EmageVAEConv(gcfg).set_precision("fp32")
+    ae.load_state_dict(synthetic.vae_state(gcfg, 0))
+    ae.to(DEV)
+    x = torch.randn(2, 40, 61, generator=gen)
+    assert np.abs(ae.forward(x.to(DEV))["rec_pose"].cpu().numpy() - g["global_rec_pose"]).max() < 2e-4
