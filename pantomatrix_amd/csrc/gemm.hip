@@ -11,7 +11,8 @@ namespace {
 
 int g_force_config = -1;   // tuning knob (tests / tools): -1 = heuristic, else a fixed configuration id
 int g_debug_skip = 0;
-int g_persist_per_cu = 0;  // tuning: >0 caps the pipelined kernel's grid at this many blocks per CU; blocks then loop over tiles      // diagnostics (tools/bench_gemm.py --ablate): 1 = no operand DMA, 2 = no LDS reads/MFMA, 4 = no epilogue
+int g_persist_per_cu = 0;
+int g_profile = 0;         // heuristic profile: 0 = one batch at a time (small tiles), 1 = several independent chains in flight (128x128 tiles)  // tuning: >0 caps the pipelined kernel's grid at this many blocks per CU; blocks then loop over tiles      // diagnostics (tools/bench_gemm.py --ablate): 1 = no operand DMA, 2 = no LDS reads/MFMA, 4 = no epilogue
 
 struct GemmArgs {
     const void* A; const void* W; const float* bias; const float* slope;
@@ -696,6 +697,8 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 27: return launch_pipe<T, 64, 192, 2, 2, 2, 8>(a, s);    // one (clip, head) per block at T = 64, hd = 192
         case 28: return launch_pipe<T, 64, 192, 2, 2, 3, 4>(a, s);
         case 29: return launch_pipe<T, 64, 192, 2, 2, 3, 8>(a, s);
+        case 30: return launch_pipe<T, 128, 128, 2, 2, 4, 8>(a, s);   // 128 KiB ring: 96 KiB of operands in flight per CU
+        case 31: return launch_pipe<T, 128, 256, 2, 2, 3, 4>(a, s);
         default: return EMAGE_EINVAL;
     }
 }
@@ -705,6 +708,12 @@ int dispatch(GemmArgs& a, hipStream_t s) {
     if (g_force_config >= 0) return run_config<T>(g_force_config, a, s);
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     const long t128 = (long)((a.M + 127) / 128) * ((ncols + 127) / 128);
+    static const int env_profile = [] { const char* e = getenv("EMAGE_GEMM_PROFILE"); return e ? atoi(e) : -1; }();
+    const int profile = env_profile >= 0 ? env_profile : g_profile;
+    // profile 1 (tools/bench_overlap.py): when 2-4 independent launch chains are in flight, 128x128 tiles with a
+    // 2-deep ring (64 KiB LDS, 2 blocks per CU) need half the L2->LDS bytes of 64x64 tiles and their exposed
+    // latency is filled by the other chains: 25-35 % less time per launch than the small-tile choice below
+    if (profile == 1 && ncols >= 512 && a.M >= 2048) return run_config<T>(18, a, s);
     // measured on MI355X (tools/bench_gemm.py): with M = 4096 the operand stream, not MFMA, bounds these
     // launches, and many small resident blocks (64x64, 5 per CU) beat large tiles except on very wide outputs
     if (ncols > 64 && t128 >= 512) return run_config<T>(26, a, s);      // wide outputs (QKV, batched K/V projections)
@@ -742,5 +751,6 @@ extern "C" int emage_set_tuning(int key, int value) {
     if (key == 0) { g_force_config = value; return 0; }
     if (key == 1) { g_debug_skip = value; return 0; }
     if (key == 2) { g_persist_per_cu = value; return 0; }
+    if (key == 3) { g_profile = value; return 0; }
     return EMAGE_EINVAL;
 }
