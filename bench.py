@@ -124,7 +124,7 @@ def profile_kernels(model, vq, audio, spk, zeros_trans):
     return fam
 
 
-def cpu_baseline(frames, seconds_budget=20.0):
+def cpu_baseline(frames, seconds_budget=15.0):
     """The CPU oracle (a port of the reference path, oracle/emage_oracle.py) on a bounded sample of the same
     workload: `bs` 128-frame clips per call, repeated until ~seconds_budget of CPU work."""
     import common
@@ -146,7 +146,7 @@ def cpu_baseline(frames, seconds_budget=20.0):
         poses, _, _ = orc.infer_clip(omodel, ovq, audio)
         times.append(time.time() - t0)
         out_frames = poses.shape[0] * poses.shape[1]
-        if time.time() - t_start > seconds_budget or len(times) >= 12:
+        if time.time() - t_start > seconds_budget or len(times) >= 200:
             break
     med = float(np.median(times))
     return {"value": out_frames / med, "unit": "motion-frames/s", "cores": torch.get_num_threads(), "kind": "port",
