@@ -38,10 +38,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return (a >> 16) | (b & 0xffff0000u);
 }
 
-constexpr int QW = 4;    // query tiles (waves) per workgroup: the waves of one (batch, head) share K / V^T through the CU's L1
+constexpr int QW = 4;    // query tiles per workgroup: the waves of one (batch, head) share K / V^T through the CU's L1
+constexpr int DS = 1;    // waves per query tile: with DS = 2 each wave recomputes the 16x64 scores and owns half of the d tiles
+                         // of P V (two shorter waves per SIMD).  Measured: 16.0 us vs 13.3 us with DS = 1 — not a win.
 
 template <typename T, int HD, int NT>
-__global__ __launch_bounds__(64 * QW, 1) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * QW * DS, 1) void attn_kernel(AttnArgs p) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = 16 / EPC;
     constexpr int NSTEP = HD / (4 * EPC);     // contraction steps over head_dim (4 chunks per step)
@@ -52,7 +54,9 @@ __global__ __launch_bounds__(64 * QW, 1) void attn_kernel(AttnArgs p) {
     const int qtiles = (p.Tq + 15) >> 4;
     const int qgroups = (qtiles + QW - 1) / QW;
     int bid = blockIdx.x;
-    const int qt = (bid % qgroups) * QW + (int)(threadIdx.x >> 6); bid /= qgroups;
+    const int wave = (int)(threadIdx.x >> 6);
+    const int qt = (bid % qgroups) * QW + wave / DS; bid /= qgroups;
+    const int dpart = wave % DS;              // this wave's share of the output d tiles
     const int h = bid % p.H;
     const int b = bid / p.H;
     if (qt >= qtiles) return;                 // no barriers below: surplus waves simply leave
@@ -72,7 +76,9 @@ __global__ __launch_bounds__(64 * QW, 1) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) qf[s] = bload128(rq, qoff, s * 64);
 
-    constexpr bool PRE = NT <= 4;             // Tk <= 64 (every inference window): everything in flight at once
+    // Tk <= 64 (every inference window): everything in flight at once — when it fits the 256 registers a wave gets with
+    // two waves per SIMD (fp32 operands are twice as wide: only up to Tk <= 32)
+    constexpr bool PRE = NT <= 4 && (DS == 1 || EPC == 8 || NT <= 2);
     constexpr int KT = PRE ? NT : 1;
     uint4 kf[KT][NSTEP];
     auto load_k = [&](int nt, uint4 (&dst)[NSTEP]) {
@@ -88,7 +94,9 @@ __global__ __launch_bounds__(64 * QW, 1) void attn_kernel(AttnArgs p) {
     // V^T chunk c of d-tile dt: keys {32c + 4g + r} U {32c + 16 + 4g + r} (bf16) / {16c + 4g + r} (fp32), r = 0..3
     const int voff = ((b * p.vt_rows + h * HD + fr) * p.ldvt + fg * 4) * ES;
     const int vstep = 16 * p.ldvt * ES;
-    constexpr int VT_ = PRE ? NDT : 1;
+    static_assert(NDT % DS == 0, "d tiles split evenly over the DS waves");
+    constexpr int NDW = NDT / DS;             // d tiles per wave
+    constexpr int VT_ = PRE ? NDW : 1;
     uint4 vf[VT_][NPC];
     auto load_v = [&](int dt, uint4 (&dst)[NPC]) {
 #pragma unroll
@@ -102,9 +110,10 @@ __global__ __launch_bounds__(64 * QW, 1) void attn_kernel(AttnArgs p) {
             }
         }
     };
+    const int dt0 = dpart * NDW;
     if constexpr (PRE) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) load_v(dt, vf[dt]);
+        for (int dt = 0; dt < NDW; ++dt) load_v(dt0 + dt, vf[dt]);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -172,11 +181,12 @@ __global__ __launch_bounds__(64 * QW, 1) void attn_kernel(AttnArgs p) {
     const int qq = q0 + fr;
     T* orow = O + ((long)b * p.Tq + qq) * p.ldo + h * HD + fg * 4;
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
+    for (int dw = 0; dw < NDW; ++dw) {
+        const int dt = dt0 + dw;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if constexpr (!PRE) load_v(dt, vf[0]);
 #pragma unroll
-        for (int c = 0; c < NPC; ++c) acc = Elem<T>::mma(vf[PRE ? dt : 0][c], pc[c], acc);
+        for (int c = 0; c < NPC; ++c) acc = Elem<T>::mma(vf[PRE ? dw : 0][c], pc[c], acc);
         if (qq < p.Tq) {
             if constexpr (EPC == 8) {
                 uint2 t;
@@ -195,9 +205,9 @@ int dispatch(AttnArgs& a, int hd, hipStream_t s) {
     if (hd != 192) return EMAGE_EINVAL;
     const int qtiles = (a.Tq + 15) / 16;
     const int grid = a.B * a.H * ((qtiles + QW - 1) / QW);
-    if (a.Tk <= 32) hipLaunchKernelGGL((attn_kernel<T, 192, 2>), dim3(grid), dim3(64 * QW), 0, s, a);
-    else if (a.Tk <= 64) hipLaunchKernelGGL((attn_kernel<T, 192, 4>), dim3(grid), dim3(64 * QW), 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<T, 192, 8>), dim3(grid), dim3(64 * QW), 0, s, a);
+    if (a.Tk <= 32) hipLaunchKernelGGL((attn_kernel<T, 192, 2>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
+    else if (a.Tk <= 64) hipLaunchKernelGGL((attn_kernel<T, 192, 4>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<T, 192, 8>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
     return launch_status();
 }
 

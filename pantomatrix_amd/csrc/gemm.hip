@@ -714,6 +714,8 @@ int dispatch(GemmArgs& a, hipStream_t s) {
     // 2-deep ring (64 KiB LDS, 2 blocks per CU) need half the L2->LDS bytes of 64x64 tiles and their exposed
     // latency is filled by the other chains: 25-35 % less time per launch than the small-tile choice below
     if (profile == 1 && ncols >= 512 && a.M >= 2048) return run_config<T>(18, a, s);
+    if (profile == 2 && a.taps == 1 && ncols >= 768 && ncols <= 2304 && a.M >= 2048) return run_config<T>(18, a, s);
+    if (profile == 3 && a.taps == 1 && ncols >= 768 && ncols <= 2304 && a.M >= 2048 && !a.out_t) return run_config<T>(18, a, s);
     // measured on MI355X (tools/bench_gemm.py): with M = 4096 the operand stream, not MFMA, bounds these
     // launches, and many small resident blocks (64x64, 5 per CU) beat large tiles except on very wide outputs
     if (ncols > 64 && t128 >= 512) return run_config<T>(26, a, s);      // wide outputs (QKV, batched K/V projections)
