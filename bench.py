@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sub-batches", type=int, default=1, help="independent clip groups issued on parallel stream lanes")
     ap.add_argument("--pipeline", type=int, default=1, help="batches in flight (PipelinedRunner depth); 1 = one batch at a time")
+    ap.add_argument("--twin", action="store_true", help="two batches per graph replay on parallel in-graph lanes (TwinBatchRunner)")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")

@@ -38,8 +38,13 @@ int emage_abi_version(void);
 const char* emage_target_arch(void);
 
 /*
- * Tuning hook for tests and tools (never needed for correctness): key 0 = force emage_gemm's tile
- * configuration id (value -1 restores the built-in heuristic).  Returns EMAGE_EINVAL for unknown keys.
+ * Tuning hook for tests and tools (never needed for correctness; process-global, not thread-safe):
+ *   key 0: force emage_gemm's tile configuration id (-1 restores the heuristic);
+ *   key 1: diagnostic ablation mask for tools/bench_gemm.py --ablate (1 no operand DMA, 2 no MFMA, 4 no epilogue);
+ *   key 2: cap the pipelined GEMM grid at `value` blocks per CU, blocks walk tiles persistently (0 = off;
+ *          environment EMAGE_GEMM_PERSIST overrides);
+ *   key 3: tile heuristic profile (0 default; 1-3 = 128x128-tile experiments; EMAGE_GEMM_PROFILE overrides).
+ * Returns EMAGE_EINVAL for unknown keys.
  */
 int emage_set_tuning(int key, int value);
 

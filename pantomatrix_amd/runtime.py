@@ -139,3 +139,60 @@ class PipelinedRunner:
             if d is not None:
                 out.append(d)
         return out
+
+
+class TwinBatchRunner:
+    """Two whole batches per graph replay, each on its own stream lane INSIDE one captured graph (the launch chains
+    of the two batches are independent, so the graph has two parallel branches; the per-batch stream lanes are
+    switched off while capturing — nested fork/join capture crashes the ROCm 7.2 graph instantiation).
+    `__call__(audio)` takes (2*batch, L) audio and returns host arrays for 2*batch clips."""
+
+    def __init__(self, model, vq_model, batch: int, n_samples: int, warmup: int = 2):
+        from .streams import Fork
+        self.model, self.vq, self.batch = model, vq_model, batch
+        dev = model.device
+        self.device = dev
+        self.audio = torch.zeros(2 * batch, n_samples, dtype=torch.float32, device=dev)
+        self.speaker_id = torch.zeros(2 * batch, 1, dtype=torch.long, device=dev)
+        self.ref_trans = torch.zeros(1, 3, device=dev)
+        parts = [model, vq_model.vq_model_face, vq_model.vq_model_upper, vq_model.vq_model_hands, vq_model.vq_model_lower,
+                 vq_model.global_motion]
+        saved = [p.concurrent for p in parts]
+        for p in parts:
+            p.concurrent = False
+
+        def clips(a, s):
+            codes = model.infer_codes(a, s, vq_model)
+            pred = vq_model.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
+            return pred["motion_axis_angle"], pred["expression"], pred["trans"]
+
+        def step():
+            outs = [None, None]
+            with Fork(dev, 2) as fk:
+                for i in range(2):
+                    with fk.lane(i):
+                        outs[i] = clips(self.audio[i * batch:(i + 1) * batch], self.speaker_id[i * batch:(i + 1) * batch])
+            return tuple(torch.cat([outs[0][k], outs[1][k]], dim=0) for k in range(3))
+
+        try:
+            for _ in range(max(1, warmup)):
+                out = step()
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                out = step()
+        finally:
+            for p, c in zip(parts, saved):
+                p.concurrent = c
+        self.out = out
+        self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)
+        self.frames_out = int(out[0].shape[1])
+
+    def __call__(self, audio=None):
+        if audio is not None:
+            self.audio.copy_(audio, non_blocking=True)
+        self.graph.replay()
+        for h, d in zip(self.host, self.out):
+            h.copy_(d, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return tuple(h.numpy() for h in self.host)

@@ -227,3 +227,30 @@ def test_deeper_vq_stacks_on_device(golden_dir):
     ae.to(DEV)
     x = torch.randn(2, 40, 61, generator=gen)
     assert np.abs(ae.forward(x.to(DEV))["rec_pose"].cpu().numpy() - g["global_rec_pose"]).max() < 2e-4
+
+
+def test_forward_odd_window_speakers_no_audio():
+    """forward() on a 37-frame window (rows per clip not a multiple of 4: scalar V^T stores, padded key columns),
+    three speakers, with and without the audio branch, against the oracle on the same weights."""
+    import pantomatrix_amd as pa
+    from pantomatrix_amd import spec
+    acfg = dict(spec.EMAGE_AUDIO_DEFAULTS, speaker_dims=3)
+    cfg = pa.EmageAudioConfig(**acfg)
+    sd = synthetic.audio_model_state(cfg, 3)
+    model = pa.EmageAudioModel(cfg).set_precision("fp32")
+    model.load_state_dict(sd)
+    model.to(DEV)
+    omodel = orc.AudioModel(sd, cfg)
+    b, t = 3, 37
+    g = torch.Generator().manual_seed(31)
+    audio = 0.1 * torch.randn(b, t * 533, generator=g)
+    motion = torch.randn(b, t, 337, generator=g) * 0.3
+    mask = (torch.rand(b, t, 337, generator=g) > 0.4).float()
+    spk = torch.tensor([[2], [0], [1]])
+    for use_audio in (True, False):
+        with torch.no_grad():
+            ref = omodel.forward(audio, spk, motion, mask, use_audio=use_audio)
+        out = model.forward(audio.to(DEV), spk.to(DEV), motion.to(DEV), mask.to(DEV), use_audio=use_audio)
+        for k in orc.OUT_KEYS:
+            assert out[k].shape == (b, t, 256)
+            assert float((out[k].cpu() - ref[k]).abs().max()) < TOL, (k, use_audio)

@@ -50,3 +50,40 @@ for (m, k, n) in ((4096, 768, 768), (4096, 768, 1536), (4096, 768, 2304), (4096,
     for cfg in cfgs:
         t1, t2, t4 = run(1, m, k, n, cfg=cfg), run(2, m, k, n, cfg=cfg), run(4, m, k, n, cfg=cfg)
         print(f"M={m} K={k} N={n} cfg {cfg:3d}: us per launch-slot  1 chain {t1:6.1f} | 2 chains {t2:6.1f} -> {t2 / 2:5.1f}/launch | 4 chains {t4:6.1f} -> {t4 / 4:5.1f}/launch")
+
+
+def run_separate_graphs(nchains, m, k, n, iters=20, cfg=-1):
+    """Same chains, but each captured in ITS OWN graph and the graphs replayed on different streams."""
+    lib.emage_set_tuning(0, cfg)
+    ins = [chain_inputs(m, k, n) for _ in range(nchains)]
+    streams = [torch.cuda.Stream() for _ in range(nchains)]
+    graphs = []
+    for (a, w, o) in ins:
+        ops.gemm(BF16, a, w, None, None, None, o, None, None, n=n, cp=k)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(iters):
+                ops.gemm(BF16, a, w, None, None, None, o, None, None, n=n, cp=k)
+        graphs.append(gr)
+
+    def go():
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event(); ev.record(main)
+        for s, gr in zip(streams, graphs):
+            s.wait_event(ev)
+            with torch.cuda.stream(s):
+                gr.replay()
+            e2 = torch.cuda.Event(); e2.record(s); main.wait_event(e2)
+    go(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); go(); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "separate":
+    for (m, k, n) in ((4096, 768, 768), (4096, 768, 1536)):
+        for cfg in cfgs:
+            a1, a2, a4 = run(1, m, k, n, cfg=cfg), run(2, m, k, n, cfg=cfg), run(4, m, k, n, cfg=cfg)
+            s2, s4 = run_separate_graphs(2, m, k, n, cfg=cfg), run_separate_graphs(4, m, k, n, cfg=cfg)
+            print(f"N={n} cfg {cfg}: one graph: 1ch {a1:.1f} 2ch {a2:.1f} 4ch {a4:.1f} | separate graphs: 2 -> {s2:.1f}  4 -> {s4:.1f}")
