@@ -30,7 +30,7 @@ __device__ __forceinline__ uint2 bload64(__amdgpu_buffer_rsrc_t r, int voff, int
     const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return make_uint2(v.x, v.y);
 }
-// probabilities are in [0,1]: plain round-to-nearest-even, no NaN path
+// finite inputs only (probabilities, attention outputs): plain round-to-nearest-even, no NaN path
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
     a += 0x7fffu + ((a >> 16) & 1u);
@@ -130,12 +130,13 @@ __global__ __launch_bounds__(64 * QW * DS, 1) void attn_kernel(AttnArgs p) {
 
     // softmax over keys for query column fr
     float mx = -INFINITY;
+    const bool ragged = p.Tk < NT * 16;       // wave-uniform: full windows (Tk = 64) skip the per-key mask
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int key = nt * 16 + fg * 4 + r;
-            const float v = key < p.Tk ? sc[nt][r] * p.scale : -INFINITY;
+            float v = sc[nt][r] * p.scale;
+            if (ragged && nt * 16 + fg * 4 + r >= p.Tk) v = -INFINITY;
             sc[nt][r] = v;
             mx = fmaxf(mx, v);
         }
@@ -146,7 +147,9 @@ __global__ __launch_bounds__(64 * QW * DS, 1) void attn_kernel(AttnArgs p) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float e = expf(sc[nt][r] - mx);
+            // bf16 mode rounds P to 8 bits of mantissa right after: the hardware exp2 path is ample there;
+            // the fp32 parity mode keeps the correctly-rounded expf
+            const float e = (EPC == 8) ? __expf(sc[nt][r] - mx) : expf(sc[nt][r] - mx);
             sc[nt][r] = e;
             sum += e;
         }
@@ -189,9 +192,9 @@ __global__ __launch_bounds__(64 * QW * DS, 1) void attn_kernel(AttnArgs p) {
         for (int c = 0; c < NPC; ++c) acc = Elem<T>::mma(vf[PRE ? dw : 0][c], pc[c], acc);
         if (qq < p.Tq) {
             if constexpr (EPC == 8) {
-                uint2 t;
-                t.x = (unsigned)f32_to_bf16(acc[0]) | ((unsigned)f32_to_bf16(acc[1]) << 16);
-                t.y = (unsigned)f32_to_bf16(acc[2]) | ((unsigned)f32_to_bf16(acc[3]) << 16);
+                uint2 t;                      // convex combination of finite V rows: no NaN path needed
+                t.x = pack_bf16x2(acc[0], acc[1]);
+                t.y = pack_bf16x2(acc[2], acc[3]);
                 *(uint2*)(orow + dt * 16) = t;
             } else {
                 *(float4*)(orow + dt * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
