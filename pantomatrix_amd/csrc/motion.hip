@@ -130,6 +130,38 @@ __global__ void velocity_scan_kernel(const float* __restrict__ vel, int ldv, int
     }
 }
 
+// Same recurrence with the velocities staged in LDS first: the scan itself is inherently sequential (the reference's
+// fp32 rounding order is part of the contract), but its T dependent steps should not each wait on a global load.
+__global__ __launch_bounds__(128) void velocity_scan_lds_kernel(const float* __restrict__ vel, int ldv, int col0, const float* __restrict__ init,
+                                                                float dt, float* __restrict__ trans, int T) {
+    extern __shared__ float s_v[];                     // [3][T]
+    const int b = blockIdx.x;
+    const float* v = vel + (long)b * T * ldv + col0;
+    for (int i = threadIdx.x; i < 3 * T; i += blockDim.x) {
+        const int t = i / 3, ax = i - t * 3;
+        s_v[ax * T + t] = v[(long)t * ldv + ax];
+    }
+    __syncthreads();
+    float* o = trans + (long)b * T * 3;
+    if (threadIdx.x < 2) {                             // x (axis 0) and z (axis 2) integrate
+        const int ax = threadIdx.x * 2;
+        float pos = init[b * 3 + ax];
+        float* s_p = s_v + ax * T;
+        float prev = s_p[0];
+        s_p[0] = pos;
+        for (int t = 1; t < T; ++t) {
+            pos = __fadd_rn(__fmul_rn(prev, dt), pos);
+            prev = s_p[t];
+            s_p[t] = pos;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * T; i += blockDim.x) {
+        const int t = i / 3, ax = i - t * 3;
+        o[i] = s_v[ax * T + t];                        // y (axis 1) is the decoded height, copied through
+    }
+}
+
 }  // namespace
 
 extern "C" int emage_rot6d_to_axis_angle(const float* rot6d, float* aa, int n, void* stream) {
@@ -153,6 +185,9 @@ extern "C" int emage_merge_parts(const float* face, int ldface, const float* upp
 extern "C" int emage_velocity_to_position(const float* vel, int ldv, int col0, const float* init, float dt,
                                           float* trans, int B, int T, void* stream) {
     if (!vel || !init || !trans || B <= 0 || T <= 0) return EMAGE_EINVAL;
-    hipLaunchKernelGGL(velocity_scan_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, (hipStream_t)stream, vel, ldv, col0, init, dt, trans, B, T);
+    if ((size_t)3 * T * sizeof(float) <= 60 * 1024)
+        hipLaunchKernelGGL(velocity_scan_lds_kernel, dim3(B), dim3(128), (size_t)3 * T * sizeof(float), (hipStream_t)stream, vel, ldv, col0, init, dt, trans, T);
+    else
+        hipLaunchKernelGGL(velocity_scan_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, (hipStream_t)stream, vel, ldv, col0, init, dt, trans, B, T);
     return launch_status();
 }

@@ -217,6 +217,12 @@ def test_rotations_merge_scan(golden_dir):
     ref = F.velocity_to_position(vel, 54, init, 1 / 30, 5, 120)
     got = ops.velocity_to_position(vel.to(DEV), 54, init.to(DEV), 1 / 30, 5, 120)
     assert torch.equal(got.cpu(), ref), float((got.cpu() - ref).abs().max())
+    for b, t in ((3, 1), (2, 841), (1, 6000)):       # single frame, a 28 s clip, and one beyond the LDS-staged scan's reach
+        vel = torch.randn(b * t, 61, generator=g)
+        init = torch.randn(b, 3, generator=g)
+        ref = F.velocity_to_position(vel, 54, init, 1 / 30, b, t)
+        got = ops.velocity_to_position(vel.to(DEV), 54, init.to(DEV), 1 / 30, b, t)
+        assert torch.equal(got.cpu(), ref), (b, t, float((got.cpu() - ref).abs().max()))
 
 
 def test_bad_arguments_raise():
