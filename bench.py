@@ -101,7 +101,15 @@ def profile_kernels(model, vq, audio, spk, zeros_trans):
             return (tag, 0.0, float(byts))
         return c
 
-    table = {"gemm": gemm_cost, "attention": attn_cost}
+    def layer_cost(a, k, r):
+        x, b, t = a[1], a[5], a[6]
+        d, ffn, cross = x.shape[1], k["ffn"], k.get("mem_k") is not None
+        m = b * t
+        flops = 2.0 * m * d * (3 * d + d + 2 * ffn + (2 * d if cross else 0)) + 4.0 * m * k.get("tk", t) * d * (2 if cross else 1)
+        byts = 2.0 * d * (3 * d + d + 2 * ffn + (2 * d if cross else 0)) + 2.0 * m * d * 2
+        return ("transformer_layer", flops, byts)
+
+    table = {"gemm": gemm_cost, "attention": attn_cost, "transformer_layer": layer_cost}
     for nm in ("layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin", "argmax_logsoftmax",
                "wav_conv_in", "merge_parts", "velocity_to_position"):
         table[nm] = generic_cost(nm)
@@ -168,6 +176,7 @@ def main():
     ap.add_argument("--twin", action="store_true", help="two batches per graph replay on parallel in-graph lanes (TwinBatchRunner)")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B: single stream, no fork/join lanes")
+    ap.add_argument("--fused-layers", action="store_true", help="A/B: one launch per transformer layer (emage_transformer_layer)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -187,6 +196,7 @@ def main():
     model, vq = build_models(args.precision, dev)
     model.hoist_audio = not args.no_hoist
     model.concurrent = not args.no_concurrent
+    model.fused_layers = args.fused_layers
     for part in (vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.concurrent = not args.no_concurrent
     n_samples = synthetic.samples_for_frames(args.frames)
@@ -238,7 +248,7 @@ def main():
         total_ms = sum(v[1] for v in fam.values())
         dom = max(fam.items(), key=lambda kv: kv[1][1])
         name, (cnt, ms, flops, byts) = dom
-        if name.startswith("gemm") or name == "attention":
+        if name.startswith("gemm") or name in ("attention", "transformer_layer"):
             peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}

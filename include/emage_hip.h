@@ -24,6 +24,8 @@
 
 #include <stdint.h>
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -176,6 +178,37 @@ int emage_merge_parts(const float* face, int ldface, const float* upper, int ldu
  */
 int emage_velocity_to_position(const float* vel, int ldv, int col0, const float* init, float dt,
                                float* trans, int B, int T, void* stream);
+
+/*
+ * K12 — one whole nn.TransformerDecoderLayer / nn.TransformerEncoderLayer (torch defaults: post-norm, ReLU, no masks)
+ * in ONE launch, for the geometry EMAGE instantiates (M:246-262: d_model 768, 4 heads, FFN 1536) on a full 64-frame
+ * window, bf16 mode.  Same arithmetic, in the same order, as the emage_gemm / emage_attention / emage_layernorm
+ * sequence it replaces (bit-identical output); other geometries return EMAGE_EINVAL and the caller keeps that sequence.
+ *   x:        (B*64, ldx) layer input (the residual stream)
+ *   weights:  6 packed matrices  [in_proj (2304x768), self out_proj (768x768), cross q (768x768), cross out_proj,
+ *             linear1 (1536x768), linear2 (768x1536)], biases: the 6 fp32 bias vectors; entries 2,3 unused when
+ *             mem_k == NULL (encoder layer: self-attention + FFN only)
+ *   ln_gamma / ln_beta: norm1, norm2, norm3 (decoder) or norm1, -, norm2 (encoder: index 1 unused)
+ *   mem_k:    (B*Tk, ldk) projected memory keys of THIS layer; mem_vt: this layer's first row of a (B, vt_rows, ldvt)
+ *             V^T buffer (the layout emage_gemm's out_t path writes); 32 < Tk <= 64
+ *   post_add: optional (B*64, ld_add) tensor added after the last LayerNorm (M:304-305, 312)
+ *   relu_slope: 1536 zeros (the per-column LeakyReLU slope vector of the FFN up-projection)
+ *   workspace: emage_transformer_layer_workspace(B) bytes, 256-byte aligned, private to this call until it completes
+ *   out:      (B*64, ldo)
+ * emage_transformer_layer_status (diagnostics, synchronous): nonzero when a group barrier of the last run on that
+ * workspace gave up waiting.  emage_layer_set_tuning: key 0 = operand-ring depth of the fused kernel (2..4), key 1 =
+ * ablation mask for tools/bench_layer.py (timing only).
+ */
+size_t emage_transformer_layer_workspace(int B);
+int emage_transformer_layer(int dtype, const void* x, int ldx,
+                            const void* const* weights, const float* const* biases,
+                            const float* const* ln_gamma, const float* const* ln_beta, float eps,
+                            const void* mem_k, int ldk, const void* mem_vt, int vt_rows, int ldvt, int Tk,
+                            const void* post_add, int ld_add, const float* relu_slope,
+                            void* workspace, size_t workspace_bytes, void* out, int ldo,
+                            int B, int T, int d_model, int n_head, int d_ffn, void* stream);
+int emage_transformer_layer_status(const void* workspace, int B);
+int emage_layer_set_tuning(int key, int value);
 
 #ifdef __cplusplus
 }

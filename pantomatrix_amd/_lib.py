@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p, _i, _f = C.c_void_p, C.c_int, C.c_float
 
@@ -31,7 +31,13 @@ SIGNATURES = {
     "emage_axis_angle_to_rot6d": [_p, _p, _i, _p],
     "emage_merge_parts": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p],
     "emage_velocity_to_position": [_p, _i, _i, _p, _f, _p, _i, _i, _p],
+    "emage_transformer_layer": [_i, _p, _i, _p, _p, _p, _p, _f, _p, _i, _p, _i, _i, _i, _p, _i, _p,
+                                _p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _p],
+    "emage_transformer_layer_workspace": [_i],
+    "emage_transformer_layer_status": [_p, _i],
+    "emage_layer_set_tuning": [_i, _i],
 }
+RESTYPES = {"emage_transformer_layer_workspace": C.c_size_t}
 
 _lib = None
 
@@ -52,7 +58,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.argtypes = args
-        fn.restype = _i
+        fn.restype = RESTYPES.get(name, _i)
     _lib = lib
     return lib
 

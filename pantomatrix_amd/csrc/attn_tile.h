@@ -1,0 +1,191 @@
+// Device-side body of emage_attention, shared by attention.hip (one launch per attention) and layer.hip (the fused
+// transformer-layer kernel runs it for its (clip, head) between two projection tiles).
+#pragma once
+#include "common.h"
+#include <math.h>
+
+namespace emage_dev {
+
+struct AttnArgs {
+    const void* q; const void* k; const void* vt; void* out;
+    int ldq, ldk, ldvt, vt_rows, ldo, B, H, Tq, Tk;
+    float scale;
+};
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint4 bload128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 bload64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_uint2(v.x, v.y);
+}
+// finite inputs only (probabilities, attention outputs): plain round-to-nearest-even, no NaN path
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+constexpr int QW = 4;    // query tiles per workgroup: the waves of one (batch, head) share K / V^T through the CU's L1
+constexpr int DS = 1;    // waves per query tile: with DS = 2 each wave recomputes the 16x64 scores and owns half of the d tiles
+                         // of P V (two shorter waves per SIMD).  Measured: 16.0 us vs 13.3 us with DS = 1 — not a win.
+
+// softmax(Q K^T * scale) V for query tile qt (16 queries) of (batch b, head h); one wave64 (wave `dpart` of DS for that tile).
+template <typename T, int HD, int NT>
+__device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const int h, const int qt, const int dpart) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int ES = 16 / EPC;
+    constexpr int NSTEP = HD / (4 * EPC);     // contraction steps over head_dim (4 chunks per step)
+    constexpr int NDT = HD / 16;              // output d tiles
+    constexpr int NPC = (EPC == 8) ? (NT + 1) / 2 : NT;   // P chunks (A/B operand units along the key axis)
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int q0 = qt * 16;
+
+    // The kernel is a single wave per SIMD with ~50 MFMAs of work: instruction count and exposed latency are what
+    // it costs.  Operands therefore come through buffer descriptors (one VGPR offset per row, the walk along the
+    // head dimension / key axis / d tiles in scalar or immediate offsets), and ALL of Q, K and V^T are requested
+    // before the first MFMA (this wave owns its SIMD's register file).
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)p.q, 0, (unsigned)((long)p.B * p.Tq * p.ldq * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, (unsigned)((long)p.B * p.Tk * p.ldk * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)p.vt, 0, (unsigned)((long)p.B * p.vt_rows * p.ldvt * ES), 0x00020000);
+
+    const int qrow = min(q0 + fr, p.Tq - 1);
+    const int qoff = ((b * p.Tq + qrow) * p.ldq + h * HD + fg * EPC) * ES;
+    uint4 qf[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) qf[s] = bload128(rq, qoff, s * 64);
+
+    // Tk <= 64 (every inference window): everything in flight at once — when it fits the 256 registers a wave gets with
+    // two waves per SIMD (fp32 operands are twice as wide: only up to Tk <= 32)
+    constexpr bool PRE = NT <= 4 && (DS == 1 || EPC == 8 || NT <= 2);
+    constexpr int KT = PRE ? NT : 1;
+    uint4 kf[KT][NSTEP];
+    auto load_k = [&](int nt, uint4 (&dst)[NSTEP]) {
+        const int krow = min(nt * 16 + fr, p.Tk - 1);
+        const int koff = ((b * p.Tk + krow) * p.ldk + h * HD + fg * EPC) * ES;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) dst[s] = bload128(rk, koff, s * 64);
+    };
+    if constexpr (PRE) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) load_k(nt, kf[nt]);
+    }
+    // V^T chunk c of d-tile dt: keys {32c + 4g + r} U {32c + 16 + 4g + r} (bf16) / {16c + 4g + r} (fp32), r = 0..3
+    const int voff = ((b * p.vt_rows + h * HD + fr) * p.ldvt + fg * 4) * ES;
+    const int vstep = 16 * p.ldvt * ES;
+    static_assert(NDT % DS == 0, "d tiles split evenly over the DS waves");
+    constexpr int NDW = NDT / DS;             // d tiles per wave
+    constexpr int VT_ = PRE ? NDW : 1;
+    uint4 vf[VT_][NPC];
+    auto load_v = [&](int dt, uint4 (&dst)[NPC]) {
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) {
+            if constexpr (EPC == 8) {
+                const uint2 lo = bload64(rv, voff, dt * vstep + c * 64);
+                const uint2 hi = bload64(rv, voff, dt * vstep + c * 64 + 32);
+                dst[c] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                dst[c] = bload128(rv, voff, dt * vstep + c * 64);
+            }
+        }
+    };
+    const int dt0 = dpart * NDW;
+    if constexpr (PRE) {
+#pragma unroll
+        for (int dt = 0; dt < NDW; ++dt) load_v(dt0 + dt, vf[dt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // scores S^T[key][q] = K Q^T: lane holds keys {16nt + 4g + r} of query column fr
+    f32x4 sc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!PRE) load_k(nt, kf[0]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) acc = Elem<T>::mma(kf[PRE ? nt : 0][s], qf[s], acc);
+        sc[nt] = acc;
+    }
+
+    // softmax over keys for query column fr
+    float mx = -INFINITY;
+    const bool ragged = p.Tk < NT * 16;       // wave-uniform: full windows (Tk = 64) skip the per-key mask
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = sc[nt][r] * p.scale;
+            if (ragged && nt * 16 + fg * 4 + r >= p.Tk) v = -INFINITY;
+            sc[nt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // bf16 mode rounds P to 8 bits of mantissa right after: the hardware exp2 path is ample there;
+            // the fp32 parity mode keeps the correctly-rounded expf
+            const float e = (EPC == 8) ? __expf(sc[nt][r] - mx) : expf(sc[nt][r] - mx);
+            sc[nt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    // P chunks (contraction = keys), normalised
+    uint4 pc[NPC];
+    if constexpr (EPC == 8) {
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) {
+            const f32x4 lo = sc[2 * c];
+            f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+            if (2 * c + 1 < NT) hi = sc[2 * c + 1];
+            pc[c].x = pack_bf16x2(lo[0] * inv, lo[1] * inv);
+            pc[c].y = pack_bf16x2(lo[2] * inv, lo[3] * inv);
+            pc[c].z = pack_bf16x2(hi[0] * inv, hi[1] * inv);
+            pc[c].w = pack_bf16x2(hi[2] * inv, hi[3] * inv);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) {
+            const f32x4 v = sc[c];
+            pc[c] = __builtin_bit_cast(uint4, f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv});
+        }
+    }
+
+    // O^T = V^T P^T (operands swapped): lane holds O[q = q0 + fr][d = 16dt + 4g + r], 4 consecutive d -> one
+    // 8-byte (bf16) / 16-byte (fp32) store per d tile
+    T* __restrict__ O = (T*)p.out;
+    const int qq = q0 + fr;
+    T* orow = O + ((long)b * p.Tq + qq) * p.ldo + h * HD + fg * 4;
+#pragma unroll
+    for (int dw = 0; dw < NDW; ++dw) {
+        const int dt = dt0 + dw;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!PRE) load_v(dt, vf[0]);
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) acc = Elem<T>::mma(vf[PRE ? dw : 0][c], pc[c], acc);
+        if (qq < p.Tq) {
+            if constexpr (EPC == 8) {
+                uint2 t;                      // convex combination of finite V rows: no NaN path needed
+                t.x = pack_bf16x2(acc[0], acc[1]);
+                t.y = pack_bf16x2(acc[2], acc[3]);
+                *(uint2*)(orow + dt * 16) = t;
+            } else {
+                *(float4*)(orow + dt * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+    }
+}
+
+}  // namespace emage_dev

@@ -1,32 +1,14 @@
 // Row-wise and elementwise glue kernels: LayerNorm (K5) and the add / mask / cast helpers (K11).
 // All are HBM-bound streaming kernels: one wave per row (LayerNorm) or grid-stride float4 loops.
 #include "common.h"
+#include "ln_row.h"
 #include <math.h>
 
 namespace {
 
-// 4 consecutive elements of T as floats (16-byte fp32 / 8-byte bf16 access)
-template <typename T> struct Vec4;
-template <> struct Vec4<float> {
-    __device__ static __forceinline__ float4 load(const float* p) { return *(const float4*)p; }
-    __device__ static __forceinline__ void store(float* p, float4 v) { *(float4*)p = v; }
-};
-template <> struct Vec4<bf16_t> {
-    __device__ static __forceinline__ float4 load(const bf16_t* p) {
-        const uint2 t = *(const uint2*)p;
-        return make_float4(__builtin_bit_cast(float, t.x << 16), __builtin_bit_cast(float, t.x & 0xffff0000u),
-                           __builtin_bit_cast(float, t.y << 16), __builtin_bit_cast(float, t.y & 0xffff0000u));
-    }
-    __device__ static __forceinline__ void store(bf16_t* p, float4 v) {
-        uint2 t;
-        t.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
-        t.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
-        *(uint2*)p = t;
-    }
-};
+using namespace emage_dev;
 
-// LayerNorm: one wave per row; each lane owns 4-element groups j = lane + 64*i (C % 4 == 0).  The row (the
-// residual stream, stored in the compute dtype) is read once, statistics and the affine map are fp32.
+// LayerNorm: one wave per row, 4 rows per block (body in ln_row.h)
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -35,46 +17,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
-    const int nv = C >> 2;
-    const T* xp = x + (long)row * ldx;
-    float4 v[MAXV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int j = lane + 64 * i;
-        v[i] = j < nv ? Vec4<T>::load(xp + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int j = lane + 64 * i;
-        if (j < nv) {
-            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
-        }
-    }
-    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
-    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-    const float4* gp = (const float4*)gamma;
-    const float4* bp = (const float4*)beta;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int j = lane + 64 * i;
-        if (j < nv) {
-            const float4 g = gp[j], b = bp[j];
-            float4 o;
-            o.x = (v[i].x - mean) * rstd * g.x + b.x;
-            o.y = (v[i].y - mean) * rstd * g.y + b.y;
-            o.z = (v[i].z - mean) * rstd * g.z + b.z;
-            o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            if (add) { const float4 a = Vec4<T>::load(add + (long)row * ldadd + 4 * j); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
-            if (yf) ((float4*)(yf + (long)row * ldy))[j] = o;
-            if (y) Vec4<T>::store(y + (long)row * ldy + 4 * j, o);
-        }
-    }
+    layernorm_row<T, MAXV>(x + (long)row * ldx, gamma, beta, eps, add ? add + (long)row * ldadd : nullptr,
+                           yf ? yf + (long)row * ldy : nullptr, y ? y + (long)row * ldy : nullptr, C, lane);
 }
 
 // out[m] = a[m] + b[m % mod_b] (+ c[m % mod_c]); operand k is fp32 when bit k of f32_mask is set, else T

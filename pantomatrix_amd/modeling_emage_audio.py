@@ -56,6 +56,7 @@ class _EmageModule:
         self.concurrent = True                 # issue independent launch chains on side streams (streams.py)
         self.hoist_audio = True                # inference(): waveform-only features of all full windows in one pass
         self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
+        self.fused_layers = False              # opt-in: one launch per transformer layer (bf16, T = 64); same bits, not yet faster
         self._templates = {}                   # cached default motion / mask of inference() per (batch, length, device)
         self._spec = type(self)._spec_fn(config)
         self._params = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
@@ -623,10 +624,37 @@ class EmageAudioModel(_EmageModule):
         s, _ = cx.gemm(f, name + ".ff2", res=x)
         return s
 
+    def _fused_layer(self, cx, name, x, b, t, mem_k=None, mem_vt=None, vt_rows=0, tk=None, post_add=None):
+        """The whole layer in one launch (ops.transformer_layer) when the geometry is the one the fused kernel is
+        built for (bf16, full 64-frame window); None otherwise — the caller then issues the per-op sequence, which
+        computes the same bits."""
+        d, h, w = self.config.hidden_size, spec.N_HEAD, cx.pk.w
+        ffn = w[name + ".ff1"]["n"]
+        if not (self.fused_layers and ops.transformer_layer_supported(cx.dt, t, d, h, ffn, tk)):
+            return None
+        cross = mem_k is not None
+        weights = [w[name + ".sa.qkv"], w[name + ".sa.out"], w[name + ".ca.q"] if cross else None,
+                   w[name + ".ca.out"] if cross else None, w[name + ".ff1"], w[name + ".ff2"]]
+        norms = [w[name + ".norm1"], w[name + ".norm2"] if cross else None, w[name + (".norm3" if cross else ".norm2")]]
+        out, _ = ops.transformer_layer(cx.dt, x, weights, norms, cx.pk.slope(0.0, ffn), b, t, heads=h, ffn=ffn,
+                                       mem_k=mem_k, mem_vt=mem_vt, vt_rows=vt_rows, tk=tk or 0, post_add=post_add)
+        return out
+
+    def _encoder_layer(self, cx, name, x, b, t, post_add=None):
+        """nn.TransformerEncoderLayer, post-norm, ReLU, no masks."""
+        y = self._fused_layer(cx, name, x, b, t, post_add=post_add)
+        if y is not None:
+            return y
+        x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
+        return self._ln(cx, name + ".norm2", self._ffn(cx, name, x), add=post_add)
+
     def _decoder_layer(self, cx, name, x, b, t, mem_k, mem_vt, vt_rows, tk, post_add=None):
         """nn.TransformerDecoderLayer, post-norm, ReLU, no masks.  mem_k: (B*Tk, ld) view of this
         layer's projected memory keys; mem_vt: view at this layer's first row of a (B, vt_rows, Tp) V^T buffer."""
         d, h = self.config.hidden_size, spec.N_HEAD
+        y = self._fused_layer(cx, name, x, b, t, mem_k, mem_vt, vt_rows, tk, post_add)
+        if y is not None:
+            return y
         x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
         q, _ = cx.gemm(x, name + ".ca.q")
         att = cx.lo(b * t, d)
@@ -788,9 +816,7 @@ class EmageAudioModel(_EmageModule):
             with fk.lane(0):
                 # body branch: temporal self-attention (M:297-300)
                 x, _ = cx.gemm(hint_body, "moton_proj", res=pos_spk)
-                name = "motion_self_encoder.layers.0"
-                x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
-                x = self._ln(cx, name + ".norm2", self._ffn(cx, name, x), add=pos_spk)   # + speaker + pe (M:304-305)
+                x = self._encoder_layer(cx, "motion_self_encoder.layers.0", x, b, t, post_add=pos_spk)   # + speaker + pe (M:304-305)
             # audio cross-attention stack (M:303-312) needs lane 2's projected memory
             if use_audio:
                 fk.after(0, 2)

@@ -98,6 +98,43 @@ def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
                                       b, h, tq, tk, hd, _stream()), "attention")
 
 
+def transformer_layer_supported(dtype, t, d, heads, ffn, tk=None):
+    """Geometry the fused layer kernel is built for (include/emage_hip.h: emage_transformer_layer)."""
+    return dtype == BF16 and t == 64 and d == 768 and heads == 4 and ffn == 1536 and (tk is None or 32 < tk <= 64)
+
+
+def transformer_layer(dtype, x, weights, norms, relu_slope, b, t, *, heads, ffn, mem_k=None, mem_vt=None, vt_rows=0, tk=0,
+                      post_add=None, eps=1e-5, workspace=None):
+    """One post-norm transformer layer in one launch.  x (B*T, d); weights: 6 packed entries {w, b} in the order
+    [self in_proj, self out_proj, cross q, cross out_proj, linear1, linear2] (cross entries None for an encoder
+    layer); norms: 3 entries {g, b} (index 1 None for an encoder layer); mem_k / mem_vt: this layer's projected
+    cross-attention memory.  Returns (out (B*T, d), workspace)."""
+    import ctypes as C
+    _dev(x)
+    lib = _lib.load()
+    d = x.shape[1]
+    nbytes = lib.emage_transformer_layer_workspace(b)
+    if workspace is None:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty(b * t, d, dtype=x.dtype, device=x.device)
+    arr = lambda ts: (C.c_void_p * len(ts))(*[None if v is None else v.data_ptr() for v in ts])
+    wv = arr([None if e is None else e["w"] for e in weights])
+    bv = arr([None if e is None else e["b"] for e in weights])
+    gv = arr([None if e is None else e["g"] for e in norms])
+    nv = arr([None if e is None else e["b"] for e in norms])
+    check(lib.emage_transformer_layer(dtype, _ptr(x), _ld(x), wv, bv, gv, nv, eps,
+                                      _ptr(mem_k), _ld(mem_k) if mem_k is not None else 0,
+                                      _ptr(mem_vt), vt_rows, mem_vt.shape[-1] if mem_vt is not None else 0, tk,
+                                      _ptr(post_add), _ld(post_add) if post_add is not None else 0, _ptr(relu_slope),
+                                      _ptr(workspace), workspace.numel(), _ptr(out), _ld(out),
+                                      b, t, d, heads, ffn, _stream()), "transformer_layer")
+    return out, workspace
+
+
+def transformer_layer_status(workspace, b):
+    return _lib.load().emage_transformer_layer_status(_ptr(workspace), b)
+
+
 def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
     """x / add / y are in `dtype` (the residual stream's storage type)."""
     _dev(x)

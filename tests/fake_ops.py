@@ -108,6 +108,33 @@ def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
         y[:] = v.to(TD[dtype])
 
 
+def transformer_layer(dtype, x, weights, norms, relu_slope, b, t, *, heads, ffn, mem_k=None, mem_vt=None, vt_rows=0, tk=0,
+                      post_add=None, eps=1e-5, workspace=None):
+    """The fused layer restated as the per-op sequence it replaces (same buffers, same order)."""
+    CALLS.append("transformer_layer")
+    assert dtype == BF16 and t == 64 and x.shape == (b * t, 768) and relu_slope.shape == (ffn,) and not relu_slope.any()
+    m, d = x.shape
+    hd = d // heads
+    new = lambda n: torch.empty(m, n, dtype=TD[dtype])
+    lin = lambda a, e, **kw: gemm(dtype, a, e["w"], e["b"], n=e["n"], cp=e["cp"], **kw)
+    ln = lambda s, e, add=None: (lambda y: (layernorm(dtype, s, e["g"], e["b"], eps, add, None, y), y)[1])(new(d))
+    qk, vt, att, s = new(2 * d), torch.empty(b, d, t, dtype=TD[dtype]), new(d), new(d)
+    lin(x, weights[0], out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
+    attention(dtype, qk[:, :d], qk[:, d:], vt, d, att, b, heads, t, t, hd)
+    lin(att, weights[1], res=x, out=s)
+    x1 = ln(s, norms[0])
+    if mem_k is not None:
+        q = new(d)
+        lin(x1, weights[2], out=q)
+        attention(dtype, q, mem_k, mem_vt, vt_rows, att, b, heads, t, tk, hd)
+        lin(att, weights[3], res=x1, out=s)
+        x1 = ln(s, norms[1])
+    f = new(ffn)
+    lin(x1, weights[4], slope=relu_slope, out=f)
+    lin(f, weights[5], res=x1, out=s)
+    return ln(s, norms[2], post_add), None
+
+
 def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
     CALLS.append("add")
     m = a.shape[0]
@@ -201,7 +228,7 @@ def axis_angle_to_rot6d(x):
     return orc.axis_angle_to_rotation_6d(x)
 
 
-_NAMES = ["gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["gemm", "attention", "layernorm", "transformer_layer", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

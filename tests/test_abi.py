@@ -12,7 +12,7 @@ def _declared():
     text = open(os.path.join(ROOT, "include", "emage_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(?:int|const char\*)\s+(emage_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"(?:int|size_t|const char\*)\s+(emage_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         protos[m.group(1)] = args
     return protos
@@ -39,3 +39,7 @@ def test_argument_validation_without_gpu():
     assert lib.emage_gemm(1, None, 0, None, None, None, None, 0, 0, 0, None, 0, 0, None, 0, None, 0, 0, 0,
                           0, 0, 0, 0, 0, 0, 0, 0, None) == -1
     assert lib.emage_set_tuning(99, 0) == -1
+    assert lib.emage_transformer_layer(1, None, 0, None, None, None, None, 1e-5, None, 0, None, 0, 0, 0, None, 0, None,
+                                       None, 0, None, 0, 0, 64, 768, 4, 1536, None) == -1
+    assert lib.emage_transformer_layer_workspace(0) == 0 and lib.emage_transformer_layer_workspace(64) > 64 * 64 * 768 * 2 * 7
+    assert lib.emage_layer_set_tuning(0, 7) == -1 and lib.emage_layer_set_tuning(0, 3) == 0

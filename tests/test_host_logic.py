@@ -41,11 +41,16 @@ def test_forward_window_bf16_host_logic():
     omodel, _ = common.oracle_models()
     audio, spk, motion, mask = common.window_inputs(1)
     with fake_ops.installed(), torch.no_grad():
+        model.fused_layers = True
         out = model.forward(audio, spk, motion, mask)
         ref = omodel.forward(audio, spk, motion, mask)
+        assert fake_ops.CALLS.count("transformer_layer") == 16      # 4 face + 1 self + 8 cross + 3 refinement layers
+        model.fused_layers = False
+        out_ops = model.forward(audio, spk, motion, mask)
     for k in orc.OUT_KEYS:
         rel = float((out[k] - ref[k]).norm() / ref[k].norm())
         assert rel < 0.05, (k, rel)
+        assert torch.equal(out[k], out_ops[k]), k                    # one launch per layer == the per-op sequence
 
 
 @pytest.mark.parametrize("frames,batch", [(128, 2), (70, 1), (129, 1)])
