@@ -195,8 +195,8 @@ int emage_velocity_to_position(const float* vel, int ldv, int col0, const float*
  *   relu_slope: 1536 zeros (the per-column LeakyReLU slope vector of the FFN up-projection)
  *   workspace: emage_transformer_layer_workspace(B) bytes, 256-byte aligned, private to this call until it completes
  *   out:      (B*64, ldo)
- * emage_transformer_layer_status (diagnostics, synchronous): nonzero when a group barrier of the last run on that
- * workspace gave up waiting.  emage_layer_set_tuning: key 0 = operand-ring depth of the fused kernel (2..4), key 1 =
+ * emage_transformer_layer_status (diagnostics, synchronous) for the last run on that workspace: bit 0 = a group barrier
+ * gave up waiting, bit 1 = the four workgroups of a clip were not placed on one XCD (results then not trustworthy).  emage_layer_set_tuning: key 0 = operand-ring depth of the fused kernel (2..4), key 1 =
  * ablation mask for tools/bench_layer.py (timing only).
  */
 size_t emage_transformer_layer_workspace(int B);

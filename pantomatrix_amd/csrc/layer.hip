@@ -44,7 +44,7 @@ struct LayerArgs {
     AttnArgs attn[2];      // self, cross
     LnArgs ln[3];
     Step steps[MAX_STEPS];
-    unsigned* sync;        // [B] arrive counters (zeroed by the launcher) + [1] error word
+    unsigned* sync;        // zeroed by the launcher: [B] arrive counters, [1] error word, [B] per-clip XCD masks
     int B, n_steps, dbg;   // dbg (tools/bench_layer.py ablations): 1 no spin, 2 no fences, 4 no tiles, 8 no attention, 16 no LayerNorm, 32/64 agent-scope fences
     float eps;
 };
@@ -65,6 +65,11 @@ __device__ __forceinline__ unsigned l2_atomic_add(unsigned* p, unsigned v) {
     return r;
 }
 
+// device-scope OR returning the old value (performed at the memory side: valid whichever XCDs the callers are on)
+__device__ __forceinline__ unsigned l2_atomic_or_agent(unsigned* p, unsigned v) {
+    return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Group barrier between the 4 workgroups of a clip.  They run on one XCD, so their L2 is shared and coherent: the
 // release side only has to drain this wave's stores to L2 (the vector L1 is write-through), the acquire side only has
 // to drop the CU's L1 (buffer_inv sc0) — no L2 write-back / invalidate (an agent-scope fence pair costs ~20 us here:
@@ -80,7 +85,7 @@ __device__ __forceinline__ void group_barrier(unsigned* ctr, unsigned target, un
         while (seen < target) {
             __builtin_amdgcn_s_sleep(1);
             seen = l2_atomic_add(ctr, 0u);
-            if (++spins > SPIN_LIMIT) { l2_atomic_add(err, 1u); break; }
+            if (++spins > SPIN_LIMIT) { l2_atomic_or_agent(err, 1u); break; }
         }
     }
     __syncthreads();
@@ -100,6 +105,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void transformer_layer_kernel(LayerArg
     unsigned* err = a.sync + a.B;
     unsigned arrived = 0;
     const int m0 = g * BM;
+    // The light barrier below is only coherent inside one XCD: every member publishes the XCD it runs on (XCC_ID, hwreg 20)
+    // and the first barrier checks that the clip's four agree; a mismatch raises bit 1 of the error word.
+    unsigned* xmask = a.sync + a.B + 1 + g;
+    if (threadIdx.x == 0) l2_atomic_or_agent(xmask, 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u));
+    bool placement_checked = false;
     const int wave = (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     for (int i = 0; i < a.n_steps; ++i) {
         const Step st = a.steps[i];
@@ -122,7 +132,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void transformer_layer_kernel(LayerArg
                                                nullptr, (T*)n.y + (row0 + r) * n.ldy, D, lane);
             }
         }
-        if (st.sync_after) { arrived += NH; group_barrier(ctr, arrived, err, a.dbg); }
+        if (st.sync_after) {
+            arrived += NH;
+            group_barrier(ctr, arrived, err, a.dbg);
+            if (!placement_checked) {
+                placement_checked = true;
+                if (threadIdx.x == 0) {
+                    const unsigned m = l2_atomic_or_agent(xmask, 0u);
+                    if (m & (m - 1)) l2_atomic_or_agent(err, 2u);
+                }
+            }
+        }
     }
 }
 
@@ -146,8 +166,8 @@ GemmArgs linear_args(const void* A, int lda, const void* W, const float* bias, c
 extern "C" size_t emage_transformer_layer_workspace(int B) {
     if (B <= 0) return 0;
     const size_t M = (size_t)B * TW;
-    // qk (M x 2D) | vt (B x D x TW) | att | s | x1 | x2 (M x D each) | f (M x FF), bf16; then B + 1 sync words
-    return (M * (2 * D + D + 4 * D + FF)) * 2 + ((size_t)B + 1) * 4 + 256;
+    // qk (M x 2D) | vt (B x D x TW) | att | s | x1 | x2 (M x D each) | f (M x FF), bf16; then 2B + 1 sync words
+    return (M * (2 * D + D + 4 * D + FF)) * 2 + (2 * (size_t)B + 1) * 4 + 256;
 }
 
 extern "C" int emage_transformer_layer(int dtype, const void* x, int ldx,
@@ -218,7 +238,7 @@ extern "C" int emage_transformer_layer(int dtype, const void* x, int ldx,
     a.n_steps = ns;
 
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync, 0, ((size_t)B + 1) * 4, st) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(sync, 0, (2 * (size_t)B + 1) * 4, st) != hipSuccess) return (int)hipGetLastError();
     const int grid = ((B + 7) / 8) * 32;
     if (g_ring == 2) hipLaunchKernelGGL((transformer_layer_kernel<2>), dim3(grid), dim3(NTHREADS), 0, st, a);
     else if (g_ring == 4) hipLaunchKernelGGL((transformer_layer_kernel<4>), dim3(grid), dim3(NTHREADS), 0, st, a);
@@ -226,7 +246,8 @@ extern "C" int emage_transformer_layer(int dtype, const void* x, int ldx,
     return launch_status();
 }
 
-// error word of the last layer run on this workspace: nonzero = a group barrier gave up (tests / diagnostics; synchronises)
+// error word of the last layer run on this workspace (tests / diagnostics; synchronises): bit 0 = a group barrier gave up
+// waiting, bit 1 = the four workgroups of some clip were not on one XCD (the light barrier is then not coherent)
 extern "C" int emage_transformer_layer_status(const void* workspace, int B) {
     const size_t M = (size_t)B * TW;
     const uintptr_t end = (uintptr_t)workspace + (M * (2 * D + D + 4 * D + FF)) * 2;
