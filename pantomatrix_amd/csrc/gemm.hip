@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
     gemm_epilogue<T, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg);
 }
 template <typename T, int BM, int BN, int WM, int WN, int NS, int KC>
-__global__ __launch_bounds__(NTHREADS, (lds_blocks<BM, BN, NS, KC>())) void gemm_pipe_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? lds_blocks<BM, BN, NS, KC>() : 1)) void gemm_pipe_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[pipe_smem_bytes<T, BM, BN, NS, KC>()];
     // Persistent form: a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8 or
     // the whole tile count, so a block's tiles stay on one XCD).  With grid == tile count this is the plain
@@ -220,7 +220,7 @@ int launch_pipe(GemmArgs& a, hipStream_t s) {
     static const int env_persist = [] { const char* e = getenv("EMAGE_GEMM_PERSIST"); return e ? atoi(e) : -1; }();
     const int per_cu = env_persist >= 0 ? env_persist : g_persist_per_cu;
     if (per_cu > 0 && grid > per_cu * 256) grid = per_cu * 256;   // 256 CUs; a multiple of the 8 XCDs
-    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS, KC>), dim3(grid), dim3(NTHREADS), 0, s, a);
+    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS, KC>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
     return launch_status();
 }
 
@@ -253,6 +253,12 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 29: return launch_pipe<T, 64, 192, 2, 2, 3, 8>(a, s);
         case 30: return launch_pipe<T, 128, 128, 2, 2, 4, 8>(a, s);   // 128 KiB ring: 96 KiB of operands in flight per CU
         case 31: return launch_pipe<T, 128, 256, 2, 2, 3, 4>(a, s);
+        case 32: return launch_pipe<T, 64, 192, 4, 2, 3, 8>(a, s);    // 8 waves (two per SIMD): a lone block per CU hides its own latencies
+        case 33: return launch_pipe<T, 64, 192, 4, 2, 2, 8>(a, s);
+        case 34: return launch_pipe<T, 128, 128, 4, 2, 2, 8>(a, s);
+        case 35: return launch_pipe<T, 128, 128, 4, 2, 3, 4>(a, s);
+        case 36: return launch_pipe<T, 128, 64, 4, 2, 3, 8>(a, s);
+        case 37: return launch_pipe<T, 128, 192, 4, 2, 2, 8>(a, s);
         default: return EMAGE_EINVAL;
     }
 }
@@ -270,10 +276,18 @@ int dispatch(GemmArgs& a, hipStream_t s) {
     if (profile == 1 && ncols >= 512 && a.M >= 2048) return run_config<T>(18, a, s);
     if (profile == 2 && a.taps == 1 && ncols >= 768 && ncols <= 2304 && a.M >= 2048) return run_config<T>(18, a, s);
     if (profile == 3 && a.taps == 1 && ncols >= 768 && ncols <= 2304 && a.M >= 2048 && !a.out_t) return run_config<T>(18, a, s);
-    // measured on MI355X (tools/bench_gemm.py): with M = 4096 the operand stream, not MFMA, bounds these
-    // launches, and many small resident blocks (64x64, 5 per CU) beat large tiles except on very wide outputs
-    if (ncols > 64 && t128 >= 512) return run_config<T>(26, a, s);      // wide outputs (QKV, batched K/V projections)
-    if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T>(27, a, s);   // FFN up-projection: exactly 2 blocks per CU
+    // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_sweep_8wave.txt): with M = 4096 the operand stream, not
+    // MFMA, bounds these launches.  Many small resident blocks (64x64, 5 per CU) win on narrow outputs; everywhere else
+    // 8-wave blocks (two waves per SIMD hide a block's own DMA / epilogue latency) beat the 4-wave tiles of the same shape
+    if (profile == 4) {                                                // the pre-8-wave choices, kept for A/B runs
+        if (ncols > 64 && t128 >= 512) return run_config<T>(26, a, s);
+        if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T>(27, a, s);
+        return run_config<T>(25, a, s);
+    }
+    if (a.taps >= 15 && a.M > 8192) return run_config<T>(36, a, s);     // WavEncoder convs on long sequences: 128x64, 8 waves
+    if (ncols > 64 && t128 >= 512) return run_config<T>(34, a, s);      // wide outputs (QKV, batched K/V projections): 128x128, 8 waves
+    if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T>(33, a, s);   // FFN up-projection: exactly 2 blocks per CU
+    if (a.taps == 1 && ncols == 768 && a.M >= 2048) return run_config<T>(32, a, s);   // 768-wide projections: one (clip, head) tile, 8 waves
     return run_config<T>(25, a, s);
 }
 

@@ -69,13 +69,13 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
     *(uint4*)p = t;
 }
 
-template <typename T, int BM, int BN, int CLD>
+template <typename T, int BM, int BN, int CLD, int NT = NTHREADS>
 __device__ __forceinline__ void transposed_store(const GemmArgs& p, const float* Cs, int m0, int n0, int tid) {
     T* __restrict__ out_t = (T*)p.out_t;
     const int t_ncols = p.N - p.t_col0;
     constexpr int RG = BM / 4;                          // 4-row groups per column
     const bool tvec = (p.t_rows % 4 == 0) && (p.t_ld % 4 == 0) && (((uintptr_t)out_t & 15) == 0);
-    for (int gid = tid; gid < BN * RG; gid += NTHREADS) {
+    for (int gid = tid; gid < BN * RG; gid += NT) {
         const int col = gid / RG, rg = gid - col * RG;
         const int n = n0 + col, m = m0 + rg * 4;
         if (n < p.t_col0 || n >= p.N || m >= p.M) continue;
@@ -173,7 +173,7 @@ constexpr int pipe_smem_bytes() {
 }
 
 // One BM x BN output tile at (m0, n0): operand ring, K-loop and epilogue.  Called by every thread of a 256-thread
-// block; `smem` is the block's LDS (pipe_smem_bytes, 128-byte aligned); ends with a __syncthreads() so the caller
+// (or, with WM * WN = 8, 512-thread) block; `smem` is the block's LDS (pipe_smem_bytes, 128-byte aligned); ends with a __syncthreads() so the caller
 // may start the next tile (or any other use of the LDS) right away.
 // FPRE: fetch the epilogue operands (bias, slope, residual) ahead of the K-loop whatever the tile size (the fused
 // layer kernel has the registers; a lone block per CU cannot hide their latency behind another block).
@@ -186,11 +186,12 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     constexpr int FM = WTM / 16, FN = WTN / 16;
     constexpr int RB = KC * 16;                      // bytes per tile row
     constexpr int RPI = 1024 / RB;                   // rows filled by one 1-KiB DMA wave-instruction
-    constexpr int GA = BM / (4 * RPI), GB = BN / (4 * RPI);   // DMA instructions per wave per tile
+    constexpr int NW = WM * WN;                     // waves per block (4, or 8 = two per SIMD)
+    constexpr int GA = BM / (NW * RPI), GB = BN / (NW * RPI);   // DMA instructions per wave per tile
     constexpr int G = GA + GB;
     constexpr int STAGE = (BM + BN) * RB;            // bytes per ring slot: A rows then W rows
     constexpr int NKG = KC / 4;                      // MFMA k-groups per tile
-    static_assert(WM * WN == 4 && BM % (4 * RPI) == 0 && BN % (4 * RPI) == 0, "tile shape");
+    static_assert((NW == 4 || NW == 8) && BM % (NW * RPI) == 0 && BN % (NW * RPI) == 0, "tile shape");
     static_assert(FN % 2 == 0, "fragments pair up along N");
     constexpr int FP = FN / 2;                       // fragment pairs = 8-column groups per lane per M fragment
     static_assert(NS >= 2 && NS <= 4 && (KC == 4 || KC == 8), "ring depth / row width");
@@ -223,7 +224,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     unsigned a_voff[GA]; int a_lpos[GA];
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
-        const int row = (wave + 4 * j) * RPI + lrow;
+        const int row = (wave + NW * j) * RPI + lrow;
         const int m = m0 + row;
         const unsigned chunk = (unsigned)((lslot ^ swz<KC>(row)) * 16);
         if (!is_conv) {
@@ -239,7 +240,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     unsigned b_voff[GB];
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
-        const int row = (wave + 4 * j) * RPI + lrow;
+        const int row = (wave + NW * j) * RPI + lrow;
         const int n = n0 + row;
         b_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.K * ES) + (unsigned)((lslot ^ swzW<KC>(row)) * 16) : OOB;
     }
@@ -255,12 +256,12 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
         for (int j = 0; j < GA; ++j) {
             unsigned vo = a_voff[j];
             if (is_conv) vo = (unsigned)(a_lpos[j] + is_tap) < (unsigned)p.Lin ? vo : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(base + (wave + NW * j) * 1024),
                                                      16, (int)vo, (int)soff_a, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < GB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + BM * RB + (wave + 4 * j) * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(base + BM * RB + (wave + NW * j) * 1024),
                                                      16, (int)b_voff[j], (int)soff_w, 0, 0);
         soff_w += BK * ES;
         is_c0 += BK;
@@ -468,7 +469,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                 }
             }
             __syncthreads();
-            transposed_store<T, HB, BN, CLD>(p, Cs, m0 + h * HB, n0, tid);
+            transposed_store<T, HB, BN, CLD, NW * 64>(p, Cs, m0 + h * HB, n0, tid);
         }
     }
     __syncthreads();                              // the next tile re-uses the ring / staging LDS

@@ -233,7 +233,7 @@ def test_bad_arguments_raise():
         ops.vq_argmin(torch.zeros(4, 8), torch.zeros(3, 8))                                 # CPU tensors: no fallback
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 32, 33, 34, 35, 36, 37])
 @pytest.mark.parametrize("dtype", [F32, BF16], ids=["fp32", "bf16"])
 def test_gemm_every_tile_configuration(cfg, dtype):
     """Each tile configuration (register-staged 0-3, LDS-DMA ring 10-19) on the awkward cases."""
