@@ -35,8 +35,8 @@ constexpr int QW = 4;    // query tiles per workgroup: the waves of one (batch, 
 constexpr int DS = 1;    // waves per query tile: with DS = 2 each wave recomputes the 16x64 scores and owns half of the d tiles
                          // of P V (two shorter waves per SIMD).  Measured: 16.0 us vs 13.3 us with DS = 1 — not a win.
 
-// softmax(Q K^T * scale) V for query tile qt (16 queries) of (batch b, head h); one wave64 (wave `dpart` of DS for that tile).
-template <typename T, int HD, int NT>
+// softmax(Q K^T * scale) V for query tile qt (16 queries) of (batch b, head h); one wave64 (wave `dpart` of the DSP that share that tile: each recomputes the scores and owns NDT / DSP of the output d tiles).
+template <typename T, int HD, int NT, int DSP = DS>
 __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const int h, const int qt, const int dpart) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = 16 / EPC;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
 
     // Tk <= 64 (every inference window): everything in flight at once — when it fits the 256 registers a wave gets with
     // two waves per SIMD (fp32 operands are twice as wide: only up to Tk <= 32)
-    constexpr bool PRE = NT <= 4 && (DS == 1 || EPC == 8 || NT <= 2);
+    constexpr bool PRE = NT <= 4 && (DSP == 1 || EPC == 8 || NT <= 2);
     constexpr int KT = PRE ? NT : 1;
     uint4 kf[KT][NSTEP];
     auto load_k = [&](int nt, uint4 (&dst)[NSTEP]) {
@@ -79,8 +79,8 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
     // V^T chunk c of d-tile dt: keys {32c + 4g + r} U {32c + 16 + 4g + r} (bf16) / {16c + 4g + r} (fp32), r = 0..3
     const int voff = ((b * p.vt_rows + h * HD + fr) * p.ldvt + fg * 4) * ES;
     const int vstep = 16 * p.ldvt * ES;
-    static_assert(NDT % DS == 0, "d tiles split evenly over the DS waves");
-    constexpr int NDW = NDT / DS;             // d tiles per wave
+    static_assert(NDT % DSP == 0, "d tiles split evenly over the DSP waves");
+    constexpr int NDW = NDT / DSP;            // d tiles per wave
     constexpr int VT_ = PRE ? NDW : 1;
     uint4 vf[VT_][NPC];
     auto load_v = [&](int dt, uint4 (&dst)[NPC]) {

@@ -40,6 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=64)
     ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--waves", type=int, default=4, help="waves per workgroup for the ablation runs (4 or 8)")
     ap.add_argument("--masks", type=str, default="0,4,8,16,24,256,512,1024,1792")
     args = ap.parse_args()
     model, _ = common.product_models(precision="bf16", device="cuda")
@@ -63,15 +64,18 @@ def main():
     base = timed_graph(chain) / args.reps
     print(f"per-op sequence : {1e3 * base:8.1f} us / decoder layer   (B={b})")
     model.fused_layers = True
-    for ring in (3,):
-        lib.emage_layer_set_tuning(0, ring)
-        ms = timed_graph(chain) / args.reps
-        print(f"fused, ring {ring}   : {1e3 * ms:8.1f} us / decoder layer")
+    for waves in (4, 8):
+        lib.emage_layer_set_tuning(2, waves)
+        for ring in (2, 3):
+            lib.emage_layer_set_tuning(0, ring)
+            ms = timed_graph(chain) / args.reps
+            print(f"fused, {waves} waves, ring {ring}: {1e3 * ms:8.1f} us / decoder layer")
     lib.emage_layer_set_tuning(0, 3)
+    lib.emage_layer_set_tuning(2, args.waves)
     for mask in [int(v) for v in args.masks.split(",")]:
         lib.emage_layer_set_tuning(1, mask)
         ms = timed_graph(chain) / args.reps
-        print(f"fused, ring 3, ablation mask {mask:2d}: {1e3 * ms:8.1f} us / decoder layer")
+        print(f"fused, {args.waves} waves, ring 3, ablation mask {mask:4d}: {1e3 * ms:8.1f} us / decoder layer")
     lib.emage_layer_set_tuning(1, 0)
 
 
