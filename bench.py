@@ -172,8 +172,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sub-batches", type=int, default=1, help="independent clip groups issued on parallel stream lanes")
-    ap.add_argument("--pipeline", type=int, default=1, help="batches in flight (PipelinedRunner depth); 1 = one batch at a time")
-    ap.add_argument("--twin", action="store_true", help="two batches per graph replay on parallel in-graph lanes (TwinBatchRunner)")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B: single stream, no fork/join lanes")
     ap.add_argument("--fused-layers", action="store_true", help="A/B: one launch per transformer layer (emage_transformer_layer)")
@@ -188,7 +186,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from pantomatrix_amd import dist as pdist
-    dist = pdist.init("nccl", dev)      # "nccl" == RCCL on ROCm; barriers / timing only; None without a launcher
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -212,6 +209,9 @@ def main():
     from pantomatrix_amd.runtime import ClipRunner
     log(f"models built on {dev}; capturing the clip graph")
     runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph, sub_batches=args.sub_batches)
+    # the process group (RCCL; barriers and the max-over-ranks of the timing only) is joined AFTER the graph capture, so
+    # no communicator thread is alive while the stream capture is open; None without a launcher
+    pdist.init("nccl", dev)
     log(f"warm-up x{args.warmup}")
     for _ in range(args.warmup):
         poses, _, _ = one_step(runner, audio)
@@ -241,7 +241,7 @@ def main():
                                f"{frames_per_step // args.batch} frames out per clip; synthetic seeded weights",
                    "clips_per_gpu": args.batch, "frames_in": args.frames, "frames_out_per_clip": frames_per_step // args.batch,
                    "parallelism": f"replicas x{world} (clip-sharded, no collective)",
-                   "launch": "eager" if args.no_graph else "hipGraph replay", "sub_batches": args.sub_batches, "batches_in_flight": args.pipeline},
+                   "launch": "eager" if args.no_graph else "hipGraph replay", "sub_batches": args.sub_batches, "batches_in_flight": 1},
     }
     if rank == 0 and not args.no_roofline:
         fam = profile_kernels(model, vq, audio, spk, zeros_trans)

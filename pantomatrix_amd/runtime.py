@@ -45,7 +45,7 @@ class ClipRunner:
         torch.cuda.synchronize(dev)
         if use_graph:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (an RCCL watchdog) may touch the runtime meanwhile
                 out = self._step()
         self.out = out
         self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)
@@ -179,7 +179,7 @@ class TwinBatchRunner:
                 out = step()
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (an RCCL watchdog) may touch the runtime meanwhile
                 out = step()
         finally:
             for p, c in zip(parts, saved):
