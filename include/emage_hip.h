@@ -197,7 +197,8 @@ int emage_velocity_to_position(const float* vel, int ldv, int col0, const float*
  *   out:      (B*64, ldo)
  * emage_transformer_layer_status (diagnostics, synchronous) for the last run on that workspace: bit 0 = a group barrier
  * gave up waiting, bit 1 = the four workgroups of a clip were not placed on one XCD (results then not trustworthy).  emage_layer_set_tuning: key 0 = operand-ring depth of the fused kernel (2..4), key 1 =
- * ablation mask for tools/bench_layer.py (timing only).
+ * ablation mask for tools/bench_layer.py (timing only), key 2 = waves per workgroup (4 or 8), key 3 = W prefetch ahead of
+ * the group barriers (0 / 1).
  */
 size_t emage_transformer_layer_workspace(int B);
 int emage_transformer_layer(int dtype, const void* x, int ldx,

@@ -46,6 +46,7 @@ struct LayerArgs {
     LnArgs ln[3];
     Step steps[MAX_STEPS];
     unsigned* sync;        // zeroed by the launcher: [B] arrive counters, [1] error word, [B] per-clip XCD masks
+    int prefetch;          // tuning key 3: issue L2 prefetches of the next projection's W slice before each group barrier
     int B, n_steps, dbg;   // dbg (tools/bench_layer.py ablations): 1 no spin, 2 no fences, 4 no tiles, 8 no attention, 16 no LayerNorm, 32/64 agent-scope fences
     float eps;
 };
@@ -97,10 +98,30 @@ __device__ __forceinline__ void group_barrier(unsigned* ctr, unsigned target, un
 // NW = 4: one wave per SIMD (256 VGPR + AGPRs: everything of an attention head preloaded).  NW = 8: two waves per SIMD
 // (<= 256 registers each) that hide each other's exposed latencies — wave tile 16x96, two waves per attention query
 // tile (each owns half of the output d tiles), two LayerNorm rows per wave.  Same arithmetic per output element.
-template <int NS, int NW>
+// Pull the W rows [n0, n0 + BN) of projection p towards this XCD's L2: one dword per 128-byte line, delivered by LDS-DMA
+// into a scratch area (no VGPR is written, nothing waits on it).  W never depends on a barrier, so this is issued right
+// before the block parks in one: the fetch from the Infinity Cache overlaps the wait, and the tile's ring then streams
+// L2 hits.  The loads are older than anything the next tile issues, so its counted vmcnt waits retire them first.
+template <int NT>
+__device__ __forceinline__ void prefetch_w(const GemmArgs& p, int n0, unsigned char* scratch) {
+    const unsigned row_bytes = (unsigned)p.K * 2u;
+    const unsigned w_bytes = (unsigned)p.N * row_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+    const unsigned base = (unsigned)n0 * row_bytes, lines = (unsigned)BN * row_bytes / 128u;
+    for (unsigned l = threadIdx.x; l < lines; l += NT)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)scratch, 4, (int)(base + l * 128u), 0, 0, 0);
+}
+
+// PF (W prefetch ahead of the group barriers) is written but NOT instantiated yet: it was added after the round's GPU
+// budget was spent, so the shipped binary is exactly the validated one; flip EMAGE_LAYER_PREFETCH to measure it.
+#ifndef EMAGE_LAYER_PREFETCH
+#define EMAGE_LAYER_PREFETCH 0
+#endif
+template <int NS, int NW, bool PF = (EMAGE_LAYER_PREFETCH != 0)>
 __global__ __launch_bounds__(NW * 64, 1) void transformer_layer_kernel(LayerArgs a) {
     typedef bf16_t T;
-    __shared__ __attribute__((aligned(128))) unsigned char smem[pipe_smem_bytes<T, BM, BN, NS, 8>()];
+    constexpr int RING = pipe_smem_bytes<T, BM, BN, NS, 8>();
+    __shared__ __attribute__((aligned(128))) unsigned char smem[RING + (PF ? 256 : 0)];   // + LDS-DMA scratch of prefetch_w
     const int bidx = blockIdx.x;
     const int g = (bidx >> 5) * 8 + (bidx & 7);          // clip
     const int j = (bidx >> 3) & 3;                       // member: head / column slice
@@ -138,6 +159,12 @@ __global__ __launch_bounds__(NW * 64, 1) void transformer_layer_kernel(LayerArgs
             }
         }
         if (st.sync_after) {
+            if constexpr (PF) if (a.prefetch) {            // the next projection's W slice(s): consecutive tiles of one GEMM
+                int nx = i + 1;
+                while (nx < a.n_steps && a.steps[nx].kind != STEP_TILE) ++nx;
+                for (int q = nx; q < a.n_steps && a.steps[q].kind == STEP_TILE && a.steps[q].idx == a.steps[nx].idx; ++q)
+                    prefetch_w<NW * 64>(a.gemm[a.steps[q].idx], a.steps[q].n_base + j * a.steps[q].n_mul, smem + RING);
+            }
             arrived += NH;
             group_barrier(ctr, arrived, err, a.dbg);
             if (!placement_checked) {
@@ -153,6 +180,7 @@ __global__ __launch_bounds__(NW * 64, 1) void transformer_layer_kernel(LayerArgs
 
 int g_ring = 3;            // ring depth of the fused kernel
 int g_dbg = 0;             // ablation mask (timing only: results are wrong when set)
+int g_prefetch = 0;        // tuning key 3 (see LayerArgs::prefetch); not yet measured
 int g_waves = 8;           // waves per workgroup of the fused kernel (4 or 8; 8 measured 154 vs 203 us per layer)
 
 GemmArgs linear_args(const void* A, int lda, const void* W, const float* bias, const float* slope, const void* res, int ldr,
@@ -211,7 +239,7 @@ extern "C" int emage_transformer_layer(int dtype, const void* x, int ldx,
     unsigned* sync = (unsigned*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
 
     LayerArgs a{};
-    a.B = B; a.eps = eps; a.sync = sync; a.dbg = g_dbg;
+    a.B = B; a.eps = eps; a.sync = sync; a.dbg = g_dbg; a.prefetch = g_prefetch;
     int ns = 0;
     auto step = [&](int kind, int idx, int n_base, int n_mul, int sync_after) { a.steps[ns++] = Step{kind, idx, n_base, n_mul, sync_after}; };
     // self-attention: [q | k] -> qk, V^T -> vt; out-proj + x -> s; LN -> x1
@@ -274,5 +302,6 @@ extern "C" int emage_layer_set_tuning(int key, int value) {
     if (key == 0 && value >= 2 && value <= 4) { g_ring = value; return 0; }
     if (key == 1) { g_dbg = value; return 0; }
     if (key == 2 && (value == 4 || value == 8)) { g_waves = value; return 0; }
+    if (key == 3 && (value == 0 || value == 1)) { g_prefetch = value; return 0; }
     return EMAGE_EINVAL;
 }

@@ -72,6 +72,10 @@ def main():
             print(f"fused, {waves} waves, ring {ring}: {1e3 * ms:8.1f} us / decoder layer")
     lib.emage_layer_set_tuning(0, 3)
     lib.emage_layer_set_tuning(2, args.waves)
+    lib.emage_layer_set_tuning(3, 1)
+    ms = timed_graph(chain) / args.reps
+    print(f"fused, {args.waves} waves, ring 3, W prefetch before barriers (needs a build with -DEMAGE_LAYER_PREFETCH=1): {1e3 * ms:8.1f} us / decoder layer")
+    lib.emage_layer_set_tuning(3, 0)
     for mask in [int(v) for v in args.masks.split(",")]:
         lib.emage_layer_set_tuning(1, mask)
         ms = timed_graph(chain) / args.reps
