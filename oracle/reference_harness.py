@@ -95,3 +95,17 @@ def reference_train_step(model, vq, model_cfg: dict, batch: dict, iteration: int
                                  lr_scheduler=sched, ClsFn=torch.nn.NLLLoss(), iteration=iteration)
     grads = {k: prm.grad.detach().clone() for k, prm in model.named_parameters() if prm.grad is not None}
     return {k: float(v.detach()) for k, v in losses.items()}, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def build_reference_lstm_model(kind: str, cfg: dict, state_dict):
+    """Instantiate the reference's DiscoAudioModel / CamnAudioModel (kind "disco" / "camn") with the given weights."""
+    import importlib
+    import_reference()
+    mod = importlib.import_module(f"models.{kind}_audio")
+    cls_cfg = getattr(mod, "DiscoAudioConfig" if kind == "disco" else "CamnAudioConfig")
+    cls = getattr(mod, "DiscoAudioModel" if kind == "disco" else "CamnAudioModel")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = cls(cls_cfg(**cfg))
+    model.load_state_dict(state_dict, strict=True)
+    return model.eval()
