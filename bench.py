@@ -168,7 +168,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU per step (BASELINE config 2: 64)")
     ap.add_argument("--frames", type=int, default=128)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp32"],
+                    help="f16x3 (default): fp32 storage, split-f16 MFMA — the parity-green fast mode; bf16: bf16 operands "
+                         "(not index-exact); fp32: exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sub-batches", type=int, default=1, help="independent clip groups issued on parallel stream lanes")

@@ -16,8 +16,13 @@
  *   - `dtype` selects the storage/MFMA operand type of activations and weights:
  *       EMAGE_F32  : float32 operands, v_mfma_f32_16x16x4_f32  (exact fp32, parity mode)
  *       EMAGE_BF16 : bfloat16 operands, v_mfma_f32_16x16x32_bf16, fp32 accumulate
+ *       EMAGE_F16X3: (emage_gemm only) float32 activations, weights pre-split into two fp16 planes; every
+ *                    product runs as three v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate):
+ *                    ~22 mantissa bits per product, i.e. fp32-grade results at 1/3 of the fp16 MFMA rate
+ *                    instead of the 1/16 of the fp32 MFMA.  Every other entry point takes EMAGE_F32 tensors
+ *                    in this mode (the storage type IS float32).
  *     accumulators, biases, LayerNorm statistics, softmax and every index are fp32 / int64 in
- *     both modes.
+ *     all modes.
  */
 #ifndef EMAGE_HIP_H
 #define EMAGE_HIP_H
@@ -32,6 +37,7 @@ extern "C" {
 
 #define EMAGE_F32 0
 #define EMAGE_BF16 1
+#define EMAGE_F16X3 2
 
 #define EMAGE_EINVAL (-1)   /* unsupported size / alignment / null pointer */
 
@@ -42,11 +48,8 @@ const char* emage_target_arch(void);
 /*
  * Tuning hook for tests and tools (never needed for correctness; process-global, not thread-safe):
  *   key 0: force emage_gemm's tile configuration id (-1 restores the heuristic);
- *   key 1: diagnostic ablation mask for tools/bench_gemm.py --ablate (1 no operand DMA, 2 no MFMA, 4 no epilogue);
- *   key 2: cap the pipelined GEMM grid at `value` blocks per CU, blocks walk tiles persistently (0 = off;
- *          environment EMAGE_GEMM_PERSIST overrides);
- *   key 3: tile heuristic profile (0 default; 1-3 = 128x128-tile experiments; EMAGE_GEMM_PROFILE overrides).
- * Returns EMAGE_EINVAL for unknown keys.
+ *   key 1: diagnostic ablation mask for tools/bench_gemm.py --ablate (1 no operand DMA, 2 no MFMA, 4 no epilogue).
+ * The product path never calls it.  Returns EMAGE_EINVAL for unknown keys.
  */
 int emage_set_tuning(int key, int value);
 
@@ -95,13 +98,18 @@ int emage_gather_rows(const float* table, const int64_t* idx, void* out, int ldo
  *        tails finite for the next contraction).   out_f32: (M, ldf) fp32 or NULL.
  * out_t: transposed destination or NULL: columns n >= t_col0 go to out_t[(b*(N-t_col0) + n-t_col0)*t_ld + l]
  *        instead of `out` (b = m / t_rows, l = m % t_rows) — used to emit V^T for emage_attention.
+ * EMAGE_F16X3: A / res / out / out_t are float32; W is the host-packed split image of (W * w_scale): per row and per
+ *        32-k tile 128 bytes = [4 hi chunks | 4 lo chunks], chunk g = 8 fp16 for k = 4g..4g+3, 16+4g..16+4g+3 of the
+ *        tile (hi = rne_f16(w*w_scale), lo = rne_f16(w*w_scale - hi)); A is multiplied by a_scale before its own
+ *        split and the accumulators by 1/(a_scale*w_scale) after the K-loop — both scales are powers of two chosen so
+ *        that the fp16 planes stay in the normal range (|A*a_scale| must stay below 65504).  Other dtypes ignore them.
  */
 int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
                const void* res, int ldr, int res_is_f32, int res_first,
                void* out, int ldo, int n_store, float* out_f32, int ldf,
                void* out_t, int t_col0, int t_rows, int t_ld,
                int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
-               void* stream);
+               float a_scale, float w_scale, void* stream);
 
 /*
  * K1 first layer — WavEncoder block 0 on the raw waveform (Cin = 1), P:301 + P:283-290:

@@ -8,8 +8,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 
-F32, BF16 = 0, 1
-ABI_VERSION = 3
+F32, BF16, F16X3 = 0, 1, 2
+ABI_VERSION = 4
 
 _p, _i, _f = C.c_void_p, C.c_int, C.c_float
 
@@ -20,7 +20,7 @@ SIGNATURES = {
     "emage_argmax_logsoftmax_f32": [_p, _i, _p, _i, _i, _p],
     "emage_gather_rows": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_gemm": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i,
-                   _i, _i, _i, _i, _i, _i, _i, _i, _p],
+                   _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p],
     "emage_wav_conv_in": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "emage_attention": [_i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],

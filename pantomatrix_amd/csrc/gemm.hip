@@ -13,10 +13,9 @@ namespace {
 
 using namespace emage_dev;
 
-int g_force_config = -1;   // tuning knob (tests / tools): -1 = heuristic, else a fixed configuration id
-int g_debug_skip = 0;
-int g_persist_per_cu = 0;
-int g_profile = 0;         // heuristic profile: 0 = one batch at a time (small tiles), 1 = several independent chains in flight (128x128 tiles)  // tuning: >0 caps the pipelined kernel's grid at this many blocks per CU; blocks then loop over tiles      // diagnostics (tools/bench_gemm.py --ablate): 1 = no operand DMA, 2 = no LDS reads/MFMA, 4 = no epilogue
+// test / tool hooks (emage_set_tuning; never touched by the product path): process-global, not thread-safe
+int g_force_config = -1;   // -1 = heuristic, else a fixed tile configuration id
+int g_debug_skip = 0;      // tools/bench_gemm.py --ablate: 1 = no operand DMA, 2 = no LDS reads / MFMA, 4 = no epilogue
 
 // epilogue shared by both kernels: lane holds rows (lane>>4)*4 + r, column lane&15 of each 16x16 fragment
 template <typename T, int FM, int FN>
@@ -184,22 +183,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
 
     gemm_epilogue<T, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg);
 }
-template <typename T, int BM, int BN, int WM, int WN, int NS, int KC>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool X3>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? lds_blocks<BM, BN, NS, KC>() : 1)) void gemm_pipe_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[pipe_smem_bytes<T, BM, BN, NS, KC>()];
-    // Persistent form: a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8 or
-    // the whole tile count, so a block's tiles stay on one XCD).  With grid == tile count this is the plain
-    // one-tile-per-block launch.
+    // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so each XCD walks a contiguous run of
+    // tiles (neighbouring tiles share A rows / W columns in that XCD's L2)
     const int nblk = p.tiles_m * p.tiles_n;
-    for (int tile = blockIdx.x; tile < nblk; tile += gridDim.x) {
-        int bid = tile;
-        {
-            const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        }
-        const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-        gemm_pipe_tile<T, BM, BN, WM, WN, NS, KC>(p, tile_m * BM, tile_n * BN, smem);
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    gemm_pipe_tile<T, BM, BN, WM, WN, NS, KC, false, X3>(p, tile_m * BM, tile_n * BN, smem);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -211,84 +207,50 @@ int launch(GemmArgs& a, hipStream_t s) {
     return launch_status();
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, int KC = 8>
+template <typename T, bool X3, int BM, int BN, int WM, int WN, int NS, int KC = 8>
 int launch_pipe(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M + BM - 1) / BM;
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     a.tiles_n = (ncols + BN - 1) / BN;
-    int grid = a.tiles_m * a.tiles_n;
-    static const int env_persist = [] { const char* e = getenv("EMAGE_GEMM_PERSIST"); return e ? atoi(e) : -1; }();
-    const int per_cu = env_persist >= 0 ? env_persist : g_persist_per_cu;
-    if (per_cu > 0 && grid > per_cu * 256) grid = per_cu * 256;   // 256 CUs; a multiple of the 8 XCDs
-    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS, KC>), dim3(grid), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS, KC, X3>), dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), 0, s, a);
     return launch_status();
 }
 
-template <typename T>
+// Tile configurations.  0 / 3: register-staged kernels (the independent implementation tools/bench_gemm.py validates
+// the ring kernels against).  The rest are LDS-DMA ring kernels; 25, 32, 33, 34, 36 are what the heuristic selects,
+// 18 / 27 / 37 are kept for tools/bench_gemm.py sweeps.
+template <typename T, bool X3>
 int run_config(int cfg, GemmArgs& a, hipStream_t s) {
+    if constexpr (!X3) {
+        if (cfg == 0) return launch<T, 128, 128, 2, 2>(a, s);
+        if (cfg == 3) return launch<T, 64, 64, 2, 2>(a, s);
+    }
     switch (cfg) {
-        case 0: return launch<T, 128, 128, 2, 2>(a, s);          // register-staged, 2 LDS buffers
-        case 1: return launch<T, 64, 128, 1, 4>(a, s);
-        case 2: return launch<T, 128, 64, 4, 1>(a, s);
-        case 3: return launch<T, 64, 64, 2, 2>(a, s);
-        case 10: return launch_pipe<T, 128, 128, 2, 2, 3>(a, s);  // LDS-DMA ring
-        case 11: return launch_pipe<T, 64, 128, 2, 2, 3>(a, s);
-        case 12: return launch_pipe<T, 64, 128, 2, 2, 4>(a, s);
-        case 13: return launch_pipe<T, 128, 64, 2, 2, 3>(a, s);
-        case 14: return launch_pipe<T, 128, 64, 4, 1, 4>(a, s);
-        case 15: return launch_pipe<T, 64, 64, 2, 2, 4>(a, s);
-        case 16: return launch_pipe<T, 256, 64, 4, 1, 3>(a, s);
-        case 17: return launch_pipe<T, 64, 128, 1, 4, 3>(a, s);
-        case 18: return launch_pipe<T, 128, 128, 2, 2, 2>(a, s);
-        case 19: return launch_pipe<T, 64, 64, 2, 2, 3>(a, s);
-        case 20: return launch_pipe<T, 128, 128, 2, 2, 3, 4>(a, s);   // 64-B rows (K-tile of 4 chunks): 3 blocks/CU
-        case 21: return launch_pipe<T, 128, 128, 2, 2, 4, 4>(a, s);
-        case 22: return launch_pipe<T, 64, 128, 2, 2, 4, 4>(a, s);
-        case 23: return launch_pipe<T, 128, 64, 2, 2, 4, 4>(a, s);
-        case 24: return launch_pipe<T, 64, 64, 2, 2, 4, 4>(a, s);
-        case 25: return launch_pipe<T, 64, 64, 2, 2, 2>(a, s);
-        case 26: return launch_pipe<T, 128, 128, 2, 2, 2, 4>(a, s);
-        case 27: return launch_pipe<T, 64, 192, 2, 2, 2, 8>(a, s);    // one (clip, head) per block at T = 64, hd = 192
-        case 28: return launch_pipe<T, 64, 192, 2, 2, 3, 4>(a, s);
-        case 29: return launch_pipe<T, 64, 192, 2, 2, 3, 8>(a, s);
-        case 30: return launch_pipe<T, 128, 128, 2, 2, 4, 8>(a, s);   // 128 KiB ring: 96 KiB of operands in flight per CU
-        case 31: return launch_pipe<T, 128, 256, 2, 2, 3, 4>(a, s);
-        case 32: return launch_pipe<T, 64, 192, 4, 2, 3, 8>(a, s);    // 8 waves (two per SIMD): a lone block per CU hides its own latencies
-        case 33: return launch_pipe<T, 64, 192, 4, 2, 2, 8>(a, s);
-        case 34: return launch_pipe<T, 128, 128, 4, 2, 2, 8>(a, s);
-        case 35: return launch_pipe<T, 128, 128, 4, 2, 3, 4>(a, s);
-        case 36: return launch_pipe<T, 128, 64, 4, 2, 3, 8>(a, s);
-        case 37: return launch_pipe<T, 128, 192, 4, 2, 2, 8>(a, s);
+        case 18: return launch_pipe<T, X3, 128, 128, 2, 2, 2>(a, s);
+        case 25: return launch_pipe<T, X3, 64, 64, 2, 2, 2>(a, s);
+        case 27: return launch_pipe<T, X3, 64, 192, 2, 2, 2, 8>(a, s);    // one (clip, head) per block at T = 64, hd = 192
+        case 32: return launch_pipe<T, X3, 64, 192, 4, 2, 3, 8>(a, s);    // 8 waves (two per SIMD): a lone block per CU hides its own latencies
+        case 33: return launch_pipe<T, X3, 64, 192, 4, 2, 2, 8>(a, s);
+        case 34: return launch_pipe<T, X3, 128, 128, 4, 2, 2, 8>(a, s);
+        case 36: return launch_pipe<T, X3, 128, 64, 4, 2, 3, 8>(a, s);
+        case 37: return launch_pipe<T, X3, 128, 192, 4, 2, 2, 8>(a, s);
         default: return EMAGE_EINVAL;
     }
 }
 
-template <typename T>
+template <typename T, bool X3>
 int dispatch(GemmArgs& a, hipStream_t s) {
-    if (g_force_config >= 0) return run_config<T>(g_force_config, a, s);
+    if (g_force_config >= 0) return run_config<T, X3>(g_force_config, a, s);
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     const long t128 = (long)((a.M + 127) / 128) * ((ncols + 127) / 128);
-    static const int env_profile = [] { const char* e = getenv("EMAGE_GEMM_PROFILE"); return e ? atoi(e) : -1; }();
-    const int profile = env_profile >= 0 ? env_profile : g_profile;
-    // profile 1 (tools/bench_overlap.py): when 2-4 independent launch chains are in flight, 128x128 tiles with a
-    // 2-deep ring (64 KiB LDS, 2 blocks per CU) need half the L2->LDS bytes of 64x64 tiles and their exposed
-    // latency is filled by the other chains: 25-35 % less time per launch than the small-tile choice below
-    if (profile == 1 && ncols >= 512 && a.M >= 2048) return run_config<T>(18, a, s);
-    if (profile == 2 && a.taps == 1 && ncols >= 768 && ncols <= 2304 && a.M >= 2048) return run_config<T>(18, a, s);
-    if (profile == 3 && a.taps == 1 && ncols >= 768 && ncols <= 2304 && a.M >= 2048 && !a.out_t) return run_config<T>(18, a, s);
     // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_sweep_8wave.txt): with M = 4096 the operand stream, not
     // MFMA, bounds these launches.  Many small resident blocks (64x64, 5 per CU) win on narrow outputs; everywhere else
     // 8-wave blocks (two waves per SIMD hide a block's own DMA / epilogue latency) beat the 4-wave tiles of the same shape
-    if (profile == 4) {                                                // the pre-8-wave choices, kept for A/B runs
-        if (ncols > 64 && t128 >= 512) return run_config<T>(26, a, s);
-        if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T>(27, a, s);
-        return run_config<T>(25, a, s);
-    }
-    if (a.taps >= 15 && a.M > 8192) return run_config<T>(36, a, s);     // WavEncoder convs on long sequences: 128x64, 8 waves
-    if (ncols > 64 && t128 >= 512) return run_config<T>(34, a, s);      // wide outputs (QKV, batched K/V projections): 128x128, 8 waves
-    if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T>(33, a, s);   // FFN up-projection: exactly 2 blocks per CU
-    if (a.taps == 1 && ncols == 768 && a.M >= 2048) return run_config<T>(32, a, s);   // 768-wide projections: one (clip, head) tile, 8 waves
-    return run_config<T>(25, a, s);
+    if (a.taps >= 15 && a.M > 8192) return run_config<T, X3>(36, a, s);     // WavEncoder convs on long sequences: 128x64, 8 waves
+    if (ncols > 64 && t128 >= 512) return run_config<T, X3>(34, a, s);      // wide outputs (QKV, batched K/V projections): 128x128, 8 waves
+    if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T, X3>(33, a, s);   // FFN up-projection: exactly 2 blocks per CU
+    if (a.taps == 1 && ncols == 768 && a.M >= 2048) return run_config<T, X3>(32, a, s);   // 768-wide projections: one (clip, head) tile, 8 waves
+    return run_config<T, X3>(25, a, s);
 }
 
 }  // namespace
@@ -298,29 +260,31 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
                           void* out, int ldo, int n_store, float* out_f32, int ldf,
                           void* out_t, int t_col0, int t_rows, int t_ld,
                           int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
-                          void* stream) {
+                          float a_scale, float w_scale, void* stream) {
     const int epc = dtype == EMAGE_BF16 ? 8 : 4;
     if (!A || !W || M <= 0 || N <= 0 || taps <= 0 || Cp <= 0 || Cp % 64 != 0) return EMAGE_EINVAL;
-    if (dtype != EMAGE_BF16 && dtype != EMAGE_F32) return EMAGE_EINVAL;
+    if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3) return EMAGE_EINVAL;
     if (lda % epc != 0 || lda < Cp) return EMAGE_EINVAL;                 // 16-byte aligned operand rows
     if (((uintptr_t)A | (uintptr_t)W) & 15) return EMAGE_EINVAL;
     if (Lout <= 0 || Lin <= 0 || M % Lout != 0 || stride <= 0) return EMAGE_EINVAL;
     if (!out && !out_f32 && !out_t) return EMAGE_EINVAL;
     if (out_t && (t_rows <= 0 || M % t_rows != 0 || t_ld < t_rows || t_col0 < 0 || t_col0 > N)) return EMAGE_EINVAL;
+    if (dtype == EMAGE_F16X3 && !(a_scale > 0.f && w_scale > 0.f)) return EMAGE_EINVAL;
     GemmArgs a;
     a.A = A; a.W = W; a.bias = bias; a.slope = slope; a.res = res; a.out = out; a.out_f32 = out_f32; a.out_t = out_t;
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.ldf = ldf; a.res_is_f32 = res_is_f32; a.res_first = res_first; a.n_store = out ? n_store : 0;
     a.t_col0 = out_t ? t_col0 : N; a.t_rows = t_rows > 0 ? t_rows : 1; a.t_ld = t_ld;
     a.dbg = g_debug_skip;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
+    a.a_scale = dtype == EMAGE_F16X3 ? a_scale : 1.f;
+    a.o_scale = dtype == EMAGE_F16X3 ? 1.f / (a_scale * w_scale) : 1.f;
     hipStream_t s = (hipStream_t)stream;
-    return dtype == EMAGE_BF16 ? dispatch<bf16_t>(a, s) : dispatch<float>(a, s);
+    if (dtype == EMAGE_F16X3) return dispatch<float, true>(a, s);
+    return dtype == EMAGE_BF16 ? dispatch<bf16_t, false>(a, s) : dispatch<float, false>(a, s);
 }
 
 extern "C" int emage_set_tuning(int key, int value) {
     if (key == 0) { g_force_config = value; return 0; }
     if (key == 1) { g_debug_skip = value; return 0; }
-    if (key == 2) { g_persist_per_cu = value; return 0; }
-    if (key == 3) { g_profile = value; return 0; }
     return EMAGE_EINVAL;
 }

@@ -15,6 +15,7 @@ struct GemmArgs {
     int M, N, K, Cp, taps, stride, pad, Lin, Lout;
     int tiles_m, tiles_n;
     int dbg;
+    float a_scale, o_scale;   // split-f16 mode: A is multiplied by a_scale before the hi/lo split, accumulators by o_scale after the K-loop
 };
 
 constexpr int NTHREADS = 256;
@@ -117,6 +118,25 @@ __device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+// ---- split-f16 operands (EMAGE_F16X3): fp32 activations are split in registers into two fp16 planes,
+// x*s = hi + lo with |x*s - hi - lo| <= 2^-23 |x*s| (hi = rne(x*s), lo = rne(x*s - hi); the difference is exact in
+// fp32), the weights arrive pre-split from the host in the same k order.  Three v_mfma_f32_16x16x32_f16
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate) then carry ~22 mantissa bits per product: fp32-grade results at a third
+// of the fp16 MFMA rate instead of the 1/16 of v_mfma_f32_16x16x4_f32.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_f16(const u32x4& c0, const u32x4& c1, const float s, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float xs = __builtin_bit_cast(float, e < 4 ? c0[e] : c1[e - 4]) * s;
+        const _Float16 h = (_Float16)xs;
+        hi[e] = h;
+        lo[e] = (_Float16)(xs - (float)h);
+    }
+}
+__device__ __forceinline__ f32x4 mma_f16(const f16x8& a, const f16x8& b, const f32x4& acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
 
@@ -177,7 +197,10 @@ constexpr int pipe_smem_bytes() {
 // may start the next tile (or any other use of the LDS) right away.
 // FPRE: fetch the epilogue operands (bias, slope, residual) ahead of the K-loop whatever the tile size (the fused
 // layer kernel has the registers; a lone block per CU cannot hide their latency behind another block).
-template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool FPRE = false>
+// X3: split-f16 MFMA on fp32 operands (T = float, KC = 8): the K-tile is 32 k; a lane's two chunks (k = 4g..4g+3 and
+// 16+4g..16+4g+3 of the tile) form the 8 k-values of one 16x16x32 MFMA; the W tile row holds [4 hi chunks | 4 lo chunks]
+// packed by the host in exactly that k order (pantomatrix_amd.modeling_emage_audio._Packed._split_f16).
+template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool FPRE = false, bool X3 = false>
 __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = 16 / EPC;                     // element size in bytes
@@ -195,6 +218,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     static_assert(FN % 2 == 0, "fragments pair up along N");
     constexpr int FP = FN / 2;                       // fragment pairs = 8-column groups per lane per M fragment
     static_assert(NS >= 2 && NS <= 4 && (KC == 4 || KC == 8), "ring depth / row width");
+    static_assert(!X3 || (EPC == 4 && KC == 8), "split-f16 mode: fp32 storage, 128-byte tile rows");
 
     constexpr int CLD = BN + 4;                      // fp32 row stride of the V^T staging tile
     constexpr int EP = (BM * CLD * 4 <= NS * STAGE) ? 1 : 2;   // staging passes (row halves) so it fits the ring
@@ -340,8 +364,30 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
         u32x4 af0[FM], bf0[FN];
         const unsigned a0 = a_rd0 + sb, b0 = b_rd0 + sb;
         [&]<int... I>(std::integer_sequence<int, I...>) { ((af0[I] = lds_read128_off<I * 16 * RB>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
-        [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
-        if constexpr (NKG == 2) {
+        if constexpr (X3) {
+            // read order: both activation chunks first (they need the VALU split), then the W hi / lo chunks
+            u32x4 af1[FM], bf1[FN];
+            const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
+            wait_lgkmcnt<2 * FN>();                   // both activation chunks are there: split them while the W reads land
+            __builtin_amdgcn_sched_barrier(0);
+            f16x8 ah[FM], al[FM];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) split_f16(af0[i], af1[i], p.a_scale, ah[i], al[i]);
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            // three sweeps over the fragments (small terms first), so back-to-back MFMAs never share an accumulator
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = mma_f16(__builtin_bit_cast(f16x8, t == 0 ? bf1[j] : bf0[j]), t == 1 ? al[i] : ah[i], acc[i][j]);
+        } else if constexpr (NKG == 2) {
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
             u32x4 af1[FM], bf1[FN];
             const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
             [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
@@ -362,6 +408,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf1[j]), __builtin_bit_cast(uint4, af1[i]), acc[i][j]);
         } else {
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
             wait_lgkmcnt<0>();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -378,6 +425,13 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     // ---- epilogue.  With the permuted W rows, lane (fr, fg) holds for M fragment i and fragment pair jp the 8
     // consecutive columns  out[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + jp*32 + fg*8 + e],
     // e = 0..3 from acc[i][2jp], e = 4..7 from acc[i][2jp+1]. ----
+    if constexpr (X3) {
+        const float os = p.o_scale;                   // a power of two: exact
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = acc[i][j] * os;
+    }
     if (p.dbg & 4) {                                  // diagnostics: keep the accumulators live, store nothing
         if (acc[0][0][0] == 123.456f) ((float*)p.out_f32)[0] = 0.f;
         __syncthreads();

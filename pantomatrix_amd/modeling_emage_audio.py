@@ -26,11 +26,12 @@ import torch
 
 from . import ops, spec, synthetic
 from .streams import Fork
-from ._lib import BF16, F32
+from ._lib import BF16, F32, F16X3
 from .configuration_emage_audio import EmageAudioConfig, EmageVAEConvConfig, EmageVQVAEConvConfig
 
 OUT_KEYS = ("rec_face", "rec_upper", "rec_hands", "rec_lower", "cls_face", "cls_upper", "cls_hands", "cls_lower")
-_PRECISIONS = {"bf16": BF16, "fp32": F32}
+_PRECISIONS = {"bf16": BF16, "fp32": F32, "f16x3": F16X3}
+_PRECISION_NAMES = {v: k for k, v in _PRECISIONS.items()}
 _WAV_TAPS = spec.WAV_KERNEL
 
 
@@ -123,7 +124,7 @@ class _EmageModule:
 
     @property
     def precision(self):
-        return "bf16" if self._dt == BF16 else "fp32"
+        return _PRECISION_NAMES[self._dt]
 
     # ---- persistence ---------------------------------------------------------------
     def save_pretrained(self, save_directory):
@@ -187,12 +188,19 @@ class _Packed:
     def f32(self, name):
         return self.p[name].to(torch.float32).contiguous()
 
+    def _operand(self, w2d):
+        """(N, K) fp32 with K already padded -> the MFMA operand image of this precision and its scale."""
+        if self.dt == F16X3:
+            return ops.split_f16_weights(w2d.contiguous())
+        return w2d.to(self.tdt).contiguous(), 1.0
+
     def _pack_mat(self, w2d):
         n, k = w2d.shape
         kp = _rup(k)
         if kp != k:
             w2d = torch.nn.functional.pad(w2d, (0, kp - k))
-        return w2d.to(self.tdt).contiguous(), kp
+        w, ws = self._operand(w2d)
+        return w, kp, ws
 
     def linear(self, key, names, rows=None):
         """Stack nn.Linear weights along N (optionally row-slices `rows[i]` of each) -> entry `key`."""
@@ -204,8 +212,8 @@ class _Packed:
             ws.append(w)
             bs.append(b)
         k_real = ws[0].shape[1]
-        w, kp = self._pack_mat(torch.cat(ws, 0).float())
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real)
+        w, kp, wsc = self._pack_mat(torch.cat(ws, 0).float())
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc)
 
     def in_proj(self, key, names, parts):
         """Row blocks of packed in_proj weights: parts e.g. "qkv", "q", "kv"; several layers stack as
@@ -218,8 +226,8 @@ class _Packed:
                 ws.append(self.p[nm + ".in_proj_weight"][sl[part]])
                 bs.append(self.p[nm + ".in_proj_bias"][sl[part]])
         k_real = ws[0].shape[1]
-        w, kp = self._pack_mat(torch.cat(ws, 0).float())
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real)
+        w, kp, wsc = self._pack_mat(torch.cat(ws, 0).float())
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc)
 
     def folded(self, cname, bn=None):
         """Raw Conv1d (weight (Cout,Cin,k), bias) with an eval-mode BatchNorm1d folded in:
@@ -243,8 +251,8 @@ class _Packed:
         w = w.permute(0, 2, 1)                                   # (Cout, k, Cin)
         if cp != cin:
             w = torch.nn.functional.pad(w, (0, cp - cin))
-        self.w[key] = dict(w=w.reshape(cout, k * cp).to(self.tdt).contiguous(), b=b.contiguous(), n=cout, cp=cp, taps=k,
-                           k_real=k * cin)
+        wp, wsc = self._operand(w.reshape(cout, k * cp))
+        self.w[key] = dict(w=wp, b=b.contiguous(), n=cout, cp=cp, taps=k, k_real=k * cin, ws=wsc)
 
     def norm(self, key, name):
         self.w[key] = dict(g=self.f32(name + ".weight"), b=self.f32(name + ".bias"))
@@ -257,7 +265,10 @@ class _Ctx:
     """One forward's launch context: packed weights + dtype + allocation helpers."""
 
     def __init__(self, pk: _Packed):
-        self.pk, self.dt, self.tdt, self.dev = pk, pk.dt, pk.tdt, pk.device
+        # dt: storage / elementwise-kernel type of activations; gdt: emage_gemm's operand mode (F16X3 = float32 storage,
+        # split-f16 MFMA; equal to dt otherwise)
+        self.pk, self.gdt, self.tdt, self.dev = pk, pk.dt, pk.tdt, pk.device
+        self.dt = F32 if pk.dt == F16X3 else pk.dt
 
     def lo(self, m, n):
         return torch.empty(m, n, dtype=self.tdt, device=self.dev)
@@ -270,7 +281,7 @@ class _Ctx:
         """Run one contraction.  want: "lo", "f32", "both" allocate the outputs when not passed in.
         conv = (stride, pad, lin, lout) turns it into the implicit-GEMM Conv1d with the entry's tap count."""
         e = w if w is not None else self.pk.w[key]
-        dt = self.dt if dt is None else dt
+        dt = self.gdt if dt is None else dt
         m = a.shape[0] if m is None else m
         n = e["n"]
         if out is None and out_t is None and want in ("lo", "both"):
@@ -283,7 +294,7 @@ class _Ctx:
             stride, pad, lin, lout = conv
             kw = dict(taps=e["taps"], stride=stride, pad=pad, lin=lin, lout=lout)
         ops.gemm(dt, a, e["w"], e["b"], sl, res, out, out_f32, out_t, n=n, cp=e["cp"], n_store=n_store,
-                 t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, k_real=e.get("k_real"), **kw)
+                 t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, k_real=e.get("k_real"), w_scale=e.get("ws", 1.0), **kw)
         return out, out_f32
 
     def conv3(self, a, key, t, **kw):

@@ -6,9 +6,33 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, check
+from ._lib import F32, BF16, F16X3, check
 
-TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+# storage type of activations per precision code; F16X3 is a GEMM-only operand mode over float32 storage
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32}
+A_SCALE_F16X3 = 16.0    # activations are multiplied by this power of two before the fp16 hi/lo split (|x| < 4094 stays finite)
+
+
+def split_f16_weights(w2d):
+    """Host packing of an (N, K) fp32 weight matrix for EMAGE_F16X3 (include/emage_hip.h: emage_gemm), K % 32 == 0.
+    Returns (packed (N, K) float32-typed buffer holding the fp16 planes, w_scale).  w_scale is the power of two that
+    puts max|w| into [2^12, 2^13): both planes stay normal fp16 numbers for every weight above max|w| * 2^-16."""
+    import math
+    n, k = w2d.shape
+    assert k % 32 == 0
+    w = w2d.to(torch.float32)
+    mx = float(w.abs().max())
+    scale = 2.0 ** (12 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+    ws = w * scale
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.to(torch.float32)).to(torch.float16)
+
+    def chunked(plane):      # k = 32*kt + 16*g2 + 4*g + e  ->  [kt][g][g2][e]: chunk g holds k = 4g..4g+3, 16+4g..16+4g+3
+        return plane.view(n, k // 32, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(n, k // 32, 32)
+
+    packed = torch.stack([chunked(hi), chunked(lo)], dim=2).reshape(n, 2 * k).contiguous()
+    return packed.view(torch.float32), scale
+
 
 
 def _ptr(t):
@@ -65,9 +89,10 @@ def gather_rows(table, idx, dtype, n_store=None):
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None):
+         k_real=None, w_scale=1.0, a_scale=None):
     """See include/emage_hip.h:emage_gemm.  `a` (rows, lda) and `w` (n, taps*cp) are in `dtype`.  `k_real` (the
-    unpadded contraction length) is bookkeeping for bench.py's algorithmic-flop count; the kernel ignores it."""
+    unpadded contraction length) is bookkeeping for bench.py's algorithmic-flop count; the kernel ignores it.
+    dtype F16X3: `a` is float32, `w` / `w_scale` come from `split_f16_weights`."""
     _dev(a)
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin
@@ -79,7 +104,8 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
                                  _ptr(out), _ld(out) if out is not None else 0, n_store,
                                  _ptr(out_f32), _ld(out_f32) if out_f32 is not None else 0,
                                  _ptr(out_t), t_col0, t_rows, t_ld,
-                                 m, n, cp, taps, stride, pad, lin, lout, _stream()), "gemm")
+                                 m, n, cp, taps, stride, pad, lin, lout,
+                                 float(A_SCALE_F16X3 if a_scale is None else a_scale), float(w_scale), _stream()), "gemm")
 
 
 def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad):

@@ -41,6 +41,19 @@ def window_inputs(batch, frames=64, seed=7):
     return audio, torch.zeros(batch, 1, dtype=torch.long), motion, mask
 
 
+def vq_api_inputs(batch=3, frames=24, seed=41):
+    """Seeded inputs of EmageVQModel.map2index / map2latent: (rot6d (B,T,330), expression (B,T,100), contact (B,T,4) in
+    {0,1}, trans (B,T,3))."""
+    from oracle import emage_oracle as orc
+    g = torch.Generator().manual_seed(seed)
+    aa = 0.4 * torch.randn(batch, frames, 55, 3, generator=g)
+    rot6d = orc.axis_angle_to_rotation_6d(aa).reshape(batch, frames, 330)
+    expr = 0.5 * torch.randn(batch, frames, 100, generator=g)
+    contact = (torch.rand(batch, frames, 4, generator=g) > 0.5).float()
+    trans = 0.1 * torch.randn(batch, frames, 3, generator=g)
+    return rot6d, expr, contact, trans
+
+
 def product_models(seed=0, vae_layer=2, precision="fp32", device="cpu"):
     """pantomatrix_amd model objects loaded with the same synthetic weights as `oracle_models`."""
     import pantomatrix_amd as pa

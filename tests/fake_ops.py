@@ -14,9 +14,9 @@ import torch
 
 from pantomatrix_amd import modeling_emage_audio as M
 from pantomatrix_amd import ops
-from pantomatrix_amd._lib import BF16, F32
+from pantomatrix_amd._lib import BF16, F32, F16X3
 
-TD = {F32: torch.float32, BF16: torch.bfloat16}
+TD = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32}
 CALLS = []
 
 
@@ -24,9 +24,16 @@ def _leaky(v, s):
     return torch.where(v > 0, v, v * s)
 
 
+def unsplit_f16_weights(packed, n, k):
+    """Inverse of ops.split_f16_weights: (N, K) float32-typed image -> (hi, lo) fp32 planes of W * w_scale in natural k order."""
+    planes = packed.view(torch.float16).reshape(n, k // 32, 2, 4, 2, 4)          # [kt][plane][g][g2][e]
+    nat = planes.permute(2, 0, 1, 4, 3, 5).reshape(2, n, k).float()                # k = 32 kt + 16 g2 + 4 g + e
+    return nat[0], nat[1]
+
+
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None):
+         k_real=None, w_scale=1.0, a_scale=None):
     CALLS.append("gemm")
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin
@@ -48,7 +55,19 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         r = (b_ * lin + pos.clamp(0, lin - 1))
         cols.append(af[r] * valid[:, None].float())
     x = torch.cat(cols, dim=1)                                   # (M, taps*cp)
-    v = x @ w.float().t()
+    if dtype == F16X3:
+        # the kernel's arithmetic: fp16 hi/lo planes of A * a_scale against the host-split planes of W * w_scale,
+        # hi*hi + hi*lo + lo*hi (the lo*lo term is dropped), accumulated wide, scaled back by exact powers of two
+        sa = ops.A_SCALE_F16X3 if a_scale is None else a_scale
+        wh, wl = unsplit_f16_weights(w, n, taps * cp)
+        xs = x * sa
+        xh = xs.to(torch.float16).float()
+        xl = (xs - xh).to(torch.float16).float()
+        assert torch.isfinite(xh).all(), "activation overflows fp16 after a_scale"
+        xh, xl, wh, wl = xh.double(), xl.double(), wh.double(), wl.double()
+        v = ((xh @ wh.t() + (xh @ wl.t() + xl @ wh.t())) / (sa * w_scale)).float()
+    else:
+        v = x @ w.float().t()
     if bias is not None:
         v = v + bias
     rv = 0.0

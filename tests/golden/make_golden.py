@@ -38,11 +38,56 @@ def ref_infer_clip(model, vq, audio):
     return lat, pred, idx
 
 
+def golden_b64(model, vq):
+    """BASELINE config 2 itself: the 64 x 128-frame batch.  All four code-index arrays of all 64 clips (int16) plus the
+    decoded poses / expressions / trans of every 8th clip (the decode of the other clips is checked through the
+    oracle from the golden indices) — keeps the fixture near 1 MB."""
+    a = synthetic.synthetic_audio(64, synthetic.samples_for_frames(128))
+    lat, pred, idx = ref_infer_clip(model, vq, a)
+    sub = slice(0, 64, 8)
+    np.savez_compressed(os.path.join(HERE, "infer_128f_b64.npz"),
+                        poses_sub=pred["motion_axis_angle"][sub].numpy(), expressions_sub=pred["expression"][sub].numpy(),
+                        trans_sub=pred["trans"][sub].numpy(),
+                        **{f"index_{p}": idx[p].numpy().astype(np.int16) for p in common.PARTS})
+
+
+def golden_vq_api(acfg, vqc, gc):
+    """EmageVQModel.spilt_inputs / map2index / map2latent (M:97-124) and EmageVQVAEConv.forward (M:42-46, P:144-156:
+    straight-through latents, embedding_loss, perplexity) on seeded rot-6D motion — the calls train_emage_audio.py:149-150
+    makes.  Inputs are regenerated from the seed by the tests."""
+    _, vq = rh.build_reference(acfg, vqc, gc, seed=0)
+    rot6d, expr, contact, trans = common.vq_api_inputs()
+    rec = {}
+    with torch.no_grad():
+        sp = vq.spilt_inputs(rot6d, expr, contact, trans)
+        idx = vq.map2index(rot6d, expr, contact, trans)
+        lat = vq.map2latent(rot6d, expr, contact, trans)
+        idx0 = vq.map2index(rot6d, expr)                      # tar_contact / tar_trans default to zeros
+        for p in common.PARTS:
+            rec[f"split_{p}"] = sp[p].numpy()
+            rec[f"index_{p}"] = idx[p].numpy()
+            rec[f"index0_{p}"] = idx0[p].numpy()
+            rec[f"latent_{p}"] = lat[p].numpy()
+            fw = getattr(vq, f"vq_model_{p}")(sp[p])
+            rec[f"fwd_{p}_poses_feat"] = fw["poses_feat"].numpy()
+            rec[f"fwd_{p}_rec_pose"] = fw["rec_pose"].numpy()
+            rec[f"fwd_{p}_embedding_loss"] = fw["embedding_loss"].numpy()
+            rec[f"fwd_{p}_perplexity"] = fw["perplexity"].numpy()
+    np.savez_compressed(os.path.join(HERE, "vq_api.npz"), **rec)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     acfg, vqc, gc = common.cfg_dicts(vae_layer=2)
     model, vq = rh.build_reference(acfg, vqc, gc, seed=0)
+    if "--only-new" in sys.argv:             # round-2 additions only (the round-1 fixtures are unchanged)
+        golden_b64(model, vq)
+        golden_vq_api(acfg, vqc, gc)
+        print("wrote infer_128f_b64.npz, vq_api.npz")
+        return
+    golden_b64(model, vq)
+    golden_vq_api(acfg, vqc, gc)
 
     # 1. one forward() window, B=1, partly masked motion
     audio, spk, motion, mask = common.window_inputs(1)

@@ -53,12 +53,32 @@ def test_forward_window_bf16_host_logic():
         assert torch.equal(out[k], out_ops[k]), k                    # one launch per layer == the per-op sequence
 
 
-@pytest.mark.parametrize("frames,batch", [(128, 2), (70, 1), (129, 1)])
-def test_inference_and_decode_host_logic(golden_dir, frames, batch):
+def test_forward_window_f16x3_host_logic(golden_dir):
+    """The split-f16 operand mode: weights packed by ops.split_f16_weights (hi / lo fp16 planes in the kernel's k order,
+    power-of-two scale), activations float32 — through the fake's restatement of the three-product arithmetic the window
+    must stay at fp32-grade distance from the reference (this is what lets the fast mode keep the VQ code indices)."""
+    model, _ = common.product_models(precision="f16x3")
+    assert model.precision == "f16x3"
+    g = np.load(os.path.join(golden_dir, "forward_b1.npz"))
+    audio, spk, motion, mask = common.window_inputs(1)
+    with fake_ops.installed(), torch.no_grad():
+        out1 = model.forward(audio, spk, motion, mask)
+    for k in orc.OUT_KEYS:
+        np.testing.assert_allclose(out1[k].numpy(), g[k], atol=3e-4, rtol=0)
+    from pantomatrix_amd import ops
+    w = torch.randn(40, 192) * 0.02
+    packed, scale = ops.split_f16_weights(w)
+    hi, lo = fake_ops.unsplit_f16_weights(packed, 40, 192)
+    assert packed.dtype == torch.float32 and packed.shape == (40, 192) and 4096 <= float(w.abs().max()) * scale < 8192
+    assert float(((hi + lo) / scale - w).abs().max()) <= 2.0 ** -22 * float(w.abs().max())
+
+
+@pytest.mark.parametrize("frames,batch,precision", [(128, 2, "fp32"), (70, 1, "fp32"), (129, 1, "fp32"), (129, 1, "f16x3")])
+def test_inference_and_decode_host_logic(golden_dir, frames, batch, precision):
     """Whole clip: window schedule, seed carry-over through the VQ decode, tail windows with T+1 audio
     frames, final decode with global translation — against the REFERENCE's golden outputs."""
     g = np.load(os.path.join(golden_dir, f"infer_{frames}f_b{batch}.npz"))
-    model, vq = common.product_models(precision="fp32")
+    model, vq = common.product_models(precision=precision)
     audio = synthetic.synthetic_audio(batch, synthetic.samples_for_frames(frames))
     with fake_ops.installed(), torch.no_grad():
         (poses, expr, trans), lat = common.product_infer_clip(model, vq, audio)

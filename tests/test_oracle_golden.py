@@ -95,3 +95,47 @@ def test_window_schedule():
     for frames, expect in ((70, 70), (84, 84), (128, 120), (129, 129), (133, 133)):
         rounds, remain = (frames - 4) // 60, (frames - 4) % 60
         assert 60 * rounds + (4 + remain if remain > 4 else 0) == expect
+
+
+def test_vq_model_api(golden_dir):
+    """EmageVQModel.spilt_inputs / map2index / map2latent (M:97-124) and EmageVQVAEConv.forward incl. the Quantizer's
+    embedding_loss and perplexity (M:42-46, P:144-156) against the reference's outputs."""
+    g = _load(golden_dir, "vq_api.npz")
+    _, vq = common.oracle_models()
+    rot6d, expr, contact, trans = common.vq_api_inputs()
+    with torch.no_grad():
+        sp = vq.split_inputs(rot6d, expr, contact, trans)
+        idx = vq.map2index(rot6d, expr, contact, trans)
+        idx0 = vq.map2index(rot6d, expr)
+        lat = vq.map2latent(rot6d, expr, contact, trans)
+        for p in common.PARTS:
+            assert np.array_equal(sp[p].numpy(), g[f"split_{p}"])
+            assert np.array_equal(idx[p].numpy(), g[f"index_{p}"]) and np.array_equal(idx0[p].numpy(), g[f"index0_{p}"])
+            np.testing.assert_allclose(lat[p].numpy(), g[f"latent_{p}"], atol=1e-6, rtol=0)
+            fw = getattr(vq, p).forward(sp[p])
+            np.testing.assert_allclose(fw["poses_feat"].numpy(), g[f"fwd_{p}_poses_feat"], atol=ATOL, rtol=0)
+            np.testing.assert_allclose(fw["rec_pose"].numpy(), g[f"fwd_{p}_rec_pose"], atol=ATOL, rtol=0)
+            np.testing.assert_allclose(float(fw["embedding_loss"]), float(g[f"fwd_{p}_embedding_loss"]), rtol=1e-4)
+            np.testing.assert_allclose(float(fw["perplexity"]), float(g[f"fwd_{p}_perplexity"]), rtol=1e-5)
+
+
+def test_batch64_indices(golden_dir):
+    """BASELINE config 2 (64 x 128-frame clips): the oracle reproduces every VQ code index of the reference's run and the
+    decoded motion of the stored clips; the decode of golden indices is what the GPU test uses for the other clips."""
+    g = _load(golden_dir, "infer_128f_b64.npz")
+    model, vq = common.oracle_models()
+    torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+    audio = synthetic.synthetic_audio(64, synthetic.samples_for_frames(128))
+    spk = torch.zeros(64, 1, dtype=torch.long)
+    with torch.no_grad():
+        lat = model.inference(audio, spk, vq)
+        sel = model.select_codes(lat)
+        face_idx = orc.vq_nearest(lat["rec_face"], vq.face.sd["quantizer.embedding.weight"])
+        pred = vq.decode(**sel, get_global_motion=True, ref_trans=torch.zeros(1, 3))
+    for p in ("upper", "hands", "lower"):
+        assert np.array_equal(sel[f"{p}_index"].numpy(), g[f"index_{p}"].astype(np.int64)), p
+    assert np.array_equal(face_idx.numpy(), g["index_face"].astype(np.int64))
+    sub = slice(0, 64, 8)
+    np.testing.assert_allclose(pred["motion_axis_angle"][sub].numpy(), g["poses_sub"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(pred["expression"][sub].numpy(), g["expressions_sub"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(pred["trans"][sub].numpy(), g["trans_sub"], atol=1e-3, rtol=0)
