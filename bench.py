@@ -3,16 +3,26 @@
 
 One "step" = one pass of the hot path over one batch of 64 synthetic 128-frame clips per GPU:
 `EmageAudioModel.inference` (2 dependent 64-frame windows) + the final `EmageVQModel.decode(get_global_motion=
-True)` + D2H of poses/expressions/trans, audio already resident in HBM.  120 frames are emitted per clip.
-N > 1: one process per GPU (torchrun), clips sharded across ranks, no data-path collective ("replicas only",
-weak scaling); timing is barrier + synchronize bracketed, max over ranks.
+True)` + D2H of poses/expressions/trans, audio already resident in HBM (the PCIe-inclusive rate is measured beside it
+and reported as `pcie_inclusive`, never as `value`).  120 frames are emitted per clip.
 
-Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (dominant kernel, HIP-event timed)
-and `cpu_baseline` (the CPU oracle, a port of the reference, timed on this host on a bounded sample).
+Precision: `f16x3` (default) is the parity-green mode — float32 storage, every contraction as three split-fp16 MFMAs
+with fp32 accumulate: VQ code indices identical to the reference on every golden clip incl. the 64-clip batch, SMPL-X
+parameters within 1e-3 (tests/test_parity_gpu.py).  The pure-bf16 mode (not index-exact) is timed beside it and
+reported under `other_precisions`.
+
+N > 1: one process per GPU; `python bench.py --gpus N` without a launcher re-executes itself under
+torch.distributed.run (127.0.0.1 rendezvous).  Clips are sharded across ranks, no data-path collective ("replicas
+only", weak scaling); RCCL carries the barriers and the max-over-ranks of the timing only.
+
+Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (dominant kernel family; every kernel of one
+serialized step timed live with HIP events on the launch stream), `cpu_baseline` (the CPU oracle, a port of the
+reference, timed on this host on a bounded sample) and `pcie_inclusive`.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,9 +33,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
+F16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md
 F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+METRIC = "motion-frames/sec (30fps SMPL-X) EMAGE infer, 128-frame clips"
+PRECISION_NOTE = {
+    "f16x3": "float32 storage, each product as 3 split-fp16 MFMAs (hi*hi + hi*lo + lo*hi), fp32 accumulate: parity-green "
+             "(bit-exact VQ indices, 1e-3 rotations vs the reference)",
+    "bf16": "bf16 operands, fp32 accumulate: NOT index-exact (about 97.5 % of frames keep all body codes)",
+    "fp32": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity-green, slow",
+}
 
 
 def usable_cores():
@@ -43,29 +60,66 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def build_models(precision, device):
-    import common
-    return common.product_models(precision=precision, device=device)
+# ----------------------------------------------------------------------------------------------------------------------
+# multi-GPU launch: one process per GPU
+# ----------------------------------------------------------------------------------------------------------------------
+def spawn_command(argv, n_gpus, port):
+    """The command `python bench.py --gpus N` re-executes when no launcher set WORLD_SIZE: the driver's own recipe."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
-def one_step(runner, audio):
-    """The timed unit: audio (already in HBM) -> runner (hipGraph replay of inference + final decode) -> poses /
-    expressions / trans on the host."""
-    return runner(audio)
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def profile_kernels(model, vq, audio, spk, zeros_trans):
-    def eager_step():
-        lat = model.inference(audio, spk, vq)
-        pred = vq.decode(**model._select_codes(lat), get_global_motion=True, ref_trans=zeros_trans)
-        return pred["motion_axis_angle"].cpu()
+def timed_steps(step, steps, warmup, barrier, reduce_max):
+    """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier +
+    device synchronisation on both sides; returns (max-over-ranks seconds, last step's result)."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    barrier()
+    return reduce_max(time.perf_counter() - t0), out
 
-    """One extra, untimed step with a HIP-event pair around every kernel launch (same stream the kernels run
-    on).  Returns {family: [count, total_ms, algorithmic flops, algorithmic bytes]}."""
-    from pantomatrix_amd import ops
+
+def result_line(precision, elapsed, steps, warmup, world, frames_per_step, batch, frames_in, launch):
+    return {
+        "metric": METRIC,
+        "value": frames_per_step * world * steps / elapsed,
+        "unit": "motion-frames/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": precision, "data": "synthetic",
+        "config": {"workload": f"EMAGE inference {precision}, batch={batch}x{frames_in}-frame synthetic clips per GPU "
+                               f"(BASELINE configs[1]): 2 windows of 64 frames + final VQ decode with global motion, "
+                               f"{frames_per_step // batch} frames out per clip; synthetic seeded weights",
+                   "precision": PRECISION_NOTE[precision],
+                   "clips_per_gpu": batch, "frames_in": frames_in, "frames_out_per_clip": frames_per_step // batch,
+                   "parallelism": f"replicas x{world} (clip-sharded, no collective)", "launch": launch},
+    }
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# live per-kernel timing of one serialized step
+# ----------------------------------------------------------------------------------------------------------------------
+def profile_kernels(runner, model, vq):
+    """One extra, untimed pass of the SAME launch sequence the timed graph replays (`ClipRunner._step`: the lean code
+    path), issued eagerly on ONE stream (no fork / join lanes) with a HIP-event pair around every kernel launch on that
+    stream.  A backlog of filler GEMMs is enqueued first so that the host runs ahead of the device: each event pair then
+    brackets exactly one kernel's device time (plus the event markers), not host launch latency.
+    Returns (records, families): records = [(tag, scope, ms, flops, bytes)]."""
+    from pantomatrix_amd import ops, modeling_emage_audio as M
     from pantomatrix_amd._lib import BF16
-    records = []
-    saved = {}
+    records, saved, scope = [], {}, {"name": None}
 
     def wrap(name, fn, cost):
         def inner(*a, **k):
@@ -73,24 +127,27 @@ def profile_kernels(model, vq, audio, spk, zeros_trans):
             e0.record()
             r = fn(*a, **k)
             e1.record()
-            records.append((name, e0, e1) + cost(a, k, r))
+            records.append((e0, e1, scope["name"]) + cost(a, k, r))
             return r
         return inner
 
     def gemm_cost(a, k, r):
-        dtype, A, W = a[0], a[1], a[2]
+        dtype, A = a[0], a[1]
         n, cp, taps = k["n"], k["cp"], k.get("taps", 1)
         m = k.get("m") or A.shape[0]
         es = 2 if dtype == BF16 else 4
         kk = k.get("k_real") or taps * cp                    # unpadded contraction length
-        flops = 2.0 * m * n * kk
-        byts = (m * cp * es) + n * taps * cp * es + m * n * es
-        return ("gemm_bf16" if dtype == BF16 else "gemm_f32", flops, byts)
+        return ("emage_gemm", 2.0 * m * n * kk, float(m * cp * es + n * taps * cp * es + m * n * es))
 
     def attn_cost(a, k, r):
         dtype, b, h, tq, tk, hd = a[0], a[6], a[7], a[8], a[9], a[10]
         es = 2 if dtype == BF16 else 4
-        return ("attention", 4.0 * b * h * tq * tk * hd, (2 * b * tq + 2 * b * tk) * h * hd * es)
+        return ("emage_attention", 4.0 * b * h * tq * tk * hd, float((2 * b * tq + 2 * b * tk) * h * hd * es))
+
+    def vq_cost(a, k, r):
+        z, cb = a[0], a[1]
+        n, d = z.shape
+        return ("emage_vq_argmin", 2.0 * n * cb.shape[0] * d, float(n * d * 4 + cb.shape[0] * d * 4 + n * 8))
 
     def generic_cost(tag):
         def c(a, k, r):
@@ -98,38 +155,120 @@ def profile_kernels(model, vq, audio, spk, zeros_trans):
             for t in list(a) + list(k.values()) + (list(r) if isinstance(r, tuple) else [r]):
                 if torch.is_tensor(t):
                     byts += t.numel() * t.element_size()
-            return (tag, 0.0, float(byts))
+            return ("emage_" + tag, 0.0, float(byts))
         return c
 
-    def layer_cost(a, k, r):
-        x, b, t = a[1], a[5], a[6]
-        d, ffn, cross = x.shape[1], k["ffn"], k.get("mem_k") is not None
-        m = b * t
-        flops = 2.0 * m * d * (3 * d + d + 2 * ffn + (2 * d if cross else 0)) + 4.0 * m * k.get("tk", t) * d * (2 if cross else 1)
-        byts = 2.0 * d * (3 * d + d + 2 * ffn + (2 * d if cross else 0)) + 2.0 * m * d * 2
-        return ("transformer_layer", flops, byts)
-
-    table = {"gemm": gemm_cost, "attention": attn_cost, "transformer_layer": layer_cost}
-    for nm in ("layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin", "argmax_logsoftmax",
-               "wav_conv_in", "merge_parts", "velocity_to_position"):
+    table = {"gemm": gemm_cost, "attention": attn_cost, "vq_argmin": vq_cost}
+    for nm in ("layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "argmax_logsoftmax", "wav_conv_in", "merge_parts",
+               "velocity_to_position"):
         table[nm] = generic_cost(nm)
+
+    def scoped(fn, name):
+        def inner(*a, **k):
+            prev, scope["name"] = scope["name"], name
+            try:
+                return fn(*a, **k)
+            finally:
+                scope["name"] = prev
+        return inner
+
+    parts = [model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion]
+    concurrent = [p.concurrent for p in parts]
+    layer_fns = {nm: getattr(M.EmageAudioModel, nm) for nm in ("_decoder_layer", "_encoder_layer", "_memory_kv")}
     try:
         for nm, cost in table.items():
             saved[nm] = getattr(ops, nm)
             setattr(ops, nm, wrap(nm, saved[nm], cost))
-        eager_step()
+        for nm, fn in layer_fns.items():                    # the 16 transformer layers incl. their memory K/V projections
+            setattr(M.EmageAudioModel, nm, scoped(fn, "transformer_blocks"))
+        for p in parts:
+            p.concurrent = False
+        filler_a = torch.randn(8192, 8192, device=model.device, dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+        for _ in range(40):                                 # ~1.1 TFLOP each: tens of ms of device backlog
+            torch.mm(filler_a, filler_a)
+        runner._step()
         torch.cuda.synchronize()
     finally:
         for nm, fn in saved.items():
             setattr(ops, nm, fn)
+        for nm, fn in layer_fns.items():
+            setattr(M.EmageAudioModel, nm, fn)
+        for p, c in zip(parts, concurrent):
+            p.concurrent = c
+    return [(tag, sc, e0.elapsed_time(e1), flops, byts) for (e0, e1, sc, tag, flops, byts) in records]
+
+
+def roofline_report(records, precision, ms_per_step):
     fam = {}
-    for name, e0, e1, tag, flops, byts in records:
+    for tag, sc, ms, flops, byts in records:
         f = fam.setdefault(tag, [0, 0.0, 0.0, 0.0])
         f[0] += 1
-        f[1] += e0.elapsed_time(e1)
+        f[1] += ms
         f[2] += flops
         f[3] += byts
-    return fam
+    total_ms = sum(v[1] for v in fam.values())
+    name, (cnt, ms, flops, byts) = max(fam.items(), key=lambda kv: kv[1][1])
+    mfma_peak = F32_MFMA_PEAK_TFLOPS if precision == "fp32" else F16_MFMA_PEAK_TFLOPS
+    if flops > 0 and name in ("emage_gemm", "emage_attention"):
+        ach = flops / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s", "frac": ach / mfma_peak}
+    else:
+        ach = byts / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        with open(tfile) as f:
+            traffic = json.load(f).get(f"{name}:{precision}")
+    roof.update({
+        "traffic": traffic, "kernel": name, "launches_per_step": cnt, "avg_launch_us": 1e3 * ms / cnt,
+        "algorithmic_gflop_per_launch": flops / cnt / 1e9,
+        "note": "algorithmic flops (2*M*N*K, unpadded K) / serialized kernel time; in f16x3 every product issues 3 MFMAs, so the "
+                "MFMA pipes are busy for about 3x this fraction",
+        "how": "one extra eager pass of the timed launch sequence on ONE stream, HIP-event pair per kernel, device backlogged so "
+               "the host runs ahead; the timed region replays the same sequence as a hipGraph with independent chains on "
+               "parallel branches, hence ms_per_step < serialized_kernel_ms",
+        "serialized_kernel_ms": total_ms, "timed_ms_per_step": ms_per_step,
+        "share_of_kernel_time": ms / total_ms if total_ms else None,
+        "kernel_time_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
+        "launches_by_family": {k: v[0] for k, v in fam.items()},
+    })
+    # north_star: MFMA utilisation of the transformer blocks, achieved GB/s of the VQ arg-min
+    tb = [r for r in records if r[1] == "transformer_blocks"]
+    tb_ms, tb_flops = sum(r[2] for r in tb), sum(r[3] for r in tb)
+    if tb_ms > 0:
+        roof["transformer_blocks"] = {"launches": len(tb), "ms": tb_ms, "algorithmic_gflop": tb_flops / 1e9,
+                                      "achieved_tflops": tb_flops / (tb_ms * 1e-3) / 1e12,
+                                      "frac_of_mfma_peak": tb_flops / (tb_ms * 1e-3) / 1e12 / mfma_peak,
+                                      "target": 0.40,
+                                      "scope": "16 layers x 2 windows: their GEMMs (incl. memory K/V projections), attention, LayerNorm"}
+    vq = fam.get("emage_vq_argmin")
+    if vq:
+        roof["vq_argmin"] = {"in_step": {"launches": vq[0], "avg_us": 1e3 * vq[1] / vq[0], "achieved_gbs": vq[3] / (vq[1] * 1e-3) / 1e9,
+                                          "bytes_per_launch": vq[3] / vq[0]}}
+    return roof
+
+
+def vq_argmin_large(device, n=1 << 20, iters=5):
+    """the arg-min's HBM figure is only meaningful at N >= 1 M vectors (at N = 4096 it is launch-bound)."""
+    from pantomatrix_amd import ops
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(n, 256, generator=g).to(device)
+    cb = torch.randn(256, 256, generator=g).to(device)
+    idx = torch.empty(n, dtype=torch.int64, device=device)
+    ops.vq_argmin(z, cb, out=idx)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops.vq_argmin(z, cb, out=idx)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    byts = n * 256 * 4 + 256 * 256 * 4 + n * 8
+    return {"n": n, "ms": ms, "achieved_gbs": byts / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "fp32_mfma_tflops": 2.0 * n * 256 * 256 / (ms * 1e-3) / 1e12}
 
 
 def cpu_baseline(frames, seconds_budget=15.0):
@@ -158,7 +297,22 @@ def cpu_baseline(frames, seconds_budget=15.0):
             break
     med = float(np.median(times))
     return {"value": out_frames / med, "unit": "motion-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{bs} clips x {frames} frames per call, median of {len(times)} calls ({sum(times):.1f} s CPU), fp32 torch CPU oracle"}
+            "sample": f"{bs} clips x {frames} frames per call (the survey measured B = 64 slower per frame than B = 8 on CPU), "
+                      f"median of {len(times)} calls ({sum(times):.1f} s CPU), fp32 torch CPU oracle = a port of the reference "
+                      f"(the reference itself cannot travel to this box)"}
+
+
+def build(precision, device, args):
+    import common
+    from pantomatrix_amd import synthetic
+    from pantomatrix_amd.runtime import ClipRunner
+    model, vq = common.product_models(precision=precision, device=device)
+    model.hoist_audio = not args.no_hoist
+    for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
+        part.concurrent = not args.no_concurrent
+    n_samples = synthetic.samples_for_frames(args.frames)
+    runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph)
+    return model, vq, runner, n_samples
 
 
 def main():
@@ -171,107 +325,83 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "fp32"],
                     help="f16x3 (default): fp32 storage, split-f16 MFMA — the parity-green fast mode; bf16: bf16 operands "
                          "(not index-exact); fp32: exact-fp32 MFMA")
+    ap.add_argument("--also", default="bf16", help="comma list of further precisions timed beside the reported one ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--sub-batches", type=int, default=1, help="independent clip groups issued on parallel stream lanes")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
-    ap.add_argument("--no-concurrent", action="store_true", help="A/B: single stream, no fork/join lanes")
-    ap.add_argument("--fused-layers", action="store_true", help="A/B: one launch per transformer layer (emage_transformer_layer)")
+    ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one — one process per GPU, the driver's own torchrun recipe
+        if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible")
+        cmd = spawn_command(sys.argv[1:], args.gpus, free_port())
+        log("no launcher in the environment: re-executing as " + " ".join(cmd[1:8]) + " ...")
+        raise SystemExit(subprocess.call(cmd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}: launch with --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from pantomatrix_amd import dist as pdist
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-
     from pantomatrix_amd import synthetic
-    model, vq = build_models(args.precision, dev)
-    model.hoist_audio = not args.no_hoist
-    model.concurrent = not args.no_concurrent
-    model.fused_layers = args.fused_layers
-    for part in (vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
-        part.concurrent = not args.no_concurrent
-    n_samples = synthetic.samples_for_frames(args.frames)
-    # clip i of the global batch lives on rank i % world; every rank gets `batch` clips
-    audio = synthetic.synthetic_audio(args.batch, n_samples, seed=1234 + rank).to(dev)
-    spk = torch.zeros(args.batch, 1, dtype=torch.long, device=dev)
-    zeros_trans = torch.zeros(1, 3, device=dev)
+
+    log(f"rank {rank}/{world}: building the {args.precision} models on {dev} and capturing the clip graph")
+    model, vq, runner, n_samples = build(args.precision, dev, args)
+    # clip i of the global batch lives on rank i % world; every rank gets `batch` clips (weak scaling)
+    audio_host = synthetic.synthetic_audio(args.batch, n_samples, seed=1234 + rank).pin_memory()
+    audio = audio_host.to(dev)
+    # the process group (RCCL; barriers and the max-over-ranks of the timing only) is joined AFTER the graph capture, so
+    # no communicator thread is alive while the stream capture is open; None without a launcher
+    pdist.init("nccl", dev)
 
     def barrier():
         pdist.barrier()
         torch.cuda.synchronize()
 
-    from pantomatrix_amd.runtime import ClipRunner
-    log(f"models built on {dev}; capturing the clip graph")
-    runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph, sub_batches=args.sub_batches)
-    # the process group (RCCL; barriers and the max-over-ranks of the timing only) is joined AFTER the graph capture, so
-    # no communicator thread is alive while the stream capture is open; None without a launcher
-    pdist.init("nccl", dev)
-    log(f"warm-up x{args.warmup}")
-    for _ in range(args.warmup):
-        poses, _, _ = one_step(runner, audio)
-    log("timed region")
-    frames_per_step = poses.shape[0] * poses.shape[1] if args.warmup else None
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        poses, expr, trans = one_step(runner, audio)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    reduce_max = lambda v: pdist.max_over_ranks(v, dev)
+    log(f"warm-up x{args.warmup}, then {args.steps} timed steps")
+    elapsed, out = timed_steps(lambda: runner(audio), args.steps, args.warmup, barrier, reduce_max)
+    poses = out[0]
     frames_per_step = poses.shape[0] * poses.shape[1]
-    elapsed = pdist.max_over_ranks(elapsed, dev)
     assert np.isfinite(poses).all()
     log(f"timed: {1e3 * elapsed / args.steps:.2f} ms/step")
+    result = result_line(args.precision, elapsed, args.steps, args.warmup, world, frames_per_step, args.batch, args.frames,
+                         "eager" if args.no_graph else "hipGraph replay")
 
-    result = {
-        "metric": "motion-frames/sec (30fps SMPL-X) EMAGE infer, 128-frame clips",
-        "value": frames_per_step * world * args.steps / elapsed,
-        "unit": "motion-frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"EMAGE inference {args.precision}, batch={args.batch}x{args.frames}-frame synthetic clips per GPU "
-                               f"(BASELINE configs[1]): 2 windows of 64 frames + final VQ decode with global motion, "
-                               f"{frames_per_step // args.batch} frames out per clip; synthetic seeded weights",
-                   "clips_per_gpu": args.batch, "frames_in": args.frames, "frames_out_per_clip": frames_per_step // args.batch,
-                   "parallelism": f"replicas x{world} (clip-sharded, no collective)",
-                   "launch": "eager" if args.no_graph else "hipGraph replay", "sub_batches": args.sub_batches, "batches_in_flight": 1},
-    }
+    # the same step with the audio batch crossing PCIe inside the timed region (pinned host -> HBM), SURVEY §8(d)
+    el_pcie, _ = timed_steps(lambda: runner(audio_host), args.steps, 1, barrier, reduce_max)
+    result["pcie_inclusive"] = {"value": frames_per_step * world * args.steps / el_pcie, "ms_per_step": 1e3 * el_pcie / args.steps,
+                                "h2d_bytes_per_step": audio_host.numel() * 4,
+                                "note": "audio batch copied pinned-host -> HBM inside every timed step; `value` above is HBM-resident"}
+
     if rank == 0 and not args.no_roofline:
-        fam = profile_kernels(model, vq, audio, spk, zeros_trans)
-        total_ms = sum(v[1] for v in fam.values())
-        dom = max(fam.items(), key=lambda kv: kv[1][1])
-        name, (cnt, ms, flops, byts) = dom
-        if name.startswith("gemm") or name in ("attention", "transformer_layer"):
-            peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
-            ach = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
-        else:
-            ach = byts / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            with open(tfile) as f:
-                traffic = json.load(f).get(name)
-        roof.update({"traffic": traffic, "kernel": name, "launches_per_step": cnt, "avg_launch_us": 1e3 * ms / cnt,
-                     "algorithmic_gflop_per_launch": flops / cnt / 1e9,
-                     "share_of_kernel_time": ms / total_ms if total_ms else None,
-                     "kernel_time_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
-                     "launches_by_family": {k: v[0] for k, v in fam.items()}})
-        result["roofline"] = roof
+        records = profile_kernels(runner, model, vq)
+        result["roofline"] = roofline_report(records, args.precision, result["ms_per_step"])
+        if world == 1:
+            result["roofline"].setdefault("vq_argmin", {})["n_1m"] = vq_argmin_large(dev)
+    if world == 1 and args.also:
+        others = {}
+        del runner, model, vq
+        torch.cuda.empty_cache()
+        for p in [x for x in args.also.split(",") if x and x != args.precision]:
+            m2, v2, r2, _ = build(p, dev, args)
+            el2, _ = timed_steps(lambda: r2(audio), args.steps, args.warmup, barrier, reduce_max)
+            others[p] = {"value": frames_per_step * args.steps / el2, "ms_per_step": 1e3 * el2 / args.steps, "precision": PRECISION_NOTE[p]}
+            del m2, v2, r2
+            torch.cuda.empty_cache()
+        result["other_precisions"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.frames)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     pdist.finalize()
 
 

@@ -57,10 +57,14 @@ int emage_set_tuning(int key, int value);
  * K6 — VQ nearest neighbour.  Replaces Quantizer.map2index / Quantizer.forward's argmin (P:144-164)
  * and EmageVQVAEConv.decode_from_latent's inline copy (M:60-67):
  *   d[n][k] = (sum_j z[n][j]^2 + sum_j e[k][j]^2) - 2 * sum_j z[n][j] e[k][j];  idx[n] = argmin_k d[n][k]
- * fp32 throughout, first minimum wins ties (torch.argmin).  z: (N,D) fp32 row stride ldz;
- * codebook: (K,D) fp32 contiguous; idx: (N,) int64.  D % 4 == 0, D <= 1024, K <= 4096.
+ * fp32 throughout, first minimum wins ties and a NaN distance wins outright (torch.argmin).  z: (N,D) fp32 row stride
+ * ldz; codebook: (K,D) fp32 contiguous.  D % 4 == 0, D <= 1024, K <= 4096.
+ * idx: int64, addressed as a 2-D view — element n is written at idx[(n / idx_rows) * idx_ld + n % idx_rows], so a
+ * (B, T) window of a longer (B, L) code buffer is filled in place (idx_rows = T, idx_ld = L); idx_rows <= 0: a
+ * plain (N,) list.  The same view convention is used by emage_argmax_logsoftmax_f32 (output) and emage_gather_rows
+ * (input, with an extra frame stride idx_tstride in {0, 1}: 0 broadcasts one id per clip over its idx_rows frames).
  */
-int emage_vq_argmin_f32(const float* z, int ldz, const float* codebook, int64_t* idx,
+int emage_vq_argmin_f32(const float* z, int ldz, const float* codebook, int64_t* idx, int idx_rows, long idx_ld,
                         int N, int K, int D, void* stream);
 
 /*
@@ -68,14 +72,15 @@ int emage_vq_argmin_f32(const float* z, int ldz, const float* codebook, int64_t*
  * (M:398-401, test_emage_audio.py:39-42): y = (x - max) - log(sum exp(x - max)) in fp32, first maximum.
  * logits: (N,C) fp32 row stride ld; idx: (N,) int64.  C <= 4096.
  */
-int emage_argmax_logsoftmax_f32(const float* logits, int ld, int64_t* idx, int N, int C, void* stream);
+int emage_argmax_logsoftmax_f32(const float* logits, int ld, int64_t* idx, int idx_rows, long idx_ld, int N, int C, void* stream);
 
 /*
  * K7 — codebook / embedding gather.  Replaces Quantizer.get_codebook_entry (P:166-170).
- * table: (K,D) fp32; idx: (N,) int64; out: (N, ldo) in `dtype`, columns [D, n_store) zero-filled.
+ * table: (K,D) fp32; idx: int64 view (see emage_vq_argmin_f32), clamped to [0, K); out: (N, ldo) in `dtype`,
+ * columns [D, n_store) zero-filled.
  */
-int emage_gather_rows(const float* table, const int64_t* idx, void* out, int ldo, int n_store,
-                      int N, int K, int D, int dtype, void* stream);
+int emage_gather_rows(const float* table, const int64_t* idx, int idx_rows, long idx_ld, int idx_tstride,
+                      void* out, int ldo, int n_store, int N, int K, int D, int dtype, void* stream);
 
 /*
  * K1/K2/K3 — the one contraction kernel: Linear and Conv1d as (implicit) GEMM with a fused epilogue.
@@ -114,11 +119,15 @@ int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bi
 /*
  * K1 first layer — WavEncoder block 0 on the raw waveform (Cin = 1), P:301 + P:283-290:
  *   out[b][l][c] = leaky( sum_k wav[b][l*stride + k - pad] * w[c][k] + bias[c], slope[c] )
- * wav: (B, L) fp32; w: (C, taps) fp32 (eval BatchNorm folded); out: (B*Lout, ldo) `dtype`.
+ * wav: fp32, clip b at wav + b*ldw; the launch covers `nwin` windows of L samples per clip, window i starting at
+ * sample i*hop of its clip (inference()'s sliding windows, M:393-394, read in place: no slicing copy); samples
+ * outside [0, L) of a window are the conv's zero padding.  Output sequence (i*B + b) holds window i of clip b:
+ * out: (nwin*B*Lout, ldo) `dtype`.  w: (C, taps) fp32 (eval BatchNorm folded).
  * Computes conv1 and the downsample shortcut (same input, same geometry) in one pass: the host
  * stacks their filters along C and gives the shortcut channels slope 1.  C % 8 == 0, taps <= 16.
  */
-int emage_wav_conv_in(int dtype, const float* wav, int L, const float* w, const float* bias, const float* slope,
+int emage_wav_conv_in(int dtype, const float* wav, long ldw, int L, int nwin, long hop,
+                      const float* w, const float* bias, const float* slope,
                       void* out, int ldo, int B, int Lout, int C, int taps, int stride, int pad, void* stream);
 
 /*
@@ -150,14 +159,18 @@ int emage_layernorm(int dtype, const void* x, int ldx, const float* gamma, const
  * emage_add: out[m] = a[m] + b[m % mod_b] (+ c[m % mod_c]); operand k (a=0,b=1,c=2) is fp32 when bit k of
  *   f32_mask is set, else `dtype` (mod_* = 0: no wrap; mod = T broadcasts a (T,C) positional table over the
  *   batch, P:341-343); writes fp32 and/or `dtype`.  C % 4 == 0.
- * emage_pack_motion: where(mask == 1, mask_embedding, motion) (M:267-268) -> `dtype`, (M, ldo),
- *   columns [C, n_store) zero.
+ * emage_pack_motion: one window of the masked-motion input -> `dtype`, (B*T, ldo), columns [C, n_store) zero:
+ *   where(mask == 1, mask_embedding, motion) (M:267-268); with `seed` != NULL the first `pre` frames are
+ *   where(mask == 0, motion, seed) and count as unmasked — the seed splice of inference() (M:386-391).  motion / mask:
+ *   fp32, frame (b, t) at b*ldb + t*C (a window of a longer (B, L, C) tensor is read in place); seed: frame (b, t) at
+ *   b*ld_seed + t*C.
  * emage_cast_pad: fp32 (M,C) -> `dtype` (M, ldo) with zero tail [C, n_store).
  */
 int emage_add(int dtype, const void* a, int lda, const void* b, int ldb, int mod_b, const void* c, int ldc, int mod_c,
               int f32_mask, float* out_f32, void* out, int ldo, int M, int C, void* stream);
-int emage_pack_motion(int dtype, const float* motion, const float* mask, const float* mask_embedding,
-                      void* out, int ldo, int n_store, int M, int C, void* stream);
+int emage_pack_motion(int dtype, const float* motion, const float* mask, long ldb, const float* mask_embedding,
+                      const float* seed, long ld_seed, int pre,
+                      void* out, int ldo, int n_store, int B, int T, int C, void* stream);
 int emage_cast_pad(int dtype, const float* src, int lds, void* out, int ldo, int n_store, int M, int C, void* stream);
 
 /*
@@ -182,42 +195,11 @@ int emage_merge_parts(const float* face, int ldface, const float* upper, int ldu
  * K10 — velocity2position (P:107-115) for get_global_motion (M:195-205):
  *   trans[b][0][x|z] = init[b][x|z]; trans[b][t][x|z] = vel[b][t-1][x|z]*dt + trans[b][t-1][x|z]
  *   trans[b][t][y] = vel[b][t][y]        (sequential fp32, product rounded before the add)
- * vel: (B*T, ldv) fp32, the 3 velocity channels start at column col0; init: (B,3) fp32.
+ * vel: (B*T, ldv) fp32, the 3 velocity channels start at column col0; init: fp32, clip b at init + b*ld_init
+ * (ld_init = 0 broadcasts one start position, M:198-200).
  */
-int emage_velocity_to_position(const float* vel, int ldv, int col0, const float* init, float dt,
+int emage_velocity_to_position(const float* vel, int ldv, int col0, const float* init, int ld_init, float dt,
                                float* trans, int B, int T, void* stream);
-
-/*
- * K12 — one whole nn.TransformerDecoderLayer / nn.TransformerEncoderLayer (torch defaults: post-norm, ReLU, no masks)
- * in ONE launch, for the geometry EMAGE instantiates (M:246-262: d_model 768, 4 heads, FFN 1536) on a full 64-frame
- * window, bf16 mode.  Same arithmetic, in the same order, as the emage_gemm / emage_attention / emage_layernorm
- * sequence it replaces (bit-identical output); other geometries return EMAGE_EINVAL and the caller keeps that sequence.
- *   x:        (B*64, ldx) layer input (the residual stream)
- *   weights:  6 packed matrices  [in_proj (2304x768), self out_proj (768x768), cross q (768x768), cross out_proj,
- *             linear1 (1536x768), linear2 (768x1536)], biases: the 6 fp32 bias vectors; entries 2,3 unused when
- *             mem_k == NULL (encoder layer: self-attention + FFN only)
- *   ln_gamma / ln_beta: norm1, norm2, norm3 (decoder) or norm1, -, norm2 (encoder: index 1 unused)
- *   mem_k:    (B*Tk, ldk) projected memory keys of THIS layer; mem_vt: this layer's first row of a (B, vt_rows, ldvt)
- *             V^T buffer (the layout emage_gemm's out_t path writes); 32 < Tk <= 64
- *   post_add: optional (B*64, ld_add) tensor added after the last LayerNorm (M:304-305, 312)
- *   relu_slope: 1536 zeros (the per-column LeakyReLU slope vector of the FFN up-projection)
- *   workspace: emage_transformer_layer_workspace(B) bytes, 256-byte aligned, private to this call until it completes
- *   out:      (B*64, ldo)
- * emage_transformer_layer_status (diagnostics, synchronous) for the last run on that workspace: bit 0 = a group barrier
- * gave up waiting, bit 1 = the four workgroups of a clip were not placed on one XCD (results then not trustworthy).  emage_layer_set_tuning: key 0 = operand-ring depth of the fused kernel (2..4), key 1 =
- * ablation mask for tools/bench_layer.py (timing only), key 2 = waves per workgroup (4 or 8), key 3 = W prefetch ahead of
- * the group barriers (0 / 1).
- */
-size_t emage_transformer_layer_workspace(int B);
-int emage_transformer_layer(int dtype, const void* x, int ldx,
-                            const void* const* weights, const float* const* biases,
-                            const float* const* ln_gamma, const float* const* ln_beta, float eps,
-                            const void* mem_k, int ldk, const void* mem_vt, int vt_rows, int ldvt, int Tk,
-                            const void* post_add, int ld_add, const float* relu_slope,
-                            void* workspace, size_t workspace_bytes, void* out, int ldo,
-                            int B, int T, int d_model, int n_head, int d_ffn, void* stream);
-int emage_transformer_layer_status(const void* workspace, int B);
-int emage_layer_set_tuning(int key, int value);
 
 #ifdef __cplusplus
 }

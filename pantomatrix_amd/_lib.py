@@ -11,33 +11,28 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 F32, BF16, F16X3 = 0, 1, 2
 ABI_VERSION = 4
 
-_p, _i, _f = C.c_void_p, C.c_int, C.c_float
+_p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
 # name -> argtypes, exactly the prototypes of include/emage_hip.h
 SIGNATURES = {
     "emage_set_tuning": [_i, _i],
-    "emage_vq_argmin_f32": [_p, _i, _p, _p, _i, _i, _i, _p],
-    "emage_argmax_logsoftmax_f32": [_p, _i, _p, _i, _i, _p],
-    "emage_gather_rows": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "emage_vq_argmin_f32": [_p, _i, _p, _p, _i, _l, _i, _i, _i, _p],
+    "emage_argmax_logsoftmax_f32": [_p, _i, _p, _i, _l, _i, _i, _p],
+    "emage_gather_rows": [_p, _p, _i, _l, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_gemm": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i,
                    _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p],
-    "emage_wav_conv_in": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "emage_wav_conv_in": [_i, _p, _l, _i, _i, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "emage_attention": [_i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p],
-    "emage_pack_motion": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "emage_pack_motion": [_i, _p, _p, _l, _p, _p, _l, _i, _p, _i, _i, _i, _i, _i, _p],
     "emage_cast_pad": [_i, _p, _i, _p, _i, _i, _i, _i, _p],
     "emage_rot6d_to_axis_angle": [_p, _p, _i, _p],
     "emage_axis_angle_to_rot6d": [_p, _p, _i, _p],
     "emage_merge_parts": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p],
-    "emage_velocity_to_position": [_p, _i, _i, _p, _f, _p, _i, _i, _p],
-    "emage_transformer_layer": [_i, _p, _i, _p, _p, _p, _p, _f, _p, _i, _p, _i, _i, _i, _p, _i, _p,
-                                _p, C.c_size_t, _p, _i, _i, _i, _i, _i, _i, _p],
-    "emage_transformer_layer_workspace": [_i],
-    "emage_transformer_layer_status": [_p, _i],
-    "emage_layer_set_tuning": [_i, _i],
+    "emage_velocity_to_position": [_p, _i, _i, _p, _i, _f, _p, _i, _i, _p],
 }
-RESTYPES = {"emage_transformer_layer_workspace": C.c_size_t}
+RESTYPES = {}
 
 _lib = None
 

@@ -31,14 +31,41 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return (a >> 16) | (b & 0xffff0000u);
 }
 
+// ---- split-f16 form (EMAGE_F16X3): fp32 operands, every 16x16x32 product as three fp16 MFMAs (hi*hi + hi*lo + lo*hi,
+// fp32 accumulate) instead of eight v_mfma_f32_16x16x4_f32 — fp32-grade scores and outputs at bf16-like kernel time.
+// Two consecutive fp32 chunks of a lane (8 values) form one MFMA operand; x*s = hi + lo with both planes fp16.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+struct SplitF16 { h16x8 hi, lo; };
+__device__ __forceinline__ SplitF16 split_chunks(const uint4& c0, const uint4& c1, const float s) {
+    const float x[8] = {__builtin_bit_cast(float, c0.x), __builtin_bit_cast(float, c0.y), __builtin_bit_cast(float, c0.z), __builtin_bit_cast(float, c0.w),
+                        __builtin_bit_cast(float, c1.x), __builtin_bit_cast(float, c1.y), __builtin_bit_cast(float, c1.z), __builtin_bit_cast(float, c1.w)};
+    SplitF16 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float xs = x[e] * s;
+        const _Float16 h = (_Float16)xs;
+        r.hi[e] = h;
+        r.lo[e] = (_Float16)(xs - (float)h);
+    }
+    return r;
+}
+__device__ __forceinline__ f32x4 mma_split(const SplitF16& a, const SplitF16& b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, acc, 0, 0, 0);
+}
+constexpr float ATT_QKV_SCALE = 16.0f;     // Q, K, V planes: |x| < 4094 stays finite in fp16
+constexpr float ATT_P_SCALE = 1024.0f;     // probabilities are <= 1
+
 constexpr int QW = 4;    // query tiles per workgroup: the waves of one (batch, head) share K / V^T through the CU's L1
 constexpr int DS = 1;    // waves per query tile: with DS = 2 each wave recomputes the 16x64 scores and owns half of the d tiles
                          // of P V (two shorter waves per SIMD).  Measured: 16.0 us vs 13.3 us with DS = 1 — not a win.
 
 // softmax(Q K^T * scale) V for query tile qt (16 queries) of (batch b, head h); one wave64 (wave `dpart` of the DSP that share that tile: each recomputes the scores and owns NDT / DSP of the output d tiles).
-template <typename T, int HD, int NT, int DSP = DS>
+template <typename T, int HD, int NT, int DSP = DS, bool X3 = false>
 __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const int h, const int qt, const int dpart) {
     constexpr int EPC = Elem<T>::EPC;
+    static_assert(!X3 || (EPC == 4 && NT % 2 == 0), "split-f16 attention: fp32 operands, key tiles pair up");
     constexpr int ES = 16 / EPC;
     constexpr int NSTEP = HD / (4 * EPC);     // contraction steps over head_dim (4 chunks per step)
     constexpr int NDT = HD / 16;              // output d tiles
@@ -104,13 +131,28 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
 
     // scores S^T[key][q] = K Q^T: lane holds keys {16nt + 4g + r} of query column fr
     f32x4 sc[NT];
+    if constexpr (X3) {
+        SplitF16 qs[NSTEP / 2];                // Q is re-used by every key tile: split once
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (!PRE) load_k(nt, kf[0]);
+        for (int s = 0; s < NSTEP / 2; ++s) qs[s] = split_chunks(qf[2 * s], qf[2 * s + 1], ATT_QKV_SCALE);
 #pragma unroll
-        for (int s = 0; s < NSTEP; ++s) acc = Elem<T>::mma(kf[PRE ? nt : 0][s], qf[s], acc);
-        sc[nt] = acc;
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!PRE) load_k(nt, kf[0]);
+#pragma unroll
+            for (int s = 0; s < NSTEP / 2; ++s)
+                acc = mma_split(split_chunks(kf[PRE ? nt : 0][2 * s], kf[PRE ? nt : 0][2 * s + 1], ATT_QKV_SCALE), qs[s], acc);
+            sc[nt] = acc * (1.0f / (ATT_QKV_SCALE * ATT_QKV_SCALE));
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!PRE) load_k(nt, kf[0]);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) acc = Elem<T>::mma(kf[PRE ? nt : 0][s], qf[s], acc);
+            sc[nt] = acc;
+        }
     }
 
     // softmax over keys for query column fr
@@ -168,13 +210,25 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
     T* __restrict__ O = (T*)p.out;
     const int qq = q0 + fr;
     T* orow = O + ((long)b * p.Tq + qq) * p.ldo + h * HD + fg * 4;
+    SplitF16 ps[X3 ? NPC / 2 : 1];             // P is re-used by every d tile: split once (pairs of 4-key chunks = 8 keys)
+    if constexpr (X3) {
+#pragma unroll
+        for (int c = 0; c < NPC / 2; ++c) ps[c] = split_chunks(pc[2 * c], pc[2 * c + 1], ATT_P_SCALE);
+    }
 #pragma unroll
     for (int dw = 0; dw < NDW; ++dw) {
         const int dt = dt0 + dw;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if constexpr (!PRE) load_v(dt, vf[0]);
+        if constexpr (X3) {
 #pragma unroll
-        for (int c = 0; c < NPC; ++c) acc = Elem<T>::mma(vf[PRE ? dw : 0][c], pc[c], acc);
+            for (int c = 0; c < NPC / 2; ++c)
+                acc = mma_split(split_chunks(vf[PRE ? dw : 0][2 * c], vf[PRE ? dw : 0][2 * c + 1], ATT_QKV_SCALE), ps[c], acc);
+            acc = acc * (1.0f / (ATT_QKV_SCALE * ATT_P_SCALE));
+        } else {
+#pragma unroll
+            for (int c = 0; c < NPC; ++c) acc = Elem<T>::mma(vf[PRE ? dw : 0][c], pc[c], acc);
+        }
         if (qq < p.Tq) {
             if constexpr (EPC == 8) {
                 uint2 t;                      // convex combination of finite V rows: no NaN path needed

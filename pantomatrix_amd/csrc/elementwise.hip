@@ -43,15 +43,26 @@ __global__ __launch_bounds__(256) void add_kernel(const void* __restrict__ a, in
     }
 }
 
-// where(mask == 1, mask_embedding, motion) -> T, zero channel tail
+// One window of the masked-motion input (M:267-268 + the seed splice of inference(), M:386-391):
+//   frames t <  pre (seed given): v = mask == 0 ? motion : seed      (and the frame counts as unmasked)
+//   other frames:                 v = mask == 1 ? mask_embedding : motion
+// motion / mask: frame (b, t) at b*ldb + t*C (a window cut out of a longer (B, L, C) tensor needs no copy);
+// seed: frame (b, t) at b*ld_seed + t*C.  Output (B*T, ldo) in T with a zero channel tail.
 template <typename T>
-__global__ __launch_bounds__(256) void pack_motion_kernel(const float* __restrict__ motion, const float* __restrict__ mask,
-                                                          const float* __restrict__ emb, T* __restrict__ out, int ldo, int n_store, int M, int C) {
-    const long total = (long)M * n_store;
+__global__ __launch_bounds__(256) void pack_motion_kernel(const float* __restrict__ motion, const float* __restrict__ mask, long ldb,
+                                                          const float* __restrict__ emb, const float* __restrict__ seed, long ld_seed, int pre,
+                                                          T* __restrict__ out, int ldo, int n_store, int B, int Tn, int C) {
+    const long total = (long)B * Tn * n_store;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / n_store), n = (int)(i - (long)m * n_store);
+        const int b = m / Tn, t = m - b * Tn;
         float v = 0.f;
-        if (n < C) v = mask[(long)m * C + n] == 1.0f ? emb[n] : motion[(long)m * C + n];
+        if (n < C) {
+            const long src = (long)b * ldb + (long)t * C + n;
+            const float mk = mask[src], mv = motion[src];
+            if (seed && t < pre) v = mk == 0.0f ? mv : seed[(long)b * ld_seed + (long)t * C + n];
+            else v = mk == 1.0f ? emb[n] : mv;
+        }
         out[(long)m * ldo + n] = Elem<T>::to(v);
     }
 }
@@ -97,13 +108,15 @@ extern "C" int emage_add(int dtype, const void* a, int lda, const void* b, int l
     return launch_status();
 }
 
-extern "C" int emage_pack_motion(int dtype, const float* motion, const float* mask, const float* mask_embedding,
-                                 void* out, int ldo, int n_store, int M, int C, void* stream) {
-    if (!motion || !mask || !mask_embedding || !out || M <= 0 || C <= 0 || n_store < C || ldo < n_store) return EMAGE_EINVAL;
+extern "C" int emage_pack_motion(int dtype, const float* motion, const float* mask, long ldb, const float* mask_embedding,
+                                 const float* seed, long ld_seed, int pre,
+                                 void* out, int ldo, int n_store, int B, int T, int C, void* stream) {
+    if (!motion || !mask || !mask_embedding || !out || B <= 0 || T <= 0 || C <= 0 || n_store < C || ldo < n_store) return EMAGE_EINVAL;
+    if (ldb < (long)T * C || (seed && (pre <= 0 || pre > T || ld_seed < (long)pre * C))) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(grid_for((long)M * n_store)), block(256);
-    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((pack_motion_kernel<bf16_t>), grid, block, 0, s, motion, mask, mask_embedding, (bf16_t*)out, ldo, n_store, M, C);
-    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((pack_motion_kernel<float>), grid, block, 0, s, motion, mask, mask_embedding, (float*)out, ldo, n_store, M, C);
+    const dim3 grid(grid_for((long)B * T * n_store)), block(256);
+    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((pack_motion_kernel<bf16_t>), grid, block, 0, s, motion, mask, ldb, mask_embedding, seed, ld_seed, pre, (bf16_t*)out, ldo, n_store, B, T, C);
+    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((pack_motion_kernel<float>), grid, block, 0, s, motion, mask, ldb, mask_embedding, seed, ld_seed, pre, (float*)out, ldo, n_store, B, T, C);
     else return EMAGE_EINVAL;
     return launch_status();
 }

@@ -234,6 +234,11 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 34: return launch_pipe<T, X3, 128, 128, 4, 2, 2, 8>(a, s);
         case 36: return launch_pipe<T, X3, 128, 64, 4, 2, 3, 8>(a, s);
         case 37: return launch_pipe<T, X3, 128, 192, 4, 2, 2, 8>(a, s);
+        case 38: return launch_pipe<T, X3, 128, 128, 4, 2, 3, 8>(a, s);   // deeper rings / fatter tiles: sweeps of the per-CU operand stream
+        case 39: return launch_pipe<T, X3, 128, 128, 4, 2, 4, 8>(a, s);
+        case 40: return launch_pipe<T, X3, 64, 192, 4, 2, 4, 8>(a, s);
+        case 41: return launch_pipe<T, X3, 128, 256, 4, 2, 2, 8>(a, s);
+        case 42: return launch_pipe<T, X3, 128, 192, 4, 2, 3, 8>(a, s);
         default: return EMAGE_EINVAL;
     }
 }

@@ -138,7 +138,7 @@ __device__ __forceinline__ f32x4 mma_f16(const f16x8& a, const f16x8& b, const f
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N > 15 ? 15 : N) : "memory"); }   // 4-bit counter
 
 // LDS image per ring slot: rows of KC 16-byte chunks (KC = 8: 128-B rows, two MFMA k-groups per tile;
 // KC = 4: 64-B rows, one k-group).  16-B slot of chunk g in row r: g ^ swz(r), chosen so that each 16-lane

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(const float* __restric
 }
 
 // one thread per (batch, axis): x and z integrate, y copies  (P:107-115, M:195-205)
-__global__ void velocity_scan_kernel(const float* __restrict__ vel, int ldv, int col0, const float* __restrict__ init, float dt,
+__global__ void velocity_scan_kernel(const float* __restrict__ vel, int ldv, int col0, const float* __restrict__ init, int ld_init, float dt,
                                      float* __restrict__ trans, int B, int T) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * 3) return;
@@ -121,7 +121,7 @@ __global__ void velocity_scan_kernel(const float* __restrict__ vel, int ldv, int
     if (ax == 1) {
         for (int t = 0; t < T; ++t) o[(long)t * 3] = v[(long)t * ldv];
     } else {
-        float pos = init[b * 3 + ax];
+        float pos = init[(long)b * ld_init + ax];
         o[0] = pos;
         for (int t = 1; t < T; ++t) {
             pos = __fadd_rn(__fmul_rn(v[(long)(t - 1) * ldv], dt), pos);
@@ -132,7 +132,7 @@ __global__ void velocity_scan_kernel(const float* __restrict__ vel, int ldv, int
 
 // Same recurrence with the velocities staged in LDS first: the scan itself is inherently sequential (the reference's
 // fp32 rounding order is part of the contract), but its T dependent steps should not each wait on a global load.
-__global__ __launch_bounds__(128) void velocity_scan_lds_kernel(const float* __restrict__ vel, int ldv, int col0, const float* __restrict__ init,
+__global__ __launch_bounds__(128) void velocity_scan_lds_kernel(const float* __restrict__ vel, int ldv, int col0, const float* __restrict__ init, int ld_init,
                                                                 float dt, float* __restrict__ trans, int T) {
     extern __shared__ float s_v[];                     // [3][T]
     const int b = blockIdx.x;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(128) void velocity_scan_lds_kernel(const float* __r
     float* o = trans + (long)b * T * 3;
     if (threadIdx.x < 2) {                             // x (axis 0) and z (axis 2) integrate
         const int ax = threadIdx.x * 2;
-        float pos = init[b * 3 + ax];
+        float pos = init[(long)b * ld_init + ax];
         float* s_p = s_v + ax * T;
         float prev = s_p[0];
         s_p[0] = pos;
@@ -182,12 +182,12 @@ extern "C" int emage_merge_parts(const float* face, int ldface, const float* upp
                        axis_angle, motion, expression, M);
     return launch_status();
 }
-extern "C" int emage_velocity_to_position(const float* vel, int ldv, int col0, const float* init, float dt,
+extern "C" int emage_velocity_to_position(const float* vel, int ldv, int col0, const float* init, int ld_init, float dt,
                                           float* trans, int B, int T, void* stream) {
-    if (!vel || !init || !trans || B <= 0 || T <= 0) return EMAGE_EINVAL;
+    if (!vel || !init || !trans || B <= 0 || T <= 0 || ld_init < 0) return EMAGE_EINVAL;
     if ((size_t)3 * T * sizeof(float) <= 60 * 1024)
-        hipLaunchKernelGGL(velocity_scan_lds_kernel, dim3(B), dim3(128), (size_t)3 * T * sizeof(float), (hipStream_t)stream, vel, ldv, col0, init, dt, trans, T);
+        hipLaunchKernelGGL(velocity_scan_lds_kernel, dim3(B), dim3(128), (size_t)3 * T * sizeof(float), (hipStream_t)stream, vel, ldv, col0, init, ld_init, dt, trans, T);
     else
-        hipLaunchKernelGGL(velocity_scan_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, (hipStream_t)stream, vel, ldv, col0, init, dt, trans, B, T);
+        hipLaunchKernelGGL(velocity_scan_kernel, dim3((B * 3 + 63) / 64), dim3(64), 0, (hipStream_t)stream, vel, ldv, col0, init, ld_init, dt, trans, B, T);
     return launch_status();
 }

@@ -5,12 +5,26 @@
 
 namespace {
 
-// (value, index) "less" with the first-minimum rule
+// (value, index) "less" with torch's rules: the first extremum wins ties, and a NaN is the extremum (torch.argmin /
+// argmax / max return the position of the first NaN), so a NaN upstream surfaces as its own index instead of a
+// plausible-looking code
 __device__ __forceinline__ void take_min(float& d, int& i, float od, int oi) {
-    if (od < d || (od == d && oi < i)) { d = od; i = oi; }
+    const bool od_nan = od != od, d_nan = d != d;
+    if (od < d || (od == d && oi < i) || (od_nan && (!d_nan || oi < i))) { d = od; i = oi; }
 }
 __device__ __forceinline__ void take_max(float& d, int& i, float od, int oi) {
-    if (od > d || (od == d && oi < i)) { d = od; i = oi; }
+    const bool od_nan = od != od, d_nan = d != d;
+    if (od > d || (od == d && oi < i) || (od_nan && (!d_nan || oi < i))) { d = od; i = oi; }
+}
+
+// Index tensors are addressed as 2-D views: element n of a flat (N,) index list lives at (n / rows)*ld + (n % rows)*ts,
+// so a (B, T) window cut out of a longer (B, L) code buffer (ld = L), or one id per clip broadcast over T frames
+// (ts = 0), is read / written in place.  rows <= 0 means a plain contiguous list.
+struct IdxView { int rows; long ld; int ts; };
+__device__ __forceinline__ long idx_at(const IdxView v, int n) {
+    if (v.rows <= 0) return n;
+    const int b = n / v.rows;
+    return (long)b * v.ld + (long)(n - b * v.rows) * v.ts;
 }
 
 // One block = 4 waves = 16 rows of z.  Wave w scores code tiles {w, w+4, ...} (16 codes each) against
@@ -19,7 +33,7 @@ __device__ __forceinline__ void take_max(float& d, int& i, float od, int oi) {
 // inside the wave (16 lanes per row group, xor-shuffles), then the 4 waves meet in LDS.
 template <int D>
 __global__ __launch_bounds__(256) void vq_argmin_mfma(const float* __restrict__ z, int ldz,
-                                                      const float* __restrict__ cb, int64_t* __restrict__ idx,
+                                                      const float* __restrict__ cb, int64_t* __restrict__ idx, IdxView iv,
                                                       int N, int K) {
     constexpr int NS = D / 16;
     __shared__ float s_d[4][16];
@@ -87,13 +101,13 @@ __global__ __launch_bounds__(256) void vq_argmin_mfma(const float* __restrict__ 
     if (threadIdx.x < 16 && r0 + threadIdx.x < N) {
         float d = s_d[0][threadIdx.x]; int i = s_i[0][threadIdx.x];
         for (int w = 1; w < 4; ++w) take_min(d, i, s_d[w][threadIdx.x], s_i[w][threadIdx.x]);
-        idx[r0 + threadIdx.x] = (int64_t)i;
+        idx[idx_at(iv, r0 + threadIdx.x)] = (int64_t)i;
     }
 }
 
 // Generic-D fallback: one wave per row, lane c scores codes c, c+64, ... with an fmaf chain.
 __global__ __launch_bounds__(256) void vq_argmin_generic(const float* __restrict__ z, int ldz,
-                                                         const float* __restrict__ cb, int64_t* __restrict__ idx,
+                                                         const float* __restrict__ cb, int64_t* __restrict__ idx, IdxView iv,
                                                          int N, int K, int D) {
     __shared__ float s_z[4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,11 +128,11 @@ __global__ __launch_bounds__(256) void vq_argmin_generic(const float* __restrict
         const float od = __shfl_xor(bd, m); const int oi = __shfl_xor(bi, m);
         take_min(bd, bi, od, oi);
     }
-    if (lane == 0) idx[row] = (int64_t)bi;
+    if (lane == 0) idx[idx_at(iv, row)] = (int64_t)bi;
 }
 
 // One wave per row: y = (x - max) - log(sum exp(x - max)); first maximum of y.
-__global__ __launch_bounds__(256) void argmax_logsoftmax(const float* __restrict__ x, int ld, int64_t* __restrict__ idx, int N, int C) {
+__global__ __launch_bounds__(256) void argmax_logsoftmax(const float* __restrict__ x, int ld, int64_t* __restrict__ idx, IdxView iv, int N, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= N) return;
@@ -136,14 +150,14 @@ __global__ __launch_bounds__(256) void argmax_logsoftmax(const float* __restrict
         const float od = __shfl_xor(bd, m); const int oi = __shfl_xor(bi, m);
         take_max(bd, bi, od, oi);
     }
-    if (lane == 0) idx[row] = (int64_t)bi;
+    if (lane == 0) idx[idx_at(iv, row)] = (int64_t)bi;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gather_rows(const float* __restrict__ table, const int64_t* __restrict__ idx,
+__global__ __launch_bounds__(256) void gather_rows(const float* __restrict__ table, const int64_t* __restrict__ idx, IdxView iv,
                                                    T* __restrict__ out, int ldo, int n_store, int N, int K, int D) {
     const int row = blockIdx.x;
-    long k = idx[row];
+    long k = idx[idx_at(iv, row)];
     k = k < 0 ? 0 : (k >= K ? K - 1 : k);
     for (int j = threadIdx.x; j < n_store; j += blockDim.x)
         out[(long)row * ldo + j] = Elem<T>::to(j < D ? table[k * D + j] : 0.f);
@@ -151,30 +165,35 @@ __global__ __launch_bounds__(256) void gather_rows(const float* __restrict__ tab
 
 }  // namespace
 
-extern "C" int emage_vq_argmin_f32(const float* z, int ldz, const float* codebook, int64_t* idx,
+extern "C" int emage_vq_argmin_f32(const float* z, int ldz, const float* codebook, int64_t* idx, int idx_rows, long idx_ld,
                                    int N, int K, int D, void* stream) {
     if (!z || !codebook || !idx || N <= 0 || K <= 0 || K > 4096 || D <= 0 || D > 1024 || D % 4 || ldz < D) return EMAGE_EINVAL;
+    if (idx_rows > 0 && (N % idx_rows != 0 || idx_ld < idx_rows)) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    const IdxView iv{idx_rows, idx_ld, 1};
     const bool aligned = (ldz % 4 == 0) && !(((uintptr_t)z | (uintptr_t)codebook) & 15);
     if (D == 256 && aligned)
-        hipLaunchKernelGGL((vq_argmin_mfma<256>), dim3((N + 15) / 16), dim3(256), 0, s, z, ldz, codebook, idx, N, K);
+        hipLaunchKernelGGL((vq_argmin_mfma<256>), dim3((N + 15) / 16), dim3(256), 0, s, z, ldz, codebook, idx, iv, N, K);
     else
-        hipLaunchKernelGGL(vq_argmin_generic, dim3((N + 3) / 4), dim3(256), 0, s, z, ldz, codebook, idx, N, K, D);
+        hipLaunchKernelGGL(vq_argmin_generic, dim3((N + 3) / 4), dim3(256), 0, s, z, ldz, codebook, idx, iv, N, K, D);
     return launch_status();
 }
 
-extern "C" int emage_argmax_logsoftmax_f32(const float* logits, int ld, int64_t* idx, int N, int C, void* stream) {
+extern "C" int emage_argmax_logsoftmax_f32(const float* logits, int ld, int64_t* idx, int idx_rows, long idx_ld, int N, int C, void* stream) {
     if (!logits || !idx || N <= 0 || C <= 0 || C > 4096 || ld < C) return EMAGE_EINVAL;
-    hipLaunchKernelGGL(argmax_logsoftmax, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, idx, N, C);
+    if (idx_rows > 0 && (N % idx_rows != 0 || idx_ld < idx_rows)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(argmax_logsoftmax, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, idx, IdxView{idx_rows, idx_ld, 1}, N, C);
     return launch_status();
 }
 
-extern "C" int emage_gather_rows(const float* table, const int64_t* idx, void* out, int ldo, int n_store,
-                                 int N, int K, int D, int dtype, void* stream) {
+extern "C" int emage_gather_rows(const float* table, const int64_t* idx, int idx_rows, long idx_ld, int idx_tstride,
+                                 void* out, int ldo, int n_store, int N, int K, int D, int dtype, void* stream) {
     if (!table || !idx || !out || N <= 0 || K <= 0 || D <= 0 || n_store < D || ldo < n_store) return EMAGE_EINVAL;
+    if (idx_rows > 0 && (N % idx_rows != 0 || idx_tstride < 0 || idx_tstride > 1)) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((gather_rows<bf16_t>), dim3(N), dim3(128), 0, s, table, idx, (bf16_t*)out, ldo, n_store, N, K, D);
-    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((gather_rows<float>), dim3(N), dim3(128), 0, s, table, idx, (float*)out, ldo, n_store, N, K, D);
+    const IdxView iv{idx_rows, idx_ld, idx_tstride};
+    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((gather_rows<bf16_t>), dim3(N), dim3(128), 0, s, table, idx, iv, (bf16_t*)out, ldo, n_store, N, K, D);
+    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((gather_rows<float>), dim3(N), dim3(128), 0, s, table, idx, iv, (float*)out, ldo, n_store, N, K, D);
     else return EMAGE_EINVAL;
     return launch_status();
 }

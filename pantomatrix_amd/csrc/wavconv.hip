@@ -18,17 +18,18 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void wav_conv_in_kernel(const float* __restrict__ wav, int L, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void wav_conv_in_kernel(const float* __restrict__ wav, long ldw, int L, int nclip, long hop, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const float* __restrict__ slope,
                                                           T* __restrict__ out, int ldo, int Lout, int C, int taps, int stride, int pad) {
     extern __shared__ float s_x[];                       // ROWS*stride + taps samples
-    const int b = blockIdx.y;
+    const int b = blockIdx.y;                            // output sequence b = window*nclip + clip
+    const float* __restrict__ src = wav + (long)(b % nclip) * ldw + (long)(b / nclip) * hop;
     const int l0 = blockIdx.x * ROWS;
     const int span = (ROWS - 1) * stride + taps;
     const int x0 = l0 * stride - pad;
     for (int i = threadIdx.x; i < span; i += blockDim.x) {
         const int xi = x0 + i;
-        s_x[i] = (xi >= 0 && xi < L) ? wav[(long)b * L + xi] : 0.f;
+        s_x[i] = (xi >= 0 && xi < L) ? src[xi] : 0.f;
     }
     __syncthreads();
     const int ngroups = C >> 2;                          // 4 channels per thread
@@ -66,15 +67,17 @@ __global__ __launch_bounds__(256) void wav_conv_in_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int emage_wav_conv_in(int dtype, const float* wav, int L, const float* w, const float* bias, const float* slope,
+extern "C" int emage_wav_conv_in(int dtype, const float* wav, long ldw, int L, int nwin, long hop,
+                                 const float* w, const float* bias, const float* slope,
                                  void* out, int ldo, int B, int Lout, int C, int taps, int stride, int pad, void* stream) {
     if (!wav || !w || !out || B <= 0 || Lout <= 0 || C <= 0 || C % 8 || taps <= 0 || taps > MAXTAPS || stride <= 0 || ldo < C) return EMAGE_EINVAL;
     if (256 % (C / 4) != 0 || C / 4 > 256 || ldo % 4 != 0 || ((uintptr_t)out & 15)) return EMAGE_EINVAL;
+    if (nwin <= 0 || hop < 0 || L <= 0 || ldw < (long)(nwin - 1) * hop + L || (long)nwin * B > 65535) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((Lout + ROWS - 1) / ROWS, B), block(256);
+    const dim3 grid((Lout + ROWS - 1) / ROWS, nwin * B), block(256);
     const size_t lds = ((ROWS - 1) * stride + taps) * sizeof(float);
-    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((wav_conv_in_kernel<bf16_t>), grid, block, lds, s, wav, L, w, bias, slope, (bf16_t*)out, ldo, Lout, C, taps, stride, pad);
-    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((wav_conv_in_kernel<float>), grid, block, lds, s, wav, L, w, bias, slope, (float*)out, ldo, Lout, C, taps, stride, pad);
+    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((wav_conv_in_kernel<bf16_t>), grid, block, lds, s, wav, ldw, L, B, hop, w, bias, slope, (bf16_t*)out, ldo, Lout, C, taps, stride, pad);
+    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((wav_conv_in_kernel<float>), grid, block, lds, s, wav, ldw, L, B, hop, w, bias, slope, (float*)out, ldo, Lout, C, taps, stride, pad);
     else return EMAGE_EINVAL;
     return launch_status();
 }

@@ -57,7 +57,6 @@ class _EmageModule:
         self.concurrent = True                 # issue independent launch chains on side streams (streams.py)
         self.hoist_audio = True                # inference(): waveform-only features of all full windows in one pass
         self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
-        self.fused_layers = False              # opt-in: one launch per transformer layer (bf16, T = 64); same bits, not yet faster
         self._templates = {}                   # cached default motion / mask of inference() per (batch, length, device)
         self._spec = type(self)._spec_fn(config)
         self._params = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
@@ -152,7 +151,7 @@ class _EmageModule:
             from safetensors.torch import load_file
             sd = load_file(st)
         else:
-            sd = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu")
+            sd = torch.load(os.path.join(d, "pytorch_model.bin"), map_location="cpu", weights_only=True)
         model.load_state_dict(sd, strict=True)
         return model
 
@@ -389,13 +388,14 @@ class EmageVQVAEConv(_EmageModule):
         _, pre = _conv_encoder(cx, "encoder", x, t, c.vae_layer, c.vae_length, True)
         return pre                                                  # fp32 (B*T, vae_length)
 
-    def _nearest(self, cx, z2d):
+    def _nearest(self, cx, z2d, out=None):
         assert z2d.shape[-1] == self.config.vae_length               # P:145,159
-        return ops.vq_argmin(z2d, cx.pk.w["codebook"])
+        return ops.vq_argmin(z2d, cx.pk.w["codebook"], out=out)
 
-    def _decode_idx(self, cx, idx_flat, b, t):
+    def _decode_idx(self, cx, idx, b, t):
+        """idx: (B*T,) list or a (B, T) view of a longer code buffer (read in place, ops.index_view)."""
         c = self.config
-        zq = ops.gather_rows(cx.pk.w["codebook"], idx_flat, cx.dt, _rup(c.vae_length))
+        zq = ops.gather_rows(cx.pk.w["codebook"], idx, cx.dt, _rup(c.vae_length))
         return _conv_decoder(cx, "decoder", zq, t, c.vae_layer, c.vae_length, c.vae_test_dim)   # fp32 (B*T, dim)
 
     # -- reference API ---------------------------------------------------------------------
@@ -411,7 +411,7 @@ class EmageVQVAEConv(_EmageModule):
     def decode(self, index):                                         # M:56-59
         cx = _Ctx(self._engine())
         b, t = index.shape
-        return self._decode_idx(cx, index.reshape(-1), b, t).view(b, t, -1)
+        return self._decode_idx(cx, index, b, t).view(b, t, -1)
 
     def decode_from_latent(self, latent):                            # M:60-70
         cx = _Ctx(self._engine())
@@ -511,7 +511,7 @@ class EmageVQModel:
                 with fk.lane(lane):
                     if index is not None:
                         cx = _Ctx(model._engine())
-                        parts[name] = model._decode_idx(cx, index.reshape(-1).contiguous(), bs, t)
+                        parts[name] = model._decode_idx(cx, index, bs, t)
                     elif latent is not None:
                         cx = _Ctx(model._engine())
                         idx = model._nearest(cx, latent.reshape(m, -1).float().contiguous())
@@ -530,9 +530,9 @@ class EmageVQModel:
     def get_global_motion(self, lower_body, ref_trans):                                          # M:195-205
         bs, t, _ = lower_body.shape
         rec = self.global_motion.forward(lower_body)["rec_pose"]                                 # (B,T,61) fp32
-        if ref_trans.dim() == 2:
-            ref_trans = ref_trans.unsqueeze(0).repeat(bs, 1, 1)
-        init = ref_trans[:, 0, :].to(device=rec.device, dtype=torch.float32).contiguous()
+        # M:198-200: a 2-D ref_trans is shared by every clip; only its first frame is used.  Views, no copies:
+        init = ref_trans[0:1] if ref_trans.dim() == 2 else ref_trans[:, 0, :]
+        init = init.to(device=rec.device, dtype=torch.float32)
         return ops.velocity_to_position(rec.view(bs * t, -1), 54, init, 1 / 30, bs, t)
 
 
@@ -620,7 +620,7 @@ class EmageAudioModel(_EmageModule):
         vt = cx.vt_buffer(b, d, t)
         cx.gemm(x, name + ".sa.qkv", out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
         att = cx.lo(m, d)
-        ops.attention(cx.dt, qk[:, :d], qk[:, d:], vt, d, att, b, h, t, t, d // h)
+        ops.attention(cx.gdt, qk[:, :d], qk[:, d:], vt, d, att, b, h, t, t, d // h)
         s, _ = cx.gemm(att, name + ".sa.out", res=x)
         return s
 
@@ -635,27 +635,8 @@ class EmageAudioModel(_EmageModule):
         s, _ = cx.gemm(f, name + ".ff2", res=x)
         return s
 
-    def _fused_layer(self, cx, name, x, b, t, mem_k=None, mem_vt=None, vt_rows=0, tk=None, post_add=None):
-        """The whole layer in one launch (ops.transformer_layer) when the geometry is the one the fused kernel is
-        built for (bf16, full 64-frame window); None otherwise — the caller then issues the per-op sequence, which
-        computes the same bits."""
-        d, h, w = self.config.hidden_size, spec.N_HEAD, cx.pk.w
-        ffn = w[name + ".ff1"]["n"]
-        if not (self.fused_layers and ops.transformer_layer_supported(cx.dt, t, d, h, ffn, tk)):
-            return None
-        cross = mem_k is not None
-        weights = [w[name + ".sa.qkv"], w[name + ".sa.out"], w[name + ".ca.q"] if cross else None,
-                   w[name + ".ca.out"] if cross else None, w[name + ".ff1"], w[name + ".ff2"]]
-        norms = [w[name + ".norm1"], w[name + ".norm2"] if cross else None, w[name + (".norm3" if cross else ".norm2")]]
-        out, _ = ops.transformer_layer(cx.dt, x, weights, norms, cx.pk.slope(0.0, ffn), b, t, heads=h, ffn=ffn,
-                                       mem_k=mem_k, mem_vt=mem_vt, vt_rows=vt_rows, tk=tk or 0, post_add=post_add)
-        return out
-
     def _encoder_layer(self, cx, name, x, b, t, post_add=None):
         """nn.TransformerEncoderLayer, post-norm, ReLU, no masks."""
-        y = self._fused_layer(cx, name, x, b, t, post_add=post_add)
-        if y is not None:
-            return y
         x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
         return self._ln(cx, name + ".norm2", self._ffn(cx, name, x), add=post_add)
 
@@ -663,13 +644,10 @@ class EmageAudioModel(_EmageModule):
         """nn.TransformerDecoderLayer, post-norm, ReLU, no masks.  mem_k: (B*Tk, ld) view of this
         layer's projected memory keys; mem_vt: view at this layer's first row of a (B, vt_rows, Tp) V^T buffer."""
         d, h = self.config.hidden_size, spec.N_HEAD
-        y = self._fused_layer(cx, name, x, b, t, mem_k, mem_vt, vt_rows, tk, post_add)
-        if y is not None:
-            return y
         x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
         q, _ = cx.gemm(x, name + ".ca.q")
         att = cx.lo(b * t, d)
-        ops.attention(cx.dt, q, mem_k, mem_vt, vt_rows, att, b, h, t, tk, d // h)
+        ops.attention(cx.gdt, q, mem_k, mem_vt, vt_rows, att, b, h, t, tk, d // h)
         s, _ = cx.gemm(att, name + ".ca.out", res=x)
         x = self._ln(cx, name + ".norm2", s)
         return self._ln(cx, name + ".norm3", self._ffn(cx, name, x), add=post_add)
@@ -693,13 +671,14 @@ class EmageAudioModel(_EmageModule):
             raise RuntimeError(f"audio window of {l} samples is too short for the WavEncoder")
         return lens
 
-    def _wav_first_layer(self, cx, audio, lens):
-        """Block 0's conv1 and downsample shortcut of BOTH encoders in one launch: (B*L0, 4q) =
-        [face conv1 | face shortcut | body conv1 | body shortcut]."""
+    def _wav_first_layer(self, cx, audio, lens, nwin=1, hop=0, win_len=None):
+        """Block 0's conv1 and downsample shortcut of BOTH encoders in one launch: (nwin*B*L0, 4q) =
+        [face conv1 | face shortcut | body conv1 | body shortcut]; `nwin` sliding windows per clip are read in place."""
         blocks = spec.wav_encoder_blocks(self.config.audio_f)
         w_in = cx.pk.w["wav_in"]
-        y0 = cx.lo(audio.shape[0] * lens[0], 4 * blocks[0][1])
-        ops.wav_conv_in(cx.dt, audio, w_in["w"], w_in["b"], w_in["slope"], y0, lens[0], blocks[0][2], blocks[0][3])
+        y0 = cx.lo(nwin * audio.shape[0] * lens[0], 4 * blocks[0][1])
+        ops.wav_conv_in(cx.dt, audio, w_in["w"], w_in["b"], w_in["slope"], y0, lens[0], blocks[0][2], blocks[0][3],
+                        nwin=nwin, hop=hop, win_len=win_len)
         return y0
 
     def _wav_encoder_chain(self, cx, enc, e, y0, b, lens, dest=None):
@@ -725,21 +704,22 @@ class EmageAudioModel(_EmageModule):
         return x
 
     # ---- forward -------------------------------------------------------------------------
-    def _audio_features(self, cx, audio, b, t, use_audio, fk, lane_face, lane_body):
+    def _audio_features(self, cx, audio, b, t, use_audio, fk, lane_face, lane_body, nwin=1, hop=0, win_len=None):
         """Everything that depends on the waveform only (M:275-281, 303 and the cross-attention K/V projections):
         both WavEncoders, `audio_body_motion_proj` and the 8 layers' memory K / V^T.  Returns a dict
         {memcat (B*T, audio_f+motion_f) with the face features in its first audio_f columns, bk, bvt, ta}.
-        Runs on two stream lanes of `fk`; `inference()` calls it once for ALL full windows of a batch."""
+        Runs on two stream lanes of `fk`; `inference()` calls it once for ALL full windows of a batch: `audio` is then
+        the whole-clip tensor, `nwin` windows of `win_len` samples every `hop` samples, b = nwin * clips sequences."""
         c = self.config
         af, mf, nc = c.audio_f, c.motion_f, spec.N_CROSS_LAYERS
-        lens = self._wav_lengths(audio.shape[1])
+        lens = self._wav_lengths(audio.shape[1] if win_len is None else win_len)
         ta = lens[-1]
         if ta < t:
             raise RuntimeError(f"Sizes of tensors must match: audio features {ta} frames vs motion {t} frames")
         m = b * t
         feats = dict(memcat=cx.lo(m, af + mf), bk=None, bvt=None, ta=ta)            # [audio2face | body_hint_face] (M:288)
         with fk.lane(lane_face):
-            y0 = self._wav_first_layer(cx, audio, lens)
+            y0 = self._wav_first_layer(cx, audio, lens, nwin, hop, win_len)
         fk.after(lane_body, lane_face)
         with fk.lane(lane_face):
             a_face = self._wav_encoder_chain(cx, "audio_encoder_face", 0, y0, b, lens, dest=feats["memcat"][:, :af])
@@ -758,7 +738,7 @@ class EmageAudioModel(_EmageModule):
         only, so `inference()` builds them once for all full windows."""
         pk, dev, d = cx.pk, cx.dev, self.config.hidden_size
         m = b * t
-        sid = speaker_id.to(dev).reshape(b, 1).expand(b, t).reshape(-1).contiguous()
+        sid = speaker_id.to(dev).reshape(b, 1).expand(b, t)                 # one id per clip, broadcast over T by the kernel
         spk_body = ops.gather_rows(pk.w["spk_body"], sid, F32)              # (M,d) fp32
         spk_face = ops.gather_rows(pk.w["spk_face"], sid, F32)
         pe = pk.w["pe"][:t]
@@ -767,12 +747,15 @@ class EmageAudioModel(_EmageModule):
         ops.add(cx.dt, spk_body, pe, out=pos_spk, mod_b=t)                  # speaker_body + pe, used twice
         return dict(spk_body=spk_body, face0=face0, pos_spk=pos_spk, t=t)
 
-    def forward(self, audio, speaker_id, masked_motion, mask, use_audio=True, _audio_feats=None, _tables=None, _lean=False):
+    def forward(self, audio, speaker_id, masked_motion, mask, use_audio=True, _audio_feats=None, _tables=None, _lean=False,
+                _seed=None):
         """EmageAudioModel.forward (M:265-341), eval mode.  audio (B,L) fp32, speaker_id (B,1) int64,
         masked_motion / mask (B,T,337) fp32 -> dict of 8 (B,T,256) fp32 tensors.
         `_audio_feats` / `_tables` (internal): waveform-only features and speaker tables already computed by
-        `inference()`; `_lean` (internal, `infer_codes`): skip the outputs the decode does not consume (the
-        classifier of a latent-routed part, the fp32 copy of a classified part's latent)."""
+        `inference()`; `_seed` (internal): (B, seed_frames, 337) view spliced into the first frames by the packing
+        kernel (M:386-391); `_lean` (internal, `infer_codes`): skip the outputs the decode does not consume (the
+        classifier of a latent-routed part, the fp32 copy of a classified part's latent).
+        audio / masked_motion / mask may be windows (views) of longer clip tensors: they are read in place."""
         c = self.config
         cx = _Ctx(self._engine())
         pk = cx.pk
@@ -783,9 +766,13 @@ class EmageAudioModel(_EmageModule):
         if t > pk.w["pe"].shape[0]:
             raise RuntimeError(f"sequence of {t} frames exceeds the positional table ({pk.w['pe'].shape[0]})")
         if _audio_feats is None:
-            audio = audio.to(device=dev, dtype=torch.float32).contiguous()
-        motion2d = masked_motion.to(device=dev, dtype=torch.float32).reshape(m, cm).contiguous()
-        mask2d = mask.to(device=dev, dtype=torch.float32).reshape(m, cm).contiguous()
+            audio = audio.to(device=dev, dtype=torch.float32)
+            if audio.stride(1) != 1:
+                audio = audio.contiguous()
+        motion3 = self._frames_view(masked_motion.to(device=dev, dtype=torch.float32))
+        mask3 = self._frames_view(mask.to(device=dev, dtype=torch.float32))
+        if b > 1 and motion3.stride(0) != mask3.stride(0):      # the packing kernel takes one clip stride for both
+            motion3, mask3 = motion3.contiguous(), mask3.contiguous()
 
         out = {}
         parts = ("upper", "hands", "lower")
@@ -804,7 +791,7 @@ class EmageAudioModel(_EmageModule):
 
             with fk.lane(0):
                 # masked motion -> spatial hints (M:267-273)
-                x0 = ops.pack_motion(cx.dt, motion2d, mask2d, pk.w["mask_emb"], _rup(cm))
+                x0 = ops.pack_motion(cx.dt, motion3, mask3, pk.w["mask_emb"], _rup(cm), seed=_seed)
                 hint, _ = _conv_encoder(cx, "motion_encoder", x0, t, spec.MOTION_ENC_LAYERS, mf, False)
                 hh, _ = cx.gemm(hint, "bodyhints.fc1", slope=0.1)               # [face | body] hidden, (M, 2d)
                 cx.gemm(hh[:, :d], "bodyhints_face.fc2", out=memcat[:, af:])
@@ -867,21 +854,48 @@ class EmageAudioModel(_EmageModule):
 
     __call__ = forward
 
+    @staticmethod
+    def _frames_view(x):
+        """(B, T, C) tensor whose frames are contiguous rows (strides (any, C, 1)): used as is, else made contiguous."""
+        b, t, c = x.shape
+        return x if (x.stride(2) == 1 and (x.stride(1) == c or t == 1)) else x.contiguous()
+
     # ---- inference -----------------------------------------------------------------------
-    def _select_codes(self, net_out):
-        """Latent-vs-index routing (M:398-410; test_emage_audio.py:34-42): argmax(log_softmax(cls)) when the
-        part is classified (c* > 0), the regressed latent when only l* > 0."""
+    _PARTS = ("face", "upper", "hands", "lower")
+
+    def _routes(self):
+        """Latent-vs-index routing per part (M:398-410; test_emage_audio.py:34-42): "cls" = argmax(log_softmax(cls_*))
+        when the part is classified (c* > 0), "lat" = the regressed latent when only l* > 0, None when neither."""
         c = self.config
+        cfg = {"face": (c.lf, c.cf), "upper": (c.lu, c.cu), "hands": (c.lh, c.ch), "lower": (c.ll, c.cl)}
+        return {p: ("cls" if c_ > 0 else ("lat" if l_ > 0 else None)) for p, (l_, c_) in cfg.items()}
+
+    def _select_codes(self, net_out):
+        """The keyword arguments test_emage_audio.py:34-47 builds for `EmageVQModel.decode` from the eight outputs."""
         kw = {}
-        for p, l_, c_ in (("face", c.lf, c.cf), ("upper", c.lu, c.cu), ("hands", c.lh, c.ch), ("lower", c.ll, c.cl)):
-            kw[f"{p}_latent"] = net_out.get(f"rec_{p}") if (l_ > 0 and c_ == 0) else None
-            if c_ > 0:
+        for p, route in self._routes().items():
+            kw[f"{p}_latent"] = net_out.get(f"rec_{p}") if route == "lat" else None
+            if route == "cls":
                 logits = net_out[f"cls_{p}"]
                 bsz, t, k = logits.shape
                 kw[f"{p}_index"] = ops.argmax_logsoftmax(logits.reshape(bsz * t, k)).view(bsz, t)
             else:
                 kw[f"{p}_index"] = None
         return kw
+
+    def _window_codes(self, net, vq_model, codes, col0, bs, t):
+        """Write one window's code indices straight into columns [col0, col0+t) of the (B, L) code buffers: arg-max of
+        the classifier logits, or the nearest code of a latent-routed part (what `decode_from_latent` would compute
+        from the concatenated latents — the same per-row arithmetic, so the same indices)."""
+        for p, route in self._routes().items():
+            if route is None:
+                continue
+            dst = codes[p][:, col0:col0 + t]
+            if route == "cls":
+                ops.argmax_logsoftmax(net[f"cls_{p}"].reshape(bs * t, -1), out=dst)
+            else:
+                part = getattr(vq_model, f"vq_model_{p}")
+                part._nearest(_Ctx(part._engine()), net[f"rec_{p}"].reshape(bs * t, -1), out=dst)
 
     def inference(self, audio, speaker_id, vq_model, masked_motion=None, mask=None):
         """EmageAudioModel.inference (M:343-490): sliding 64-frame windows with 4 seed frames carried over
@@ -894,18 +908,20 @@ class EmageAudioModel(_EmageModule):
         return {k: torch.cat(chunks[k], dim=1) for k in OUT_KEYS}
 
     def infer_codes(self, audio, speaker_id, vq_model, masked_motion=None, mask=None):
-        """The same window loop, returning what `EmageVQModel.decode` consumes (the keyword arguments built at
-        test_emage_audio.py:34-47) instead of the eight full-length tensors: per-window code indices / latents are
-        sliced and concatenated directly — identical values (arg-max is per frame), without materialising and
-        re-scanning (B,T,256) logits.  Used by `runtime.ClipRunner`."""
-        sel = {}
+        """The same window loop, returning what `EmageVQModel.decode` consumes instead of the eight full-length
+        tensors: `{part}_index` (B, frames) int64 for every routed part (a latent-routed part — the face in the
+        shipped configuration — comes back as the index of its nearest code, which is what `decode(face_latent=...)`
+        would compute first).  Every kernel of a window writes its codes straight into the (B, L) code buffers and the
+        seed decode reads them in place: no slicing / concatenation copies.  Used by `runtime.ClipRunner`."""
+        frames = 0
+        codes = None
         for net, keep in self._windows(audio, speaker_id, vq_model, masked_motion, mask, want_codes=True):
-            for k, v in net["_codes"].items():
-                if v is not None:
-                    sel.setdefault(k, []).append(v[:, :keep])
+            codes = net["_codes"]
+            frames += keep
         out = {k: None for k in ("face_latent", "upper_latent", "hands_latent", "lower_latent",
                                  "face_index", "upper_index", "hands_index", "lower_index")}
-        out.update({k: torch.cat(v, dim=1) for k, v in sel.items()})
+        if codes is not None:
+            out.update({f"{p}_index": v[:, :frames] for p, v in codes.items()})
         return out
 
     def _seed_decode_frames(self, vq_model, t):
@@ -916,10 +932,13 @@ class EmageAudioModel(_EmageModule):
         return min(t, self.config.seed_frames + r)
 
     def _windows(self, audio, speaker_id, vq_model, masked_motion=None, mask=None, want_codes=False):
-        """Generator over the autoregressive windows of M:343-470; yields (forward outputs, frames to keep)."""
+        """Generator over the autoregressive windows of M:343-470; yields (forward outputs, frames to keep).  Windows
+        of the clip tensors (audio, motion, mask, code buffers) are passed to the kernels as views."""
         c = self.config
         dev = self._device
         audio = audio.to(device=dev, dtype=torch.float32)
+        if audio.stride(1) != 1:
+            audio = audio.contiguous()
         bs = audio.shape[0]
         length = audio.shape[1] * 30 // 16000                                                   # M:345
         key = (bs, length, str(dev))
@@ -938,63 +957,76 @@ class EmageAudioModel(_EmageModule):
         window, pre = c.pose_length, c.seed_frames
         rounds, remain = (length - pre) // (window - pre), (length - pre) % (window - pre)       # M:364-368
         spf = 16000 // 30
-        last = motion[:, :pre]
+        hop = window - pre
+        last = motion[:, :pre]                                                                   # M:370: seed of window 0
+        routes = self._routes()
+        codes = {p: torch.empty(bs, max(length, 1), dtype=torch.int64, device=dev) for p, r in routes.items() if r} \
+            if want_codes else None
 
         # The waveform-only part of every full window (WavEncoders, audio projection, cross-attention K/V) does not
         # depend on the autoregressive motion state: compute it for all `rounds` windows in one set of launches
-        # (rows = rounds*B clips) ahead of the sequential loop.
+        # (rows = rounds*B sequences, read in place from the clip tensor) ahead of the sequential loop.
         hoisted = None
+        open_fork = None
         tables = self._speaker_tables(_Ctx(self._engine()), speaker_id, bs, window) if rounds > 0 else None
-        if rounds > 0 and self.hoist_audio:
-            cx = _Ctx(self._engine())
-            wins = torch.stack([audio[:, i * (window - pre) * spf: i * (window - pre) * spf + window * spf]
-                                for i in range(rounds)]).reshape(rounds * bs, window * spf).contiguous()   # M:393-394
-            # Issued on the side streams the first window's forward() will use for its own lanes 1 and 2 and NOT
-            # joined here: window 0's motion path (lane 0) starts at once, its face decoder and cross-attention
-            # queue behind this work by stream order, and forward()'s join closes the fork.
-            fk = Fork(dev, 3, self.concurrent)
-            fk.__enter__()
-            hoisted = self._audio_features(cx, wins, rounds * bs, window, True, fk, 1, 2)
-            if hoisted["ta"] != window:
-                fk.__exit__(None, None, None)
-                hoisted = None
+        try:
+            if rounds > 0 and self.hoist_audio:
+                cx = _Ctx(self._engine())
+                # Issued on the side streams the first window's forward() will use for its own lanes 1 and 2 and NOT
+                # joined here: window 0's motion path (lane 0) starts at once, its face decoder and cross-attention
+                # queue behind this work by stream order, and forward()'s join closes the fork.
+                open_fork = Fork(dev, 3, self.concurrent)
+                open_fork.__enter__()
+                hoisted = self._audio_features(cx, audio, rounds * bs, window, True, open_fork, 1, 2,
+                                               nwin=rounds, hop=hop * spf, win_len=window * spf)           # M:393-394
+                if hoisted["ta"] != window:
+                    open_fork.__exit__(None, None, None)
+                    open_fork, hoisted = None, None
 
-        def window_feats(i):
-            if hoisted is None:
-                return None
-            ta, mrows = hoisted["ta"], bs * window
-            return dict(memcat=hoisted["memcat"][i * mrows:(i + 1) * mrows], ta=ta,
-                        bk=hoisted["bk"][i * bs * ta:(i + 1) * bs * ta], bvt=hoisted["bvt"][i * bs:(i + 1) * bs])
+            def window_feats(i):
+                if hoisted is None:
+                    return None
+                ta, mrows = hoisted["ta"], bs * window
+                return dict(memcat=hoisted["memcat"][i * mrows:(i + 1) * mrows], ta=ta,
+                            bk=hoisted["bk"][i * bs * ta:(i + 1) * bs * ta], bvt=hoisted["bvt"][i * bs:(i + 1) * bs])
 
-        def run_window(start, end, need_seed, feats=None):
-            w_mask = full_mask[:, start:end].clone()
-            w_motion = motion[:, start:end].clone()
-            w_motion[:, :pre] = torch.where(w_mask[:, :pre] == 0, motion[:, start:start + pre], last)   # M:386-390
-            w_mask[:, :pre] = 0
-            a = audio[:, start * spf:start * spf + (end - start) * spf]                          # M:393-394
-            net = self.forward(a, speaker_id, w_motion, w_mask, use_audio=True, _audio_feats=feats, _tables=tables,
-                               _lean=want_codes)
-            codes = self._select_codes(net) if (need_seed or want_codes) else None
-            net["_codes"] = codes
-            seed = None
-            if need_seed:
-                # only the last `seed_frames` of the decode feed the next window (M:418): decode just the frames
-                # that can influence them (exact, see _seed_decode_frames)
-                ts = self._seed_decode_frames(vq_model, end - start) if self.seed_only_decode else end - start
-                tail = {k: (None if v is None else v[:, -ts:].contiguous()) for k, v in codes.items()}
-                seed = vq_model.decode(**tail)["all_motion4inference"][:, -pre:]
-            return net, seed
+            def run_window(start, end, need_seed, feats=None):
+                nonlocal open_fork
+                t = end - start
+                a = audio[:, start * spf:start * spf + t * spf]                                      # M:393-394
+                # the seed splice (M:386-391) happens inside the packing kernel: frames < pre take `last` where masked
+                net = self.forward(a, speaker_id, motion[:, start:end], full_mask[:, start:end], use_audio=True,
+                                   _audio_feats=feats, _tables=tables, _lean=want_codes, _seed=last)
+                open_fork = None                        # forward()'s own fork joined the side streams
+                seed = None
+                if want_codes:
+                    self._window_codes(net, vq_model, codes, start, bs, t)
+                    net["_codes"] = codes
+                    sel = {f"{p}_index": v[:, start:end] for p, v in codes.items()}
+                elif need_seed:
+                    sel = self._select_codes(net)
+                if need_seed:
+                    # only the last `seed_frames` of the decode feed the next window (M:418): decode just the frames
+                    # that can influence them (exact, see _seed_decode_frames)
+                    ts = self._seed_decode_frames(vq_model, t) if self.seed_only_decode else t
+                    tail_sel = {k: (None if v is None else v[:, t - ts:]) for k, v in sel.items()}
+                    dec = vq_model.decode(**tail_sel)["all_motion4inference"]
+                    seed = dec[:, ts - pre:]                                                         # (B, pre, 337) view
+                return net, seed
 
-        tail = remain > pre
-        for i in range(rounds):                                                                  # M:380-426
-            start = i * (window - pre)
-            # the decode only feeds the next window's seed: the reference also runs it after the last window
-            # where its result is discarded; skipping that one changes no output
-            net, seed = run_window(start, start + window, need_seed=(i + 1 < rounds) or tail, feats=window_feats(i))
-            if seed is not None:
-                last = seed
-            yield net, window - pre
-        if tail:                                                                                 # M:428-470
-            start = rounds * (window - pre)
-            net, _ = run_window(start, start + pre + remain, need_seed=False)
-            yield net, pre + remain
+            tail = remain > pre
+            for i in range(rounds):                                                                  # M:380-426
+                start = i * hop
+                # the decode only feeds the next window's seed: the reference also runs it after the last window
+                # where its result is discarded; skipping that one changes no output
+                net, seed = run_window(start, start + window, need_seed=(i + 1 < rounds) or tail, feats=window_feats(i))
+                if seed is not None:
+                    last = seed
+                yield net, window - pre
+            if tail:                                                                                 # M:428-470
+                start = rounds * hop
+                net, _ = run_window(start, start + pre + remain, need_seed=False)
+                yield net, pre + remain
+        finally:
+            if open_fork is not None:                   # abandoned before the first window ran: join the side streams
+                open_fork.__exit__(None, None, None)

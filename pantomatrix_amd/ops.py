@@ -58,32 +58,53 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def vq_argmin(z2d, codebook):
-    """z2d (N,D) fp32, codebook (K,D) fp32 contiguous -> (N,) int64."""
+def index_view(idx):
+    """(rows, ld, tstride) of an int64 index tensor as the kernels address it (include/emage_hip.h: emage_vq_argmin_f32):
+    a 1-D contiguous list -> (0, 0, 1); a 2-D (B, T) view with frame stride 1 or 0 (one id per clip expanded over T)
+    and any clip stride is used in place — no gather / contiguous copy."""
+    assert idx.dtype == torch.int64
+    if idx.dim() == 1:
+        assert idx.stride(0) == 1 or idx.numel() <= 1
+        return 0, 0, 1
+    assert idx.dim() == 2 and idx.stride(1) in (0, 1), (idx.shape, idx.stride())
+    return idx.shape[1], idx.stride(0), idx.stride(1)
+
+
+def vq_argmin(z2d, codebook, out=None):
+    """z2d (N,D) fp32, codebook (K,D) fp32 contiguous -> int64 nearest-code indices; `out`: an (N,) tensor or a (B, T)
+    view (B*T == N) of a larger code buffer to fill in place."""
     _dev(z2d)
     assert z2d.dtype == torch.float32 and codebook.dtype == torch.float32 and codebook.is_contiguous()
     n, d = z2d.shape
-    idx = torch.empty(n, dtype=torch.int64, device=z2d.device)
-    check(_lib.load().emage_vq_argmin_f32(_ptr(z2d), _ld(z2d), _ptr(codebook), _ptr(idx), n, codebook.shape[0], d, _stream()), "vq_argmin")
+    idx = torch.empty(n, dtype=torch.int64, device=z2d.device) if out is None else out
+    rows, ld, ts = index_view(idx)
+    assert idx.numel() == n and ts == 1
+    check(_lib.load().emage_vq_argmin_f32(_ptr(z2d), _ld(z2d), _ptr(codebook), _ptr(idx), rows, ld, n, codebook.shape[0], d, _stream()), "vq_argmin")
     return idx
 
 
-def argmax_logsoftmax(logits2d):
+def argmax_logsoftmax(logits2d, out=None):
     _dev(logits2d)
     assert logits2d.dtype == torch.float32
     n, c = logits2d.shape
-    idx = torch.empty(n, dtype=torch.int64, device=logits2d.device)
-    check(_lib.load().emage_argmax_logsoftmax_f32(_ptr(logits2d), _ld(logits2d), _ptr(idx), n, c, _stream()), "argmax_logsoftmax")
+    idx = torch.empty(n, dtype=torch.int64, device=logits2d.device) if out is None else out
+    rows, ld, ts = index_view(idx)
+    assert idx.numel() == n and ts == 1
+    check(_lib.load().emage_argmax_logsoftmax_f32(_ptr(logits2d), _ld(logits2d), _ptr(idx), rows, ld, n, c, _stream()), "argmax_logsoftmax")
     return idx
 
 
 def gather_rows(table, idx, dtype, n_store=None):
+    """table (K,D) fp32 rows selected by an int64 index list / (B,T) view (see `index_view`) -> (N, n_store) in `dtype`."""
     _dev(table)
     k, d = table.shape
     n_store = d if n_store is None else n_store
-    idx = idx.reshape(-1).contiguous()
-    out = torch.empty(idx.numel(), n_store, dtype=TORCH_DTYPE[dtype], device=table.device)
-    check(_lib.load().emage_gather_rows(_ptr(table), _ptr(idx), _ptr(out), n_store, n_store, idx.numel(), k, d, dtype, _stream()), "gather_rows")
+    if idx.dim() > 2 or (idx.dim() == 2 and idx.stride(1) not in (0, 1)) or (idx.dim() == 1 and idx.numel() > 1 and idx.stride(0) != 1):
+        idx = idx.reshape(-1).contiguous()
+    rows, ld, ts = index_view(idx)
+    n = idx.numel()
+    out = torch.empty(n, n_store, dtype=TORCH_DTYPE[dtype], device=table.device)
+    check(_lib.load().emage_gather_rows(_ptr(table), _ptr(idx), rows, ld, ts, _ptr(out), n_store, n_store, n, k, d, dtype, _stream()), "gather_rows")
     return out
 
 
@@ -108,11 +129,16 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
                                  float(A_SCALE_F16X3 if a_scale is None else a_scale), float(w_scale), _stream()), "gemm")
 
 
-def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad):
+def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad, nwin=1, hop=0, win_len=None):
+    """wav (B, L) fp32 view with unit sample stride (any clip stride).  nwin > 1: `nwin` windows of `win_len` samples per
+    clip, window i at sample i*hop, written as output sequences i*B + b — the sliding windows are read in place."""
     _dev(wav)
+    assert wav.dim() == 2 and wav.stride(1) == 1 and wav.dtype == torch.float32
     b, l = wav.shape
+    win_len = l if win_len is None else win_len
+    assert (nwin - 1) * hop + win_len <= l
     c, taps = w.shape
-    check(_lib.load().emage_wav_conv_in(dtype, _ptr(wav), l, _ptr(w), _ptr(bias), _ptr(slope), _ptr(out), _ld(out),
+    check(_lib.load().emage_wav_conv_in(dtype, _ptr(wav), wav.stride(0), win_len, nwin, hop, _ptr(w), _ptr(bias), _ptr(slope), _ptr(out), _ld(out),
                                         b, lout, c, taps, stride, pad, _stream()), "wav_conv_in")
 
 
@@ -122,43 +148,6 @@ def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
     _dev(q)
     check(_lib.load().emage_attention(dtype, _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(vt), vt.shape[-1], vt_rows, _ptr(out), _ld(out),
                                       b, h, tq, tk, hd, _stream()), "attention")
-
-
-def transformer_layer_supported(dtype, t, d, heads, ffn, tk=None):
-    """Geometry the fused layer kernel is built for (include/emage_hip.h: emage_transformer_layer)."""
-    return dtype == BF16 and t == 64 and d == 768 and heads == 4 and ffn == 1536 and (tk is None or 32 < tk <= 64)
-
-
-def transformer_layer(dtype, x, weights, norms, relu_slope, b, t, *, heads, ffn, mem_k=None, mem_vt=None, vt_rows=0, tk=0,
-                      post_add=None, eps=1e-5, workspace=None):
-    """One post-norm transformer layer in one launch.  x (B*T, d); weights: 6 packed entries {w, b} in the order
-    [self in_proj, self out_proj, cross q, cross out_proj, linear1, linear2] (cross entries None for an encoder
-    layer); norms: 3 entries {g, b} (index 1 None for an encoder layer); mem_k / mem_vt: this layer's projected
-    cross-attention memory.  Returns (out (B*T, d), workspace)."""
-    import ctypes as C
-    _dev(x)
-    lib = _lib.load()
-    d = x.shape[1]
-    nbytes = lib.emage_transformer_layer_workspace(b)
-    if workspace is None:
-        workspace = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    out = torch.empty(b * t, d, dtype=x.dtype, device=x.device)
-    arr = lambda ts: (C.c_void_p * len(ts))(*[None if v is None else v.data_ptr() for v in ts])
-    wv = arr([None if e is None else e["w"] for e in weights])
-    bv = arr([None if e is None else e["b"] for e in weights])
-    gv = arr([None if e is None else e["g"] for e in norms])
-    nv = arr([None if e is None else e["b"] for e in norms])
-    check(lib.emage_transformer_layer(dtype, _ptr(x), _ld(x), wv, bv, gv, nv, eps,
-                                      _ptr(mem_k), _ld(mem_k) if mem_k is not None else 0,
-                                      _ptr(mem_vt), vt_rows, mem_vt.shape[-1] if mem_vt is not None else 0, tk,
-                                      _ptr(post_add), _ld(post_add) if post_add is not None else 0, _ptr(relu_slope),
-                                      _ptr(workspace), workspace.numel(), _ptr(out), _ld(out),
-                                      b, t, d, heads, ffn, _stream()), "transformer_layer")
-    return out, workspace
-
-
-def transformer_layer_status(workspace, b):
-    return _lib.load().emage_transformer_layer_status(_ptr(workspace), b)
 
 
 def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
@@ -189,12 +178,24 @@ def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
                                 mask, _ptr(out_f32), _ptr(out), ldo, m, n, _stream()), "add")
 
 
-def pack_motion(dtype, motion2d, mask2d, emb, n_store):
-    _dev(motion2d)
-    m, c = motion2d.shape
-    assert motion2d.is_contiguous() and mask2d.is_contiguous()
-    out = torch.empty(m, n_store, dtype=TORCH_DTYPE[dtype], device=motion2d.device)
-    check(_lib.load().emage_pack_motion(dtype, _ptr(motion2d), _ptr(mask2d), _ptr(emb), _ptr(out), n_store, n_store, m, c, _stream()), "pack_motion")
+def pack_motion(dtype, motion, mask, emb, n_store, seed=None):
+    """motion / mask: (B, T, C) fp32 views with contiguous frames (strides (ldb, C, 1), the same ldb for both): a window
+    of a longer clip tensor is read in place.  seed: optional (B, pre, C) view spliced into the first `pre` frames
+    where the mask is set (inference()'s seed carry-over, M:386-391).  -> (B*T, n_store) in `dtype`."""
+    _dev(motion)
+    b, t, c = motion.shape
+    for x in (motion, mask):
+        assert x.dtype == torch.float32 and x.shape == (b, t, c) and x.stride(2) == 1 and (x.stride(1) == c or t == 1), (x.shape, x.stride())
+    ldb = motion.stride(0) if b > 1 else t * c
+    assert b == 1 or mask.stride(0) == ldb
+    pre, ld_seed = 0, 0
+    if seed is not None:
+        pre = seed.shape[1]
+        assert seed.dtype == torch.float32 and seed.shape == (b, pre, c) and seed.stride(2) == 1 and (seed.stride(1) == c or pre == 1)
+        ld_seed = seed.stride(0) if b > 1 else pre * c
+    out = torch.empty(b * t, n_store, dtype=TORCH_DTYPE[dtype], device=motion.device)
+    check(_lib.load().emage_pack_motion(dtype, _ptr(motion), _ptr(mask), ldb, _ptr(emb), _ptr(seed), ld_seed, pre,
+                                        _ptr(out), n_store, n_store, b, t, c, _stream()), "pack_motion")
     return out
 
 
@@ -234,7 +235,10 @@ def merge_parts(face, upper, hands, lower, m, device, want_motion=True):
 
 
 def velocity_to_position(vel2d, col0, init, dt, b, t):
+    """init: (B, 3) fp32 view (any clip stride) or (1, 3) = one start position for every clip (clip stride 0)."""
     _dev(vel2d)
+    assert init.dtype == torch.float32 and init.dim() == 2 and init.shape[1] == 3 and init.stride(1) == 1 and init.shape[0] in (1, b)
+    ld_init = 0 if init.shape[0] == 1 and b > 1 else init.stride(0)
     trans = torch.empty(b, t, 3, dtype=torch.float32, device=vel2d.device)
-    check(_lib.load().emage_velocity_to_position(_ptr(vel2d), _ld(vel2d), col0, _ptr(init), dt, _ptr(trans), b, t, _stream()), "velocity_to_position")
+    check(_lib.load().emage_velocity_to_position(_ptr(vel2d), _ld(vel2d), col0, _ptr(init), ld_init, dt, _ptr(trans), b, t, _stream()), "velocity_to_position")
     return trans

@@ -127,33 +127,6 @@ def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
         y[:] = v.to(TD[dtype])
 
 
-def transformer_layer(dtype, x, weights, norms, relu_slope, b, t, *, heads, ffn, mem_k=None, mem_vt=None, vt_rows=0, tk=0,
-                      post_add=None, eps=1e-5, workspace=None):
-    """The fused layer restated as the per-op sequence it replaces (same buffers, same order)."""
-    CALLS.append("transformer_layer")
-    assert dtype == BF16 and t == 64 and x.shape == (b * t, 768) and relu_slope.shape == (ffn,) and not relu_slope.any()
-    m, d = x.shape
-    hd = d // heads
-    new = lambda n: torch.empty(m, n, dtype=TD[dtype])
-    lin = lambda a, e, **kw: gemm(dtype, a, e["w"], e["b"], n=e["n"], cp=e["cp"], **kw)
-    ln = lambda s, e, add=None: (lambda y: (layernorm(dtype, s, e["g"], e["b"], eps, add, None, y), y)[1])(new(d))
-    qk, vt, att, s = new(2 * d), torch.empty(b, d, t, dtype=TD[dtype]), new(d), new(d)
-    lin(x, weights[0], out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
-    attention(dtype, qk[:, :d], qk[:, d:], vt, d, att, b, heads, t, t, hd)
-    lin(att, weights[1], res=x, out=s)
-    x1 = ln(s, norms[0])
-    if mem_k is not None:
-        q = new(d)
-        lin(x1, weights[2], out=q)
-        attention(dtype, q, mem_k, mem_vt, vt_rows, att, b, heads, t, tk, hd)
-        lin(att, weights[3], res=x1, out=s)
-        x1 = ln(s, norms[1])
-    f = new(ffn)
-    lin(x1, weights[4], slope=relu_slope, out=f)
-    lin(f, weights[5], res=x1, out=s)
-    return ln(s, norms[2], post_add), None
-
-
 def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
     CALLS.append("add")
     m = a.shape[0]
@@ -167,11 +140,20 @@ def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
         out[:] = v.to(TD[dtype])
 
 
-def pack_motion(dtype, motion2d, mask2d, emb, n_store):
+def pack_motion(dtype, motion, mask, emb, n_store, seed=None):
     CALLS.append("pack_motion")
-    m, c = motion2d.shape
-    out = torch.zeros(m, n_store, dtype=TD[dtype])
-    out[:, :c] = torch.where(mask2d == 1, emb.expand_as(motion2d), motion2d).to(TD[dtype])
+    b, t, c = motion.shape
+    assert mask.shape == motion.shape and motion.stride(2) == 1 and mask.stride(2) == 1
+    assert (motion.stride(1) == c and mask.stride(1) == c) or t == 1
+    assert b == 1 or motion.stride(0) == mask.stride(0), "the kernel takes one clip stride for motion and mask"
+    motion, mask = motion.clone(), mask.clone()
+    if seed is not None:                          # M:386-391: masked seed frames take the carried-over motion and count as unmasked
+        pre = seed.shape[1]
+        assert seed.shape == (b, pre, c) and seed.stride(2) == 1 and (seed.stride(1) == c or pre == 1)
+        motion[:, :pre] = torch.where(mask[:, :pre] == 0, motion[:, :pre], seed)
+        mask[:, :pre] = 0
+    out = torch.zeros(b * t, n_store, dtype=TD[dtype])
+    out[:, :c] = torch.where(mask == 1, emb.expand_as(motion), motion).reshape(b * t, c).to(TD[dtype])
     return out
 
 
@@ -187,24 +169,39 @@ def gather_rows(table, idx, dtype, n_store=None):
     CALLS.append("gather_rows")
     k, d = table.shape
     n_store = d if n_store is None else n_store
+    if idx.dim() == 2:
+        ops.index_view(idx)                       # the strides the kernel would be handed must be supported
     out = torch.zeros(idx.numel(), n_store, dtype=TD[dtype])
     out[:, :d] = table[idx.reshape(-1)].to(TD[dtype])
     return out
 
 
-def vq_argmin(z2d, codebook):
+def _store_idx(res, out):
+    if out is None:
+        return res
+    ops.index_view(out)
+    assert out.numel() == res.numel()
+    out.copy_(res.view(out.shape))                # in place into the (B, T) view of the code buffer
+    return out
+
+
+def vq_argmin(z2d, codebook, out=None):
     CALLS.append("vq_argmin")
     d = (torch.sum(z2d ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1)) - 2 * (z2d @ codebook.t())
-    return torch.argmin(d, dim=1)
+    return _store_idx(torch.argmin(d, dim=1), out)
 
 
-def argmax_logsoftmax(logits2d):
+def argmax_logsoftmax(logits2d, out=None):
     CALLS.append("argmax_logsoftmax")
-    return torch.max(torch.log_softmax(logits2d, dim=1), dim=1)[1]
+    return _store_idx(torch.max(torch.log_softmax(logits2d, dim=1), dim=1)[1], out)
 
 
-def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad):
+def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad, nwin=1, hop=0, win_len=None):
     CALLS.append("wav_conv_in")
+    assert wav.stride(1) == 1
+    if win_len is not None:                       # nwin sliding windows per clip, output sequence i*B + b = window i of clip b
+        assert (nwin - 1) * hop + win_len <= wav.shape[1]
+        wav = torch.cat([wav[:, i * hop:i * hop + win_len] for i in range(nwin)], dim=0)
     y = torch.nn.functional.conv1d(wav.unsqueeze(1), w.unsqueeze(1), bias, stride=stride, padding=pad)   # (B,C,Lout)
     assert y.shape[2] == lout
     y = _leaky(y, slope.view(1, -1, 1)).permute(0, 2, 1).reshape(-1, w.shape[0])
@@ -231,6 +228,8 @@ def merge_parts(face, upper, hands, lower, m, device, want_motion=True):
 def velocity_to_position(vel2d, col0, init, dt, b, t):
     CALLS.append("velocity_to_position")
     from oracle import emage_oracle as orc
+    assert init.dim() == 2 and init.shape[0] in (1, b) and init.shape[1] == 3 and init.stride(1) == 1
+    init = init.expand(b, 3)
     v = torch.as_strided(vel2d, (b * t, 3), (vel2d.stride(0), 1), vel2d.storage_offset() + col0).reshape(b, t, 3)
     x = orc.velocity2position(v[:, :, 0:1], dt, init[:, 0:1])
     zz = orc.velocity2position(v[:, :, 2:3], dt, init[:, 2:3])
@@ -247,7 +246,7 @@ def axis_angle_to_rot6d(x):
     return orc.axis_angle_to_rotation_6d(x)
 
 
-_NAMES = ["gemm", "attention", "layernorm", "transformer_layer", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

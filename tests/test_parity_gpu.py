@@ -219,10 +219,14 @@ def test_lean_code_path_is_exact_on_device(exact_models, precision):
         ref = model._select_codes(model.inference(audio, spk, vq))
     finally:
         model.seed_only_decode = True
-    for k, v in ref.items():
-        assert (v is None) == (codes[k] is None)
-        if v is not None:
-            assert torch.equal(v, codes[k]), k
+    for p in common.PARTS:
+        assert codes[f"{p}_latent"] is None
+        if ref[f"{p}_index"] is not None:
+            assert torch.equal(ref[f"{p}_index"], codes[f"{p}_index"]), p
+        else:        # latent-routed part: the lean path hands over the index of the nearest code of that very latent
+            part = getattr(vq, f"vq_model_{p}")
+            want = part._nearest(common_ctx(part), ref[f"{p}_latent"].reshape(-1, 256).contiguous()).view(2, -1)
+            assert torch.equal(want, codes[f"{p}_index"]), p
 
 
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])

@@ -26,12 +26,26 @@ def _stub_forward(audio, speaker_id, masked_motion, mask, use_audio=True, **_):
     return out
 
 
-def _stub_decode(**kw):
-    """Frame-local decode: 337 channels from whichever codes / latents arrive (index parts as floats)."""
+def _stub_forward_product(audio, speaker_id, masked_motion, mask, use_audio=True, _seed=None, **_):
+    """The product hands forward() the window views plus the seed; the splice of M:386-391 happens in its packing
+    kernel.  The stand-in restates that splice, then is the same frame-local function."""
+    if _seed is not None:
+        pre = _seed.shape[1]
+        masked_motion, mask = masked_motion.clone(), mask.clone()
+        masked_motion[:, :pre] = torch.where(mask[:, :pre] == 0, masked_motion[:, :pre], _seed)
+        mask[:, :pre] = 0
+    return _stub_forward(audio, speaker_id, masked_motion, mask, use_audio)
+
+
+def _stub_decode(codebooks, **kw):
+    """Frame-local decode: 337 channels from the code indices; a latent goes through its nearest code first, like
+    `decode_from_latent` (M:60-70) — so the index a lean code path hands over decodes like the latent it came from."""
     parts = []
     for p in ("face", "upper", "hands", "lower"):
         v = kw.get(f"{p}_index")
-        parts.append(v.float().unsqueeze(-1) / 256.0 if v is not None else kw[f"{p}_latent"].mean(dim=2, keepdim=True))
+        if v is None:
+            v = orc.vq_nearest(kw[f"{p}_latent"], codebooks[p])
+        parts.append(v.float().unsqueeze(-1) / 256.0)
     x = torch.cat(parts, dim=2)                                                            # (B,T,4)
     return {"all_motion4inference": torch.cos(x.sum(dim=2, keepdim=True) * torch.arange(1, 338).view(1, 1, 337) * 0.01)}
 
@@ -39,13 +53,17 @@ def _stub_decode(**kw):
 class _StubVQ:
     def __init__(self, real):
         self._real = real
+        if hasattr(real, "vq_model_face"):       # product classes / oracle classes
+            self._cb = {p: getattr(real, f"vq_model_{p}").state_dict()["quantizer.embedding.weight"] for p in common.PARTS}
+        else:
+            self._cb = {p: getattr(real, p).codebook for p in common.PARTS}
 
     def __getattr__(self, name):                 # config lookups (vae_layer) of the seed-only decode
         return getattr(self._real, name)
 
     def decode(self, **kw):
         kw.pop("get_global_motion", None), kw.pop("ref_trans", None)
-        return _stub_decode(**kw)
+        return _stub_decode(self._cb, **kw)
 
 
 LENGTHS = [5, 30, 63, 64, 65, 68, 69, 70, 100, 123, 124, 125, 128, 129, 184, 185, 188, 189, 250]
@@ -67,7 +85,7 @@ def test_window_schedule_matches_oracle(frames, monkeypatch):
         mm = torch.randn(bs, n, 337, generator=g)
         mk = (torch.rand(bs, n, 337, generator=g) > 0.5).float()
     monkeypatch.setattr(type(omodel), "forward", lambda self, *a, **k: _stub_forward(*a, **k))
-    monkeypatch.setattr(type(model), "forward", lambda self, *a, **k: _stub_forward(*a, **k))
+    monkeypatch.setattr(type(model), "forward", lambda self, *a, **k: _stub_forward_product(*a, **k))
     length = audio.shape[1] * 30 // 16000
     window, pre = 64, 4
     rounds, remain = (length - pre) // (window - pre), (length - pre) % (window - pre)
@@ -87,8 +105,10 @@ def test_window_schedule_matches_oracle(frames, monkeypatch):
         assert got[k].shape == ref[k].shape == (bs, expect, 256), (k, got[k].shape, ref[k].shape, expect)
         assert torch.equal(got[k], ref[k]), k
     sel = omodel.select_codes(ref)               # the lean per-window code path selects the same frames
-    for k, v in sel.items():
-        if v is None:
-            assert codes[k] is None
-        else:
-            assert torch.equal(codes[k], v), k
+    for p in common.PARTS:
+        assert codes[f"{p}_latent"] is None
+        if sel[f"{p}_index"] is not None:
+            assert torch.equal(codes[f"{p}_index"], sel[f"{p}_index"]), p
+        else:                                    # latent-routed part: the lean path returns the index of its nearest code
+            want = orc.vq_nearest(sel[f"{p}_latent"], getattr(ovq, p).codebook)
+            assert torch.equal(codes[f"{p}_index"], want), p

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pantomatrix_amd import _lib, ops  # noqa: E402
-from pantomatrix_amd._lib import BF16, F32  # noqa: E402
+from pantomatrix_amd._lib import BF16, F32, F16X3  # noqa: E402
 
 SHAPES = [
     # name, (nb, lin, lout), cin, n, taps, stride, pad, extras
@@ -33,7 +33,7 @@ SHAPES = [
     ("wav b5.conv1+ds 128->512 s3", (64, 205, 64), 128, 512, 15, 3, 0, dict()),
     ("wav b5.conv2 256->256", (64, 64, 64), 256, 256, 15, 1, 7, dict()),
 ]
-CONFIGS = [10, 11, 13, 15, 18, 19, 20, 21, 22, 23, 24, 25, 26]
+CONFIGS = [25, 18, 27, 32, 33, 34, 36, 37]
 
 
 def main():
@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--ablate", action="store_true", help="time each config with DMA / MFMA / epilogue removed (diagnostic)")
     ap.add_argument("--configs", default="")
     args = ap.parse_args()
-    dt = BF16 if args.dtype == "bf16" else F32
+    dt = {"bf16": BF16, "fp32": F32, "f16x3": F16X3}[args.dtype]
     td = ops.TORCH_DTYPE[dt]
     lib = _lib.load()
     dev = "cuda"
@@ -59,7 +59,11 @@ def main():
         a[:, :cin] = torch.randn(nb * lin, cin, generator=g)
         w = torch.zeros(n, taps, cp)
         w[:, :, :cin] = torch.randn(n, taps, cin, generator=g) / (cin * taps) ** 0.5
-        a, w = a.to(td).to(dev), w.reshape(n, taps * cp).to(td).to(dev)
+        a, w = a.to(td).to(dev), w.reshape(n, taps * cp).to(td)
+        w_scale = 1.0
+        if dt == F16X3:
+            w, w_scale = ops.split_f16_weights(w)
+        w = w.to(dev)
         bias = (torch.randn(n, generator=g) * 0.1).to(dev)
         slope = torch.full((n,), float(ex["slope"]), device=dev) if "slope" in ex else None
         res = torch.randn(m, n, generator=g).to(dev) if ex.get("res") else None
@@ -73,7 +77,7 @@ def main():
             out_f = torch.zeros(m, ncol, device=dev) if res is not None else None
             out_t = torch.zeros(nb, n - vt0, ops.round_up(lout, 32), dtype=td, device=dev) if vt0 else None
             call = lambda: ops.gemm(dt, a, w, bias, slope, res, out, out_f, out_t, n=n, cp=cp, t_col0=vt0 or 0,
-                                    t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m)
+                                    t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m, w_scale=w_scale)
             call()
             torch.cuda.synchronize()
             # replay a captured graph of `iters` launches so the host launch cost (~8 us/op from Python) is excluded
