@@ -201,6 +201,45 @@ int emage_merge_parts(const float* face, int ldface, const float* upper, int ldu
 int emage_velocity_to_position(const float* vel, int ldv, int col0, const float* init, int ld_init, float dt,
                                float* trans, int B, int T, void* stream);
 
+/*
+ * ---- DisCo / CaMN: models/disco_audio/modeling_disco_audio.py (D:), models/camn_audio/
+ * modeling_camn_audio.py (C:).  Their WavEncoder, MLPs and the LSTM input projections run on emage_wav_conv_in /
+ * emage_gemm; the entry points below are what is specific to them.  float32 tensors throughout.
+ *
+ * emage_lstm_step — one time step of ONE direction of nn.LSTM (D:190-195,252; C:204-218,261-268) for the whole batch:
+ *   gates = gates_x[b] + h_prev[b] W_hh^T;  c' = sigmoid(f) c + sigmoid(i) tanh(g);  h' = sigmoid(o) tanh(c')
+ * with the gate rows INTERLEAVED per hidden unit: column 4u + g of `gates` (g = input, forget, cell, output — torch's
+ * packed order regrouped by the host), so one lane owns all four gates of a unit.  h_prev: (B, ld_hprev) the previous
+ * step's hidden state (zeros for the first step); w_hh: (4H, H) in `dtype` (EMAGE_F32, or EMAGE_F16X3 = the host-split
+ * image of emage_gemm with w_scale / a_scale); gates_x: (B, ld_gx) this step's rows of the input projection
+ * x_t W_ih^T + b_ih + b_hh (same interleaved layout); cstate: (B, ldc) updated in place; h_out: (B, ld_hout).
+ * Rows may be strided views (step t of a (B, T, .) tensor: ld = T * width).  H % 64 == 0.
+ */
+int emage_lstm_step(int dtype, const float* h_prev, int ld_hprev, const void* w_hh, float w_scale, float a_scale,
+                    const float* gates_x, int ld_gx, float* cstate, int ldc, float* h_out, int ld_hout,
+                    int B, int H, void* stream);
+
+/* DisCo's content blend (D:244-247): out = softmax(sel[:, 0:2])[0] * c1 + softmax(...)[1] * c2, rows of C channels. */
+int emage_softmax2_mix(const float* sel, int ld_sel, const float* c1, int ld1, const float* c2, int ld2,
+                       float* out, int ldo, int M, int C, void* stream);
+
+/*
+ * The [speaker | seed motion | is-seed | zero pad] tail of the LSTM input rows (D:200-243, C:224-259): row (b, t) gets
+ * speaker_table[speaker_id[b]] (speaker_f values), then the reference's padded seed tensor at frame src_map[t]
+ * (frames < seed_frames carry seed_motion[b][frame] (pose_dims values, or zeros when seed_motion is NULL) and flag 1;
+ * src_map[t] < 0 or >= seed_frames: zeros), then zeros up to n_store.  src_map: T ints on the device.
+ */
+int emage_lstm_inputs(const float* speaker_table, const int64_t* speaker_id, int speaker_f,
+                      const float* seed_motion, long ld_seed_b, int pose_dims, int seed_frames, const int* src_map,
+                      float* out, int ldo, int n_store, int B, int T, void* stream);
+
+/*
+ * rot-6D -> axis-angle scattered into the SMPL-X joint order (D:256-258 + recover_from_mask_ts D:81-96):
+ * joint j takes the conversion of rot6d[m][6*slot .. 6*slot+5] with slot = slot_of_joint[j], or zeros when slot < 0.
+ * rot6d: (M, ld) fp32; slot_of_joint: n_joints ints on the device; axis_angle: (M, n_joints*3).
+ */
+int emage_rot6d_scatter(const float* rot6d, int ld, const int* slot_of_joint, float* axis_angle, int M, int n_joints, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,15 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int dbg;
     float a_scale, o_scale;   // split-f16 mode: A is multiplied by a_scale before the hi/lo split, accumulators by o_scale after the K-loop
+    float* cstate; int ldc;   // EPI_LSTM: the (M, N/4) cell state, updated in place
 };
+
+// Epilogue kinds of gemm_pipe_tile.  EPI_LSTM (emage_lstm_step): the contraction is h_{t-1} W_hh^T with the gate rows of
+// W_hh interleaved per hidden unit (column 4u + g, g = input / forget / cell / output), `res` holds the step's input
+// projection x_t W_ih^T + b_ih + b_hh in the same layout, and the epilogue applies the LSTM cell (torch.nn.LSTM:
+// c' = sigmoid(f) c + sigmoid(i) tanh(g), h' = sigmoid(o) tanh(c')) — c' to cstate[m][u], h' to out_f32[m][u].
+constexpr int EPI_LINEAR = 0, EPI_LSTM = 1;
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 constexpr int NTHREADS = 256;
 constexpr int KCH = 8;   // 16-byte chunks per K-tile row
@@ -200,7 +208,7 @@ constexpr int pipe_smem_bytes() {
 // X3: split-f16 MFMA on fp32 operands (T = float, KC = 8): the K-tile is 32 k; a lane's two chunks (k = 4g..4g+3 and
 // 16+4g..16+4g+3 of the tile) form the 8 k-values of one 16x16x32 MFMA; the W tile row holds [4 hi chunks | 4 lo chunks]
 // packed by the host in exactly that k order (pantomatrix_amd.modeling_emage_audio._Packed._split_f16).
-template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool FPRE = false, bool X3 = false>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool FPRE = false, bool X3 = false, int EPI = EPI_LINEAR>
 __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = 16 / EPC;                     // element size in bytes
@@ -466,6 +474,23 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                     } else if (p.res) {
                         if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, rv);
                         else load8<T>((const T*)p.res + (long)m * p.ldr + n, rv);
+                    }
+                    if constexpr (EPI == EPI_LSTM) {
+                        // 8 consecutive columns = 2 hidden units x (i, f, g, o); rv = the input projection of this step
+                        float2 cs = *(const float2*)(p.cstate + (long)m * p.ldc + (n >> 2));
+                        float hv[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const f32x4 a4 = acc[i][2 * jp + u];
+                            const float gi = sigmoid_f(a4[0] + rv[4 * u + 0]), gf = sigmoid_f(a4[1] + rv[4 * u + 1]);
+                            const float gg = tanhf(a4[2] + rv[4 * u + 2]), go = sigmoid_f(a4[3] + rv[4 * u + 3]);
+                            const float cn = gf * (u == 0 ? cs.x : cs.y) + gi * gg;
+                            (u == 0 ? cs.x : cs.y) = cn;
+                            hv[u] = go * tanhf(cn);
+                        }
+                        *(float2*)(p.cstate + (long)m * p.ldc + (n >> 2)) = cs;
+                        *(float2*)(p.out_f32 + (long)m * p.ldf + (n >> 2)) = make_float2(hv[0], hv[1]);
+                        continue;
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {

@@ -537,12 +537,93 @@ class EmageVQModel:
 
 
 # ======================================================================================
+# WavEncoder (P:263-314; the DisCo / CaMN model files carry the same module with other widths)
+# ======================================================================================
+class _WavEncoderMixin:
+    """Six BasicBlocks of Conv1d(k=15) + BatchNorm + LeakyReLU(0.01) with conv+BN shortcuts, on the raw waveform.
+    `_wav_blocks()` gives the geometry [(cin, cout, stride, pad, has_shortcut)]; eval BatchNorm is folded into the convs,
+    block 0 (Cin = 1) of every encoder of the model is one `emage_wav_conv_in` launch, each later block is two
+    implicit-GEMM launches (conv1 stacked with its shortcut conv; conv2 with the shortcut add + activation fused)."""
+
+    def _wav_blocks(self):
+        raise NotImplementedError
+
+    def _pack_wav_encoders(self, pk, encoders):
+        w0, b0, s0 = [], [], []
+        for enc in encoders:
+            for i, (cin, cout, stride, pad, ds) in enumerate(self._wav_blocks()):
+                base = f"{enc}.feat_extractor.{i}"
+                if i == 0:
+                    for conv, bn, sl in ((base + ".conv1", base + ".bn1", 0.01), (base + ".downsample.0", base + ".downsample.1", 1.0)):
+                        w, b = pk.folded(conv, bn)
+                        w0.append(w.reshape(cout, _WAV_TAPS))
+                        b0.append(b)
+                        s0.append(torch.full((cout,), sl, device=pk.device))
+                else:
+                    pk.conv(base + ".conv1", base + ".conv1", fold_bn=base + ".bn1",
+                            extra=(base + ".downsample.0", base + ".downsample.1") if ds else None)
+                    n1 = cout * (2 if ds else 1)
+                    pk.w[base + ".conv1"]["slope"] = torch.cat([torch.full((cout,), 0.01, device=pk.device),
+                                                                torch.ones(n1 - cout, device=pk.device)]).contiguous()
+                pk.conv(base + ".conv2", base + ".conv2", fold_bn=base + ".bn2")
+        pk.w["wav_in"] = dict(w=torch.cat(w0, 0).float().contiguous(), b=torch.cat(b0).float().contiguous(),
+                              slope=torch.cat(s0).float().contiguous())
+
+    def _wav_lengths(self, l):
+        """Frame counts after each of the 6 BasicBlocks (P:301-306) for an l-sample window."""
+        lens, cur = [], l
+        for (_ci, _co, stride, pad, _ds) in self._wav_blocks():
+            cur = (cur + 2 * pad - _WAV_TAPS) // stride + 1
+            lens.append(cur)
+        if min(lens) <= 0:
+            raise RuntimeError(f"audio window of {l} samples is too short for the WavEncoder")
+        return lens
+
+    def _wav_first_layer(self, cx, audio, lens, nwin=1, hop=0, win_len=None):
+        """Block 0's conv1 and downsample shortcut of EVERY encoder of the model in one launch: (nwin*B*L0, n_enc*2q) =
+        [enc0 conv1 | enc0 shortcut | enc1 conv1 | enc1 shortcut]; `nwin` sliding windows per clip are read in place."""
+        blocks = self._wav_blocks()
+        w_in = cx.pk.w["wav_in"]
+        y0 = cx.lo(nwin * audio.shape[0] * lens[0], w_in["w"].shape[0])
+        ops.wav_conv_in(cx.dt, audio, w_in["w"], w_in["b"], w_in["slope"], y0, lens[0], blocks[0][2], blocks[0][3],
+                        nwin=nwin, hop=hop, win_len=win_len)
+        return y0
+
+    def _wav_encoder_chain(self, cx, enc, e, y0, b, lens, dest=None):
+        """Blocks 0..5 of one WavEncoder (P:283-314) after the shared first layer.  Returns (B*T', 256); written
+        straight into `dest` (a 2-D view) when its row count matches."""
+        blocks = self._wav_blocks()
+        k, q = _WAV_TAPS, blocks[0][1]
+        x, lin = None, None
+        for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
+            base = f"{enc}.feat_extractor.{i}"
+            lout = lens[i]
+            if i == 0:
+                y1, sc = y0[:, e * 2 * q: e * 2 * q + q], y0[:, e * 2 * q + q: (e + 1) * 2 * q]
+            else:
+                ent = cx.pk.w[base + ".conv1"]
+                y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout, n_store=_rup(ent["n"]))
+                y1, sc = (y[:, :cout], y[:, cout:2 * cout]) if ds else (y[:, :cout], x)
+            last = i == len(blocks) - 1
+            out = dest if (last and dest is not None and dest.shape[0] == b * lout) else None
+            x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
+                           m=b * lout, out=out, n_store=0 if out is not None else _rup(cout))
+            x = x[:, :cout] if x.shape[1] != cout else x
+            lin = lout
+        return x
+
+
+
+# ======================================================================================
 # EmageAudioModel  (M:207-490)
 # ======================================================================================
-class EmageAudioModel(_EmageModule):
+class EmageAudioModel(_WavEncoderMixin, _EmageModule):
     config_class = EmageAudioConfig
     base_model_prefix = "emage_audio"
     _spec_fn = staticmethod(spec.audio_model_spec)
+
+    def _wav_blocks(self):
+        return spec.wav_encoder_blocks(self.config.audio_f)
 
     # ---- weight packing ----------------------------------------------------------------
     def _pack(self, pk):
@@ -570,27 +651,7 @@ class EmageAudioModel(_EmageModule):
             self._pack_layer(pk, nm, cross=True)
         pk.in_proj("cross.kv_all", [n + ".multihead_attn" for n in cross], "kv")
         pk.in_proj("face.kv_all", [n + ".multihead_attn" for n in face], "kv")
-        # audio encoders: block 0 of both encoders shares one first-layer launch
-        w0, b0, s0 = [], [], []
-        for enc in ("audio_encoder_face", "audio_encoder_body"):
-            blocks = spec.wav_encoder_blocks(c.audio_f)
-            for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
-                base = f"{enc}.feat_extractor.{i}"
-                if i == 0:
-                    for conv, bn, sl in ((base + ".conv1", base + ".bn1", 0.01), (base + ".downsample.0", base + ".downsample.1", 1.0)):
-                        w, b = pk.folded(conv, bn)
-                        w0.append(w.reshape(cout, _WAV_TAPS))
-                        b0.append(b)
-                        s0.append(torch.full((cout,), sl, device=pk.device))
-                else:
-                    pk.conv(base + ".conv1", base + ".conv1", fold_bn=base + ".bn1",
-                            extra=(base + ".downsample.0", base + ".downsample.1") if ds else None)
-                    n1 = cout * (2 if ds else 1)
-                    pk.w[base + ".conv1"]["slope"] = torch.cat([torch.full((cout,), 0.01, device=pk.device),
-                                                                torch.ones(n1 - cout, device=pk.device)]).contiguous()
-                pk.conv(base + ".conv2", base + ".conv2", fold_bn=base + ".bn2")
-        pk.w["wav_in"] = dict(w=torch.cat(w0, 0).float().contiguous(), b=torch.cat(b0).float().contiguous(),
-                              slope=torch.cat(s0).float().contiguous())
+        self._pack_wav_encoders(pk, ("audio_encoder_face", "audio_encoder_body"))
         pk.w["pe"] = pk.f32("position_embeddings.pe")[0].contiguous()                 # (2*pose_length, d)
         pk.w["spk_body"] = pk.f32("speaker_embedding_body.weight")
         pk.w["spk_face"] = pk.f32("speaker_embedding_face.weight")
@@ -660,48 +721,6 @@ class EmageAudioModel(_EmageModule):
         vt = cx.vt_buffer(b, n_layers * d, tk)
         cx.gemm(mem_lo, key, out=k, out_t=vt, t_col0=n_layers * d, t_rows=tk)
         return k, vt
-
-    def _wav_lengths(self, l):
-        """Frame counts after each of the 6 BasicBlocks (P:301-306) for an l-sample window."""
-        lens, cur = [], l
-        for (_ci, _co, stride, pad, _ds) in spec.wav_encoder_blocks(self.config.audio_f):
-            cur = (cur + 2 * pad - _WAV_TAPS) // stride + 1
-            lens.append(cur)
-        if min(lens) <= 0:
-            raise RuntimeError(f"audio window of {l} samples is too short for the WavEncoder")
-        return lens
-
-    def _wav_first_layer(self, cx, audio, lens, nwin=1, hop=0, win_len=None):
-        """Block 0's conv1 and downsample shortcut of BOTH encoders in one launch: (nwin*B*L0, 4q) =
-        [face conv1 | face shortcut | body conv1 | body shortcut]; `nwin` sliding windows per clip are read in place."""
-        blocks = spec.wav_encoder_blocks(self.config.audio_f)
-        w_in = cx.pk.w["wav_in"]
-        y0 = cx.lo(nwin * audio.shape[0] * lens[0], 4 * blocks[0][1])
-        ops.wav_conv_in(cx.dt, audio, w_in["w"], w_in["b"], w_in["slope"], y0, lens[0], blocks[0][2], blocks[0][3],
-                        nwin=nwin, hop=hop, win_len=win_len)
-        return y0
-
-    def _wav_encoder_chain(self, cx, enc, e, y0, b, lens, dest=None):
-        """Blocks 0..5 of one WavEncoder (P:283-314) after the shared first layer.  Returns (B*T', 256); written
-        straight into `dest` (a 2-D view) when its row count matches."""
-        blocks = spec.wav_encoder_blocks(self.config.audio_f)
-        k, q = _WAV_TAPS, blocks[0][1]
-        x, lin = None, None
-        for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
-            base = f"{enc}.feat_extractor.{i}"
-            lout = lens[i]
-            if i == 0:
-                y1, sc = y0[:, e * 2 * q: e * 2 * q + q], y0[:, e * 2 * q + q: (e + 1) * 2 * q]
-            else:
-                ent = cx.pk.w[base + ".conv1"]
-                y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout)
-                y1, sc = (y[:, :cout], y[:, cout:]) if ds else (y, x)
-            last = i == len(blocks) - 1
-            out = dest if (last and dest is not None and dest.shape[0] == b * lout) else None
-            x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
-                           m=b * lout, out=out)
-            lin = lout
-        return x
 
     # ---- forward -------------------------------------------------------------------------
     def _audio_features(self, cx, audio, b, t, use_audio, fk, lane_face, lane_body, nwin=1, hop=0, win_len=None):

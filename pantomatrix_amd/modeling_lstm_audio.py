@@ -1,0 +1,232 @@
+"""MI355X-native DisCo and CaMN — the two LSTM speech-to-gesture generators next to EMAGE.
+
+Same public surface as
+  D: /root/reference/models/disco_audio/modeling_disco_audio.py   DiscoAudioModel.forward D:199-266
+  C: /root/reference/models/camn_audio/modeling_camn_audio.py     CamnAudioModel.forward  C:223-280
+(`forward(audio, speaker_id, seed_frames=4, seed_motion=None, return_axis_angle=True)` -> dict; the same state-dict keys,
+`pantomatrix_amd/spec.py`), eval mode.  Kernel plan, all through libemage_hip.so:
+
+* WavEncoder (32..128 channels, 15 fps): `emage_wav_conv_in` + implicit-GEMM convs (the EMAGE WavEncoder code, narrower);
+* MLPs, the selector, and the LSTM input projection x W_ih^T of ALL time steps (both directions stacked, one launch per
+  layer): `emage_gemm`, writing straight into the column blocks of the next operand (no concatenation copies);
+* the recurrence: `emage_lstm_step`, one launch per time step and direction (h W_hh^T on MFMA with the LSTM cell in the
+  epilogue), forward and backward directions on two stream lanes; a whole forward is captured in a hipGraph by
+  `LstmClipRunner`;
+* rot-6D -> axis-angle -> 55 SMPL-X joints: `emage_rot6d_scatter`.
+Precision: "f16x3" (default, fp32 storage + split-f16 MFMA: fp32-grade, what the parity tests use) or "fp32".
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops, spec
+from ._lib import F32, F16X3
+from .configuration_emage_audio import _AttrConfig
+from .modeling_emage_audio import _EmageModule, _WavEncoderMixin, _Ctx, _rup
+from .streams import Fork
+
+
+class DiscoAudioConfig(_AttrConfig):
+    model_type = "disco_audio"
+
+
+class CamnAudioConfig(_AttrConfig):
+    model_type = "camn_audio"
+
+
+class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
+    def __init__(self, config):
+        super().__init__(config)
+        self._dt = F16X3
+        self.pose_rep = getattr(config, "pose_rep", "smplx")
+
+    def set_precision(self, precision: str):
+        if precision == "bf16":
+            raise ValueError("the LSTM models run in f16x3 or fp32 (their recurrences are not bf16-safe at the parity bar)")
+        return super().set_precision(precision)
+
+    def _wav_blocks(self):
+        return spec.lstm_wav_encoder_blocks()
+
+    # ---- packing ---------------------------------------------------------------------
+    def _pack_lstm(self, pk, name, n_layer):
+        """torch's packed gate rows [i | f | g | o] (each H rows) regrouped per hidden unit (row 4u + g), so one lane of
+        `emage_lstm_step` owns the four gates of a unit; both directions' input projections stacked along N."""
+        hid = self.config.hidden_size
+        perm = torch.arange(4 * hid).view(4, hid).t().reshape(-1)                 # new row 4u + g  <-  old row g*H + u
+        for k in range(n_layer):
+            w_ih, b_all = [], []
+            for d, suffix in enumerate(("", "_reverse")):
+                p = f"{name}.weight_ih_l{k}{suffix}"
+                w_ih.append(pk.p[p].float()[perm])
+                b_all.append((pk.p[f"{name}.bias_ih_l{k}{suffix}"].float() + pk.p[f"{name}.bias_hh_l{k}{suffix}"].float())[perm])
+                w, kp, ws = pk._pack_mat(pk.p[f"{name}.weight_hh_l{k}{suffix}"].float()[perm])
+                pk.w[f"{name}.hh.{k}.{d}"] = dict(w=w, ws=ws)
+            w, kp, ws = pk._pack_mat(torch.cat(w_ih, 0))
+            pk.w[f"{name}.ih.{k}"] = dict(w=w, b=torch.cat(b_all).contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=w_ih[0].shape[1], ws=ws)
+
+    def _pack_common(self, pk):
+        self._pack_wav_encoders(pk, ("audio_encoder",))
+        if self.config.speaker_f > 0:
+            pk.w["spk"] = pk.f32("speaker_embedding.weight")
+        jm = getattr(self.config, "joint_mask", "local_upper")
+        joints = spec.LOCAL_UPPER_JOINTS if jm == "local_upper" else list(range(1, 55))
+        slot = torch.full((55,), -1, dtype=torch.int32)
+        for i, j in enumerate(joints):
+            slot[j] = i
+        pk.w["slot_of_joint"] = slot.to(pk.device)
+
+    # ---- building blocks ---------------------------------------------------------------
+    def _audio_feat(self, cx, audio, b):
+        lens = self._wav_lengths(audio.shape[1])
+        y0 = self._wav_first_layer(cx, audio, lens)
+        return self._wav_encoder_chain(cx, "audio_encoder", 0, y0, b, lens), lens[-1]      # (B*T, audio_f) fp32
+
+    def _seed_src_map(self, t, seed_motion):
+        """Which frame of the reference's padded seed tensor each of the T input frames shows (D:229-242 verbatim,
+        including the shorter-seed quirk: `cat(seed, seed[:, -diff:])` with diff < 0 appends the frames from |diff| on)."""
+        if seed_motion is None:
+            return list(range(t))
+        t_m = seed_motion.shape[1]
+        if t_m == t:
+            return list(range(t))
+        diff = t_m - t
+        if diff > 0:
+            return list(range(t))
+        m = list(range(t_m)) + list(range(-diff, t_m))
+        if len(m) != t:
+            raise RuntimeError(f"Sizes of tensors must match except in dimension 2. Expected size {t} but got size {len(m)} "
+                               f"(seed motion of {t_m} frames vs {t} audio frames)")
+        return m
+
+    def _mlp(self, cx, name, x, out=None, out_f32=None):
+        """MLP (D:152-164): Linear + LeakyReLU(0.1) + Linear; the result lands in `out` (and `out_f32`) when given."""
+        h, _ = cx.gemm(x, name + ".fc1", slope=0.1)
+        return cx.gemm(h, name + ".fc2", out=out, out_f32=out_f32)[0]
+
+    def _bilstm(self, cx, name, x, b, t, n_layer):
+        """nn.LSTM(bidirectional=True, batch_first=True), eval: x (B*T, Cp) -> (B*T, 2H) [forward | backward]."""
+        hid = self.config.hidden_size
+        zeros = torch.zeros(b, hid, dtype=torch.float32, device=cx.dev)
+        for k in range(n_layer):
+            gx, _ = cx.gemm(x, f"{name}.ih.{k}")                                     # (B*T, 8H): all steps, both directions
+            hseq = torch.empty(b * t, 2 * hid, dtype=torch.float32, device=cx.dev)
+            g3, h3 = gx.view(b, t, 8 * hid), hseq.view(b, t, 2 * hid)
+            cstate = torch.zeros(2, b, hid, dtype=torch.float32, device=cx.dev)
+            with Fork(cx.dev, 2, self.concurrent) as fk:
+                for d in range(2):                                                   # the two directions are independent chains
+                    with fk.lane(d):
+                        w = cx.pk.w[f"{name}.hh.{k}.{d}"]
+                        prev = zeros
+                        for s in (range(t) if d == 0 else range(t - 1, -1, -1)):
+                            cur = h3[:, s, d * hid:(d + 1) * hid]
+                            ops.lstm_step(cx.gdt, prev, w["w"], g3[:, s, d * 4 * hid:(d + 1) * 4 * hid], cstate[d], cur, w_scale=w["ws"])
+                            prev = cur
+            x = hseq
+        return x
+
+    def _lstm_head(self, cx, name, out_name, in_fea, b, t, out=None, out_f32=None):
+        hid = self.config.hidden_size
+        y = self._bilstm(cx, name, in_fea, b, t, self.config.n_layer)
+        s = torch.empty(b * t, hid, dtype=torch.float32, device=cx.dev)
+        ops.add(cx.dt, y[:, :hid], y[:, hid:], out=s)                               # forward + backward halves (D:253)
+        return self._mlp(cx, out_name, s, out=out, out_f32=out_f32)
+
+    def _axis_angle(self, cx, rot6d2d, b, t):
+        return ops.rot6d_scatter(rot6d2d, cx.pk.w["slot_of_joint"]).view(b, t, 165)
+
+    def _tail_inputs(self, cx, in_fea, col0, speaker_id, seed_frames, seed_motion, b, t):
+        c = self.config
+        key = (t, None if seed_motion is None else seed_motion.shape[1], str(cx.dev))
+        if key not in self._templates:             # small constant table, built once per shape (never inside a graph capture)
+            self._templates[key] = torch.tensor(self._seed_src_map(t, seed_motion), dtype=torch.int32, device=cx.dev)
+        src = self._templates[key]
+        sm = None if seed_motion is None else seed_motion.to(device=cx.dev, dtype=torch.float32).contiguous()
+        sid = speaker_id.to(cx.dev).reshape(-1).contiguous()
+        ops.lstm_inputs(in_fea[:, col0:], cx.pk.w.get("spk"), sid if c.speaker_f > 0 else None, sm, c.pose_dims, seed_frames, src, b, t)
+
+    __call__ = lambda self, *a, **k: self.forward(*a, **k)
+
+
+class DiscoAudioModel(_LstmAudioModel):
+    config_class = DiscoAudioConfig
+    base_model_prefix = "camn_audio"          # (sic) D:174
+    _spec_fn = staticmethod(spec.disco_model_spec)
+
+    def _pack(self, pk):
+        c = self.config
+        self._pack_common(pk)
+        pk.linear("enc.fc1", [f"{n}.fc1" for n in ("audio_encoder_c1", "audio_encoder_c2", "audio_encoder_r", "selector")])
+        for nm in ("audio_encoder_c1", "audio_encoder_c2", "audio_encoder_r", "selector"):
+            pk.linear(nm + ".fc2", [nm + ".fc2"])
+        self._pack_lstm(pk, "body_motion_decoder", c.n_layer)
+        pk.linear("body_out.fc1", ["body_out.fc1"])
+        pk.linear("body_out.fc2", ["body_out.fc2"])
+
+    def forward(self, audio, speaker_id, seed_frames=4, seed_motion=None, return_axis_angle=True):
+        """DiscoAudioModel.forward (D:199-266), eval mode: audio (B, L) fp32, speaker_id (B, 1) int64 ->
+        {motion (B,T,258), motion_axis_angle (B,T,165), audio_fea_c (B,T,128), audio_fea_r (B,T,128)}."""
+        c = self.config
+        cx = _Ctx(self._engine())
+        dev = cx.dev
+        audio = audio.to(device=dev, dtype=torch.float32)
+        b = audio.shape[0]
+        af, hid = c.audio_f, c.hidden_size
+        feat, t = self._audio_feat(cx, audio, b)
+        m = b * t
+        cin = 2 * af + c.speaker_f + c.pose_dims + 1
+        in_fea = torch.empty(m, _rup(cin), dtype=torch.float32, device=dev)          # [c | r | speaker | seed | flag | 0]
+        hcat, _ = cx.gemm(feat, "enc.fc1", slope=0.1)                                 # the four MLPs' hidden layers in one launch
+        c1, _ = cx.gemm(hcat[:, 0:hid], "audio_encoder_c1.fc2")
+        c2, _ = cx.gemm(hcat[:, hid:2 * hid], "audio_encoder_c2.fc2")
+        cx.gemm(hcat[:, 2 * hid:3 * hid], "audio_encoder_r.fc2", out=in_fea[:, af:2 * af])
+        sel, _ = cx.gemm(hcat[:, 3 * hid:4 * hid], "selector.fc2")
+        ops.softmax2_mix(sel, c1, c2, in_fea[:, :af])                                # D:244-247
+        self._tail_inputs(cx, in_fea, 2 * af, speaker_id, seed_frames, seed_motion, b, t)
+        motion = self._lstm_head(cx, "body_motion_decoder", "body_out", in_fea, b, t)
+        out = {"motion": motion.view(b, t, c.pose_dims),
+               "motion_axis_angle": self._axis_angle(cx, motion, b, t) if return_axis_angle else None,
+               "audio_fea_c": in_fea[:, :af].reshape(b, t, af), "audio_fea_r": in_fea[:, af:2 * af].reshape(b, t, af)}
+        return out
+
+
+class CamnAudioModel(_LstmAudioModel):
+    config_class = CamnAudioConfig
+    base_model_prefix = "camn_audio"
+    _spec_fn = staticmethod(spec.camn_model_spec)
+
+    def _pack(self, pk):
+        c = self.config
+        self._pack_common(pk)
+        self._pack_lstm(pk, "body_motion_decoder", c.n_layer)
+        self._pack_lstm(pk, "hands_motion_decoder", c.n_layer)
+        for nm in ("body_out", "hands_out"):
+            pk.linear(nm + ".fc1", [nm + ".fc1"])
+            pk.linear(nm + ".fc2", [nm + ".fc2"])
+
+    def forward(self, audio, speaker_id, seed_frames=4, seed_motion=None, return_axis_angle=True):
+        """CamnAudioModel.forward (C:223-280), eval mode, pose_rep "smplx": the body LSTM, then the hands LSTM on
+        [inputs | body output]; `motion` is (B, T, 43, 6) with the body joints first (C:272-276)."""
+        c = self.config
+        cx = _Ctx(self._engine())
+        dev = cx.dev
+        audio = audio.to(device=dev, dtype=torch.float32)
+        b = audio.shape[0]
+        af = c.audio_f
+        cin = af + c.speaker_f + c.pose_dims + 1
+        lens = self._wav_lengths(audio.shape[1])
+        t = lens[-1]
+        m = b * t
+        # one buffer holds the hands LSTM's input [audio | speaker | seed | flag | body (78) | 0]; the body LSTM reads its first
+        # `cin` columns — there its zero-padded weight columns meet the (finite) body block, contributing exactly 0
+        wide = torch.zeros(m, _rup(cin + c.body_dims), dtype=torch.float32, device=dev)
+        y0 = self._wav_first_layer(cx, audio, lens)
+        self._wav_encoder_chain(cx, "audio_encoder", 0, y0, b, lens, dest=wide[:, :af])
+        self._tail_inputs(cx, wide[:, :_rup(cin)], af, speaker_id, seed_frames, seed_motion, b, t)
+        motion = torch.empty(m, c.pose_dims, dtype=torch.float32, device=dev)                          # body joints, then hand joints
+        # body_out's last GEMM writes the body block twice: into the hands LSTM's input and into the result
+        self._lstm_head(cx, "body_motion_decoder", "body_out", wide[:, :_rup(cin)], b, t,
+                        out=wide[:, cin:cin + c.body_dims], out_f32=motion[:, :c.body_dims])
+        self._lstm_head(cx, "hands_motion_decoder", "hands_out", wide, b, t, out=motion[:, c.body_dims:])
+        return {"motion": motion.view(b, t, c.pose_dims // 6, 6),
+                "motion_axis_angle": self._axis_angle(cx, motion, b, t) if return_axis_angle else None}

@@ -242,3 +242,52 @@ def velocity_to_position(vel2d, col0, init, dt, b, t):
     trans = torch.empty(b, t, 3, dtype=torch.float32, device=vel2d.device)
     check(_lib.load().emage_velocity_to_position(_ptr(vel2d), _ld(vel2d), col0, _ptr(init), ld_init, dt, _ptr(trans), b, t, _stream()), "velocity_to_position")
     return trans
+
+
+# ---- DisCo / CaMN (include/emage_hip.h: emage_lstm_step ...) -------------------------------------------------------------
+def lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, *, w_scale=1.0, a_scale=None):
+    """One time step of one LSTM direction for the whole batch.  h_prev (B, H) / gates_x (B, 4H) / h_out (B, H): fp32 row
+    views with unit column stride (step t of a (B, T, .) tensor is a strided view); cstate (B, H) updated in place."""
+    _dev(h_prev)
+    b, h = cstate.shape
+    for t in (h_prev, gates_x, cstate, h_out):
+        assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] == b
+    assert h_prev.shape[1] == h and h_out.shape[1] == h and gates_x.shape[1] == 4 * h
+    ld = lambda t: t.stride(0) if b > 1 else max(t.shape[1], t.stride(0))
+    check(_lib.load().emage_lstm_step(dtype, _ptr(h_prev), ld(h_prev), _ptr(w_hh), float(w_scale),
+                                      float(A_SCALE_F16X3 if a_scale is None else a_scale),
+                                      _ptr(gates_x), ld(gates_x), _ptr(cstate), ld(cstate), _ptr(h_out), ld(h_out),
+                                      b, h, _stream()), "lstm_step")
+
+
+def softmax2_mix(sel, c1, c2, out):
+    """out = softmax(sel[:, :2])[0] * c1 + softmax(sel[:, :2])[1] * c2   (fp32 2-D views)."""
+    _dev(sel)
+    m, c = c1.shape
+    check(_lib.load().emage_softmax2_mix(_ptr(sel), _ld(sel), _ptr(c1), _ld(c1), _ptr(c2), _ld(c2), _ptr(out), _ld(out), m, c, _stream()),
+          "softmax2_mix")
+    return out
+
+
+def lstm_inputs(out, speaker_table, speaker_id, seed_motion, pose_dims, seed_frames, src_map, b, t):
+    """Fill `out` (B*T, n_store) = a column block of the LSTM input rows with [speaker | seed | is-seed | 0...]."""
+    _dev(out)
+    f = 0 if speaker_table is None else speaker_table.shape[1]
+    ld_seed = 0
+    if seed_motion is not None:
+        assert seed_motion.dtype == torch.float32 and seed_motion.dim() == 3 and seed_motion.shape[2] == pose_dims
+        assert seed_motion.stride(2) == 1 and seed_motion.stride(1) == pose_dims
+        ld_seed = seed_motion.stride(0) if b > 1 else seed_motion.shape[1] * pose_dims
+    assert src_map.dtype == torch.int32 and src_map.numel() == t
+    check(_lib.load().emage_lstm_inputs(_ptr(speaker_table), _ptr(speaker_id), f, _ptr(seed_motion), ld_seed, pose_dims, seed_frames,
+                                        _ptr(src_map), _ptr(out), _ld(out), out.shape[1], b, t, _stream()), "lstm_inputs")
+    return out
+
+
+def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
+    """rot6d2d (M, n_sel*6) fp32 view -> (M, n_joints*3) axis-angle, joint j from slot slot_of_joint[j] (or zeros)."""
+    _dev(rot6d2d)
+    m = rot6d2d.shape[0]
+    out = torch.empty(m, n_joints * 3, dtype=torch.float32, device=rot6d2d.device)
+    check(_lib.load().emage_rot6d_scatter(_ptr(rot6d2d), _ld(rot6d2d), _ptr(slot_of_joint), _ptr(out), m, n_joints, _stream()), "rot6d_scatter")
+    return out

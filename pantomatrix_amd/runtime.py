@@ -96,102 +96,46 @@ class ClipRunner:
         return tuple(h.numpy() for h in self.host)
 
 
-class PipelinedRunner:
-    """`depth` independent ClipRunners (own graph, own static buffers), used round-robin on `depth` streams:
-    batch i+1 is launched while batch i is still executing, so the tail of one batch (one small kernel at a time
-    in the 8-layer cross-attention stack) overlaps the head of the next.  `submit()` enqueues a batch and returns
-    the results of the batch submitted `depth` calls earlier (None while the pipe fills); `drain()` returns the rest.
-    Results are numpy views of pinned buffers that stay valid until that slot is reused."""
+class LstmClipRunner:
+    """One DisCo / CaMN forward (WavEncoder, input projections, thousands of `emage_lstm_step` launches, output MLPs,
+    rot-6D -> axis-angle) captured as ONE hipGraph for a fixed (batch, audio length): the recurrence is one small launch
+    per time step and direction, so replaying a graph instead of issuing ~10 us Python calls per launch is what makes the
+    sequential part run at device speed.  `__call__(audio)` returns (motion (B,T,pose_dims), axis_angle (B,T,165)) as
+    numpy arrays (views of pinned buffers, valid until the next call)."""
 
-    def __init__(self, model, vq_model, batch: int, n_samples: int, depth: int = 2, use_graph: bool = True):
-        self.runners = [ClipRunner(model, vq_model, batch, n_samples, use_graph=use_graph) for _ in range(depth)]
-        self.streams = [torch.cuda.Stream(device=model.device) for _ in range(depth)]
-        self.pending = [None] * depth
-        self.i = 0
-        self.frames_out = self.runners[0].frames_out
-
-    def _collect(self, slot):
-        if self.pending[slot] is None:
-            return None
-        self.pending[slot].synchronize()
-        self.pending[slot] = None
-        return tuple(h.numpy() for h in self.runners[slot].host)
-
-    def submit(self, audio, speaker_id=None):
-        slot = self.i % len(self.runners)
-        self.i += 1
-        done = self._collect(slot)
-        r, s = self.runners[slot], self.streams[slot]
-        s.wait_stream(torch.cuda.current_stream(r.device))
-        with torch.cuda.stream(s):
-            r.run_device(audio, speaker_id)
-            r._to_host(r.host)
-            ev = torch.cuda.Event()
-            ev.record(s)
-        self.pending[slot] = ev
-        return done
-
-    def drain(self):
-        out = []
-        for k in range(len(self.runners)):
-            slot = (self.i + k) % len(self.runners)
-            d = self._collect(slot)
-            if d is not None:
-                out.append(d)
-        return out
-
-
-class TwinBatchRunner:
-    """Two whole batches per graph replay, each on its own stream lane INSIDE one captured graph (the launch chains
-    of the two batches are independent, so the graph has two parallel branches; the per-batch stream lanes are
-    switched off while capturing — nested fork/join capture crashes the ROCm 7.2 graph instantiation).
-    `__call__(audio)` takes (2*batch, L) audio and returns host arrays for 2*batch clips."""
-
-    def __init__(self, model, vq_model, batch: int, n_samples: int, warmup: int = 2):
-        from .streams import Fork
-        self.model, self.vq, self.batch = model, vq_model, batch
+    def __init__(self, model, batch: int, n_samples: int, use_graph: bool = True, warmup: int = 1):
         dev = model.device
-        self.device = dev
-        self.audio = torch.zeros(2 * batch, n_samples, dtype=torch.float32, device=dev)
-        self.speaker_id = torch.zeros(2 * batch, 1, dtype=torch.long, device=dev)
-        self.ref_trans = torch.zeros(1, 3, device=dev)
-        parts = [model, vq_model.vq_model_face, vq_model.vq_model_upper, vq_model.vq_model_hands, vq_model.vq_model_lower,
-                 vq_model.global_motion]
-        saved = [p.concurrent for p in parts]
-        for p in parts:
-            p.concurrent = False
-
-        def clips(a, s):
-            codes = model.infer_codes(a, s, vq_model)
-            pred = vq_model.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
-            return pred["motion_axis_angle"], pred["expression"], pred["trans"]
-
-        def step():
-            outs = [None, None]
-            with Fork(dev, 2) as fk:
-                for i in range(2):
-                    with fk.lane(i):
-                        outs[i] = clips(self.audio[i * batch:(i + 1) * batch], self.speaker_id[i * batch:(i + 1) * batch])
-            return tuple(torch.cat([outs[0][k], outs[1][k]], dim=0) for k in range(3))
-
-        try:
-            for _ in range(max(1, warmup)):
-                out = step()
-            torch.cuda.synchronize(dev)
+        if dev.type != "cuda":
+            raise RuntimeError("LstmClipRunner needs the model on an MI355X device")
+        self.model, self.device = model, dev
+        self.audio = torch.zeros(batch, n_samples, dtype=torch.float32, device=dev)
+        self.speaker_id = torch.zeros(batch, 1, dtype=torch.long, device=dev)
+        self.graph = None
+        for _ in range(max(1, warmup)):
+            out = self._step()
+        torch.cuda.synchronize(dev)
+        if use_graph:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (an RCCL watchdog) may touch the runtime meanwhile
-                out = step()
-        finally:
-            for p, c in zip(parts, saved):
-                p.concurrent = c
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                out = self._step()
         self.out = out
         self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)
         self.frames_out = int(out[0].shape[1])
 
-    def __call__(self, audio=None):
+    def _step(self):
+        o = self.model.forward(self.audio, self.speaker_id)
+        b = self.audio.shape[0]
+        return o["motion"].reshape(b, o["motion"].shape[1], -1), o["motion_axis_angle"]
+
+    def __call__(self, audio=None, speaker_id=None):
         if audio is not None:
             self.audio.copy_(audio, non_blocking=True)
-        self.graph.replay()
+        if speaker_id is not None:
+            self.speaker_id.copy_(speaker_id, non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.out = self._step()
         for h, d in zip(self.host, self.out):
             h.copy_(d, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()

@@ -205,3 +205,72 @@ def default_vq_cfg_dict(part: str, vae_layer: int = 2):
 
 def default_global_cfg_dict(vae_layer: int = 4, vae_length: int = 240):
     return dict(vae_layer=vae_layer, vae_length=vae_length, vae_test_dim=61)
+
+
+# ======================================================================================
+# DisCo / CaMN: checkpoint layouts of
+#   DiscoAudioModel   /root/reference/models/disco_audio/modeling_disco_audio.py:171-197   (D:)
+#   CamnAudioModel    /root/reference/models/camn_audio/modeling_camn_audio.py:180-221     (C:)
+# ======================================================================================
+def lstm_wav_encoder_blocks():
+    """WavEncoder of DisCo / CaMN (D:133-142): widths 32,32,32,64,64,128, strides 5,6,1,6,1,6 (15 fps features)."""
+    return [(1, 32, 5, 1600, True), (32, 32, 6, 0, True), (32, 32, 1, 7, False), (32, 64, 6, 0, True),
+            (64, 64, 1, 7, False), (64, 128, 6, 0, True)]
+
+
+LSTM_MODEL_DEFAULTS = dict(pose_dims=258, body_dims=78, hands_dims=180, audio_f=128, speaker_f=16, speaker_dims=1,
+                           hidden_size=512, n_layer=4, dropout_prob=0.1, seed_frames=4, joint_mask="local_upper",
+                           pose_rep="smplx", pose_fps=15, motion_f=256)      # configs/disco_audio.yaml, configs/camn_audio.yaml
+
+# MASK_DICT["local_upper"] (D:19-27): the 13 upper-body joints and the 30 hand joints, in joint order
+LOCAL_UPPER_JOINTS = [j for j in range(55) if j in (3, 6, 9, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21) or j >= 25]
+
+
+def _lstm_wav_encoder(spec, name):
+    for i, (cin, cout, _stride, _pad, ds) in enumerate(lstm_wav_encoder_blocks()):
+        b = f"{name}.feat_extractor.{i}"
+        _conv(spec, b + ".conv1", cout, cin, WAV_KERNEL)
+        _bn(spec, b + ".bn1", cout)
+        _conv(spec, b + ".conv2", cout, cout, WAV_KERNEL)
+        _bn(spec, b + ".bn2", cout)
+        if ds:
+            _conv(spec, b + ".downsample.0", cout, cin, WAV_KERNEL)
+            _bn(spec, b + ".downsample.1", cout)
+
+
+def _lstm(spec, name, cin, hid, n_layers):
+    """torch.nn.LSTM(bidirectional=True) parameter names; gate order in the packed rows: input, forget, cell, output."""
+    for k in range(n_layers):
+        for suffix in ("", "_reverse"):
+            spec[f"{name}.weight_ih_l{k}{suffix}"] = ((4 * hid, cin if k == 0 else 2 * hid), "linear_w")
+            spec[f"{name}.weight_hh_l{k}{suffix}"] = ((4 * hid, hid), "linear_w")
+            spec[f"{name}.bias_ih_l{k}{suffix}"] = ((4 * hid,), "bias")
+            spec[f"{name}.bias_hh_l{k}{suffix}"] = ((4 * hid,), "bias")
+
+
+def disco_model_spec(cfg) -> Dict:
+    spec = OrderedDict()
+    af, hid, pd = cfg.audio_f, cfg.hidden_size, cfg.pose_dims
+    _lstm_wav_encoder(spec, "audio_encoder")
+    if cfg.speaker_f > 0:
+        spec["speaker_embedding.weight"] = ((cfg.speaker_dims, cfg.speaker_f), "embedding")
+    for nm in ("audio_encoder_c1", "audio_encoder_c2", "audio_encoder_r"):
+        _mlp(spec, nm, af, hid, af)
+    _mlp(spec, "selector", af, hid, 2)
+    _lstm(spec, "body_motion_decoder", pd + 1 + cfg.speaker_f + 2 * af, hid, cfg.n_layer)
+    _mlp(spec, "body_out", hid, hid, pd)
+    return spec
+
+
+def camn_model_spec(cfg) -> Dict:
+    spec = OrderedDict()
+    af, hid, pd = cfg.audio_f, cfg.hidden_size, cfg.pose_dims
+    _lstm_wav_encoder(spec, "audio_encoder")
+    if cfg.speaker_f > 0:
+        spec["speaker_embedding.weight"] = ((cfg.speaker_dims, cfg.speaker_f), "embedding")
+    cin = pd + 1 + cfg.speaker_f + af
+    _lstm(spec, "body_motion_decoder", cin, hid, cfg.n_layer)
+    _mlp(spec, "body_out", hid, hid, cfg.body_dims)
+    _lstm(spec, "hands_motion_decoder", cin + cfg.body_dims, hid, cfg.n_layer)
+    _mlp(spec, "hands_out", hid, hid, cfg.hands_dims)
+    return spec

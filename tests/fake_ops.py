@@ -246,7 +246,56 @@ def axis_angle_to_rot6d(x):
     return orc.axis_angle_to_rotation_6d(x)
 
 
-_NAMES = ["gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+def lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, *, w_scale=1.0, a_scale=None):
+    """emage_lstm_step: gate columns interleaved per hidden unit (4u + g, g = i, f, g, o)."""
+    CALLS.append("lstm_step")
+    b, hid = cstate.shape
+    assert h_prev.stride(1) == 1 and gates_x.stride(1) == 1 and h_out.stride(1) == 1 and gates_x.shape == (b, 4 * hid)
+    pre = torch.empty(b, 4 * hid)
+    gemm(dtype, h_prev.contiguous(), w_hh, None, None, gates_x.contiguous(), None, pre, None, n=4 * hid, cp=hid, w_scale=w_scale, a_scale=a_scale)
+    i, f, g, o = pre.view(b, hid, 4).unbind(dim=2)
+    c_new = torch.sigmoid(f) * cstate + torch.sigmoid(i) * torch.tanh(g)
+    cstate.copy_(c_new)
+    h_out.copy_(torch.sigmoid(o) * torch.tanh(c_new))
+
+
+def softmax2_mix(sel, c1, c2, out):
+    CALLS.append("softmax2_mix")
+    w = torch.softmax(sel[:, :2], dim=1)
+    out.copy_(w[:, 0:1] * c1 + w[:, 1:2] * c2)
+    return out
+
+
+def lstm_inputs(out, speaker_table, speaker_id, seed_motion, pose_dims, seed_frames, src_map, b, t):
+    CALLS.append("lstm_inputs")
+    f = 0 if speaker_table is None else speaker_table.shape[1]
+    n_store = out.shape[1]
+    assert n_store >= f + pose_dims + 1 and src_map.dtype == torch.int32 and src_map.numel() == t
+    rows = torch.zeros(b, t, n_store)
+    if f:
+        rows[:, :, :f] = speaker_table[speaker_id.reshape(-1)].view(b, 1, f)
+    t_m = t if seed_motion is None else seed_motion.shape[1]
+    padded = torch.zeros(b, max(t_m, int(src_map.max()) + 1), pose_dims + 1)       # the reference's seed tensor (D:229-232)
+    if seed_motion is not None:
+        padded[:, :seed_frames, :pose_dims] = seed_motion[:, :seed_frames]
+    padded[:, :seed_frames, pose_dims] = 1
+    rows[:, :, f:f + pose_dims + 1] = padded[:, src_map.long()]
+    out.copy_(rows.view(b * t, n_store))
+    return out
+
+
+def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
+    CALLS.append("rot6d_scatter")
+    from oracle import emage_oracle as orc
+    m = rot6d2d.shape[0]
+    out = torch.zeros(m, n_joints, 3)
+    sel = (slot_of_joint >= 0).nonzero().reshape(-1)
+    d6 = rot6d2d[:, :].reshape(m, -1, 6)[:, slot_of_joint[sel].long()]
+    out[:, sel] = orc.rotation_6d_to_axis_angle(d6)
+    return out.reshape(m, n_joints * 3)
+
+
+_NAMES = ["lstm_step", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

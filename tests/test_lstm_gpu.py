@@ -1,0 +1,128 @@
+"""DisCo / CaMN on the MI355X (BASELINE configs[3] / [4]): the LSTM-specific kernels against their CPU
+restatements, both models against the REFERENCE's golden outputs (tests/golden/lstm_models.npz, generated from the real
+modules by tests/golden/make_golden_lstm.py) and the oracle, and size-independent properties at the BASELINE batch sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fake_ops as F
+from oracle import lstm_models_oracle as lo
+from pantomatrix_amd import ops
+from pantomatrix_amd._lib import F32, F16X3
+from test_lstm_host_logic import product
+from test_lstm_models_oracle import CFG, inputs, weights, run_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("dtype", [F32, F16X3], ids=["fp32", "f16x3"])
+@pytest.mark.parametrize("b", [2, 130, 256])
+def test_lstm_step_kernel(dtype, b):
+    """Two consecutive steps of one direction as strided views of (B, T, .) tensors, against the CPU restatement."""
+    g = torch.Generator().manual_seed(b)
+    hid, t = 512, 3
+    w = torch.randn(4 * hid, hid, generator=g) / hid ** 0.5
+    wp, ws = (ops.split_f16_weights(w) if dtype == F16X3 else (w, 1.0))
+    gx = torch.randn(b, t, 8 * hid, generator=g)
+    c0 = 0.5 * torch.randn(b, hid, generator=g)
+    h0 = torch.tanh(torch.randn(b, hid, generator=g))
+
+    def run(mod, dev):
+        gxd, c, hseq, h_init = gx.to(dev), c0.clone().to(dev), torch.zeros(b, t, 2 * hid, device=dev), h0.to(dev)
+        prev = h_init
+        for s in (1, 2):                                                # direction 1 of the layout: columns [H, 2H), gates [4H, 8H)
+            cur = hseq[:, s, hid:]
+            mod.lstm_step(dtype, prev, wp.to(dev), gxd[:, s, 4 * hid:], c, cur, w_scale=ws)
+            prev = cur
+        return hseq.cpu(), c.cpu()
+
+    got_h, got_c = run(ops, DEV)
+    ref_h, ref_c = run(F, "cpu")
+    assert float((got_h - ref_h).abs().max()) < 2e-5 and float((got_c - ref_c).abs().max()) < 2e-5
+    assert float(got_h[:, 0].abs().max()) == 0.0 and float(got_h[:, :, :hid].abs().max()) == 0.0      # nothing written elsewhere
+
+
+def test_small_lstm_kernels():
+    g = torch.Generator().manual_seed(4)
+    m = 300
+    sel, c1, c2 = torch.randn(m, 2, generator=g) * 3, torch.randn(m, 128, generator=g), torch.randn(m, 128, generator=g)
+    buf = torch.zeros(m, 576)
+    F.softmax2_mix(sel, c1, c2, buf[:, :128])
+    dbuf = torch.zeros(m, 576, device=DEV)
+    ops.softmax2_mix(sel.to(DEV), c1.to(DEV), c2.to(DEV), dbuf[:, :128])
+    assert float((dbuf.cpu() - buf).abs().max()) < 2e-6
+    # input tail: speaker | seed | flag | zeros, written into a column block of the LSTM input rows
+    b, t, pd = 3, 20, 258
+    table, sid = torch.randn(4, 16, generator=g), torch.tensor([2, 0, 3])
+    seed = torch.randn(b, 11, pd, generator=g)
+    src = torch.tensor(list(range(11)) + list(range(2, 11)), dtype=torch.int32)       # the shorter-seed map of D:238-242
+    for sm in (seed, None):
+        ref = torch.full((b * t, 576), 7.0)
+        F.lstm_inputs(ref[:, 256:], table, sid, sm, pd, 4, src, b, t)
+        got = torch.full((b * t, 576), 7.0, device=DEV)
+        ops.lstm_inputs(got[:, 256:], table.to(DEV), sid.to(DEV), None if sm is None else sm.to(DEV), pd, 4, src.to(DEV), b, t)
+        assert torch.equal(got.cpu(), ref)
+    # rot-6D -> axis-angle scattered to the 55 joints
+    from pantomatrix_amd import spec
+    slot = torch.full((55,), -1, dtype=torch.int32)
+    for i, j in enumerate(spec.LOCAL_UPPER_JOINTS):
+        slot[j] = i
+    r6 = torch.randn(m, 258, generator=g)
+    got = ops.rot6d_scatter(r6.to(DEV), slot.to(DEV)).cpu()
+    ref = F.rot6d_scatter(r6, slot)
+    assert float((got - ref).abs().max()) < 1e-3 and float(got.view(m, 55, 3)[:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("kind", ["disco", "camn"])
+def test_models_match_reference_golden(golden_dir, kind, precision):
+    g = np.load(os.path.join(golden_dir, "lstm_models.npz"))
+    model = product(kind, precision, DEV)
+    for tag, wsm in (("plain", False), ("seeded", True)):
+        audio, spk, motion = inputs(with_seed_motion=wsm)
+        out = model(audio.to(DEV), spk.to(DEV), seed_frames=CFG["seed_frames"], seed_motion=None if motion is None else motion.to(DEV))
+        err_m = float(np.abs(out["motion"].reshape(2, -1, 258).cpu().numpy() - g[f"{kind}_{tag}_motion"]).max())
+        err_a = float(np.abs(out["motion_axis_angle"].cpu().numpy() - g[f"{kind}_{tag}_axis_angle"]).max())
+        print(f"{kind} {precision} {tag}: rot-6D max|err| {err_m:.2e}, axis-angle max|err| {err_a:.2e} vs the reference")
+        assert err_m < 2e-4 and err_a < 1e-3          # north_star: 1e-3 on rotation parameters
+        if kind == "disco":
+            ref = run_oracle(kind, weights(kind), audio, spk, motion)
+            for k in ("audio_fea_c", "audio_fea_r"):
+                assert float((out[k].cpu() - ref[k]).abs().max()) < 1e-4, k
+
+
+@pytest.mark.parametrize("kind,batch,seconds", [("disco", 128, 4.3), ("camn", 256, 28.0)])
+def test_baseline_batch_properties(kind, batch, seconds):
+    """BASELINE configs[3] (DisCo, batch 128) and configs[4] (CaMN, batch 256 long clips): finite, deterministic, and each
+    clip independent of its batch-mates (clips 0-1 against the same clips run as a batch of 2 and against the oracle)."""
+    from pantomatrix_amd import synthetic
+    model = product(kind, "f16x3", DEV)
+    n = int(seconds * 16000)
+    audio = synthetic.synthetic_audio(batch, n, seed=77)
+    spk = torch.zeros(batch, 1, dtype=torch.long)
+    out = model(audio.to(DEV), spk.to(DEV))["motion"].reshape(batch, -1, 258).cpu()
+    again = model(audio.to(DEV), spk.to(DEV))["motion"].reshape(batch, -1, 258).cpu()
+    small = model(audio[:2].to(DEV), spk[:2].to(DEV))["motion"].reshape(2, -1, 258).cpu()
+    t = out.shape[1]
+    assert t == int(seconds * 15) or abs(t - seconds * 15) <= 1
+    assert torch.isfinite(out).all() and torch.equal(out, again)
+    assert float((out[:2] - small).abs().max()) < 1e-4
+    ref = run_oracle(kind, weights(kind), audio[:2], spk[:2], None)["motion"].reshape(2, -1, 258)
+    err = float((out[:2] - ref).abs().max())
+    print(f"{kind} B={batch} T={t}: clips 0-1 vs the CPU oracle max|err| {err:.2e}")
+    assert err < 5e-4
+
+
+def test_graph_runner_matches_eager():
+    from pantomatrix_amd.runtime import LstmClipRunner
+    model = product("camn", "f16x3", DEV)
+    audio, spk, _ = inputs(bs=4, frames=40)
+    eager = model(audio.to(DEV), spk.to(DEV))
+    runner = LstmClipRunner(model, 4, audio.shape[1])
+    for _ in range(2):
+        motion, aa = runner(audio.to(DEV))
+        assert np.array_equal(motion, eager["motion"].reshape(4, -1, 258).cpu().numpy())
+        assert np.array_equal(aa, eager["motion_axis_angle"].cpu().numpy())
