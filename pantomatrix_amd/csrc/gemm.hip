@@ -275,6 +275,11 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
     if (!out && !out_f32 && !out_t) return EMAGE_EINVAL;
     if (out_t && (t_rows <= 0 || M % t_rows != 0 || t_ld < t_rows || t_col0 < 0 || t_col0 > N)) return EMAGE_EINVAL;
     if (dtype == EMAGE_F16X3 && !(a_scale > 0.f && w_scale > 0.f)) return EMAGE_EINVAL;
+    {   // operands are addressed through 32-bit buffer offsets: each must span less than 2 GiB (the host splits larger batches)
+        const long es = dtype == EMAGE_BF16 ? 2 : 4;
+        const long a_span = ((((long)(M / Lout)) * Lin - 1) * lda + Cp + (long)pad * lda) * es;
+        if (a_span >= (1L << 31) || (long)N * taps * Cp * es >= (1L << 31)) return EMAGE_EINVAL;
+    }
     GemmArgs a;
     a.A = A; a.W = W; a.bias = bias; a.slope = slope; a.res = res; a.out = out; a.out_f32 = out_f32; a.out_t = out_t;
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.ldf = ldf; a.res_is_f32 = res_is_f32; a.res_first = res_first; a.n_store = out ? n_store : 0;

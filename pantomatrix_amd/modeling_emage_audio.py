@@ -548,6 +548,13 @@ class _WavEncoderMixin:
     def _wav_blocks(self):
         raise NotImplementedError
 
+    def _wav_clip_chunk(self, cx, n_seq, lens):
+        """Sequences per launch so that the largest intermediate (block 0's (seq * L0, n_enc*2q) output) stays below the
+        2 GiB a kernel operand may span (32-bit buffer offsets, include/emage_hip.h: emage_gemm)."""
+        es = 2 if cx.tdt == torch.bfloat16 else 4
+        per_seq = lens[0] * cx.pk.w["wav_in"]["w"].shape[0] * es
+        return max(1, min(n_seq, ((1 << 31) - (1 << 20)) // per_seq))
+
     def _pack_wav_encoders(self, pk, encoders):
         w0, b0, s0 = [], [], []
         for enc in encoders:

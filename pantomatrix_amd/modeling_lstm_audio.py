@@ -77,10 +77,19 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         pk.w["slot_of_joint"] = slot.to(pk.device)
 
     # ---- building blocks ---------------------------------------------------------------
-    def _audio_feat(self, cx, audio, b):
+    def _audio_feat(self, cx, audio, b, dest=None):
+        """WavEncoder of all clips -> (B*T, audio_f) fp32, written into `dest` (a 2-D view) when given.  Long clips at
+        large batch (CaMN: 256 x 28 s) exceed what one launch's operand may span: the clips are encoded in groups."""
         lens = self._wav_lengths(audio.shape[1])
-        y0 = self._wav_first_layer(cx, audio, lens)
-        return self._wav_encoder_chain(cx, "audio_encoder", 0, y0, b, lens), lens[-1]      # (B*T, audio_f) fp32
+        t = lens[-1]
+        if dest is None:
+            dest = torch.empty(b * t, self.config.audio_f, dtype=torch.float32, device=cx.dev)
+        step = self._wav_clip_chunk(cx, b, lens)
+        for c0 in range(0, b, step):
+            n = min(step, b - c0)
+            y0 = self._wav_first_layer(cx, audio[c0:c0 + n], lens)
+            self._wav_encoder_chain(cx, "audio_encoder", 0, y0, n, lens, dest=dest[c0 * t:(c0 + n) * t])
+        return dest, t
 
     def _seed_src_map(self, t, seed_motion):
         """Which frame of the reference's padded seed tensor each of the T input frames shows (D:229-242 verbatim,
@@ -220,8 +229,7 @@ class CamnAudioModel(_LstmAudioModel):
         # one buffer holds the hands LSTM's input [audio | speaker | seed | flag | body (78) | 0]; the body LSTM reads its first
         # `cin` columns — there its zero-padded weight columns meet the (finite) body block, contributing exactly 0
         wide = torch.zeros(m, _rup(cin + c.body_dims), dtype=torch.float32, device=dev)
-        y0 = self._wav_first_layer(cx, audio, lens)
-        self._wav_encoder_chain(cx, "audio_encoder", 0, y0, b, lens, dest=wide[:, :af])
+        self._audio_feat(cx, audio, b, dest=wide[:, :af])
         self._tail_inputs(cx, wide[:, :_rup(cin)], af, speaker_id, seed_frames, seed_motion, b, t)
         motion = torch.empty(m, c.pose_dims, dtype=torch.float32, device=dev)                          # body joints, then hand joints
         # body_out's last GEMM writes the body block twice: into the hands LSTM's input and into the result

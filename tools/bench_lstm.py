@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Throughput of the DisCo / CaMN inference path at the BASELINE configs[3] / [4] sizes (run on the MI355X):
+  DisCo  batch 128 x 8.5 s clips (128 frames at 15 fps);  CaMN  batch 256 x 28 s clips (~420 frames).
+One step = one hipGraph replay of the whole forward (runtime.LstmClipRunner) + D2H of the motion; prints one JSON line per
+model with motion-frames/s, the share of the recurrence, and the CPU oracle timed on a 2-clip sample beside it."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--models", default="disco,camn")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    from pantomatrix_amd import synthetic
+    from pantomatrix_amd.runtime import LstmClipRunner
+    from test_lstm_host_logic import product
+    from test_lstm_models_oracle import weights, run_oracle
+    dev = "cuda"
+    for kind, batch, seconds in (("disco", 128, 8.5), ("camn", 256, 28.0)):
+        if kind not in args.models.split(","):
+            continue
+        n = int(seconds * 16000)
+        model = product(kind, "f16x3", dev)
+        audio = synthetic.synthetic_audio(batch, n, seed=5).to(dev)
+        t0 = time.time()
+        runner = LstmClipRunner(model, batch, n)
+        t_capture = time.time() - t0
+        runner(audio)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            motion, aa = runner(audio)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        frames = motion.shape[0] * motion.shape[1]
+        line = {"model": kind, "batch": batch, "frames_per_clip": int(motion.shape[1]), "ms_per_step": ms, "value": frames / (ms * 1e-3),
+                "unit": "motion-frames/s (15 fps)", "dtype": "f16x3", "launch": "hipGraph replay", "graph_capture_s": t_capture,
+                "lstm_step_launches": (1 if kind == "disco" else 2) * 4 * 2 * int(motion.shape[1])}
+        if not args.no_cpu:
+            torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+            sd = weights(kind)
+            a2 = audio[:2].cpu()
+            spk = torch.zeros(2, 1, dtype=torch.long)
+            run_oracle(kind, sd, a2[:, :n // 4], spk, None)
+            t0 = time.time()
+            ref = run_oracle(kind, sd, a2, spk, None)
+            dt = time.time() - t0
+            line["cpu_baseline"] = {"value": 2 * ref["motion"].shape[1] / dt, "kind": "port", "cores": torch.get_num_threads(), "sample": "2 clips, one call"}
+            line["max_err_vs_oracle_clip0_1"] = float((torch.from_numpy(motion[:2]) - ref["motion"].reshape(2, -1, 258)).abs().max())
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
