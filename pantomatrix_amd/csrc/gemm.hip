@@ -251,6 +251,17 @@ int dispatch(GemmArgs& a, hipStream_t s) {
     // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_sweep_8wave.txt): with M = 4096 the operand stream, not
     // MFMA, bounds these launches.  Many small resident blocks (64x64, 5 per CU) win on narrow outputs; everywhere else
     // 8-wave blocks (two waves per SIMD hide a block's own DMA / epilogue latency) beat the 4-wave tiles of the same shape
+    if constexpr (X3) {
+        // split-f16 mode (fp32 operand bytes; profiles/r02_gemm_sweep_f16x3.txt): the strided WavEncoder convs with their
+        // stacked shortcut (N >= 128) and the QKV projection prefer 128x128 / 64x192 tiles with a 2-deep ring; 2-deep rings
+        // (<= 64 KiB of LDS, ~100 VGPRs) also let kernels of two stream lanes share a CU
+        if (a.taps >= 15 && a.stride > 1 && a.M > 8192) return run_config<T, X3>(34, a, s);
+        if (a.taps >= 15 && a.M > 8192) return run_config<T, X3>(36, a, s);
+        if (ncols > 64 && t128 >= 512) return run_config<T, X3>(ncols <= 2304 && ncols % 192 == 0 ? 33 : 34, a, s);
+        if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T, X3>(33, a, s);
+        if (a.taps == 1 && ncols == 768 && a.M >= 2048) return run_config<T, X3>(33, a, s);
+        return run_config<T, X3>(25, a, s);
+    }
     if (a.taps >= 15 && a.M > 8192) return run_config<T, X3>(36, a, s);     // WavEncoder convs on long sequences: 128x64, 8 waves
     if (ncols > 64 && t128 >= 512) return run_config<T, X3>(34, a, s);      // wide outputs (QKV, batched K/V projections): 128x128, 8 waves
     if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T, X3>(33, a, s);   // FFN up-projection: exactly 2 blocks per CU

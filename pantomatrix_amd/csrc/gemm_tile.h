@@ -315,7 +315,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                (!p.res || (p.ldr % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
                (!p.bias || ((uintptr_t)p.bias & 15) == 0) && (!p.slope || ((uintptr_t)p.slope & 15) == 0);
     };
-    constexpr bool PRE = FM * FN <= 8 || FPRE;       // up to 8 fragments (unless forced): the prefetch costs 4 VGPRs per fragment
+    constexpr bool PRE = FM * FN <= 4 || FPRE;       // small tiles only (unless forced): the prefetch costs 4 VGPRs per fragment
     constexpr int PM = PRE ? FM : 1, PP = PRE ? FP : 1;
     float pre_b[PP][8], pre_s[PP][8], pre_r[PM][PP][8];
     bool vec = false;
@@ -359,27 +359,33 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     const unsigned b_rd0 = lds0 + BM * RB + brow * RB + ((fg ^ swzW<KC>(brow)) << 4);
     const unsigned a_rd1 = a_rd0 ^ 64u, b_rd1 = b_rd0 ^ 64u;   // lds0 is 128-B aligned, so the xor acts on the slot bit
 
-    // ---- K-loop, software-pipelined through registers: the fragments of tile kt+1 are read from LDS while the MFMAs of
-    // tile kt (already in registers) execute — with one barrier per K-tile every wave of the block would otherwise read
-    // LDS at the same time and then issue MFMAs at the same time, and the two pipes would take turns instead of
-    // overlapping.  A tile's ring slot is free as soon as every wave holds it in registers, i.e. one barrier earlier
-    // than its MFMAs: the ring keeps NS - 1 tiles in flight behind the one being read.
-    constexpr bool TWO = NKG == 2 || X3;              // two 16-byte chunks per lane and row per K-tile
-    struct Frag { u32x4 a0[FM], a1[TWO ? FM : 1], b0[FN], b1[TWO ? FN : 1]; };
-    auto load_frags = [&](Frag& R, const unsigned sbyte) {
-        const unsigned a0 = a_rd0 + sbyte, b0 = b_rd0 + sbyte, a1 = a_rd1 + sbyte, b1 = b_rd1 + sbyte;
-        [&]<int... I>(std::integer_sequence<int, I...>) { ((R.a0[I] = lds_read128_off<I * 16 * RB>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
-        if constexpr (TWO)
-            [&]<int... I>(std::integer_sequence<int, I...>) { ((R.a1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
-        [&]<int... J>(std::integer_sequence<int, J...>) { ((R.b0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
-        if constexpr (TWO)
-            [&]<int... J>(std::integer_sequence<int, J...>) { ((R.b1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
-    };
-    auto mma_frags = [&](const Frag& R) {
+    unsigned sb = 0;                                  // byte offset of the slot being consumed
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed; tiles issued after it (at most NS-2) may stay in flight
+        const int newer = nk - 1 - kt;
+        if (NS >= 4 && newer >= 2) wait_vmcnt<2 * G>();
+        else if (NS >= 3 && newer >= 1) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue();
+        if (p.dbg & 2) continue;
+        u32x4 af0[FM], bf0[FN];
+        const unsigned a0 = a_rd0 + sb, b0 = b_rd0 + sb;
+        [&]<int... I>(std::integer_sequence<int, I...>) { ((af0[I] = lds_read128_off<I * 16 * RB>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
         if constexpr (X3) {
+            // read order: both activation chunks first (they need the VALU split), then the W hi / lo chunks
+            u32x4 af1[FM], bf1[FN];
+            const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
+            wait_lgkmcnt<2 * FN>();                   // both activation chunks are there: split them while the W reads land
+            __builtin_amdgcn_sched_barrier(0);
             f16x8 ah[FM], al[FM];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) split_f16(R.a0[i], R.a1[i], p.a_scale, ah[i], al[i]);
+            for (int i = 0; i < FM; ++i) split_f16(af0[i], af1[i], p.a_scale, ah[i], al[i]);
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
             // three sweeps over the fragments (small terms first), so back-to-back MFMAs never share an accumulator
 #pragma unroll
             for (int t = 0; t < 3; ++t)
@@ -387,55 +393,41 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
-                        acc[i][j] = mma_f16(__builtin_bit_cast(f16x8, t == 0 ? R.b1[j] : R.b0[j]), t == 1 ? al[i] : ah[i], acc[i][j]);
-        } else {
+                        acc[i][j] = mma_f16(__builtin_bit_cast(f16x8, t == 0 ? bf1[j] : bf0[j]), t == 1 ? al[i] : ah[i], acc[i][j]);
+        } else if constexpr (NKG == 2) {
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
+            u32x4 af1[FM], bf1[FN];
+            const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
+            wait_lgkmcnt<FM + FN>();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, R.b0[j]), __builtin_bit_cast(uint4, R.a0[i]), acc[i][j]);
-            if constexpr (TWO) {
+                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, R.b1[j]), __builtin_bit_cast(uint4, R.a1[i]), acc[i][j]);
-            }
-        }
-    };
-    // wait until tile `t` has landed: the tiles issued after it (at most NS - 2 of them) may stay in flight
-    auto wait_tile = [&](const int newer) {
-        if (NS >= 4 && newer >= 2) wait_vmcnt<2 * G>();
-        else if (NS >= 3 && newer >= 1) wait_vmcnt<G>();
-        else wait_vmcnt<0>();
-    };
-    const bool compute = !(p.dbg & 2);
-    Frag R0, R1;
-    unsigned sb = 0;                                  // byte offset of the ring slot of the tile being fetched into registers
-    wait_tile(nk - 1);                                // tile 0 (tiles 1 .. NS-2 stay in flight)
-    __builtin_amdgcn_s_barrier();
-    if (NS - 1 < nk) issue();                         // tile NS-1 into the last free slot
-    if (compute) load_frags(R0, 0u);
-    wait_lgkmcnt<0>();
-    auto step = [&](const int kt, const Frag& cur, Frag& nxt) {
-        const bool more = kt + 1 < nk;
-        if (more) {
-            wait_tile(nk - 2 - kt);                   // tile kt+1 has landed
-            __builtin_amdgcn_s_barrier();             // ... in every wave's view, and every wave holds tile kt in registers
-            if (kt + NS < nk) issue();                // so tile kt's slot takes tile kt+NS
-            sb += STAGE;
-            if (sb == NS * STAGE) sb = 0;
-            if (compute) load_frags(nxt, sb);
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf1[j]), __builtin_bit_cast(uint4, af1[i]), acc[i][j]);
+        } else {
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (compute) mma_frags(cur);                  // issued behind the LDS reads: the two pipes overlap
-        __builtin_amdgcn_sched_barrier(0);
-        wait_lgkmcnt<0>();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, R0, R1);
-        if (kt + 1 < nk) step(kt + 1, R1, R0);
+        sb += STAGE;
+        if (sb == NS * STAGE) sb = 0;
     }
 
     // ---- epilogue.  With the permuted W rows, lane (fr, fg) holds for M fragment i and fragment pair jp the 8

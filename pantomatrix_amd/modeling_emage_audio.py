@@ -43,15 +43,26 @@ def _rup(x, m=64):
 # parameter container with the HuggingFace-style persistence the reference gets from
 # transformers.PreTrainedModel (config.json + model.safetensors / pytorch_model.bin)
 # ======================================================================================
-class _EmageModule:
+class _ParamNode(torch.nn.Module):
+    """A bare node of the module tree: it only holds the parameters / buffers registered under the reference's names."""
+
+
+_BUFFER_ROLES = ("bn_mean", "bn_var", "bn_count", "ppe")       # BatchNorm running statistics, the positional table
+
+
+class _EmageModule(torch.nn.Module):
+    """torch.nn.Module whose parameter tree reproduces the reference module's names (so `state_dict()`,
+    `load_state_dict()`, `named_parameters()`, `.to()`, hooks, wrapping all behave as for the reference classes), and
+    whose forward is a sequence of libemage_hip.so launches over lazily packed copies of those parameters.  The packed
+    copies are dropped whenever the parameters may have changed (`load_state_dict`, `.to()` / `.cuda()` / dtype casts,
+    `set_precision`, or an explicit `invalidate_packed()` after in-place edits)."""
     config_class = None
     _spec_fn = None
 
     def __init__(self, config):
+        super().__init__()
         self.config = config
         self.cfg = config                      # the reference exposes `.cfg` (M:214, test_emage_audio.py:34-42)
-        self.training = False
-        self._device = torch.device("cpu")
         self._dt = BF16
         self._packed = None
         self.concurrent = True                 # issue independent launch chains on side streams (streams.py)
@@ -59,59 +70,59 @@ class _EmageModule:
         self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
         self._templates = {}                   # cached default motion / mask of inference() per (batch, length, device)
         self._spec = type(self)._spec_fn(config)
-        self._params = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
-                                                      prefix=type(self).__name__ + "/")
+        init = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
+                                              prefix=type(self).__name__ + "/")
+        for name, (_shape, role) in self._spec.items():
+            node, parts = self, name.split(".")
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _ParamNode())
+                node = node._modules[part]
+            if role in _BUFFER_ROLES:
+                node.register_buffer(parts[-1], init[name])
+            else:
+                node.register_parameter(parts[-1], torch.nn.Parameter(init[name], requires_grad=init[name].is_floating_point()))
+        self.eval()
 
-    # ---- nn.Module-like surface -------------------------------------------------------
+    # ---- nn.Module surface ------------------------------------------------------------
     @property
     def device(self):
-        return self._device
+        return next(self.parameters()).device
 
-    def state_dict(self):
-        return OrderedDict((k, v) for k, v in self._params.items())
+    def state_dict(self, *args, **kwargs):
+        """The reference's keys in the reference's order (`pantomatrix_amd/spec.py`)."""
+        sd = super().state_dict(*args, **kwargs)
+        if args or kwargs.get("destination") is not None:      # called by a parent module: it owns the destination dict
+            return sd
+        prefix = kwargs.get("prefix", "")
+        ordered = type(sd)((prefix + k, sd[prefix + k]) for k in self._spec if prefix + k in sd)
+        for k, v in sd.items():
+            ordered.setdefault(k, v)
+        if hasattr(sd, "_metadata"):
+            ordered._metadata = sd._metadata
+        return ordered
 
-    def load_state_dict(self, state_dict, strict=True):
-        missing = [k for k in self._spec if k not in state_dict]
-        unexpected = [k for k in state_dict if k not in self._spec]
-        if strict and (missing or unexpected):
-            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing {missing[:5]}, unexpected {unexpected[:5]}")
-        for k, (shape, _role) in self._spec.items():
-            if k in state_dict:
-                v = state_dict[k]
-                if tuple(v.shape) != tuple(shape):
-                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(shape)}")
-                self._params[k] = v.detach().to(device=self._device, dtype=self._params[k].dtype).clone()
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self.invalidate_packed()
+        return out
+
+    def _apply(self, fn, recurse=True):         # .to() / .cuda() / .cpu() / .float() ... all funnel through here
+        out = super()._apply(fn, recurse)
+        self.invalidate_packed()
+        return out
+
+    def invalidate_packed(self):
+        """Drop the packed operand copies; the next forward re-packs from the current parameters."""
         self._packed = None
-        return self
-
-    def parameters(self):
-        return (v for k, v in self._params.items() if self._spec[k][1] not in ("bn_mean", "bn_var", "bn_count", "ppe"))
-
-    def to(self, device):
-        device = torch.device(device)
-        if device.type == "cuda" and device.index is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        if device != self._device:
-            self._params = OrderedDict((k, v.to(device)) for k, v in self._params.items())
-            self._device = device
-            self._packed = None
-        return self
-
-    def cuda(self, index=None):
-        return self.to(torch.device("cuda", torch.cuda.current_device() if index is None else index))
-
-    def eval(self):
-        self.training = False
+        self._templates = {}
         return self
 
     def train(self, mode=True):
         if mode:
             raise NotImplementedError("training through the HIP path is not built yet (SURVEY.md §8f row 1); "
                                       "the accelerated modules run eval-mode inference only")
-        return self.eval()
-
-    def requires_grad_(self, flag=False):
-        return self
+        return super().train(False)
 
     def set_precision(self, precision: str):
         if precision not in _PRECISIONS:
@@ -129,7 +140,7 @@ class _EmageModule:
     def save_pretrained(self, save_directory):
         from safetensors.torch import save_file
         self.config.save_pretrained(save_directory)
-        save_file({k: v.detach().cpu().contiguous() for k, v in self._params.items()},
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
                   os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
 
     @classmethod
@@ -157,13 +168,18 @@ class _EmageModule:
 
     # ---- engine plumbing -------------------------------------------------------------
     def _engine(self):
-        if self._device.type != "cuda":
+        dev = self.device
+        if dev.type != "cuda":
             raise RuntimeError(f"{type(self).__name__} runs only on an MI355X device: call .to('cuda') first "
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests only)")
-        if self._packed is None:
-            self._packed = _Packed(self._params, self._device, self._dt)
+        if self._packed is None or self._packed.device != dev:
+            self._packed = _Packed(self._flat_params(), dev, self._dt)
             self._pack(self._packed)
         return self._packed
+
+    def _flat_params(self):
+        """name -> detached tensor, the view of the parameter tree the packer reads."""
+        return {k: v.detach() for k, v in super().state_dict(keep_vars=True).items()}
 
     def _pack(self, pk):
         raise NotImplementedError
@@ -367,7 +383,6 @@ class EmageVAEConv(_EmageModule):
         rec = _conv_decoder(cx, "decoder", h, t, c.vae_layer, c.vae_length, c.vae_test_dim)
         return {"rec_pose": rec.view(b, t, c.vae_test_dim)}
 
-    __call__ = forward
 
 
 class EmageVQVAEConv(_EmageModule):
@@ -434,14 +449,14 @@ class EmageVQVAEConv(_EmageModule):
         return {"poses_feat": zq.view(b, t, -1), "embedding_loss": loss, "perplexity": perplexity,
                 "rec_pose": rec.view(b, t, -1)}
 
-    __call__ = forward
 
 
 # ======================================================================================
 # EmageVQModel  (M:72-205)
 # ======================================================================================
-class EmageVQModel:
+class EmageVQModel(torch.nn.Module):
     def __init__(self, face_model, upper_model, hands_model, lower_model, global_model):
+        super().__init__()
         # joint partition of the 55 SMPL-X joints, M:75-90 (boolean masks in the reference)
         self.joint_mask_upper = [j in (3, 6, 9, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21) for j in range(55)]
         self.joint_mask_lower = [j in (0, 1, 2, 4, 5, 7, 8, 10, 11) for j in range(55)]
@@ -453,14 +468,6 @@ class EmageVQModel:
 
     def _models(self):
         return (self.vq_model_face, self.vq_model_upper, self.vq_model_hands, self.vq_model_lower, self.global_motion)
-
-    def to(self, device):
-        for m in self._models():
-            m.to(device)
-        return self
-
-    def eval(self):
-        return self
 
     def set_precision(self, precision):
         for m in self._models():
@@ -878,7 +885,6 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                         _, out[f"cls_{p}"] = cx.gemm(hc, f"motion_cls_{p}.fc2", want="f32")
         return {k: (out[k].view(b, t, -1) if out.get(k) is not None else None) for k in OUT_KEYS}
 
-    __call__ = forward
 
     @staticmethod
     def _frames_view(x):
@@ -961,7 +967,7 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
         """Generator over the autoregressive windows of M:343-470; yields (forward outputs, frames to keep).  Windows
         of the clip tensors (audio, motion, mask, code buffers) are passed to the kernels as views."""
         c = self.config
-        dev = self._device
+        dev = self.device
         audio = audio.to(device=dev, dtype=torch.float32)
         if audio.stride(1) != 1:
             audio = audio.contiguous()

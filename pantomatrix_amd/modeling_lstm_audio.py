@@ -154,7 +154,6 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         sid = speaker_id.to(cx.dev).reshape(-1).contiguous()
         ops.lstm_inputs(in_fea[:, col0:], cx.pk.w.get("spk"), sid if c.speaker_f > 0 else None, sm, c.pose_dims, seed_frames, src, b, t)
 
-    __call__ = lambda self, *a, **k: self.forward(*a, **k)
 
 
 class DiscoAudioModel(_LstmAudioModel):

@@ -1,12 +1,28 @@
-"""Tensor-level wrappers over the C ABI: pointer/stride extraction, output allocation, stream selection.
-PyTorch is plumbing here (device memory + the current HIP stream); every kernel is in libemage_hip.so.
-All tensors must live on a ROCm device; nothing here runs on CPU."""
+"""PyTorch-ROCm custom ops over the C ABI ("invoked from Python via PyTorch-ROCm custom ops").
+
+Every entry point of include/emage_hip.h is registered as an operator of the `emage` torch.library namespace
+(`torch.ops.emage.gemm`, `torch.ops.emage.attention`, ...).  Each op has ONE implementation, for the CUDA (= ROCm)
+dispatch key: pointer / stride extraction and a launch into libemage_hip.so on torch's current HIP stream.  There is no
+CPU kernel behind any of them, so dispatching an op on CPU tensors fails in the dispatcher — the path has no fallback.
+The public functions below (what the model classes call) allocate outputs, fill in defaults and call the op.
+PyTorch is plumbing here (device memory, streams, the dispatcher); every kernel is in libemage_hip.so."""
 from __future__ import annotations
 
 import torch
 
 from . import _lib
 from ._lib import F32, BF16, F16X3, check
+
+_LIBRARY = torch.library.Library("emage", "DEF")
+
+
+def _op(name, schema):
+    """Register `emage::name` with `schema`; the decorated function is its CUDA implementation."""
+    def deco(fn):
+        _LIBRARY.define(name + schema)
+        _LIBRARY.impl(name, fn, "CUDA")
+        return getattr(torch.ops.emage, name)
+    return deco
 
 # storage type of activations per precision code; F16X3 is a GEMM-only operand mode over float32 storage
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32}
@@ -70,6 +86,13 @@ def index_view(idx):
     return idx.shape[1], idx.stride(0), idx.stride(1)
 
 
+@_op("vq_argmin", "(Tensor z, Tensor codebook, Tensor(a!) idx) -> ()")
+def _vq_argmin(z, codebook, idx):
+    rows, ld, _ts = index_view(idx)
+    n, d = z.shape
+    check(_lib.load().emage_vq_argmin_f32(_ptr(z), _ld(z), _ptr(codebook), _ptr(idx), rows, ld, n, codebook.shape[0], d, _stream()), "vq_argmin")
+
+
 def vq_argmin(z2d, codebook, out=None):
     """z2d (N,D) fp32, codebook (K,D) fp32 contiguous -> int64 nearest-code indices; `out`: an (N,) tensor or a (B, T)
     view (B*T == N) of a larger code buffer to fill in place."""
@@ -77,10 +100,16 @@ def vq_argmin(z2d, codebook, out=None):
     assert z2d.dtype == torch.float32 and codebook.dtype == torch.float32 and codebook.is_contiguous()
     n, d = z2d.shape
     idx = torch.empty(n, dtype=torch.int64, device=z2d.device) if out is None else out
-    rows, ld, ts = index_view(idx)
-    assert idx.numel() == n and ts == 1
-    check(_lib.load().emage_vq_argmin_f32(_ptr(z2d), _ld(z2d), _ptr(codebook), _ptr(idx), rows, ld, n, codebook.shape[0], d, _stream()), "vq_argmin")
+    assert idx.numel() == n and index_view(idx)[2] == 1
+    _vq_argmin(z2d, codebook, idx)
     return idx
+
+
+@_op("argmax_logsoftmax", "(Tensor logits, Tensor(a!) idx) -> ()")
+def _argmax_logsoftmax(logits, idx):
+    rows, ld, _ts = index_view(idx)
+    n, c = logits.shape
+    check(_lib.load().emage_argmax_logsoftmax_f32(_ptr(logits), _ld(logits), _ptr(idx), rows, ld, n, c, _stream()), "argmax_logsoftmax")
 
 
 def argmax_logsoftmax(logits2d, out=None):
@@ -88,10 +117,17 @@ def argmax_logsoftmax(logits2d, out=None):
     assert logits2d.dtype == torch.float32
     n, c = logits2d.shape
     idx = torch.empty(n, dtype=torch.int64, device=logits2d.device) if out is None else out
-    rows, ld, ts = index_view(idx)
-    assert idx.numel() == n and ts == 1
-    check(_lib.load().emage_argmax_logsoftmax_f32(_ptr(logits2d), _ld(logits2d), _ptr(idx), rows, ld, n, c, _stream()), "argmax_logsoftmax")
+    assert idx.numel() == n and index_view(idx)[2] == 1
+    _argmax_logsoftmax(logits2d, idx)
     return idx
+
+
+@_op("gather_rows", "(Tensor table, Tensor idx, Tensor(a!) out, int dtype) -> ()")
+def _gather_rows(table, idx, out, dtype):
+    rows, ld, ts = index_view(idx)
+    k, d = table.shape
+    n, n_store = out.shape
+    check(_lib.load().emage_gather_rows(_ptr(table), _ptr(idx), rows, ld, ts, _ptr(out), _ld(out), n_store, n, k, d, dtype, _stream()), "gather_rows")
 
 
 def gather_rows(table, idx, dtype, n_store=None):
@@ -101,11 +137,24 @@ def gather_rows(table, idx, dtype, n_store=None):
     n_store = d if n_store is None else n_store
     if idx.dim() > 2 or (idx.dim() == 2 and idx.stride(1) not in (0, 1)) or (idx.dim() == 1 and idx.numel() > 1 and idx.stride(0) != 1):
         idx = idx.reshape(-1).contiguous()
-    rows, ld, ts = index_view(idx)
-    n = idx.numel()
-    out = torch.empty(n, n_store, dtype=TORCH_DTYPE[dtype], device=table.device)
-    check(_lib.load().emage_gather_rows(_ptr(table), _ptr(idx), rows, ld, ts, _ptr(out), n_store, n_store, n, k, d, dtype, _stream()), "gather_rows")
+    out = torch.empty(idx.numel(), n_store, dtype=TORCH_DTYPE[dtype], device=table.device)
+    _gather_rows(table, idx, out, dtype)
     return out
+
+
+@_op("gemm", "(int dtype, Tensor a, Tensor w, Tensor? bias, Tensor? slope, Tensor? res, Tensor(a!)? out, Tensor(b!)? out_f32, "
+             "Tensor(c!)? out_t, int n, int cp, int n_store, int t_col0, int t_rows, bool res_first, int taps, int stride, int pad, "
+             "int lin, int lout, int m, float w_scale, float a_scale) -> ()")
+def _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, res_first, taps, stride, pad, lin, lout, m,
+          w_scale, a_scale):
+    res_f32 = 1 if (res is not None and res.dtype == torch.float32) else 0
+    t_ld = out_t.shape[-1] if out_t is not None else 0
+    check(_lib.load().emage_gemm(dtype, _ptr(a), _ld(a), _ptr(w), _ptr(bias), _ptr(slope),
+                                 _ptr(res), _ld(res) if res is not None else 0, res_f32, 1 if res_first else 0,
+                                 _ptr(out), _ld(out) if out is not None else 0, n_store,
+                                 _ptr(out_f32), _ld(out_f32) if out_f32 is not None else 0,
+                                 _ptr(out_t), t_col0, t_rows, t_ld,
+                                 m, n, cp, taps, stride, pad, lin, lout, a_scale, w_scale, _stream()), "gemm")
 
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
@@ -118,15 +167,16 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin
     lout = m if lout is None else lout
-    res_f32 = 1 if (res is not None and res.dtype == torch.float32) else 0
-    t_ld = out_t.shape[-1] if out_t is not None else 0
-    check(_lib.load().emage_gemm(dtype, _ptr(a), _ld(a), _ptr(w), _ptr(bias), _ptr(slope),
-                                 _ptr(res), _ld(res) if res is not None else 0, res_f32, 1 if res_first else 0,
-                                 _ptr(out), _ld(out) if out is not None else 0, n_store,
-                                 _ptr(out_f32), _ld(out_f32) if out_f32 is not None else 0,
-                                 _ptr(out_t), t_col0, t_rows, t_ld,
-                                 m, n, cp, taps, stride, pad, lin, lout,
-                                 float(A_SCALE_F16X3 if a_scale is None else a_scale), float(w_scale), _stream()), "gemm")
+    _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
+          lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale))
+
+
+@_op("wav_conv_in", "(int dtype, Tensor wav, Tensor w, Tensor? bias, Tensor? slope, Tensor(a!) out, int lout, int stride, int pad, "
+                    "int nwin, int hop, int win_len) -> ()")
+def _wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad, nwin, hop, win_len):
+    c, taps = w.shape
+    check(_lib.load().emage_wav_conv_in(dtype, _ptr(wav), wav.stride(0), win_len, nwin, hop, _ptr(w), _ptr(bias), _ptr(slope), _ptr(out), _ld(out),
+                                        wav.shape[0], lout, c, taps, stride, pad, _stream()), "wav_conv_in")
 
 
 def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad, nwin=1, hop=0, win_len=None):
@@ -137,17 +187,28 @@ def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad, nwin=1, hop=
     b, l = wav.shape
     win_len = l if win_len is None else win_len
     assert (nwin - 1) * hop + win_len <= l
-    c, taps = w.shape
-    check(_lib.load().emage_wav_conv_in(dtype, _ptr(wav), wav.stride(0), win_len, nwin, hop, _ptr(w), _ptr(bias), _ptr(slope), _ptr(out), _ld(out),
-                                        b, lout, c, taps, stride, pad, _stream()), "wav_conv_in")
+    _wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad, nwin, hop, win_len)
+
+
+@_op("attention", "(int dtype, Tensor q, Tensor k, Tensor vt, int vt_rows, Tensor(a!) out, int b, int h, int tq, int tk, int hd) -> ()")
+def _attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
+    check(_lib.load().emage_attention(dtype, _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(vt), vt.shape[-1], vt_rows, _ptr(out), _ld(out),
+                                      b, h, tq, tk, hd, _stream()), "attention")
 
 
 def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
     """q (B*Tq, ldq), k (B*Tk, ldk) 2-D views; vt a view into a (B, vt_rows, ldvt) buffer starting at this
     layer's first row; out (B*Tq, ldo)."""
     _dev(q)
-    check(_lib.load().emage_attention(dtype, _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(vt), vt.shape[-1], vt_rows, _ptr(out), _ld(out),
-                                      b, h, tq, tk, hd, _stream()), "attention")
+    _attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd)
+
+
+@_op("layernorm", "(int dtype, Tensor x, Tensor gamma, Tensor beta, float eps, Tensor? add, Tensor(a!)? y_f32, Tensor(b!)? y) -> ()")
+def _layernorm(dtype, x, gamma, beta, eps, add, y_f32, y):
+    m, c = x.shape
+    ldy = _ld(y_f32) if y_f32 is not None else _ld(y)
+    check(_lib.load().emage_layernorm(dtype, _ptr(x), _ld(x), _ptr(gamma), _ptr(beta), eps, _ptr(add), _ld(add) if add is not None else 0,
+                                      _ptr(y_f32), _ptr(y), ldy, m, c, _stream()), "layernorm")
 
 
 def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
@@ -155,11 +216,17 @@ def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
     _dev(x)
     m, c = x.shape
     assert x.dtype == TORCH_DTYPE[dtype] and (add is None or add.dtype == x.dtype)
-    ldy = _ld(y_f32) if y_f32 is not None else _ld(y)
     if y_f32 is not None and y is not None:
         assert _ld(y) == _ld(y_f32)
-    check(_lib.load().emage_layernorm(dtype, _ptr(x), _ld(x), _ptr(gamma), _ptr(beta), eps, _ptr(add), _ld(add) if add is not None else 0,
-                                      _ptr(y_f32), _ptr(y), ldy, m, c, _stream()), "layernorm")
+    _layernorm(dtype, x, gamma, beta, float(eps), add, y_f32, y)
+
+
+@_op("add", "(int dtype, Tensor a, Tensor b, Tensor? c, Tensor(a!)? out_f32, Tensor(b!)? out, int mod_b, int mod_c, int f32_mask) -> ()")
+def _add(dtype, a, b, c, out_f32, out, mod_b, mod_c, f32_mask):
+    m, n = a.shape
+    ldo = _ld(out_f32) if out_f32 is not None else _ld(out)
+    check(_lib.load().emage_add(dtype, _ptr(a), _ld(a), _ptr(b), _ld(b), mod_b, _ptr(c), _ld(c) if c is not None else 0, mod_c,
+                                f32_mask, _ptr(out_f32), _ptr(out), ldo, m, n, _stream()), "add")
 
 
 def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
@@ -171,11 +238,21 @@ def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
         if t is not None:
             assert t.dtype in (torch.float32, TORCH_DTYPE[dtype])
             mask |= (1 << bit) if t.dtype == torch.float32 else 0
-    ldo = _ld(out_f32) if out_f32 is not None else _ld(out)
     if out_f32 is not None and out is not None:
         assert _ld(out) == _ld(out_f32)
-    check(_lib.load().emage_add(dtype, _ptr(a), _ld(a), _ptr(b), _ld(b), mod_b, _ptr(c), _ld(c) if c is not None else 0, mod_c,
-                                mask, _ptr(out_f32), _ptr(out), ldo, m, n, _stream()), "add")
+    _add(dtype, a, b, c, out_f32, out, mod_b, mod_c, mask)
+
+
+@_op("pack_motion", "(int dtype, Tensor motion, Tensor mask, Tensor emb, Tensor? seed, Tensor(a!) out) -> ()")
+def _pack_motion(dtype, motion, mask, emb, seed, out):
+    b, t, c = motion.shape
+    ldb = motion.stride(0) if b > 1 else t * c
+    pre, ld_seed = 0, 0
+    if seed is not None:
+        pre = seed.shape[1]
+        ld_seed = seed.stride(0) if b > 1 else pre * c
+    check(_lib.load().emage_pack_motion(dtype, _ptr(motion), _ptr(mask), ldb, _ptr(emb), _ptr(seed), ld_seed, pre,
+                                        _ptr(out), _ld(out), out.shape[1], b, t, c, _stream()), "pack_motion")
 
 
 def pack_motion(dtype, motion, mask, emb, n_store, seed=None):
@@ -186,32 +263,44 @@ def pack_motion(dtype, motion, mask, emb, n_store, seed=None):
     b, t, c = motion.shape
     for x in (motion, mask):
         assert x.dtype == torch.float32 and x.shape == (b, t, c) and x.stride(2) == 1 and (x.stride(1) == c or t == 1), (x.shape, x.stride())
-    ldb = motion.stride(0) if b > 1 else t * c
-    assert b == 1 or mask.stride(0) == ldb
-    pre, ld_seed = 0, 0
+    assert b == 1 or mask.stride(0) == motion.stride(0)
     if seed is not None:
         pre = seed.shape[1]
         assert seed.dtype == torch.float32 and seed.shape == (b, pre, c) and seed.stride(2) == 1 and (seed.stride(1) == c or pre == 1)
-        ld_seed = seed.stride(0) if b > 1 else pre * c
     out = torch.empty(b * t, n_store, dtype=TORCH_DTYPE[dtype], device=motion.device)
-    check(_lib.load().emage_pack_motion(dtype, _ptr(motion), _ptr(mask), ldb, _ptr(emb), _ptr(seed), ld_seed, pre,
-                                        _ptr(out), n_store, n_store, b, t, c, _stream()), "pack_motion")
+    _pack_motion(dtype, motion, mask, emb, seed, out)
     return out
+
+
+@_op("cast_pad", "(int dtype, Tensor src, Tensor(a!) out) -> ()")
+def _cast_pad(dtype, src, out):
+    m, c = src.shape
+    check(_lib.load().emage_cast_pad(dtype, _ptr(src), _ld(src), _ptr(out), _ld(out), out.shape[1], m, c, _stream()), "cast_pad")
 
 
 def cast_pad(dtype, src2d, n_store):
     _dev(src2d)
     m, c = src2d.shape
     out = torch.empty(m, n_store, dtype=TORCH_DTYPE[dtype], device=src2d.device)
-    check(_lib.load().emage_cast_pad(dtype, _ptr(src2d), _ld(src2d), _ptr(out), n_store, n_store, m, c, _stream()), "cast_pad")
+    _cast_pad(dtype, src2d, out)
     return out
+
+
+@_op("rot6d_to_axis_angle", "(Tensor rot6d, Tensor(a!) out) -> ()")
+def _rot6d_to_axis_angle(x, out):
+    check(_lib.load().emage_rot6d_to_axis_angle(_ptr(x), _ptr(out), x.numel() // 6, _stream()), "rot6d_to_axis_angle")
+
+
+@_op("axis_angle_to_rot6d", "(Tensor aa, Tensor(a!) out) -> ()")
+def _axis_angle_to_rot6d(x, out):
+    check(_lib.load().emage_axis_angle_to_rot6d(_ptr(x), _ptr(out), x.numel() // 3, _stream()), "axis_angle_to_rot6d")
 
 
 def rot6d_to_axis_angle(rot6d):
     _dev(rot6d)
     x = rot6d.contiguous().float()
     out = torch.empty(x.shape[:-1] + (3,), dtype=torch.float32, device=x.device)
-    check(_lib.load().emage_rot6d_to_axis_angle(_ptr(x), _ptr(out), x.numel() // 6, _stream()), "rot6d_to_axis_angle")
+    _rot6d_to_axis_angle(x, out)
     return out
 
 
@@ -219,8 +308,15 @@ def axis_angle_to_rot6d(aa):
     _dev(aa)
     x = aa.contiguous().float()
     out = torch.empty(x.shape[:-1] + (6,), dtype=torch.float32, device=x.device)
-    check(_lib.load().emage_axis_angle_to_rot6d(_ptr(x), _ptr(out), x.numel() // 3, _stream()), "axis_angle_to_rot6d")
+    _axis_angle_to_rot6d(x, out)
     return out
+
+
+@_op("merge_parts", "(Tensor? face, Tensor? upper, Tensor? hands, Tensor? lower, Tensor(a!) aa, Tensor(b!)? motion, Tensor(c!) expr) -> ()")
+def _merge_parts(face, upper, hands, lower, aa, motion, expr):
+    ld = lambda t: _ld(t) if t is not None else 0
+    check(_lib.load().emage_merge_parts(_ptr(face), ld(face), _ptr(upper), ld(upper), _ptr(hands), ld(hands), _ptr(lower), ld(lower),
+                                        _ptr(aa), _ptr(motion), _ptr(expr), aa.shape[0], _stream()), "merge_parts")
 
 
 def merge_parts(face, upper, hands, lower, m, device, want_motion=True):
@@ -228,23 +324,35 @@ def merge_parts(face, upper, hands, lower, m, device, want_motion=True):
     aa = torch.empty(m, 165, dtype=torch.float32, device=device)
     motion = torch.empty(m, 337, dtype=torch.float32, device=device) if want_motion else None
     expr = torch.empty(m, 100, dtype=torch.float32, device=device)
-    ld = lambda t: _ld(t) if t is not None else 0
-    check(_lib.load().emage_merge_parts(_ptr(face), ld(face), _ptr(upper), ld(upper), _ptr(hands), ld(hands), _ptr(lower), ld(lower),
-                                        _ptr(aa), _ptr(motion), _ptr(expr), m, _stream()), "merge_parts")
+    _merge_parts(face, upper, hands, lower, aa, motion, expr)
     return aa, motion, expr
+
+
+@_op("velocity_to_position", "(Tensor vel, int col0, Tensor init, float dt, Tensor(a!) trans) -> ()")
+def _velocity_to_position(vel, col0, init, dt, trans):
+    b, t, _ = trans.shape
+    ld_init = 0 if init.shape[0] == 1 and b > 1 else init.stride(0)
+    check(_lib.load().emage_velocity_to_position(_ptr(vel), _ld(vel), col0, _ptr(init), ld_init, dt, _ptr(trans), b, t, _stream()), "velocity_to_position")
 
 
 def velocity_to_position(vel2d, col0, init, dt, b, t):
     """init: (B, 3) fp32 view (any clip stride) or (1, 3) = one start position for every clip (clip stride 0)."""
     _dev(vel2d)
     assert init.dtype == torch.float32 and init.dim() == 2 and init.shape[1] == 3 and init.stride(1) == 1 and init.shape[0] in (1, b)
-    ld_init = 0 if init.shape[0] == 1 and b > 1 else init.stride(0)
     trans = torch.empty(b, t, 3, dtype=torch.float32, device=vel2d.device)
-    check(_lib.load().emage_velocity_to_position(_ptr(vel2d), _ld(vel2d), col0, _ptr(init), ld_init, dt, _ptr(trans), b, t, _stream()), "velocity_to_position")
+    _velocity_to_position(vel2d, col0, init, float(dt), trans)
     return trans
 
 
 # ---- DisCo / CaMN (include/emage_hip.h: emage_lstm_step ...) -------------------------------------------------------------
+@_op("lstm_step", "(int dtype, Tensor h_prev, Tensor w_hh, Tensor gates_x, Tensor(a!) cstate, Tensor(b!) h_out, float w_scale, float a_scale) -> ()")
+def _lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, w_scale, a_scale):
+    b, h = cstate.shape
+    ld = lambda t: t.stride(0) if b > 1 else max(t.shape[1], t.stride(0))
+    check(_lib.load().emage_lstm_step(dtype, _ptr(h_prev), ld(h_prev), _ptr(w_hh), w_scale, a_scale,
+                                      _ptr(gates_x), ld(gates_x), _ptr(cstate), ld(cstate), _ptr(h_out), ld(h_out), b, h, _stream()), "lstm_step")
+
+
 def lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, *, w_scale=1.0, a_scale=None):
     """One time step of one LSTM direction for the whole batch.  h_prev (B, H) / gates_x (B, 4H) / h_out (B, H): fp32 row
     views with unit column stride (step t of a (B, T, .) tensor is a strided view); cstate (B, H) updated in place."""
@@ -253,20 +361,33 @@ def lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, *, w_scale=1.0, a_sca
     for t in (h_prev, gates_x, cstate, h_out):
         assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] == b
     assert h_prev.shape[1] == h and h_out.shape[1] == h and gates_x.shape[1] == 4 * h
-    ld = lambda t: t.stride(0) if b > 1 else max(t.shape[1], t.stride(0))
-    check(_lib.load().emage_lstm_step(dtype, _ptr(h_prev), ld(h_prev), _ptr(w_hh), float(w_scale),
-                                      float(A_SCALE_F16X3 if a_scale is None else a_scale),
-                                      _ptr(gates_x), ld(gates_x), _ptr(cstate), ld(cstate), _ptr(h_out), ld(h_out),
-                                      b, h, _stream()), "lstm_step")
+    _lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale))
+
+
+@_op("softmax2_mix", "(Tensor sel, Tensor c1, Tensor c2, Tensor(a!) out) -> ()")
+def _softmax2_mix(sel, c1, c2, out):
+    m, c = c1.shape
+    check(_lib.load().emage_softmax2_mix(_ptr(sel), _ld(sel), _ptr(c1), _ld(c1), _ptr(c2), _ld(c2), _ptr(out), _ld(out), m, c, _stream()),
+          "softmax2_mix")
 
 
 def softmax2_mix(sel, c1, c2, out):
     """out = softmax(sel[:, :2])[0] * c1 + softmax(sel[:, :2])[1] * c2   (fp32 2-D views)."""
     _dev(sel)
     m, c = c1.shape
-    check(_lib.load().emage_softmax2_mix(_ptr(sel), _ld(sel), _ptr(c1), _ld(c1), _ptr(c2), _ld(c2), _ptr(out), _ld(out), m, c, _stream()),
-          "softmax2_mix")
+    _softmax2_mix(sel, c1, c2, out)
     return out
+
+
+@_op("lstm_inputs", "(Tensor(a!) out, Tensor? speaker_table, Tensor? speaker_id, Tensor? seed_motion, int pose_dims, int seed_frames, "
+                    "Tensor src_map, int b, int t) -> ()")
+def _lstm_inputs(out, speaker_table, speaker_id, seed_motion, pose_dims, seed_frames, src_map, b, t):
+    f = 0 if speaker_table is None else speaker_table.shape[1]
+    ld_seed = 0
+    if seed_motion is not None:
+        ld_seed = seed_motion.stride(0) if b > 1 else seed_motion.shape[1] * pose_dims
+    check(_lib.load().emage_lstm_inputs(_ptr(speaker_table), _ptr(speaker_id), f, _ptr(seed_motion), ld_seed, pose_dims, seed_frames,
+                                        _ptr(src_map), _ptr(out), _ld(out), out.shape[1], b, t, _stream()), "lstm_inputs")
 
 
 def lstm_inputs(out, speaker_table, speaker_id, seed_motion, pose_dims, seed_frames, src_map, b, t):
@@ -279,9 +400,14 @@ def lstm_inputs(out, speaker_table, speaker_id, seed_motion, pose_dims, seed_fra
         assert seed_motion.stride(2) == 1 and seed_motion.stride(1) == pose_dims
         ld_seed = seed_motion.stride(0) if b > 1 else seed_motion.shape[1] * pose_dims
     assert src_map.dtype == torch.int32 and src_map.numel() == t
-    check(_lib.load().emage_lstm_inputs(_ptr(speaker_table), _ptr(speaker_id), f, _ptr(seed_motion), ld_seed, pose_dims, seed_frames,
-                                        _ptr(src_map), _ptr(out), _ld(out), out.shape[1], b, t, _stream()), "lstm_inputs")
+    _lstm_inputs(out, speaker_table, speaker_id, seed_motion, pose_dims, seed_frames, src_map, b, t)
     return out
+
+
+@_op("rot6d_scatter", "(Tensor rot6d, Tensor slot_of_joint, Tensor(a!) out) -> ()")
+def _rot6d_scatter(rot6d, slot_of_joint, out):
+    m = rot6d.shape[0]
+    check(_lib.load().emage_rot6d_scatter(_ptr(rot6d), _ld(rot6d), _ptr(slot_of_joint), _ptr(out), m, slot_of_joint.numel(), _stream()), "rot6d_scatter")
 
 
 def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
@@ -289,5 +415,5 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     _dev(rot6d2d)
     m = rot6d2d.shape[0]
     out = torch.empty(m, n_joints * 3, dtype=torch.float32, device=rot6d2d.device)
-    check(_lib.load().emage_rot6d_scatter(_ptr(rot6d2d), _ld(rot6d2d), _ptr(slot_of_joint), _ptr(out), m, n_joints, _stream()), "rot6d_scatter")
+    _rot6d_scatter(rot6d2d, slot_of_joint, out)
     return out

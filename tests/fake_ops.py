@@ -307,7 +307,7 @@ def installed():
 
     def _engine(self):
         if self._packed is None:
-            self._packed = M._Packed(self._params, self._device, self._dt)
+            self._packed = M._Packed(self._flat_params(), self.device, self._dt)
             self._pack(self._packed)
         return self._packed
 

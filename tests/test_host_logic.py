@@ -157,3 +157,45 @@ def test_infer_codes_equals_inference_path(golden_dir):
     assert codes["face_latent"] is None and codes["face_index"].shape == (1, 129)
     np.testing.assert_allclose(pred["motion_axis_angle"].numpy(), g["poses"], atol=1e-3, rtol=0)
     np.testing.assert_allclose(pred["trans"].numpy(), g["trans"], atol=1e-3, rtol=0)
+
+
+def test_models_are_nn_modules_with_reference_parameter_tree():
+    """the accelerated classes are torch.nn.Modules whose parameters / buffers carry the reference's names:
+    named_parameters(), buffers, hooks, state-dict loading errors and device moves behave as for the reference classes;
+    the packed operand copies are rebuilt after anything that may have changed the parameters."""
+    from pantomatrix_amd import spec
+    model, vq = common.product_models(precision="f16x3")
+    assert isinstance(model, torch.nn.Module) and isinstance(vq, torch.nn.Module)
+    names = dict(model.named_parameters())
+    bufs = dict(model.named_buffers())
+    sp = model._spec
+    assert set(names) | set(bufs) == set(sp) and list(model.state_dict()) == list(sp)
+    assert "audio_encoder_face.feat_extractor.0.bn1.running_mean" in bufs and "position_embeddings.pe" in bufs
+    assert "audio_motion_cross_attn.layers.7.multihead_attn.in_proj_weight" in names and "mask_embedding" in names
+    assert all(k.split(".")[0] in ("vq_model_face", "vq_model_upper", "vq_model_hands", "vq_model_lower", "global_motion")
+               for k in vq.state_dict())
+    assert not model.training and sum(p.numel() for p in model.parameters()) > 100_000_000
+    # hooks run (nn.Module.__call__), and the packed copies follow the parameters
+    seen = []
+    h = model.register_forward_hook(lambda m, a, out: seen.append(sorted(out)))
+    audio, spk, motion, mask = common.window_inputs(1)
+    with fake_ops.installed(), torch.no_grad():
+        out1 = model(audio, spk, motion, mask)
+        first_pack = model._packed
+        with torch.no_grad():
+            model.get_parameter("face_out_proj.bias").add_(1.0)
+        model.invalidate_packed()
+        out2 = model(audio, spk, motion, mask)
+        assert model._packed is not first_pack
+    h.remove()
+    assert len(seen) == 2 and seen[0] == sorted(orc.OUT_KEYS)
+    assert float((out2["rec_face"] - out1["rec_face"] - 1.0).abs().max()) < 1e-5      # the edited bias reached the packed copy
+    sd = model.state_dict()
+    model.load_state_dict(sd)
+    assert model._packed is None                                                     # load_state_dict drops the packed copies
+    bad = dict(sd)
+    bad.pop("face_out_proj.bias")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        model.load_state_dict(bad)
+    with pytest.raises(NotImplementedError):
+        model.train()

@@ -107,7 +107,7 @@ def test_baseline_batch_properties(kind, batch, seconds):
     again = model(audio.to(DEV), spk.to(DEV))["motion"].reshape(batch, -1, 258).cpu()
     small = model(audio[:2].to(DEV), spk[:2].to(DEV))["motion"].reshape(2, -1, 258).cpu()
     t = out.shape[1]
-    assert t == int(seconds * 15) or abs(t - seconds * 15) <= 1
+    assert abs(t - seconds * 15) <= 0.02 * seconds * 15 + 1          # the WavEncoder loses a few frames at the borders (28 s -> 415)
     assert torch.isfinite(out).all() and torch.equal(out, again)
     assert float((out[:2] - small).abs().max()) < 1e-4
     ref = run_oracle(kind, weights(kind), audio[:2], spk[:2], None)["motion"].reshape(2, -1, 258)
