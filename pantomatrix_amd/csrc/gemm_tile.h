@@ -500,8 +500,39 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                         if (!p.res_first) x += rv[e];
                         v[e] = x;
                     }
-                    if (out) store8<T>(out + (long)m * p.ldo + n, v);
-                    if (p.out_f32) store8<float>(p.out_f32 + (long)m * p.ldf + n, v);
+                    if (p.dbg & 24) {                 // experiment (emage_set_tuning key 1, bits 8 / 16): write-through (sc1) or
+                        const int aux_sc1 = 16;       // non-temporal result stores instead of plain ones
+                        if (out) {
+                            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)m0 * p.ldo), 0, 0x7fffffff, 0x00020000);
+                            const int vo = (int)(((long)(m - m0) * p.ldo + n) * ES);
+                            if constexpr (EPC == 8) {
+                                uint4 t;
+                                t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                                t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                                t.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+                                t.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                                const u32x4 tv = {t.x, t.y, t.z, t.w};
+                                if (p.dbg & 8) __builtin_amdgcn_raw_buffer_store_b128(tv, ro, vo, 0, aux_sc1);
+                                else __builtin_amdgcn_raw_buffer_store_b128(tv, ro, vo, 0, 2);
+                            } else {
+                                const u32x4 t0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+                                const u32x4 t1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
+                                if (p.dbg & 8) { __builtin_amdgcn_raw_buffer_store_b128(t0, ro, vo, 0, aux_sc1); __builtin_amdgcn_raw_buffer_store_b128(t1, ro, vo + 16, 0, aux_sc1); }
+                                else { __builtin_amdgcn_raw_buffer_store_b128(t0, ro, vo, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(t1, ro, vo + 16, 0, 2); }
+                            }
+                        }
+                        if (p.out_f32) {
+                            const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out_f32 + (long)m0 * p.ldf), 0, 0x7fffffff, 0x00020000);
+                            const int vo = (int)(((long)(m - m0) * p.ldf + n) * 4);
+                            const u32x4 t0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+                            const u32x4 t1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
+                            if (p.dbg & 8) { __builtin_amdgcn_raw_buffer_store_b128(t0, rf, vo, 0, aux_sc1); __builtin_amdgcn_raw_buffer_store_b128(t1, rf, vo + 16, 0, aux_sc1); }
+                            else { __builtin_amdgcn_raw_buffer_store_b128(t0, rf, vo, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(t1, rf, vo + 16, 0, 2); }
+                        }
+                    } else {
+                        if (out) store8<T>(out + (long)m * p.ldo + n, v);
+                        if (p.out_f32) store8<float>(p.out_f32 + (long)m * p.ldf + n, v);
+                    }
                 }
             } else {
 #pragma unroll

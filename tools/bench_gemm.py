@@ -42,10 +42,12 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ablate", action="store_true", help="time each config with DMA / MFMA / epilogue removed (diagnostic)")
     ap.add_argument("--configs", default="")
+    ap.add_argument("--dbg", type=int, default=0, help="emage_set_tuning key 1 mask for the whole sweep (8: sc1 result stores, 16: nt result stores)")
     args = ap.parse_args()
     dt = {"bf16": BF16, "fp32": F32, "f16x3": F16X3}[args.dtype]
     td = ops.TORCH_DTYPE[dt]
     lib = _lib.load()
+    lib.emage_set_tuning(1, args.dbg)
     dev = "cuda"
     global CONFIGS
     if args.configs:
