@@ -308,6 +308,7 @@ def build(precision, device, args):
     from pantomatrix_amd.runtime import ClipRunner
     model, vq = common.product_models(precision=precision, device=device)
     model.hoist_audio = not args.no_hoist
+    model.slab_convs = not args.no_slab_convs
     for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.concurrent = not args.no_concurrent
     n_samples = synthetic.samples_for_frames(args.frames)
@@ -329,6 +330,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
+    ap.add_argument("--no-slab-convs", action="store_true", help="A/B: WavEncoder through emage_wav_conv_in + emage_gemm only (same bits)")
+    ap.add_argument("--gemm-dbg", type=int, default=0, help="experiments: emage_set_tuning key 1 mask (8: sc1 result stores, 16: nt)")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
@@ -353,6 +356,9 @@ def main():
     from pantomatrix_amd import dist as pdist
     from pantomatrix_amd import synthetic
 
+    if args.gemm_dbg:
+        from pantomatrix_amd import _lib
+        _lib.load().emage_set_tuning(1, args.gemm_dbg)
     log(f"rank {rank}/{world}: building the {args.precision} models on {dev} and capturing the clip graph")
     model, vq, runner, n_samples = build(args.precision, dev, args)
     # clip i of the global batch lives on rank i % world; every rank gets `batch` clips (weak scaling)

@@ -131,6 +131,30 @@ int emage_wav_conv_in(int dtype, const float* wav, long ldw, int L, int nwin, lo
                       void* out, int ldo, int B, int Lout, int C, int taps, int stride, int pad, void* stream);
 
 /*
+ * K1, LDS-resident input slab — the stride-1, k <= 16 convolutions with C == N in {64, 128} channels (BasicBlock conv2 of every
+ * WavEncoder block and conv1 of the stride-1 blocks, P:263-306), same arithmetic as emage_gemm with taps = k, stride 1:
+ *   out[s][l][n] = leaky( sum_{tap,c} A[s][l + tap - pad][c] * W[n][tap*C + c] + bias[n] + res[s][l][n], slope[n] )
+ * A block owns 128 positions of one sequence: its 128 + k - 1 input rows are loaded into LDS ONCE (in EMAGE_F16X3 already
+ * split into fp16 hi / lo planes) instead of once per tap, and only the W tiles stream through the LDS-DMA ring.
+ * A: (nseq*L, lda) `dtype` (float32 for EMAGE_F16X3); W / bias / slope / a_scale / w_scale as for emage_gemm (bias and
+ * slope are required); res: (nseq*L, ldr) `dtype` or NULL; out: (nseq*L, ldo) `dtype`.  Bit-identical to emage_gemm.
+ *
+ * emage_wav_block0 — WavEncoder block 0 in ONE launch (P:283-294 with Cin = 1): the slab is conv1 itself,
+ *   y1 = leaky(conv(wav, w1) + b1, slope1), evaluated from the raw waveform into LDS (eval BatchNorm folded by the host,
+ *   windows addressed as in emage_wav_conv_in); conv2 runs on it as above, and the epilogue adds the downsample shortcut
+ *   conv(wav, wds) + bds of its own outputs before the activation.  out: (nwin*nclip*L, ldo), L = block-0 output length.
+ *   Bit-identical to emage_wav_conv_in followed by emage_gemm; the (rows, 2C) first-layer tensor never reaches HBM.
+ */
+int emage_conv_slab(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
+                    const void* res, int ldr, void* out, int ldo,
+                    int nseq, int L, int C, int taps, int pad, float a_scale, float w_scale, void* stream);
+int emage_wav_block0(int dtype, const float* wav, long ldw, int Lw, int nwin, long hop, int nclip,
+                     const float* w1, const float* b1, float slope1, const float* wds, const float* bds,
+                     int taps1, int stride1, int pad1,
+                     const void* W2, const float* bias2, const float* slope2, int taps2, int pad2,
+                     void* out, int ldo, int L, int C, float a_scale, float w_scale, void* stream);
+
+/*
  * K4 — multi-head attention core, softmax(Q K^T / sqrt(hd)) V, no mask (nn.MultiheadAttention inside
  * the 15 decoder layers and 1 encoder layer, M:238-250,261).
  * q:  (B*Tq, ldq) `dtype`, head h at columns [h*hd, (h+1)*hd).

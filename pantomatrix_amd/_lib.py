@@ -22,6 +22,8 @@ SIGNATURES = {
     "emage_gemm": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i,
                    _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p],
     "emage_wav_conv_in": [_i, _p, _l, _i, _i, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "emage_conv_slab": [_i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p],
+    "emage_wav_block0": [_i, _p, _l, _i, _i, _l, _i, _p, _p, _f, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _i, _i, _f, _f, _p],
     "emage_attention": [_i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p],

@@ -68,6 +68,7 @@ class _EmageModule(torch.nn.Module):
         self.concurrent = True                 # issue independent launch chains on side streams (streams.py)
         self.hoist_audio = True                # inference(): waveform-only features of all full windows in one pass
         self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
+        self.slab_convs = True                 # WavEncoder: LDS-resident-slab convolutions + fused block 0 (A/B switch; same bits)
         self._templates = {}                   # cached default motion / mask of inference() per (batch, length, device)
         self._spec = type(self)._spec_fn(config)
         init = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
@@ -603,29 +604,54 @@ class _WavEncoderMixin:
                         nwin=nwin, hop=hop, win_len=win_len)
         return y0
 
-    def _wav_encoder_chain(self, cx, enc, e, y0, b, lens, dest=None):
-        """Blocks 0..5 of one WavEncoder (P:283-314) after the shared first layer.  Returns (B*T', 256); written
-        straight into `dest` (a 2-D view) when its row count matches."""
+    def _wav_block0_fused(self):
+        """Block 0 runs as ONE launch per encoder (`emage_wav_block0`) when its width is one the slab kernel is built for."""
+        blocks = self._wav_blocks()
+        return self.slab_convs and ops.conv_slab_supported(blocks[0][1], _WAV_TAPS, 1)
+
+    def _wav_encoder_chain(self, cx, enc, e, y0, b, lens, dest=None, wav=None, nwin=1, hop=0, win_len=None):
+        """Blocks 0..5 of one WavEncoder (P:283-314).  Block 0 is either the fused launch on the raw waveform (`wav`
+        given) or starts from the shared first-layer tensor `y0`; stride-1 convolutions of 64 / 128 channels run with
+        their input slab resident in LDS (`emage_conv_slab`), the others as implicit GEMMs.  Returns (B*T', C_out);
+        written straight into `dest` (a 2-D view) when its row count matches.  `b` counts sequences (windows x clips)."""
         blocks = self._wav_blocks()
         k, q = _WAV_TAPS, blocks[0][1]
+        w_in = cx.pk.w["wav_in"]
         x, lin = None, None
         for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
             base = f"{enc}.feat_extractor.{i}"
             lout = lens[i]
+            c2 = cx.pk.w[base + ".conv2"]
+            slab2 = self.slab_convs and ops.conv_slab_supported(cout, k, 1)
+            if i == 0 and wav is not None:
+                rows = slice(e * 2 * q, e * 2 * q + q), slice(e * 2 * q + q, (e + 1) * 2 * q)
+                x = cx.lo(b * lout, cout)
+                ops.wav_block0(cx.gdt, wav, w_in["w"][rows[0]], w_in["b"][rows[0]], 0.01, w_in["w"][rows[1]], w_in["b"][rows[1]],
+                               stride, pad, c2["w"], c2["b"], cx.pk.slope(0.01, cout), k, k // 2, x, lout,
+                               nwin=nwin, hop=hop, win_len=win_len, w_scale=c2.get("ws", 1.0))
+                lin = lout
+                continue
             if i == 0:
                 y1, sc = y0[:, e * 2 * q: e * 2 * q + q], y0[:, e * 2 * q + q: (e + 1) * 2 * q]
             else:
                 ent = cx.pk.w[base + ".conv1"]
-                y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout, n_store=_rup(ent["n"]))
+                if self.slab_convs and not ds and ops.conv_slab_supported(cout, k, stride) and cin == cout:
+                    y = cx.lo(b * lout, cout)
+                    ops.conv_slab(cx.gdt, x, ent["w"], ent["b"], ent["slope"], None, y, nseq=b, l=lout, taps=k, pad=pad, w_scale=ent.get("ws", 1.0))
+                else:
+                    y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout, n_store=_rup(ent["n"]))
                 y1, sc = (y[:, :cout], y[:, cout:2 * cout]) if ds else (y[:, :cout], x)
             last = i == len(blocks) - 1
             out = dest if (last and dest is not None and dest.shape[0] == b * lout) else None
-            x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
-                           m=b * lout, out=out, n_store=0 if out is not None else _rup(cout))
-            x = x[:, :cout] if x.shape[1] != cout else x
+            if slab2:
+                x = out if out is not None else cx.lo(b * lout, cout)
+                ops.conv_slab(cx.gdt, y1, c2["w"], c2["b"], cx.pk.slope(0.01, cout), sc, x, nseq=b, l=lout, taps=k, pad=k // 2, w_scale=c2.get("ws", 1.0))
+            else:
+                x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
+                               m=b * lout, out=out, n_store=0 if out is not None else _rup(cout))
+                x = x[:, :cout] if x.shape[1] != cout else x
             lin = lout
         return x
-
 
 
 # ======================================================================================
@@ -751,15 +777,19 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             raise RuntimeError(f"Sizes of tensors must match: audio features {ta} frames vs motion {t} frames")
         m = b * t
         feats = dict(memcat=cx.lo(m, af + mf), bk=None, bvt=None, ta=ta)            # [audio2face | body_hint_face] (M:288)
+        fused0 = self._wav_block0_fused()
+        wkw = dict(wav=audio, nwin=nwin, hop=hop, win_len=win_len) if fused0 else {}
+        y0 = None
+        if not fused0:
+            with fk.lane(lane_face):
+                y0 = self._wav_first_layer(cx, audio, lens, nwin, hop, win_len)
+            fk.after(lane_body, lane_face)
         with fk.lane(lane_face):
-            y0 = self._wav_first_layer(cx, audio, lens, nwin, hop, win_len)
-        fk.after(lane_body, lane_face)
-        with fk.lane(lane_face):
-            a_face = self._wav_encoder_chain(cx, "audio_encoder_face", 0, y0, b, lens, dest=feats["memcat"][:, :af])
+            a_face = self._wav_encoder_chain(cx, "audio_encoder_face", 0, y0, b, lens, dest=feats["memcat"][:, :af], **wkw)
             if ta > t:  # tail windows: face features trimmed to T, body features keep T' = T+1 (M:278-281, sic)
                 feats["memcat"][:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)
         with fk.lane(lane_body):
-            a_body = self._wav_encoder_chain(cx, "audio_encoder_body", 1, y0, b, lens)
+            a_body = self._wav_encoder_chain(cx, "audio_encoder_body", 1, y0, b, lens, **wkw)
             if use_audio:
                 mem_body, _ = cx.gemm(a_body, "audio_body_motion_proj")                 # M:303
                 feats["bk"], feats["bvt"] = self._memory_kv(cx, "cross.kv_all", mem_body, b, ta, nc)

@@ -190,6 +190,49 @@ def wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad, nwin=1, hop=
     _wav_conv_in(dtype, wav, w, bias, slope, out, lout, stride, pad, nwin, hop, win_len)
 
 
+@_op("conv_slab", "(int dtype, Tensor a, Tensor w, Tensor bias, Tensor slope, Tensor? res, Tensor(a!) out, int nseq, int l, int taps, int pad, "
+                  "float w_scale, float a_scale) -> ()")
+def _conv_slab(dtype, a, w, bias, slope, res, out, nseq, l, taps, pad, w_scale, a_scale):
+    c = w.shape[0]
+    check(_lib.load().emage_conv_slab(dtype, _ptr(a), _ld(a), _ptr(w), _ptr(bias), _ptr(slope), _ptr(res), _ld(res) if res is not None else 0,
+                                      _ptr(out), _ld(out), nseq, l, c, taps, pad, a_scale, w_scale, _stream()), "conv_slab")
+
+
+def conv_slab_supported(c, taps, stride):
+    """Shapes the LDS-resident-slab convolution is built for (include/emage_hip.h: emage_conv_slab)."""
+    return stride == 1 and c in (64, 128) and taps <= 16
+
+
+def conv_slab(dtype, a, w, bias, slope, res, out, *, nseq, l, taps, pad, w_scale=1.0, a_scale=None):
+    """Stride-1 Conv1d(C -> C, k = taps) + bias + shortcut + per-channel LeakyReLU with the input slab resident in LDS;
+    a (nseq*l, lda) / res / out row views in the storage type of `dtype`, w the packed (C, taps*C) weights of emage_gemm."""
+    _dev(a)
+    _conv_slab(dtype, a, w, bias, slope, res, out, nseq, l, taps, pad, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale))
+    return out
+
+
+@_op("wav_block0", "(int dtype, Tensor wav, Tensor w1, Tensor b1, float slope1, Tensor wds, Tensor bds, int stride1, int pad1, Tensor w2, Tensor bias2, "
+                   "Tensor slope2, int taps2, int pad2, Tensor(a!) out, int l_out, int nwin, int hop, int win_len, float w_scale, float a_scale) -> ()")
+def _wav_block0(dtype, wav, w1, b1, slope1, wds, bds, stride1, pad1, w2, bias2, slope2, taps2, pad2, out, l_out, nwin, hop, win_len, w_scale, a_scale):
+    c, taps1 = w1.shape
+    check(_lib.load().emage_wav_block0(dtype, _ptr(wav), wav.stride(0), win_len, nwin, hop, wav.shape[0], _ptr(w1), _ptr(b1), slope1, _ptr(wds), _ptr(bds),
+                                       taps1, stride1, pad1, _ptr(w2), _ptr(bias2), _ptr(slope2), taps2, pad2, _ptr(out), _ld(out), l_out, c,
+                                       a_scale, w_scale, _stream()), "wav_block0")
+
+
+def wav_block0(dtype, wav, w1, b1, slope1, wds, bds, stride1, pad1, w2, bias2, slope2, taps2, pad2, out, l_out, *, nwin=1, hop=0, win_len=None,
+               w_scale=1.0, a_scale=None):
+    """WavEncoder block 0 in one launch: conv1 (+ folded BN + LeakyReLU) from the raw waveform into LDS, conv2 on it, the
+    downsample shortcut added in the epilogue (P:283-294).  wav (B, L) fp32 window source as for `wav_conv_in`; w1 / wds
+    (C, taps1) fp32 row views; w2 the packed (C, taps2*C) conv2 weights; out (nwin*B*l_out, ldo) in `dtype`'s storage."""
+    _dev(wav)
+    assert wav.dim() == 2 and wav.stride(1) == 1 and w1.is_contiguous() and wds.is_contiguous()
+    win_len = wav.shape[1] if win_len is None else win_len
+    _wav_block0(dtype, wav, w1, b1, float(slope1), wds, bds, stride1, pad1, w2, bias2, slope2, taps2, pad2, out, l_out, nwin, hop, win_len,
+                float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale))
+    return out
+
+
 @_op("attention", "(int dtype, Tensor q, Tensor k, Tensor vt, int vt_rows, Tensor(a!) out, int b, int h, int tq, int tk, int hd) -> ()")
 def _attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
     check(_lib.load().emage_attention(dtype, _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(vt), vt.shape[-1], vt_rows, _ptr(out), _ld(out),

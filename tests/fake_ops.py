@@ -246,6 +246,34 @@ def axis_angle_to_rot6d(x):
     return orc.axis_angle_to_rotation_6d(x)
 
 
+def conv_slab(dtype, a, w, bias, slope, res, out, *, nseq, l, taps, pad, w_scale=1.0, a_scale=None):
+    """emage_conv_slab == emage_gemm with taps = k, stride 1, the shortcut added before the activation."""
+    c = w.shape[0]
+    assert c in (64, 128) and bias is not None and slope is not None and out.shape == (nseq * l, c)
+    mark = len(CALLS)
+    gemm(dtype, a, w, bias, slope, res, out, None, None, n=c, cp=c, res_first=True, taps=taps, stride=1, pad=pad, lin=l, lout=l, m=nseq * l,
+         w_scale=w_scale, a_scale=a_scale)
+    del CALLS[mark:]
+    CALLS.append("conv_slab")
+    return out
+
+
+def wav_block0(dtype, wav, w1, b1, slope1, wds, bds, stride1, pad1, w2, bias2, slope2, taps2, pad2, out, l_out, *, nwin=1, hop=0, win_len=None,
+               w_scale=1.0, a_scale=None):
+    """emage_wav_block0 == emage_wav_conv_in (conv1 | shortcut, stored in the mode's storage type) + emage_gemm."""
+    mark = len(CALLS)
+    c = w1.shape[0]
+    nseq = nwin * wav.shape[0]
+    y0 = torch.zeros(nseq * l_out, 2 * c, dtype=TD[dtype])
+    wav_conv_in(dtype, wav, torch.cat([w1, wds], 0), torch.cat([b1, bds]), torch.cat([torch.full((c,), float(slope1)), torch.ones(c)]), y0, l_out,
+                stride1, pad1, nwin=nwin, hop=hop, win_len=win_len)
+    gemm(dtype, y0[:, :c], w2, bias2, slope2, y0[:, c:], out, None, None, n=c, cp=c, res_first=True, taps=taps2, stride=1, pad=pad2,
+         lin=l_out, lout=l_out, m=nseq * l_out, w_scale=w_scale, a_scale=a_scale)
+    del CALLS[mark:]
+    CALLS.append("wav_block0")
+    return out
+
+
 def lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, *, w_scale=1.0, a_scale=None):
     """emage_lstm_step: gate columns interleaved per hidden unit (4u + g, g = i, f, g, o)."""
     CALLS.append("lstm_step")
@@ -295,7 +323,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["lstm_step", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["conv_slab", "wav_block0", "lstm_step", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

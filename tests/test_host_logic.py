@@ -60,6 +60,16 @@ def test_forward_window_f16x3_host_logic(golden_dir):
         out1 = model.forward(audio, spk, motion, mask)
     for k in orc.OUT_KEYS:
         np.testing.assert_allclose(out1[k].numpy(), g[k], atol=3e-4, rtol=0)
+    # WavEncoder routing: block 0 of both encoders fused, the 64 / 128-channel stride-1 convs on the LDS-resident slab
+    assert fake_ops.CALLS.count("wav_block0") == 2 and fake_ops.CALLS.count("wav_conv_in") == 0
+    assert fake_ops.CALLS.count("conv_slab") == 2 * 6            # per encoder: conv2 of blocks 1-4 and conv1 of blocks 2, 4
+    model.slab_convs = False
+    with fake_ops.installed(), torch.no_grad():
+        out2 = model.forward(audio, spk, motion, mask)
+    assert fake_ops.CALLS.count("wav_conv_in") == 1 and fake_ops.CALLS.count("conv_slab") == 0
+    model.slab_convs = True
+    for k in orc.OUT_KEYS:
+        assert float((out2[k] - out1[k]).abs().max()) < 1e-5, k
     from pantomatrix_amd import ops
     w = torch.randn(40, 192) * 0.02
     packed, scale = ops.split_f16_weights(w)

@@ -328,3 +328,63 @@ def test_gemm_every_tile_configuration(cfg, dtype):
                 test_gemm(case, dtype)
     finally:
         lib.emage_set_tuning(0, -1)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3], ids=["fp32", "bf16", "f16x3"])
+@pytest.mark.parametrize("c,nseq,l,res", [(64, 3, 1241, True), (64, 2, 200, False), (128, 5, 205, True), (128, 1, 64, True), (64, 1, 7460, True)])
+def test_conv_slab_equals_gemm_bitwise(dtype, c, nseq, l, res):
+    """The LDS-resident-slab convolution computes exactly what emage_gemm computes for the same stride-1 k = 15 conv
+    (same K order, same MFMA grouping, same epilogue association): bit-identical outputs in every precision, for
+    sequences that are not a multiple of the 128-position tile and with / without the shortcut operand."""
+    g = _g(c + nseq + l)
+    td = TD[dtype]
+    a = torch.randn(nseq * l, c, generator=g).to(td)
+    w = (torch.randn(c, 15, c, generator=g) / math.sqrt(15 * c)).reshape(c, 15 * c)
+    wp, ws = (ops.split_f16_weights(w) if dtype == F16X3 else (w.to(td), 1.0))
+    bias, slope = torch.randn(c, generator=g) * 0.1, torch.full((c,), 0.01)
+    sc = torch.randn(nseq * l, 2 * c, generator=g).to(td)[:, c:] if res else None       # a strided view, like the stacked conv1 output
+    ad, wd, bd, sd = a.to(DEV), wp.to(DEV), bias.to(DEV), slope.to(DEV)
+    scd = None
+    if res:
+        base = torch.zeros(nseq * l, 2 * c, dtype=td)
+        base[:, c:] = sc
+        scd = base.to(DEV)[:, c:]
+    ref = torch.zeros(nseq * l, c, dtype=td, device=DEV)
+    ops.gemm(dtype, ad, wd, bd, sd, scd, ref, None, None, n=c, cp=c, res_first=True, taps=15, stride=1, pad=7, lin=l, lout=l, m=nseq * l, w_scale=ws)
+    got = torch.full((nseq * l, c), 7.0, dtype=td, device=DEV)
+    ops.conv_slab(dtype, ad, wd, bd, sd, scd, got, nseq=nseq, l=l, taps=15, pad=7, w_scale=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    cpu = torch.zeros(nseq * l, c, dtype=td)
+    F.conv_slab(dtype, a, wp, bias, slope, sc, cpu, nseq=nseq, l=l, taps=15, pad=7, w_scale=ws)
+    _cmp("conv_slab vs cpu", got, cpu, atol={F32: 2e-4, BF16: 3e-2, F16X3: 2e-5}[dtype], rtol=1e-2 if dtype == BF16 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3], ids=["fp32", "bf16", "f16x3"])
+@pytest.mark.parametrize("nclip,nwin", [(3, 1), (2, 2)])
+def test_wav_block0_equals_unfused_bitwise(dtype, nclip, nwin):
+    """WavEncoder block 0 in one launch (conv1 from the waveform into LDS, conv2, shortcut in the epilogue) against the
+    unfused emage_wav_conv_in + emage_gemm sequence: bit-identical, for plain clips and for sliding windows read in place."""
+    g = _g(nclip * 10 + nwin)
+    td = TD[dtype]
+    c, win, hop = 64, 34112, 31980
+    wav = 0.1 * torch.randn(nclip, win + (nwin - 1) * hop + 5, generator=g)
+    w_first = torch.randn(2 * c, 15, generator=g) / 4                   # [conv1 | shortcut], eval BatchNorm already folded
+    b_first = torch.randn(2 * c, generator=g) * 0.1
+    s_first = torch.cat([torch.full((c,), 0.01), torch.ones(c)])
+    w2 = (torch.randn(c, 15, c, generator=g) / math.sqrt(15 * c)).reshape(c, 15 * c)
+    w2p, ws = (ops.split_f16_weights(w2) if dtype == F16X3 else (w2.to(td), 1.0))
+    b2, s2 = torch.randn(c, generator=g) * 0.1, torch.full((c,), 0.01)
+    lout, nseq = 7460, nclip * nwin
+    wd = wav.to(DEV)
+    y0 = torch.zeros(nseq * lout, 2 * c, dtype=td, device=DEV)
+    ops.wav_conv_in(dtype, wd, w_first.to(DEV), b_first.to(DEV), s_first.to(DEV), y0, lout, 5, 1600, nwin=nwin, hop=hop, win_len=win)
+    ref = torch.zeros(nseq * lout, c, dtype=td, device=DEV)
+    ops.gemm(dtype, y0[:, :c], w2p.to(DEV), b2.to(DEV), s2.to(DEV), y0[:, c:], ref, None, None, n=c, cp=c, res_first=True, taps=15, stride=1, pad=7,
+             lin=lout, lout=lout, m=nseq * lout, w_scale=ws)
+    got = torch.full((nseq * lout, c), 7.0, dtype=td, device=DEV)
+    wf = w_first.to(DEV)
+    ops.wav_block0(dtype, wd, wf[:c], b_first.to(DEV)[:c], 0.01, wf[c:], b_first.to(DEV)[c:], 5, 1600, w2p.to(DEV), b2.to(DEV), s2.to(DEV), 15, 7,
+                   got, lout, nwin=nwin, hop=hop, win_len=win, w_scale=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
