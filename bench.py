@@ -158,7 +158,21 @@ def profile_kernels(runner, model, vq):
             return ("emage_" + tag, 0.0, float(byts))
         return c
 
-    table = {"gemm": gemm_cost, "attention": attn_cost, "vq_argmin": vq_cost}
+    def slab_cost(a, k, r):
+        dtype, A, W = a[0], a[1], a[2]
+        c = W.shape[0]
+        rows = k["nseq"] * k["l"]
+        es = 2 if dtype == BF16 else 4
+        return ("emage_conv_slab", 2.0 * rows * c * k["taps"] * c, float(2 * rows * c * es + c * k["taps"] * c * es))
+
+    def block0_cost(a, k, r):
+        dtype, wav, w1, taps2, out = a[0], a[1], a[2], a[12], a[14]
+        c, t1 = w1.shape
+        rows = out.shape[0]
+        es = 2 if dtype == BF16 else 4
+        return ("emage_conv_slab", 2.0 * rows * c * taps2 * c + 2.0 * rows * 2 * c * t1, float(wav.numel() * 4 + rows * c * es))
+
+    table = {"gemm": gemm_cost, "attention": attn_cost, "vq_argmin": vq_cost, "conv_slab": slab_cost, "wav_block0": block0_cost}
     for nm in ("layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "argmax_logsoftmax", "wav_conv_in", "merge_parts",
                "velocity_to_position"):
         table[nm] = generic_cost(nm)
@@ -210,7 +224,7 @@ def roofline_report(records, precision, ms_per_step):
     total_ms = sum(v[1] for v in fam.values())
     name, (cnt, ms, flops, byts) = max(fam.items(), key=lambda kv: kv[1][1])
     mfma_peak = F32_MFMA_PEAK_TFLOPS if precision == "fp32" else F16_MFMA_PEAK_TFLOPS
-    if flops > 0 and name in ("emage_gemm", "emage_attention"):
+    if flops > 0 and name in ("emage_gemm", "emage_attention", "emage_conv_slab"):
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s", "frac": ach / mfma_peak}
     else:

@@ -49,16 +49,16 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
     constexpr int ROWS = SBM + MAXT;                  // slab rows (128 + taps - 1, rounded up)
     constexpr int BN = C, NW = 8, WM = 4, WN = 2;
     constexpr int WTN = BN / WN, FM = 2, FN = WTN / 16, FP = FN / 2;
-    constexpr int WSTAGE = BN * 128;                  // bytes of one W ring slot
-    constexpr int GB = BN / (NW * 8);                 // 1-KiB DMA instructions per wave per W stage
-    constexpr bool TWO = true;                        // KC = 8: two chunks per lane and K-tile
+    constexpr int KPS = 2;                            // K-tiles per W ring slot / barrier (the W tile of one K-tile is only C x 128 B)
+    constexpr int WSTAGE = KPS * BN * 128;            // bytes of one W ring slot: KPS consecutive K-tiles, each BN rows x 128 B
+    constexpr int GB = KPS * BN / (NW * 8);           // 1-KiB DMA instructions per wave per W stage
     static_assert((C == 64 || C == 128) && FN % 2 == 0 && GB >= 1, "channel count");
     static_assert(!X3 || EPC == 4, "split-f16 slab: fp32 storage");
 
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* slab = smem;                                   // ROWS * RBS
     unsigned char* wring = smem + ROWS * RBS;                     // NS * WSTAGE
-    float* s_x = (float*)(wring + NS * WSTAGE);                   // SRC_WAVE: waveform span, then w1 | b1 | wds | bds
+    float* s_x = (float*)(wring + NS * WSTAGE);                   // SRC_WAVE: the waveform span of this tile
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,25 +70,34 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
     // ---- W ring (as in gemm_pipe_tile: lane-fixed byte offsets, K advance in the scalar offset, permuted-row swizzle) ----
     const unsigned w_bytes = (unsigned)((long)C * p.taps * C * ES);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, w_bytes, 0x00020000);
+    // DMA instruction j of this wave fills rows (wave + NW*j)*8 .. +7 of the slot image [k-tile 0: BN rows | k-tile 1: BN rows];
+    // a K-tile past the end of K (odd tile count) reads beyond the buffer and lands as zeros
     unsigned b_voff[GB];
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
-        const int row = (wave + NW * j) * 8 + lane / 8;
-        b_voff[j] = (unsigned)row * (unsigned)(p.taps * C * ES) + (unsigned)(((lane % 8) ^ swzW<8>(row)) * 16);
+        const int srow = (wave + NW * j) * 8 + lane / 8;          // row of the slot image
+        const int sub = srow / BN, row = srow - sub * BN;
+        b_voff[j] = (unsigned)row * (unsigned)(p.taps * C * ES) + (unsigned)(sub * 128) + (unsigned)(((lane % 8) ^ swzW<8>(row)) * 16);
     }
+    const int nst = (nk + KPS - 1) / KPS;             // W stages
     unsigned soff_w = 0;
-    int is_slot = 0;
+    int is_slot = 0, is_kt = 0;
     auto issue_w = [&]() {
 #pragma unroll
-        for (int j = 0; j < GB; ++j)
+        for (int j = 0; j < GB; ++j) {
+            const int sub = ((wave + NW * j) * 8) / BN;           // wave-uniform: which K-tile of the slot this instruction fills
+            // past the last K-tile the row offset would run into the NEXT weight row: force the out-of-range offset (zeros)
+            const unsigned vo = is_kt + sub < nk ? b_voff[j] : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(wring + is_slot * WSTAGE + (wave + NW * j) * 1024),
-                                                     16, (int)b_voff[j], (int)soff_w, 0, 0);
-        soff_w += 128;
+                                                     16, (int)vo, (int)soff_w, 0, 0);
+        }
+        soff_w += KPS * 128;
+        is_kt += KPS;
         if (++is_slot == NS) is_slot = 0;
     };
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue_w();
+        if (s < nst) issue_w();
 
     // ---- slab fill: rows r <-> input position l0 - pad + r of this sequence, zeros outside [0, L) ----
     const int pos0 = l0 - p.pad;
@@ -102,42 +111,54 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
             const int xi = x0 + i;
             s_x[i] = (xi >= 0 && xi < p.Lw) ? src[xi] : 0.f;
         }
-        float* s_w1 = s_x + ((span + 3) & ~3);
-        float* s_b1 = s_w1 + C * MAXT;
-        float* s_wd = s_b1 + C;
-        float* s_bd = s_wd + C * MAXT;
-        for (int i = tid; i < C * MAXT; i += 512) {
-            const int c = i / MAXT, k = i - c * MAXT;
-            s_w1[i] = k < t1 ? p.w1[c * t1 + k] : 0.f;
-            s_wd[i] = k < t1 ? p.wds[c * t1 + k] : 0.f;
-        }
-        for (int i = tid; i < C; i += 512) { s_b1[i] = p.b1[i]; s_bd[i] = p.bds[i]; }
         __syncthreads();
-        // one item = 8 channels of one row: the two 4-channel groups that make one K-chunk pair
-        constexpr int IPR = C / 8;
-        for (int it = tid; it < ROWS * IPR; it += 512) {
-            const int r = it / IPR, q = it - r * IPR;
-            const int pos = pos0 + r;
-            const bool live = pos >= 0 && pos < p.L && r < SBM + p.taps - 1;
-            // channels: split-f16 -> {32g + 4f + e, 32g + 16 + 4f + e}; else 8 consecutive
-            const int g32 = q >> 2, f4 = q & 3;
-            const int c_lo4 = X3 ? 32 * g32 + 4 * f4 : 8 * q, c_hi4 = X3 ? c_lo4 + 16 : c_lo4 + 4;
-            float v[8];
+        // A thread owns one 8-channel item column q (the two 4-channel groups of one K-chunk pair) and every RSTEP-th row:
+        // the 15 filter taps of 4 channels stay in registers, each waveform sample is read from LDS once per row and phase
+        constexpr int IPR = C / 8, RSTEP = 512 / IPR, RPT = (ROWS + RSTEP - 1) / RSTEP;
+        const int q = tid % IPR, rb = tid / IPR;
+        const int g32 = q >> 2, f4 = q & 3;
+        // channels: split-f16 -> {32g + 4f + e, 32g + 16 + 4f + e}; else 8 consecutive
+        const int cgrp[2] = {X3 ? 32 * g32 + 4 * f4 : 8 * q, X3 ? 32 * g32 + 4 * f4 + 16 : 8 * q + 4};
+        float v[RPT][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = (e < 4 ? c_lo4 : c_hi4) + (e & 3);
-                float acc = 0.f;
+        for (int ph = 0; ph < 2; ++ph) {
+            float wr[4][MAXT], bb[4];
 #pragma unroll
-                for (int k = 0; k < MAXT; ++k)
-                    if (k < t1) acc = fmaf(s_x[r * p.stride1 + k], s_w1[c * MAXT + k], acc);
-                v[e] = live ? leaky(acc + s_b1[c], p.slope1) : 0.f;
+            for (int c = 0; c < 4; ++c) {
+                bb[c] = p.b1[cgrp[ph] + c];
+#pragma unroll
+                for (int k = 0; k < MAXT; ++k) wr[c][k] = k < t1 ? p.w1[(cgrp[ph] + c) * t1 + k] : 0.f;
             }
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int r = rb + j * RSTEP;
+                const int pos = pos0 + r;
+                const bool live = r < ROWS && pos >= 0 && pos < p.L && r < SBM + p.taps - 1;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                if (r < ROWS) {
+#pragma unroll
+                    for (int k = 0; k < MAXT; ++k) {
+                        if (k < t1) {
+                            const float xv = s_x[r * p.stride1 + k];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, wr[c][k], acc[c]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[j][4 * ph + c] = live ? leaky(acc[c] + bb[c], p.slope1) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int r = rb + j * RSTEP;
+            if (r >= ROWS) continue;
             unsigned char* rowp = slab + r * RBS;
             if constexpr (X3) {
                 f16x8 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float xs = v[e] * p.a_scale;
+                    const float xs = v[j][e] * p.a_scale;
                     const _Float16 h = (_Float16)xs;
                     hi[e] = h;
                     lo[e] = (_Float16)(xs - (float)h);
@@ -147,14 +168,14 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
                 *(f16x8*)(rowp + (((c0 + 4) ^ swzS<CH>(r)) << 4)) = lo;
             } else if constexpr (EPC == 8) {
                 uint4 t;
-                t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                t.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-                t.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+                t.x = (unsigned)f32_to_bf16(v[j][0]) | ((unsigned)f32_to_bf16(v[j][1]) << 16);
+                t.y = (unsigned)f32_to_bf16(v[j][2]) | ((unsigned)f32_to_bf16(v[j][3]) << 16);
+                t.z = (unsigned)f32_to_bf16(v[j][4]) | ((unsigned)f32_to_bf16(v[j][5]) << 16);
+                t.w = (unsigned)f32_to_bf16(v[j][6]) | ((unsigned)f32_to_bf16(v[j][7]) << 16);
                 *(uint4*)(rowp + ((q ^ swzS<CH>(r)) << 4)) = t;
             } else {
-                *(float4*)(rowp + (((2 * q) ^ swzS<CH>(r)) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
-                *(float4*)(rowp + (((2 * q + 1) ^ swzS<CH>(r)) << 4)) = make_float4(v[4], v[5], v[6], v[7]);
+                *(float4*)(rowp + (((2 * q) ^ swzS<CH>(r)) << 4)) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                *(float4*)(rowp + (((2 * q + 1) ^ swzS<CH>(r)) << 4)) = make_float4(v[j][4], v[j][5], v[j][6], v[j][7]);
             }
         }
     } else {
@@ -211,51 +232,54 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
 
     unsigned sb = 0;
     int tap = 0, h = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int newer = nk - 1 - kt;
+    for (int st = 0; st < nst; ++st) {
+        const int newer = nst - 1 - st;
         if (NS >= 4 && newer >= 2) wait_vmcnt<2 * GB>();
         else if (NS >= 3 && newer >= 1) wait_vmcnt<GB>();
         else wait_vmcnt<0>();
-        if (kt == 0) wait_lgkmcnt<0>();               // this wave's slab writes are in LDS
-        __builtin_amdgcn_s_barrier();                 // W tile kt landed in every wave's view (and, at kt = 0, the slab is complete)
-        if (kt + NS - 1 < nk) issue_w();
-        const int row = arow + tap;
-        const unsigned a0 = lds_slab + row * RBS + (((h * 8 + fg) ^ swzS<CH>(row)) << 4);
-        const unsigned a1 = a0 ^ 64u;
-        u32x4 af0[FM], af1[FM], bf0[FN], bf1[FN];
-        [&]<int... I>(std::integer_sequence<int, I...>) { ((af0[I] = lds_read128_off<I * 16 * RBS>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
-        [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RBS>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
-        [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * 128>(b_rd0 + sb)), ...); }(std::make_integer_sequence<int, FN>{});
-        [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * 128>(b_rd1 + sb)), ...); }(std::make_integer_sequence<int, FN>{});
-        wait_lgkmcnt<0>();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (X3) {
-            // both operands arrive split: chunk (c) = hi plane, chunk (c + 4) = lo plane
+        if (st == 0) wait_lgkmcnt<0>();               // this wave's slab writes are in LDS
+        __builtin_amdgcn_s_barrier();                 // W stage st landed in every wave's view (and, at st = 0, the slab is complete)
+        if (st + NS - 1 < nst) issue_w();
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+        for (int sub = 0; sub < KPS; ++sub) {
+            // a K-tile past the end (odd tile count) multiplies zero weights with the (finite) rows behind the last tap
+            const int row = arow + tap;
+            const unsigned a0 = lds_slab + row * RBS + (((h * 8 + fg) ^ swzS<CH>(row)) << 4);
+            const unsigned a1 = a0 ^ 64u;
+            const unsigned wb = sb + sub * (BN * 128);
+            u32x4 af0[FM], af1[FM], bf0[FN], bf1[FN];
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((af0[I] = lds_read128_off<I * 16 * RBS>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RBS>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * 128>(b_rd0 + wb)), ...); }(std::make_integer_sequence<int, FN>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * 128>(b_rd1 + wb)), ...); }(std::make_integer_sequence<int, FN>{});
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (X3) {
+                // both operands arrive split: chunk (c) = hi plane, chunk (c + 4) = lo plane
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = mma_f16(__builtin_bit_cast(f16x8, t == 0 ? bf1[j] : bf0[j]), __builtin_bit_cast(f16x8, t == 1 ? af1[i] : af0[i]), acc[i][j]);
+            } else {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
-                        acc[i][j] = mma_f16(__builtin_bit_cast(f16x8, t == 0 ? bf1[j] : bf0[j]), __builtin_bit_cast(f16x8, t == 1 ? af1[i] : af0[i]), acc[i][j]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
-            if constexpr (TWO) {
+                        acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
                         acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf1[j]), __builtin_bit_cast(uint4, af1[i]), acc[i][j]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (++h == KPT) { h = 0; ++tap; }
         }
-        __builtin_amdgcn_sched_barrier(0);
         sb += WSTAGE;
         if (sb == NS * WSTAGE) sb = 0;
-        if (++h == KPT) { h = 0; ++tap; }
     }
 
     // ---- epilogue: lane (fr, fg) holds rows l0 + wm*32 + i*16 + fr, columns wn*WTN + jp*32 + fg*8 + e ----
@@ -275,19 +299,23 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) rv[e] = 0.f;
             if constexpr (SRC == SRC_WAVE) {
-                // the downsample shortcut of block 0 for this output: conv(wav) + bias, no activation (P:288-290)
+                // the downsample shortcut of block 0 for this output: conv(wav) + bias, no activation (P:288-290); the filter
+                // taps of 4 columns at a time in registers, the 15 samples of the row read from LDS once per half
                 const int t1 = p.taps1;
-                const int span = (ROWS - 1) * p.stride1 + t1;
-                const float* s_wd = s_x + ((span + 3) & ~3) + C * MAXT + C;
-                const float* s_bd = s_wd + C * MAXT;
                 const float* xs = s_x + (lr + p.pad) * p.stride1;       // slab row of output l is lr + pad
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float a = 0.f;
+                for (int hf = 0; hf < 2; ++hf) {
+                    float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < MAXT; ++k)
-                        if (k < t1) a = fmaf(xs[k], s_wd[(n + e) * MAXT + k], a);
-                    rv[e] = Elem<T>::from(Elem<T>::to(a + s_bd[n + e]));   // the unfused path stores the shortcut in T
+                    for (int k = 0; k < MAXT; ++k) {
+                        if (k < t1) {
+                            const float xv = xs[k];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) a4[c] = fmaf(xv, p.wds[(n + 4 * hf + c) * t1 + k], a4[c]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) rv[4 * hf + c] = Elem<T>::from(Elem<T>::to(a4[c] + p.bds[n + 4 * hf + c]));   // the unfused path stores the shortcut in T
                 }
             } else if (p.res) {
                 load8<T>((const T*)p.res + m * p.ldr + n, rv);
@@ -307,10 +335,11 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
 template <typename T, bool X3, int C, int SRC>
 int launch_slab(SlabArgs& a, hipStream_t s) {
     constexpr int ES = 16 / Elem<T>::EPC;
-    constexpr int NS = 3;
+    constexpr int NS = 2;     // ring depth: with two K-tiles per slot and (C = 64) two blocks per CU, one slot in flight is enough,
+                              // and C = 128 in fp32 bytes (74 KiB slab + 2 x 32 KiB ring) only fits the 160 KiB this way
     a.tiles_l = (a.L + SBM - 1) / SBM;
-    size_t lds = (size_t)(SBM + MAXT) * C * ES + (size_t)NS * C * 128;
-    if (SRC == SRC_WAVE) lds += ((size_t)((SBM + MAXT - 1) * a.stride1 + a.taps1 + 3) / 4 * 4 + 2 * (size_t)C * MAXT + 2 * C) * sizeof(float);
+    size_t lds = (size_t)(SBM + MAXT) * C * ES + (size_t)NS * 2 * C * 128;
+    if (SRC == SRC_WAVE) lds += ((size_t)((SBM + MAXT - 1) * a.stride1 + a.taps1 + 3) / 4 * 4) * sizeof(float);
     if (lds > 160 * 1024) return EMAGE_EINVAL;
     auto kern = conv_slab_kernel<T, X3, C, SRC, NS>;
     // per instantiation, once (thread-safe static initialisation): allow more than 64 KiB of dynamic LDS

@@ -239,6 +239,8 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 40: return launch_pipe<T, X3, 64, 192, 4, 2, 4, 8>(a, s);
         case 41: return launch_pipe<T, X3, 128, 256, 4, 2, 2, 8>(a, s);
         case 42: return launch_pipe<T, X3, 128, 192, 4, 2, 3, 8>(a, s);
+        case 43: return launch_pipe<T, X3, 64, 64, 2, 2, 4>(a, s);         // deeper rings for small grids: a launch with <= 1 block per CU
+        case 44: return launch_pipe<T, X3, 64, 64, 2, 2, 3>(a, s);         // has nothing but its own ring to hide the L2 round trip of a K-tile
         default: return EMAGE_EINVAL;
     }
 }

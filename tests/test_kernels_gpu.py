@@ -378,7 +378,8 @@ def test_wav_block0_equals_unfused_bitwise(dtype, nclip, nwin):
     lout, nseq = 7460, nclip * nwin
     wd = wav.to(DEV)
     y0 = torch.zeros(nseq * lout, 2 * c, dtype=td, device=DEV)
-    ops.wav_conv_in(dtype, wd, w_first.to(DEV), b_first.to(DEV), s_first.to(DEV), y0, lout, 5, 1600, nwin=nwin, hop=hop, win_len=win)
+    storage = F32 if dtype == F16X3 else dtype                          # the first layer runs in the mode's storage type
+    ops.wav_conv_in(storage, wd, w_first.to(DEV), b_first.to(DEV), s_first.to(DEV), y0, lout, 5, 1600, nwin=nwin, hop=hop, win_len=win)
     ref = torch.zeros(nseq * lout, c, dtype=td, device=DEV)
     ops.gemm(dtype, y0[:, :c], w2p.to(DEV), b2.to(DEV), s2.to(DEV), y0[:, c:], ref, None, None, n=c, cp=c, res_first=True, taps=15, stride=1, pad=7,
              lin=lout, lout=lout, m=nseq * lout, w_scale=ws)

@@ -25,6 +25,8 @@ SHAPES = [
     ("conv3 256->256", (64, 64, 64), 256, 256, 3, 1, 1, dict(slope=0.2)),
     ("conv3 337->256", (64, 64, 64), 337, 256, 3, 1, 1, dict(slope=0.2)),
     ("conv3 T=120 256->256", (64, 120, 120), 256, 256, 3, 1, 1, dict(slope=0.2)),
+    ("vq conv3 seed T=17 256->256", (64, 17, 17), 256, 256, 3, 1, 1, dict(slope=0.2)),
+    ("cls fc 256->256 M=4096", (64, 64, 64), 256, 256, 1, 1, 0, dict(slope=0.1)),
     ("wav b0.conv2 64->64 k15", (64, 7460, 7460), 64, 64, 15, 1, 7, dict(slope=0.01)),
     ("wav b1.conv1+ds 64->128 s6", (64, 7460, 1241), 64, 128, 15, 6, 0, dict()),
     ("wav b1.conv2 64->64", (64, 1241, 1241), 64, 64, 15, 1, 7, dict(slope=0.01)),
