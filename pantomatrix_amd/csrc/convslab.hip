@@ -290,42 +290,55 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
         float bv[8], sv[8];
         load8<float>(p.bias + n, bv);
         load8<float>(p.slope + n, sv);
+        float rv[FM][8];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int lr = wm * 32 + i * 16 + fr, l = l0 + lr;
-            if (l >= p.L) continue;
-            const long m = (long)seq * p.L + l;
-            float rv[8];
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) rv[e] = 0.f;
-            if constexpr (SRC == SRC_WAVE) {
-                // the downsample shortcut of block 0 for this output: conv(wav) + bias, no activation (P:288-290); the filter
-                // taps of 4 columns at a time in registers, the 15 samples of the row read from LDS once per half
-                const int t1 = p.taps1;
-                const float* xs = s_x + (lr + p.pad) * p.stride1;       // slab row of output l is lr + pad
+            for (int e = 0; e < 8; ++e) rv[i][e] = 0.f;
+        if constexpr (SRC == SRC_WAVE) {
+            // the downsample shortcut of block 0 for this lane's outputs: conv(wav) + bias, no activation (P:288-290); the
+            // filter taps of 4 columns at a time in registers (loaded once for both rows), the row's samples read from LDS
+            const int t1 = p.taps1;
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
+            for (int hf = 0; hf < 2; ++hf) {
+                float wd[4][MAXT], bd[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bd[c] = p.bds[n + 4 * hf + c];
+#pragma unroll
+                    for (int k = 0; k < MAXT; ++k) wd[c][k] = k < t1 ? p.wds[(n + 4 * hf + c) * t1 + k] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const float* xs = s_x + (wm * 32 + i * 16 + fr + p.pad) * p.stride1;   // slab row of output l is its tile row + pad
                     float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < MAXT; ++k) {
                         if (k < t1) {
                             const float xv = xs[k];
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) a4[c] = fmaf(xv, p.wds[(n + 4 * hf + c) * t1 + k], a4[c]);
+                            for (int c = 0; c < 4; ++c) a4[c] = fmaf(xv, wd[c][k], a4[c]);
                         }
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) rv[4 * hf + c] = Elem<T>::from(Elem<T>::to(a4[c] + p.bds[n + 4 * hf + c]));   // the unfused path stores the shortcut in T
+                    for (int c = 0; c < 4; ++c) rv[i][4 * hf + c] = Elem<T>::from(Elem<T>::to(a4[c] + bd[c]));   // the unfused path stores the shortcut in T
                 }
-            } else if (p.res) {
-                load8<T>((const T*)p.res + m * p.ldr + n, rv);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int lr = wm * 32 + i * 16 + fr, l = l0 + lr;
+            if (l >= p.L) continue;
+            const long m = (long)seq * p.L + l;
+            if constexpr (SRC == SRC_ROWS) {
+                if (p.res) load8<T>((const T*)p.res + m * p.ldr + n, rv[i]);
             }
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float x = (e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4]);
                 if constexpr (X3) x *= p.o_scale;
-                v[e] = leaky((x + bv[e]) + rv[e], sv[e]);
+                v[e] = leaky((x + bv[e]) + rv[i][e], sv[e]);
             }
             store8<T>(out + m * p.ldo + n, v);
         }

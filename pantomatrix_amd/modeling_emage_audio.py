@@ -606,8 +606,10 @@ class _WavEncoderMixin:
 
     def _wav_block0_fused(self):
         """Block 0 runs as ONE launch per encoder (`emage_wav_block0`) when its width is one the slab kernel is built for."""
+        # measured per kernel (profiles/r02_bench_slab.txt): the fused block 0 wins in f16x3 only (786 vs 915 us); in bf16 / fp32
+        # its VALU first layer costs more than the tensor round trip it saves
         blocks = self._wav_blocks()
-        return self.slab_convs and ops.conv_slab_supported(blocks[0][1], _WAV_TAPS, 1)
+        return self.slab_convs and self._dt == F16X3 and ops.conv_slab_supported(blocks[0][1], _WAV_TAPS, 1)
 
     def _wav_encoder_chain(self, cx, enc, e, y0, b, lens, dest=None, wav=None, nwin=1, hop=0, win_len=None):
         """Blocks 0..5 of one WavEncoder (P:283-314).  Block 0 is either the fused launch on the raw waveform (`wav`
