@@ -345,6 +345,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
     ap.add_argument("--no-slab-convs", action="store_true", help="A/B: WavEncoder through emage_wav_conv_in + emage_gemm only (same bits)")
+    ap.add_argument("--gemm-variant", type=int, default=-1, help="experiments: emage_set_tuning key 2 (tile-heuristic variant)")
     ap.add_argument("--gemm-dbg", type=int, default=0, help="experiments: emage_set_tuning key 1 mask (8: sc1 result stores, 16: nt)")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
@@ -370,9 +371,11 @@ def main():
     from pantomatrix_amd import dist as pdist
     from pantomatrix_amd import synthetic
 
-    if args.gemm_dbg:
+    if args.gemm_dbg or args.gemm_variant >= 0:
         from pantomatrix_amd import _lib
         _lib.load().emage_set_tuning(1, args.gemm_dbg)
+        if args.gemm_variant >= 0:
+            _lib.load().emage_set_tuning(2, args.gemm_variant)
     log(f"rank {rank}/{world}: building the {args.precision} models on {dev} and capturing the clip graph")
     model, vq, runner, n_samples = build(args.precision, dev, args)
     # clip i of the global batch lives on rank i % world; every rank gets `batch` clips (weak scaling)

@@ -48,7 +48,9 @@ const char* emage_target_arch(void);
 /*
  * Tuning hook for tests and tools (never needed for correctness; process-global, not thread-safe):
  *   key 0: force emage_gemm's tile configuration id (-1 restores the heuristic);
- *   key 1: diagnostic ablation mask for tools/bench_gemm.py --ablate (1 no operand DMA, 2 no MFMA, 4 no epilogue).
+ *   key 1: diagnostic ablation mask for tools/bench_gemm.py --ablate (1 no operand DMA, 2 no MFMA, 4 no epilogue;
+ *          8 / 16: write-through / non-temporal result stores, a recorded negative experiment);
+ *   key 2: tile-heuristic variant for A/B runs (0: one K-tile per ring slot everywhere; 1, the default: two in f16x3).
  * The product path never calls it.  Returns EMAGE_EINVAL for unknown keys.
  */
 int emage_set_tuning(int key, int value);

@@ -38,7 +38,12 @@ struct SlabArgs {
     float a_scale, o_scale;
 };
 
-template <int CH> __device__ __forceinline__ int swzS(int row) { return CH == 8 ? ((row >> 1) & 7) : (row & 15); }
+// Slab slot swizzle: 16-byte slot of chunk c in row r is c ^ swzS(r).  A ds_read_b128 service group is 16 lanes = 16 distinct
+// rows r0 + tap .. r0 + tap + 15, eight of them (fr in {0-3, 12-15}) reading chunk c0 and eight (fr in 4..11) chunk c0 + 1.
+// (r & 7) << 1 leaves chunk bit 0 alone and gives each half of the group 8 distinct values on bits 1-3 for EVERY tap offset
+// (r & 15, the first version, collided 2-way on odd taps: SQ_LDS_BANK_CONFLICT 20 %, profiles/r02_pmc_gemm_f16x3.json).
+// 128-byte rows (bf16, C = 64) keep the two-rows-per-bank-line form of the GEMM ring.
+template <int CH> __device__ __forceinline__ int swzS(int row) { return CH == 8 ? ((row >> 1) & 7) : ((row & 7) << 1); }
 
 template <typename T, bool X3, int C, int SRC, int NS>
 __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {

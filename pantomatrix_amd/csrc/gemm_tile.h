@@ -180,9 +180,9 @@ constexpr unsigned OOB = 0x80000000u;    // > any num_records we create (buffers
 
 // blocks per CU the LDS footprint admits (capped at 3): used as the launch-bounds occupancy target so the register
 // allocator does not cost a resident block
-template <int BM, int BN, int NS, int KC>
+template <int BM, int BN, int NS, int KC, int KPS = 1>
 constexpr int lds_blocks() {
-    const int ring = NS * (BM + BN) * KC * 16;
+    const int ring = NS * KPS * (BM + BN) * KC * 16;
     const int stage_full = BM * (BN + 4) * 4;
     const int stage = stage_full <= ring ? stage_full : stage_full / 2;
     const int bytes = ring > stage ? ring : stage;
@@ -191,9 +191,9 @@ constexpr int lds_blocks() {
 }
 
 // LDS bytes a tile of this shape needs: the operand ring, or the fp32 V^T staging tile when that is larger
-template <typename T, int BM, int BN, int NS, int KC>
+template <typename T, int BM, int BN, int NS, int KC, int KPS = 1>
 constexpr int pipe_smem_bytes() {
-    constexpr int STAGE = (BM + BN) * KC * 16;
+    constexpr int STAGE = KPS * (BM + BN) * KC * 16;
     constexpr int CLD = BN + 4;
     constexpr int EP = (BM * CLD * 4 <= NS * STAGE) ? 1 : 2;
     constexpr int CBYTES = (BM / EP) * CLD * 4;
@@ -208,7 +208,11 @@ constexpr int pipe_smem_bytes() {
 // X3: split-f16 MFMA on fp32 operands (T = float, KC = 8): the K-tile is 32 k; a lane's two chunks (k = 4g..4g+3 and
 // 16+4g..16+4g+3 of the tile) form the 8 k-values of one 16x16x32 MFMA; the W tile row holds [4 hi chunks | 4 lo chunks]
 // packed by the host in exactly that k order (pantomatrix_amd.modeling_emage_audio._Packed._split_f16).
-template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool FPRE = false, bool X3 = false, int EPI = EPI_LINEAR>
+// KPS: K-tiles per ring slot (1 or 2).  With 2, a slot holds two consecutive K-tiles ([A | W] [A | W]) and the block meets at
+// ONE barrier / counted wait per TWO K-tiles: the waves of a lone block per CU spend a third of their cycles waiting at the
+// per-K-tile rendezvous (profiles/r02_pmc_gemm_f16x3.json), and in the fp32-byte modes a K-tile is only 32 k deep.  Requires
+// an even K-tile count (always true for fp32 storage: K % 64 == 0, BK = 32).
+template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool FPRE = false, bool X3 = false, int EPI = EPI_LINEAR, int KPS = 1>
 __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int ES = 16 / EPC;                     // element size in bytes
@@ -220,7 +224,9 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     constexpr int NW = WM * WN;                     // waves per block (4, or 8 = two per SIMD)
     constexpr int GA = BM / (NW * RPI), GB = BN / (NW * RPI);   // DMA instructions per wave per tile
     constexpr int G = GA + GB;
-    constexpr int STAGE = (BM + BN) * RB;            // bytes per ring slot: A rows then W rows
+    constexpr int STAGE = (BM + BN) * RB;            // bytes of one K-tile image: A rows then W rows
+    constexpr int SLOT = KPS * STAGE;                // bytes per ring slot
+    static_assert(KPS == 1 || (KPS == 2 && EPC == 4), "two K-tiles per slot: fp32-storage modes only (even K-tile count)");
     constexpr int NKG = KC / 4;                      // MFMA k-groups per tile
     static_assert((NW == 4 || NW == 8) && BM % (NW * RPI) == 0 && BN % (NW * RPI) == 0, "tile shape");
     static_assert(FN % 2 == 0, "fragments pair up along N");
@@ -229,7 +235,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     static_assert(!X3 || (EPC == 4 && KC == 8), "split-f16 mode: fp32 storage, 128-byte tile rows");
 
     constexpr int CLD = BN + 4;                      // fp32 row stride of the V^T staging tile
-    constexpr int EP = (BM * CLD * 4 <= NS * STAGE) ? 1 : 2;   // staging passes (row halves) so it fits the ring
+    constexpr int EP = (BM * CLD * 4 <= NS * SLOT) ? 1 : 2;    // staging passes (row halves) so it fits the ring
     constexpr int HB = BM / EP;
     constexpr int CBYTES = HB * CLD * 4;
     static_assert(HB % 16 == 0, "staging half must hold whole fragments");
@@ -278,12 +284,12 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     }
 
     // running position of the next tile to issue: tap, channel offset, scalar byte offsets
-    int is_tap = 0, is_c0 = 0, is_slot = 0;
+    int is_tap = 0, is_c0 = 0, is_slot = 0, is_sub = 0;
     unsigned soff_a = 0, soff_w = 0;
     const unsigned tap_step = (unsigned)(p.lda - p.Cp + BK) * ES;            // soff_a jump when the tap advances
     auto issue = [&]() {
         if (p.dbg & 1) return;
-        unsigned char* base = smem + is_slot * STAGE;
+        unsigned char* base = smem + is_slot * SLOT + is_sub * STAGE;
 #pragma unroll
         for (int j = 0; j < GA; ++j) {
             unsigned vo = a_voff[j];
@@ -298,7 +304,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
         soff_w += BK * ES;
         is_c0 += BK;
         if (is_c0 == p.Cp) { is_c0 = 0; ++is_tap; soff_a += tap_step; } else { soff_a += BK * ES; }
-        if (++is_slot == NS) is_slot = 0;
+        if (++is_sub == KPS) { is_sub = 0; if (++is_slot == NS) is_slot = 0; }
     };
 
     // Epilogue operands (residual rows, bias, slope) are fetched NOW, ahead of the operand DMA: they are the
@@ -346,12 +352,16 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = p.K / BK;                          // K-tiles
+    const int nst = nk / KPS;                         // ring stages (KPS K-tiles each)
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue();
+        if (s < nst) {
+#pragma unroll
+            for (int u = 0; u < KPS; ++u) issue();
+        }
 
-    // fragment read addresses inside a ring slot (bytes): row * RB + swizzled 16-B slot; fragment i adds the
+    // fragment read addresses inside a K-tile image (bytes): row * RB + swizzled 16-B slot; fragment i adds the
     // immediate i*16*RB (the swizzle is invariant under +16 rows); k-group 1 flips slot bit 2
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int arow = wm * WTM + fr, brow = wn * WTN + 8 * (fr >> 2) + (fr & 3);
@@ -360,22 +370,27 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     const unsigned a_rd1 = a_rd0 ^ 64u, b_rd1 = b_rd0 ^ 64u;   // lds0 is 128-B aligned, so the xor acts on the slot bit
 
     unsigned sb = 0;                                  // byte offset of the slot being consumed
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed; tiles issued after it (at most NS-2) may stay in flight
-        const int newer = nk - 1 - kt;
-        if (NS >= 4 && newer >= 2) wait_vmcnt<2 * G>();
-        else if (NS >= 3 && newer >= 1) wait_vmcnt<G>();
+    for (int st = 0; st < nst; ++st) {
+        // stage st must have landed; stages issued after it (at most NS-2) may stay in flight
+        const int newer = nst - 1 - st;
+        if (NS >= 4 && newer >= 2) wait_vmcnt<2 * KPS * G>();
+        else if (NS >= 3 && newer >= 1) wait_vmcnt<KPS * G>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) issue();
-        if (p.dbg & 2) continue;
+        if (st + NS - 1 < nst) {
+#pragma unroll
+            for (int u = 0; u < KPS; ++u) issue();
+        }
+        if (p.dbg & 2) { sb += SLOT; if (sb == NS * SLOT) sb = 0; continue; }
+#pragma unroll
+        for (int u = 0; u < KPS; ++u) {
         u32x4 af0[FM], bf0[FN];
-        const unsigned a0 = a_rd0 + sb, b0 = b_rd0 + sb;
+        const unsigned a0 = a_rd0 + sb + u * STAGE, b0 = b_rd0 + sb + u * STAGE;
         [&]<int... I>(std::integer_sequence<int, I...>) { ((af0[I] = lds_read128_off<I * 16 * RB>(a0)), ...); }(std::make_integer_sequence<int, FM>{});
         if constexpr (X3) {
             // read order: both activation chunks first (they need the VALU split), then the W hi / lo chunks
             u32x4 af1[FM], bf1[FN];
-            const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
+            const unsigned a1 = a_rd1 + sb + u * STAGE, b1 = b_rd1 + sb + u * STAGE;
             [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
             [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
             [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
@@ -397,7 +412,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
         } else if constexpr (NKG == 2) {
             [&]<int... J>(std::integer_sequence<int, J...>) { ((bf0[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b0)), ...); }(std::make_integer_sequence<int, FN>{});
             u32x4 af1[FM], bf1[FN];
-            const unsigned a1 = a_rd1 + sb, b1 = b_rd1 + sb;
+            const unsigned a1 = a_rd1 + sb + u * STAGE, b1 = b_rd1 + sb + u * STAGE;
             [&]<int... I>(std::integer_sequence<int, I...>) { ((af1[I] = lds_read128_off<I * 16 * RB>(a1)), ...); }(std::make_integer_sequence<int, FM>{});
             [&]<int... J>(std::integer_sequence<int, J...>) { ((bf1[J] = lds_read128_off<((J >> 1) * 32 + (J & 1) * 4) * RB>(b1)), ...); }(std::make_integer_sequence<int, FN>{});
             wait_lgkmcnt<FM + FN>();
@@ -426,8 +441,9 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                     acc[i][j] = Elem<T>::mma(__builtin_bit_cast(uint4, bf0[j]), __builtin_bit_cast(uint4, af0[i]), acc[i][j]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        sb += STAGE;
-        if (sb == NS * STAGE) sb = 0;
+        }
+        sb += SLOT;
+        if (sb == NS * SLOT) sb = 0;
     }
 
     // ---- epilogue.  With the permuted W rows, lane (fr, fg) holds for M fragment i and fragment pair jp the 8

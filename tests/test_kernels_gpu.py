@@ -313,12 +313,14 @@ def test_bad_arguments_raise():
         ops.vq_argmin(torch.zeros(4, 8), torch.zeros(3, 8))                                 # CPU tensors: no fallback
 
 
-@pytest.mark.parametrize("cfg", [0, 3, 18, 25, 27, 32, 33, 34, 36, 37])
+@pytest.mark.parametrize("cfg", [0, 3, 18, 25, 27, 32, 33, 34, 36, 37, 45, 46, 47, 48])
 @pytest.mark.parametrize("dtype", [F32, BF16, F16X3], ids=["fp32", "bf16", "f16x3"])
 def test_gemm_every_tile_configuration(cfg, dtype):
-    """Each compiled tile configuration (register-staged 0 / 3, LDS-DMA ring kernels) on the awkward cases."""
+    """Each compiled tile configuration (register-staged 0 / 3, LDS-DMA ring kernels, two-K-tiles-per-slot 45-48) on the awkward cases."""
     if dtype == F16X3 and cfg in (0, 3):
         pytest.skip("the register-staged kernels have no split-f16 form")
+    if dtype == BF16 and cfg >= 45:
+        pytest.skip("two K-tiles per ring slot exist for the fp32-storage modes only")
     from pantomatrix_amd import _lib
     lib = _lib.load()
     try:
