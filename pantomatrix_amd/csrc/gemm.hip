@@ -16,7 +16,8 @@ using namespace emage_dev;
 // test / tool hooks (emage_set_tuning; never touched by the product path): process-global, not thread-safe
 int g_force_config = -1;   // -1 = heuristic, else a fixed tile configuration id
 int g_debug_skip = 0;      // tools/bench_gemm.py --ablate: 1 = no operand DMA, 2 = no LDS reads / MFMA, 4 = no epilogue
-int g_variant = 1;         // heuristic variant for A/B runs (key 2): 0 = one K-tile per ring slot everywhere, 1 = two per slot in f16x3
+int g_variant = 0;         // heuristic variant for A/B runs (key 2): 0 = shipped; 1 = two K-tiles per ring slot in f16x3 (measured slower end to
+                           // end: profiles/r02_bench_two_ktiles_per_slot_ab.json); 2 = epilogue operands prefetched ahead of the K-loop for 64x192 tiles
 
 // epilogue shared by both kernels: lane holds rows (lane>>4)*4 + r, column lane&15 of each 16x16 fragment
 template <typename T, int FM, int FN>
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
 
     gemm_epilogue<T, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg);
 }
-template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool X3, int KPS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool X3, int KPS, bool FPRE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? lds_blocks<BM, BN, NS, KC, KPS>() : 1)) void gemm_pipe_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[pipe_smem_bytes<T, BM, BN, NS, KC, KPS>()];
     // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so each XCD walks a contiguous run of
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? lds_blocks<BM, BN, NS
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-    gemm_pipe_tile<T, BM, BN, WM, WN, NS, KC, false, X3, EPI_LINEAR, KPS>(p, tile_m * BM, tile_n * BN, smem);
+    gemm_pipe_tile<T, BM, BN, WM, WN, NS, KC, FPRE, X3, EPI_LINEAR, KPS>(p, tile_m * BM, tile_n * BN, smem);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -208,12 +209,12 @@ int launch(GemmArgs& a, hipStream_t s) {
     return launch_status();
 }
 
-template <typename T, bool X3, int BM, int BN, int WM, int WN, int NS, int KC = 8, int KPS = 1>
+template <typename T, bool X3, int BM, int BN, int WM, int WN, int NS, int KC = 8, int KPS = 1, bool FPRE = false>
 int launch_pipe(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M + BM - 1) / BM;
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     a.tiles_n = (ncols + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS, KC, X3, KPS>), dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_pipe_kernel<T, BM, BN, WM, WN, NS, KC, X3, KPS, FPRE>), dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), 0, s, a);
     return launch_status();
 }
 
@@ -242,6 +243,7 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 42: return launch_pipe<T, X3, 128, 192, 4, 2, 3, 8>(a, s);
         case 43: return launch_pipe<T, X3, 64, 64, 2, 2, 4>(a, s);         // deeper rings for small grids (measured: no gain,
         case 44: return launch_pipe<T, X3, 64, 64, 2, 2, 3>(a, s);         // profiles/r02_gemm_sweep_f16x3_ring_depth_small_grids.txt)
+        case 49: return launch_pipe<T, X3, 64, 192, 4, 2, 2, 8, 1, true>(a, s);   // 33 with bias / slope / residual fetched ahead of the K-loop
         default: break;
     }
     if constexpr (sizeof(T) == 4) {      // fp32-storage modes: two K-tiles per ring slot / barrier (even K-tile count guaranteed)
@@ -269,11 +271,12 @@ int dispatch(GemmArgs& a, hipStream_t s) {
         // stacked shortcut (N >= 128) and the QKV projection prefer 128x128 / 64x192 tiles with a 2-deep ring; 2-deep rings
         // (<= 64 KiB of LDS, ~100 VGPRs) also let kernels of two stream lanes share a CU
         const bool two = g_variant == 1;      // two K-tiles (64 k) per ring slot and barrier
+        const int c33 = g_variant == 2 ? 49 : 33;
         if (a.taps >= 15 && a.stride > 1 && a.M > 8192) return run_config<T, X3>(two ? 46 : 34, a, s);
         if (a.taps >= 15 && a.M > 8192) return run_config<T, X3>(two ? 48 : 36, a, s);
-        if (ncols > 64 && t128 >= 512) return run_config<T, X3>(ncols <= 2304 && ncols % 192 == 0 ? (two ? 45 : 33) : (two ? 46 : 34), a, s);
-        if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T, X3>(two ? 45 : 33, a, s);
-        if (a.taps == 1 && ncols == 768 && a.M >= 2048) return run_config<T, X3>(two ? 45 : 33, a, s);
+        if (ncols > 64 && t128 >= 512) return run_config<T, X3>(ncols <= 2304 && ncols % 192 == 0 ? (two ? 45 : c33) : (two ? 46 : 34), a, s);
+        if (ncols % 192 == 0 && (long)((a.M + 63) / 64) * (ncols / 192) == 512) return run_config<T, X3>(two ? 45 : c33, a, s);
+        if (a.taps == 1 && ncols == 768 && a.M >= 2048) return run_config<T, X3>(two ? 45 : c33, a, s);
         return run_config<T, X3>(25, a, s);
     }
     if (a.taps >= 15 && a.M > 8192) return run_config<T, X3>(36, a, s);     // WavEncoder convs on long sequences: 128x64, 8 waves
