@@ -60,3 +60,90 @@ def finalize():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Training exchange step (train_emage_audio.py:214,248-251): the ONLY collectives of the whole path.
+# One process per GPU; gradients are averaged with a few large bucketed all-reduces over RCCL (xGMI is point-to-point:
+# a ring all-reduce is bound per link, so few large messages beat many small ones) issued in backward order so the
+# first buckets overlap the rest of the backward; SyncBatchNorm's per-channel statistics of both WavEncoders travel as
+# ONE small all-reduce per block pair instead of one per BatchNorm.  Backend "nccl" == RCCL on ROCm, "gloo" in tests.
+# The HIP backward that feeds these buckets is not built yet; this is its exchange layer, tested on CPU.
+# ----------------------------------------------------------------------------------------------------------------------
+EMAGE_BUCKET_PREFIXES = (
+    # backward order of EmageAudioModel (M:315-330 run last in forward, so their gradients are ready first)
+    ("heads", ("body_motion_decoder_", "motion2latent_", "motion_out_proj_", "motion_cls_", "face_out_proj", "face_cls")),
+    ("cross", ("audio_motion_cross_attn.", "audio_body_motion_proj")),
+    ("self_face", ("motion_self_encoder.", "face_motion_decoder.", "moton_proj", "audio_face_motion_proj", "bodyhints_",
+                   "speaker_embedding_", "mask_embedding")),
+    ("encoders", ("audio_encoder_face.", "audio_encoder_body.", "motion_encoder.")),
+)
+
+
+def emage_bucket_plan(named_parameters):
+    """Partition (name, tensor) pairs into the four backward-ordered buckets; parameters the forward never uses
+    (`transformer_en_layer.*`, `audio_motion_cross_attn_layer.*` templates, M:238-242) get no gradient and no bucket."""
+    plan = [(tag, []) for tag, _ in EMAGE_BUCKET_PREFIXES]
+    unused = []
+    for name, p in named_parameters:
+        for i, (_tag, prefixes) in enumerate(EMAGE_BUCKET_PREFIXES):
+            if name.startswith(prefixes):
+                plan[i][1].append((name, p))
+                break
+        else:
+            unused.append(name)
+    return plan, unused
+
+
+class GradientBuckets:
+    """Flat fp32 gradient buffers, one per bucket; `grads[name]` are views into them, so a backward kernel that writes a
+    parameter's gradient writes straight into the message.  `reduce(i)` starts bucket i's all-reduce (async), `wait()`
+    finishes all of them and divides by the world size (the DDP average, train_emage_audio.py:251)."""
+
+    def __init__(self, plan, device="cpu", group=None):
+        self.group = group
+        self.tags = [tag for tag, _ in plan]
+        self.flat, self.grads, self._work = [], {}, []
+        for _tag, params in plan:
+            n = sum(p.numel() for _, p in params)
+            buf = torch.zeros(n, dtype=torch.float32, device=device)
+            off = 0
+            for name, p in params:
+                self.grads[name] = buf[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self.flat.append(buf)
+
+    def nbytes(self):
+        return [b.numel() * 4 for b in self.flat]
+
+    def reduce(self, i):
+        if dist.is_available() and dist.is_initialized():
+            self._work.append(dist.all_reduce(self.flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(self.group)
+            for b in self.flat:
+                b.div_(world)
+
+
+def sync_batch_stats(sums, sq_sums, count, group=None):
+    """SyncBatchNorm's exchange (train_emage_audio.py:248): per-channel sum and sum of squares of several BatchNorm layers
+    plus their element counts, summed over ranks in ONE all-reduce.  sums / sq_sums: lists of (C_i,) tensors, count: list
+    of numbers.  Returns (means, biased variances) lists over the GLOBAL batch."""
+    flat = torch.cat([torch.cat([s.reshape(-1), q.reshape(-1), torch.as_tensor([float(c)], dtype=s.dtype, device=s.device)])
+                      for s, q, c in zip(sums, sq_sums, count)])
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    means, variances, off = [], [], 0
+    for s in sums:
+        c = s.numel()
+        tot_s, tot_q, n = flat[off:off + c], flat[off + c:off + 2 * c], flat[off + 2 * c]
+        mean = tot_s / n
+        means.append(mean)
+        variances.append(tot_q / n - mean * mean)
+        off += 2 * c + 1
+    return means, variances

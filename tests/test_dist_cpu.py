@@ -46,3 +46,55 @@ def test_single_process_is_identity():
     from pantomatrix_amd import dist as pd
     assert pd.shard_clips(5, 0, 1) == [0, 1, 2, 3, 4]
     assert pd.max_over_ranks(1.5) == 1.5 and pd.job_throughput(240.0, 2.0) == 120.0
+
+
+def _train_exchange_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import common
+    from pantomatrix_amd import dist as pd
+    assert pd.init("gloo") is not None
+    model, _ = common.product_models(precision="f16x3")
+    plan, unused = pd.emage_bucket_plan(list(model.named_parameters()))
+    buckets = pd.GradientBuckets(plan)
+    g = torch.Generator().manual_seed(100 + rank)
+    for name, view in buckets.grads.items():                      # what a backward would write: rank-specific gradients
+        view.copy_(torch.randn(view.shape, generator=g))
+    local = {k: v.clone() for k, v in list(buckets.grads.items())[::37]}
+    for i in range(len(buckets.flat)):                            # backward order: heads first, encoders last
+        buckets.reduce(i)
+    buckets.wait()
+    # SyncBatchNorm statistics of two layers in one message
+    x = [torch.randn(5 + rank, 64, generator=g), torch.randn(7, 128, generator=g) + rank]
+    means, variances = pd.sync_batch_stats([t.sum(0) for t in x], [(t * t).sum(0) for t in x], [t.shape[0] for t in x])
+    np_ = lambda t: t.detach().numpy().copy()                     # by value: the parent reads after this process is gone
+    q.put((rank, [t for t, _ in plan], buckets.nbytes(), len(unused), {k: np_(v) for k, v in local.items()},
+           {k: np_(buckets.grads[k]) for k in local}, [np_(t) for t in x], [np_(t) for t in means], [np_(t) for t in variances]))
+    pd.finalize()
+
+
+def test_training_exchange_on_two_gloo_ranks():
+    """The training path's only collectives: bucketed gradient all-reduce in backward order and the
+    SyncBatchNorm statistics exchange, on 2 gloo ranks with the real EMAGE parameter tree."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, tags, nbytes, n_unused, loc0, red0, x0, m0, v0), (_, _, _, _, loc1, red1, x1, m1, v1) = res
+    assert tags == ["heads", "cross", "self_face", "encoders"] and n_unused > 0        # the unused template layers get no bucket
+    assert 500e6 < sum(nbytes) < 600e6 and min(nbytes) > 30e6                           # ~555 MB fp32 (SURVEY §8d) in 4 large messages
+    import numpy as np
+    for k in loc0:                                                                     # every rank ends with the mean gradient
+        want = (loc0[k] + loc1[k]) / 2
+        assert np.allclose(red0[k], want, atol=1e-6) and np.array_equal(red0[k], red1[k]), k
+    for i in range(2):                                                                 # global-batch statistics == one big batch
+        allx = np.concatenate([x0[i], x1[i]])
+        assert np.allclose(m0[i], allx.mean(0), atol=1e-5) and np.allclose(v0[i], allx.var(0), atol=1e-4)
+        assert np.array_equal(m0[i], m1[i])
