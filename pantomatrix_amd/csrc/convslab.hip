@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     unsigned char* slab = smem;                                   // ROWS * RBS
     unsigned char* wring = smem + ROWS * RBS;                     // NS * WSTAGE
-    float* s_x = (float*)(wring + NS * WSTAGE);                   // SRC_WAVE: the waveform span of this tile
+    float* s_x = (float*)(wring + NS * WSTAGE);                   // SRC_WAVE: the waveform span of this tile, then w1 | wds | b1 | bds
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,6 +116,18 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
             const int xi = x0 + i;
             s_x[i] = (xi >= 0 && xi < p.Lw) ? src[xi] : 0.f;
         }
+        // the two first-layer filters (conv1, shortcut) and their biases: staged once per block with coalesced loads; the
+        // register copies below then come from LDS (16-byte reads) instead of ~120 latency-bound global loads per thread
+        float* s_w1 = s_x + ((span + 3) & ~3);
+        float* s_wd = s_w1 + C * MAXT;
+        float* s_b1 = s_wd + C * MAXT;
+        float* s_bd = s_b1 + C;
+        for (int i = tid; i < C * MAXT; i += 512) {
+            const int c = i / MAXT, k = i - c * MAXT;
+            s_w1[i] = k < t1 ? p.w1[c * t1 + k] : 0.f;
+            s_wd[i] = k < t1 ? p.wds[c * t1 + k] : 0.f;
+        }
+        for (int i = tid; i < C; i += 512) { s_b1[i] = p.b1[i]; s_bd[i] = p.bds[i]; }
         __syncthreads();
         // A thread owns one 8-channel item column q (the two 4-channel groups of one K-chunk pair) and every RSTEP-th row:
         // the 15 filter taps of 4 channels stay in registers, each waveform sample is read from LDS once per row and phase
@@ -130,9 +142,12 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
             float wr[4][MAXT], bb[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                bb[c] = p.b1[cgrp[ph] + c];
+                bb[c] = s_b1[cgrp[ph] + c];
 #pragma unroll
-                for (int k = 0; k < MAXT; ++k) wr[c][k] = k < t1 ? p.w1[(cgrp[ph] + c) * t1 + k] : 0.f;
+                for (int k4 = 0; k4 < MAXT / 4; ++k4) {
+                    const float4 w4 = *(const float4*)&s_w1[(cgrp[ph] + c) * MAXT + 4 * k4];
+                    wr[c][4 * k4] = w4.x; wr[c][4 * k4 + 1] = w4.y; wr[c][4 * k4 + 2] = w4.z; wr[c][4 * k4 + 3] = w4.w;
+                }
             }
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
@@ -304,14 +319,20 @@ __global__ __launch_bounds__(512, 1) void conv_slab_kernel(SlabArgs p) {
             // the downsample shortcut of block 0 for this lane's outputs: conv(wav) + bias, no activation (P:288-290); the
             // filter taps of 4 columns at a time in registers (loaded once for both rows), the row's samples read from LDS
             const int t1 = p.taps1;
+            const int span = (ROWS - 1) * p.stride1 + t1;
+            const float* s_wd = s_x + ((span + 3) & ~3) + C * MAXT;
+            const float* s_bd = s_wd + C * MAXT + C;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 float wd[4][MAXT], bd[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    bd[c] = p.bds[n + 4 * hf + c];
+                    bd[c] = s_bd[n + 4 * hf + c];
 #pragma unroll
-                    for (int k = 0; k < MAXT; ++k) wd[c][k] = k < t1 ? p.wds[(n + 4 * hf + c) * t1 + k] : 0.f;
+                    for (int k4 = 0; k4 < MAXT / 4; ++k4) {
+                        const float4 w4 = *(const float4*)&s_wd[(n + 4 * hf + c) * MAXT + 4 * k4];
+                        wd[c][4 * k4] = w4.x; wd[c][4 * k4 + 1] = w4.y; wd[c][4 * k4 + 2] = w4.z; wd[c][4 * k4 + 3] = w4.w;
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
@@ -357,7 +378,7 @@ int launch_slab(SlabArgs& a, hipStream_t s) {
                               // and C = 128 in fp32 bytes (74 KiB slab + 2 x 32 KiB ring) only fits the 160 KiB this way
     a.tiles_l = (a.L + SBM - 1) / SBM;
     size_t lds = (size_t)(SBM + MAXT) * C * ES + (size_t)NS * 2 * C * 128;
-    if (SRC == SRC_WAVE) lds += ((size_t)((SBM + MAXT - 1) * a.stride1 + a.taps1 + 3) / 4 * 4) * sizeof(float);
+    if (SRC == SRC_WAVE) lds += ((size_t)((SBM + MAXT - 1) * a.stride1 + a.taps1 + 3) / 4 * 4 + 2 * (size_t)C * MAXT + 2 * C) * sizeof(float);
     if (lds > 160 * 1024) return EMAGE_EINVAL;
     auto kern = conv_slab_kernel<T, X3, C, SRC, NS>;
     // per instantiation, once (thread-safe static initialisation): allow more than 64 KiB of dynamic LDS

@@ -105,6 +105,93 @@ __global__ __launch_bounds__(256) void vq_argmin_mfma(const float* __restrict__ 
     }
 }
 
+// Large-N form (N >= 16 384): 64 rows per block — wave w owns rows 16w..16w+15 and scores ALL code tiles; each 16-code tile
+// is staged ONCE per block in LDS (double-buffered, rows padded by 16 B so the 16 lanes of a ds_read_b128 group hit 16
+// different bank groups) instead of being fetched from L2 by every 16-row block: 4x less codebook traffic (at N = 1 M the
+// 16-row kernel moves 17 GB of codebook through L2 for 1 GB of input).  Same arithmetic per (row, code) as above — same
+// chunk order into the exact-fp32 MFMA chain, same association — so the indices are identical.
+template <int D>
+__global__ __launch_bounds__(256) void vq_argmin_mfma_rows64(const float* __restrict__ z, int ldz,
+                                                             const float* __restrict__ cb, int64_t* __restrict__ idx, IdxView iv,
+                                                             int N, int K) {
+    constexpr int NS = D / 16;
+    constexpr int LDC = D + 4;                             // padded LDS row (floats)
+    __shared__ __attribute__((aligned(16))) float s_cb[2][16 * LDC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int r0 = blockIdx.x * 64 + wave * 16;
+
+    const int zrow = min(r0 + fr, N - 1);
+    const float* zp = z + (long)zrow * ldz + fg * 4;
+    uint4 zf[NS];
+    float z2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float4 v = *(const float4*)(zp + s * 16);
+        zf[s] = __builtin_bit_cast(uint4, v);
+        z2 += v.x * v.x; z2 += v.y * v.y; z2 += v.z * v.z; z2 += v.w * v.w;
+    }
+    z2 += __shfl_xor(z2, 16);
+    z2 += __shfl_xor(z2, 32);
+    float z2r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z2r[r] = __shfl(z2, fg * 4 + r);
+
+    // cooperative tile load: 16 codes x D floats = 4*D float4; thread t moves float4 t, t+256, ...
+    const int ktiles = (K + 15) >> 4;
+    auto stage = [&](int ct, int buf) {
+        for (int i = threadIdx.x; i < 16 * (D / 4); i += 256) {
+            const int code = i / (D / 4), c4 = i - code * (D / 4);
+            const int k = min(ct * 16 + code, K - 1);
+            *(float4*)&s_cb[buf][code * LDC + c4 * 4] = *(const float4*)(cb + (long)k * D + c4 * 4);
+        }
+    };
+    float best_d[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int best_i[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    stage(0, 0);
+    __syncthreads();
+    for (int ct = 0; ct < ktiles; ++ct) {
+        const int buf = ct & 1;
+        if (ct + 1 < ktiles) stage(ct + 1, buf ^ 1);       // the other buffer was last read two barriers ago
+        const int code = ct * 16 + fr;
+        const float* ep = &s_cb[buf][fr * LDC + fg * 4];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float e2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 v = *(const float4*)(ep + s * 16);
+            e2 += v.x * v.x; e2 += v.y * v.y; e2 += v.z * v.z; e2 += v.w * v.w;
+            acc = Elem<float>::mma(zf[s], __builtin_bit_cast(uint4, v), acc);
+        }
+        e2 += __shfl_xor(e2, 16);
+        e2 += __shfl_xor(e2, 32);
+        if (code < K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = __fsub_rn(__fadd_rn(z2r[r], e2), 2.0f * acc[r]);
+                take_min(best_d[r], best_i[r], d, code);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            const float od = __shfl_xor(best_d[r], m);
+            const int oi = __shfl_xor(best_i[r], m);
+            take_min(best_d[r], best_i[r], od, oi);
+        }
+    }
+    if (fr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + fg * 4 + r;
+            if (row < N) idx[idx_at(iv, row)] = (int64_t)best_i[r];
+        }
+    }
+}
+
 // Generic-D fallback: one wave per row, lane c scores codes c, c+64, ... with an fmaf chain.
 __global__ __launch_bounds__(256) void vq_argmin_generic(const float* __restrict__ z, int ldz,
                                                          const float* __restrict__ cb, int64_t* __restrict__ idx, IdxView iv,
@@ -172,7 +259,9 @@ extern "C" int emage_vq_argmin_f32(const float* z, int ldz, const float* codeboo
     hipStream_t s = (hipStream_t)stream;
     const IdxView iv{idx_rows, idx_ld, 1};
     const bool aligned = (ldz % 4 == 0) && !(((uintptr_t)z | (uintptr_t)codebook) & 15);
-    if (D == 256 && aligned)
+    if (D == 256 && aligned && N >= 16384)
+        hipLaunchKernelGGL((vq_argmin_mfma_rows64<256>), dim3((N + 63) / 64), dim3(256), 0, s, z, ldz, codebook, idx, iv, N, K);
+    else if (D == 256 && aligned)
         hipLaunchKernelGGL((vq_argmin_mfma<256>), dim3((N + 15) / 16), dim3(256), 0, s, z, ldz, codebook, idx, iv, N, K);
     else
         hipLaunchKernelGGL(vq_argmin_generic, dim3((N + 3) / 4), dim3(256), 0, s, z, ldz, codebook, idx, iv, N, K, D);

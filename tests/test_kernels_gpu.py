@@ -198,6 +198,20 @@ def test_layernorm_add_pack_cast_gather(dtype):
     assert torch.equal(ops.gather_rows(table.to(DEV), spk.to(DEV).expand(6, 64), dtype).cpu(), F.gather_rows(table, spk.expand(6, 64), dtype))
 
 
+def test_vq_argmin_large_n_kernel_equals_small_n_kernel():
+    """N >= 16 384 takes the 64-rows-per-block kernel with the code tiles staged in LDS: the same per-(row, code)
+    arithmetic, hence the same indices as the 16-row kernel run on slices of the same input (and as torch on the CPU)."""
+    g = _g(77)
+    n = 40000 + 7                                   # not a multiple of 64
+    z, cb = torch.randn(n, 256, generator=g), torch.randn(250, 256, generator=g)      # K not a multiple of 16
+    zd, cbd = z.to(DEV), cb.to(DEV)
+    big = ops.vq_argmin(zd, cbd)
+    small = torch.cat([ops.vq_argmin(zd[i:i + 8192], cbd) for i in range(0, n, 8192)])
+    assert torch.equal(big, small)
+    ref = orc.vq_nearest(z[:4096].unsqueeze(0), cb).reshape(-1)
+    assert torch.equal(big[:4096].cpu(), ref)
+
+
 @pytest.mark.parametrize("n,k,d", [(4096, 256, 256), (7680, 256, 256), (33, 256, 256), (500, 100, 64), (200, 37, 240)])
 def test_vq_argmin_indices_exact(n, k, d):
     g = _g(n + k)
