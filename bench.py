@@ -217,11 +217,38 @@ def profile_kernels(runner, model, vq):
             setattr(M.EmageAudioModel, nm, fn)
         for p, c in zip(parts, concurrent):
             p.concurrent = c
-    # subtract the calibrated marker-pair cost from every bracket (a kernel bracket contains exactly one pair)
-    return [(tag, sc, max(e0.elapsed_time(e1) - marker_ms, 0.0), flops, byts) for (e0, e1, sc, tag, flops, byts) in records], marker_ms
+    return [(tag, sc, e0.elapsed_time(e1), flops, byts) for (e0, e1, sc, tag, flops, byts) in records], marker_ms
 
 
-def roofline_report(records, precision, ms_per_step):
+def serialized_graph_ms(model, vq, args, n_samples, audio, steps):
+    """Wall time per step of the SAME launch sequence captured as a single-stream hipGraph (no fork / join lanes): with
+    nothing to overlap, this is the sum of the kernels' device times (rocprofv3 of that graph shows no gaps)."""
+    from pantomatrix_amd.runtime import ClipRunner
+    parts = [model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion]
+    saved = [p.concurrent for p in parts]
+    try:
+        for p in parts:
+            p.concurrent = False
+        r = ClipRunner(model, vq, args.batch, n_samples, use_graph=True)
+        r(audio)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r(audio)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps
+    finally:
+        for p, c in zip(parts, saved):
+            p.concurrent = c
+
+
+def roofline_report(records, precision, ms_per_step, serial_ms=None):
+    # An eager bracket [event, kernel, event] also contains the kernel's dispatch gap (~2 us), which a graph replay hides
+    # behind the previous kernel: the brackets give the DISTRIBUTION over kernels, their sum is normalised to the measured
+    # wall time of the single-stream graph of the same sequence.
+    raw_total = sum(r[2] for r in records)
+    k = (serial_ms / raw_total) if (serial_ms and raw_total > 0) else 1.0
+    records = [(tag, sc, ms * k, flops, byts) for tag, sc, ms, flops, byts in records]
     fam = {}
     for tag, sc, ms, flops, byts in records:
         f = fam.setdefault(tag, [0, 0.0, 0.0, 0.0])
@@ -248,10 +275,12 @@ def roofline_report(records, precision, ms_per_step):
         "algorithmic_gflop_per_launch": flops / cnt / 1e9,
         "note": "algorithmic flops (2*M*N*K, unpadded K) / serialized kernel time; in f16x3 every product issues 3 MFMAs, so the "
                 "MFMA pipes are busy for about 3x this fraction",
-        "how": "one extra eager pass of the timed launch sequence on ONE stream, HIP-event pair per kernel, device backlogged so "
-               "the host runs ahead; the timed region replays the same sequence as a hipGraph with independent chains on "
-               "parallel branches, hence ms_per_step < serialized_kernel_ms",
-        "serialized_kernel_ms": total_ms, "timed_ms_per_step": ms_per_step,
+        "how": "the timed launch sequence captured as a SINGLE-stream hipGraph and timed (serialized_kernel_ms = its wall time per step = "
+               "sum of kernel device times); its split over kernels from one extra eager pass with a HIP-event pair per kernel (device "
+               "backlogged so the host runs ahead), normalised to that wall time (the eager brackets also contain each kernel's ~2 us "
+               "dispatch gap: event_bracket_sum_ms).  The timed region replays the same sequence with independent chains on parallel "
+               "graph branches, hence ms_per_step < serialized_kernel_ms",
+        "serialized_kernel_ms": total_ms, "event_bracket_sum_ms": raw_total, "timed_ms_per_step": ms_per_step,
         "share_of_kernel_time": ms / total_ms if total_ms else None,
         "kernel_time_ms_by_family": {k: round(v[1], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
         "launches_by_family": {k: v[0] for k, v in fam.items()},
@@ -334,7 +363,7 @@ def build(precision, device, args):
     for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.concurrent = not args.no_concurrent
     n_samples = synthetic.samples_for_frames(args.frames)
-    runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph)
+    runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph, main_priority=args.main_priority)
     return model, vq, runner, n_samples
 
 
@@ -353,6 +382,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
     ap.add_argument("--no-slab-convs", action="store_true", help="A/B: WavEncoder through emage_wav_conv_in + emage_gemm only (same bits)")
+    ap.add_argument("--main-priority", action="store_true", help="experiment: capture the clip graph on a high-priority stream")
     ap.add_argument("--gemm-variant", type=int, default=-1, help="experiments: emage_set_tuning key 2 (tile-heuristic variant)")
     ap.add_argument("--gemm-dbg", type=int, default=0, help="experiments: emage_set_tuning key 1 mask (8: sc1 result stores, 16: nt)")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
@@ -414,9 +444,9 @@ def main():
                                 "note": "audio batch copied pinned-host -> HBM inside every timed step; `value` above is HBM-resident"}
 
     if rank == 0 and not args.no_roofline:
-        records, marker_ms = profile_kernels(runner, model, vq)
-        result["roofline"] = roofline_report(records, args.precision, result["ms_per_step"])
-        result["roofline"]["event_marker_us_subtracted"] = 1e3 * marker_ms
+        records, _marker_ms = profile_kernels(runner, model, vq)
+        serial_ms = None if args.no_graph else serialized_graph_ms(model, vq, args, n_samples, audio, args.steps)
+        result["roofline"] = roofline_report(records, args.precision, result["ms_per_step"], serial_ms)
         if world == 1:
             result["roofline"].setdefault("vq_argmin", {})["n_1m"] = vq_argmin_large(dev)
     if world == 1 and args.also:

@@ -245,6 +245,14 @@ int emage_lstm_step(int dtype, const float* h_prev, int ld_hprev, const void* w_
                     const float* gates_x, int ld_gx, float* cstate, int ldc, float* h_out, int ld_hout,
                     int B, int H, void* stream);
 
+/* Both directions of one layer in one launch: problem 0 = forward direction at its time step, problem 1 = backward direction at its
+ * own; arguments as for emage_lstm_step, per direction where they differ (gate rows / cell states / outputs share their row strides). */
+int emage_lstm_step_pair(int dtype, const float* h_prev0, const float* h_prev1, int ld_hprev0, int ld_hprev1,
+                         const void* w_hh0, const void* w_hh1, float w_scale0, float w_scale1, float a_scale,
+                         const float* gates_x0, const float* gates_x1, int ld_gx,
+                         float* cstate0, float* cstate1, int ldc, float* h_out0, float* h_out1, int ld_hout,
+                         int B, int H, void* stream);
+
 /* DisCo's content blend (D:244-247): out = softmax(sel[:, 0:2])[0] * c1 + softmax(...)[1] * c2, rows of C channels. */
 int emage_softmax2_mix(const float* sel, int ld_sel, const float* c1, int ld1, const float* c2, int ld2,
                        float* out, int ldo, int M, int C, void* stream);

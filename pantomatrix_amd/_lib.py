@@ -34,6 +34,7 @@ SIGNATURES = {
     "emage_merge_parts": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p],
     "emage_velocity_to_position": [_p, _i, _i, _p, _i, _f, _p, _i, _i, _p],
     "emage_lstm_step": [_i, _p, _i, _p, _f, _f, _p, _i, _p, _i, _p, _i, _i, _i, _p],
+    "emage_lstm_step_pair": [_i, _p, _p, _i, _i, _p, _p, _f, _f, _f, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_softmax2_mix": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_lstm_inputs": [_p, _p, _i, _p, _l, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "emage_rot6d_scatter": [_p, _i, _p, _p, _i, _i, _p],

@@ -24,6 +24,17 @@ __global__ __launch_bounds__(256, 3) void lstm_step_kernel(GemmArgs p) {
     gemm_pipe_tile<float, 64, 64, 2, 2, 2, 8, false, X3, EPI_LSTM>(p, tile_m * 64, tile_n * 64, smem);
 }
 
+// Both directions of a bidirectional layer in ONE launch: blockIdx.y picks the direction's problem (its own time step, h_prev,
+// W_hh, gate rows, cell state, output columns).  The two recurrences are independent, so this halves the launch count of the
+// sequential part and makes the two problems share the CUs by construction instead of by stream scheduling.
+template <bool X3>
+__global__ __launch_bounds__(256, 3) void lstm_step_pair_kernel(GemmArgs p0, GemmArgs p1) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[pipe_smem_bytes<float, 64, 64, 2, 8>()];
+    const GemmArgs& p = blockIdx.y == 0 ? p0 : p1;
+    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    gemm_pipe_tile<float, 64, 64, 2, 2, 2, 8, false, X3, EPI_LSTM>(p, tile_m * 64, tile_n * 64, smem);
+}
+
 __global__ __launch_bounds__(256) void softmax2_mix_kernel(const float* __restrict__ sel, int lds, const float* __restrict__ c1, int ld1,
                                                            const float* __restrict__ c2, int ld2, float* __restrict__ out, int ldo, int M, int C) {
     const long total = (long)M * C;
@@ -83,14 +94,49 @@ inline int grid_for(long total) {
 
 }  // namespace
 
-extern "C" int emage_lstm_step(int dtype, const float* h_prev, int ld_hprev, const void* w_hh, float w_scale, float a_scale,
-                               const float* gates_x, int ld_gx, float* cstate, int ldc, float* h_out, int ld_hout,
-                               int B, int H, void* stream) {
+static int lstm_args(GemmArgs& a, int dtype, const float* h_prev, int ld_hprev, const void* w_hh, float w_scale, float a_scale,
+                     const float* gates_x, int ld_gx, float* cstate, int ldc, float* h_out, int ld_hout, int B, int H) {
     if (!h_prev || !w_hh || !gates_x || !cstate || !h_out || B <= 0 || H <= 0 || H % 64 != 0) return EMAGE_EINVAL;
     if (dtype != EMAGE_F32 && dtype != EMAGE_F16X3) return EMAGE_EINVAL;
     if (ld_hprev % 4 || ld_hprev < H || ld_gx % 8 || ld_gx < 4 * H || ldc % 2 || ldc < H || ld_hout % 4 || ld_hout < H) return EMAGE_EINVAL;
     if (((uintptr_t)h_prev | (uintptr_t)w_hh | (uintptr_t)gates_x | (uintptr_t)h_out) & 15 || ((uintptr_t)cstate & 7)) return EMAGE_EINVAL;
     if (dtype == EMAGE_F16X3 && !(a_scale > 0.f && w_scale > 0.f)) return EMAGE_EINVAL;
+    a = GemmArgs{};
+    a.A = h_prev; a.W = w_hh; a.res = gates_x; a.out_f32 = h_out; a.cstate = cstate;
+    a.lda = ld_hprev; a.ldr = ld_gx; a.ldf = ld_hout; a.ldc = ldc; a.res_is_f32 = 1;
+    a.M = B; a.N = 4 * H; a.K = H; a.Cp = H; a.taps = 1; a.stride = 1; a.pad = 0; a.Lin = B; a.Lout = B;
+    a.t_col0 = a.N; a.t_rows = 1;
+    a.a_scale = dtype == EMAGE_F16X3 ? a_scale : 1.f;
+    a.o_scale = dtype == EMAGE_F16X3 ? 1.f / (a_scale * w_scale) : 1.f;
+    a.tiles_m = (B + 63) / 64; a.tiles_n = (4 * H) / 64;
+    return 0;
+}
+
+extern "C" int emage_lstm_step_pair(int dtype, const float* h_prev0, const float* h_prev1, int ld_hprev0, int ld_hprev1,
+                                    const void* w_hh0, const void* w_hh1, float w_scale0, float w_scale1, float a_scale,
+                                    const float* gates_x0, const float* gates_x1, int ld_gx,
+                                    float* cstate0, float* cstate1, int ldc, float* h_out0, float* h_out1, int ld_hout,
+                                    int B, int H, void* stream) {
+    GemmArgs a0, a1;
+    int rc = lstm_args(a0, dtype, h_prev0, ld_hprev0, w_hh0, w_scale0, a_scale, gates_x0, ld_gx, cstate0, ldc, h_out0, ld_hout, B, H);
+    if (rc) return rc;
+    rc = lstm_args(a1, dtype, h_prev1, ld_hprev1, w_hh1, w_scale1, a_scale, gates_x1, ld_gx, cstate1, ldc, h_out1, ld_hout, B, H);
+    if (rc) return rc;
+    const dim3 grid(a0.tiles_m * a0.tiles_n, 2), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EMAGE_F16X3) hipLaunchKernelGGL((lstm_step_pair_kernel<true>), grid, block, 0, s, a0, a1);
+    else hipLaunchKernelGGL((lstm_step_pair_kernel<false>), grid, block, 0, s, a0, a1);
+    return launch_status();
+}
+
+extern "C" int emage_lstm_step(int dtype, const float* h_prev, int ld_hprev, const void* w_hh, float w_scale, float a_scale,
+                               const float* gates_x, int ld_gx, float* cstate, int ldc, float* h_out, int ld_hout,
+                               int B, int H, void* stream) {
+    {
+        GemmArgs chk;
+        const int rc = lstm_args(chk, dtype, h_prev, ld_hprev, w_hh, w_scale, a_scale, gates_x, ld_gx, cstate, ldc, h_out, ld_hout, B, H);
+        if (rc) return rc;
+    }
     GemmArgs a{};
     a.A = h_prev; a.W = w_hh; a.res = gates_x; a.out_f32 = h_out; a.cstate = cstate;
     a.lda = ld_hprev; a.ldr = ld_gx; a.ldf = ld_hout; a.ldc = ldc; a.res_is_f32 = 1;

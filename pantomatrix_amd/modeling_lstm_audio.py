@@ -9,9 +9,9 @@ Same public surface as
 * WavEncoder (32..128 channels, 15 fps): `emage_wav_conv_in` + implicit-GEMM convs (the EMAGE WavEncoder code, narrower);
 * MLPs, the selector, and the LSTM input projection x W_ih^T of ALL time steps (both directions stacked, one launch per
   layer): `emage_gemm`, writing straight into the column blocks of the next operand (no concatenation copies);
-* the recurrence: `emage_lstm_step`, one launch per time step and direction (h W_hh^T on MFMA with the LSTM cell in the
-  epilogue), forward and backward directions on two stream lanes; a whole forward is captured in a hipGraph by
-  `LstmClipRunner`;
+* the recurrence: `emage_lstm_step_pair`, one launch per time step carrying BOTH directions (h W_hh^T on MFMA with the LSTM
+  cell in the epilogue; the forward direction at step s beside the backward one at step T-1-s); a whole forward is captured
+  in a hipGraph by `LstmClipRunner`;
 * rot-6D -> axis-angle -> 55 SMPL-X joints: `emage_rot6d_scatter`.
 Precision: "f16x3" (default, fp32 storage + split-f16 MFMA: fp32-grade, what the parity tests use) or "fp32".
 """
@@ -23,7 +23,6 @@ from . import ops, spec
 from ._lib import F32, F16X3
 from .configuration_emage_audio import _AttrConfig
 from .modeling_emage_audio import _EmageModule, _WavEncoderMixin, _Ctx, _rup
-from .streams import Fork
 
 
 class DiscoAudioConfig(_AttrConfig):
@@ -122,15 +121,14 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
             hseq = torch.empty(b * t, 2 * hid, dtype=torch.float32, device=cx.dev)
             g3, h3 = gx.view(b, t, 8 * hid), hseq.view(b, t, 2 * hid)
             cstate = torch.zeros(2, b, hid, dtype=torch.float32, device=cx.dev)
-            with Fork(cx.dev, 2, self.concurrent) as fk:
-                for d in range(2):                                                   # the two directions are independent chains
-                    with fk.lane(d):
-                        w = cx.pk.w[f"{name}.hh.{k}.{d}"]
-                        prev = zeros
-                        for s in (range(t) if d == 0 else range(t - 1, -1, -1)):
-                            cur = h3[:, s, d * hid:(d + 1) * hid]
-                            ops.lstm_step(cx.gdt, prev, w["w"], g3[:, s, d * 4 * hid:(d + 1) * 4 * hid], cstate[d], cur, w_scale=w["ws"])
-                            prev = cur
+            w0, w1 = cx.pk.w[f"{name}.hh.{k}.0"], cx.pk.w[f"{name}.hh.{k}.1"]
+            prev = [zeros, zeros]
+            for s in range(t):                                                       # step s of the forward direction runs beside
+                sf, sb = s, t - 1 - s                                                # step t-1-s of the backward one, in ONE launch
+                cur = [h3[:, sf, :hid], h3[:, sb, hid:]]
+                ops.lstm_step_pair(cx.gdt, (prev[0], w0["w"], g3[:, sf, :4 * hid], cstate[0], cur[0], w0["ws"]),
+                                   (prev[1], w1["w"], g3[:, sb, 4 * hid:], cstate[1], cur[1], w1["ws"]))
+                prev = cur
             x = hseq
         return x
 

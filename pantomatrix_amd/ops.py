@@ -407,6 +407,25 @@ def lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, *, w_scale=1.0, a_sca
     _lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale))
 
 
+@_op("lstm_step_pair", "(int dtype, Tensor h_prev0, Tensor h_prev1, Tensor w_hh0, Tensor w_hh1, Tensor gates_x0, Tensor gates_x1, Tensor(a!) cstate0, "
+                       "Tensor(b!) cstate1, Tensor(c!) h_out0, Tensor(d!) h_out1, float w_scale0, float w_scale1, float a_scale) -> ()")
+def _lstm_step_pair(dtype, h_prev0, h_prev1, w_hh0, w_hh1, gates_x0, gates_x1, cstate0, cstate1, h_out0, h_out1, w_scale0, w_scale1, a_scale):
+    b, h = cstate0.shape
+    ld = lambda t: t.stride(0) if b > 1 else max(t.shape[1], t.stride(0))
+    assert ld(gates_x0) == ld(gates_x1) and ld(cstate0) == ld(cstate1) and ld(h_out0) == ld(h_out1)
+    check(_lib.load().emage_lstm_step_pair(dtype, _ptr(h_prev0), _ptr(h_prev1), ld(h_prev0), ld(h_prev1), _ptr(w_hh0), _ptr(w_hh1), w_scale0, w_scale1,
+                                           a_scale, _ptr(gates_x0), _ptr(gates_x1), ld(gates_x0), _ptr(cstate0), _ptr(cstate1), ld(cstate0),
+                                           _ptr(h_out0), _ptr(h_out1), ld(h_out0), b, h, _stream()), "lstm_step_pair")
+
+
+def lstm_step_pair(dtype, fwd, bwd, *, a_scale=None):
+    """One time step of BOTH directions of a layer in one launch.  fwd / bwd: (h_prev, w_hh, gates_x, cstate, h_out, w_scale)
+    of the forward direction at its step and of the backward direction at its step (see `lstm_step`)."""
+    _dev(fwd[0])
+    _lstm_step_pair(dtype, fwd[0], bwd[0], fwd[1], bwd[1], fwd[2], bwd[2], fwd[3], bwd[3], fwd[4], bwd[4], float(fwd[5]), float(bwd[5]),
+                    float(A_SCALE_F16X3 if a_scale is None else a_scale))
+
+
 @_op("softmax2_mix", "(Tensor sel, Tensor c1, Tensor c2, Tensor(a!) out) -> ()")
 def _softmax2_mix(sel, c1, c2, out):
     m, c = c1.shape

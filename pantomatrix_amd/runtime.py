@@ -19,7 +19,10 @@ import torch
 
 class ClipRunner:
     def __init__(self, model, vq_model, batch: int, n_samples: int, use_graph: bool = True, warmup: int = 2,
-                 sub_batches: int = 1):
+                 sub_batches: int = 1, main_priority: bool = False):
+        """main_priority (experiment): capture on a HIGH-priority stream, so the launch chain issued on lane 0 (the critical
+        path: motion encoder -> body stack -> decode) outranks the side lanes (face decoder, WavEncoders) when both have
+        ready kernels — if the runtime's graph kernel nodes inherit the capturing stream's priority."""
         self.model, self.vq = model, vq_model
         dev = model.device
         if dev.type != "cuda":
@@ -45,7 +48,8 @@ class ClipRunner:
         torch.cuda.synchronize(dev)
         if use_graph:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # other threads (an RCCL watchdog) may touch the runtime meanwhile
+            kw = dict(stream=torch.cuda.Stream(device=dev, priority=-1)) if main_priority else {}
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local", **kw):   # other threads (an RCCL watchdog) may touch the runtime meanwhile
                 out = self._step()
         self.out = out
         self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)

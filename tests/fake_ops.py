@@ -287,6 +287,15 @@ def lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, *, w_scale=1.0, a_sca
     h_out.copy_(torch.sigmoid(o) * torch.tanh(c_new))
 
 
+def lstm_step_pair(dtype, fwd, bwd, *, a_scale=None):
+    """Both directions in one launch == two independent emage_lstm_step problems."""
+    mark = len(CALLS)
+    for h_prev, w_hh, gates_x, cstate, h_out, w_scale in (fwd, bwd):
+        lstm_step(dtype, h_prev, w_hh, gates_x, cstate, h_out, w_scale=w_scale, a_scale=a_scale)
+    del CALLS[mark:]
+    CALLS.append("lstm_step_pair")
+
+
 def softmax2_mix(sel, c1, c2, out):
     CALLS.append("softmax2_mix")
     w = torch.softmax(sel[:, :2], dim=1)
@@ -323,7 +332,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["conv_slab", "wav_block0", "lstm_step", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

@@ -45,6 +45,43 @@ def test_lstm_step_kernel(dtype, b):
     assert float(got_h[:, 0].abs().max()) == 0.0 and float(got_h[:, :, :hid].abs().max()) == 0.0      # nothing written elsewhere
 
 
+@pytest.mark.parametrize("dtype", [F32, F16X3], ids=["fp32", "f16x3"])
+def test_lstm_step_pair_kernel(dtype):
+    """Both directions in one launch: forward direction at steps 0, 1 beside the backward one at steps T-1, T-2 — the same
+    results as two independent emage_lstm_step launches (and as the CPU restatement)."""
+    g = torch.Generator().manual_seed(5)
+    b, hid, t = 130, 512, 4
+    ws, wp = [], []
+    for _ in range(2):
+        w = torch.randn(4 * hid, hid, generator=g) / hid ** 0.5
+        p, s = (ops.split_f16_weights(w) if dtype == F16X3 else (w, 1.0))
+        wp.append(p)
+        ws.append(s)
+    gx = torch.randn(b, t, 8 * hid, generator=g)
+
+    def run(mod, dev, paired):
+        gxd, c, hseq = gx.to(dev), torch.zeros(2, b, hid, device=dev), torch.zeros(b, t, 2 * hid, device=dev)
+        prev = [torch.zeros(b, hid, device=dev), torch.zeros(b, hid, device=dev)]
+        for s in range(2):
+            sf, sb = s, t - 1 - s
+            cur = [hseq[:, sf, :hid], hseq[:, sb, hid:]]
+            fwd = (prev[0], wp[0].to(dev), gxd[:, sf, :4 * hid], c[0], cur[0], ws[0])
+            bwd = (prev[1], wp[1].to(dev), gxd[:, sb, 4 * hid:], c[1], cur[1], ws[1])
+            if paired:
+                mod.lstm_step_pair(dtype, fwd, bwd)
+            else:
+                for h_prev, w, gt, cs, ho, sc in (fwd, bwd):
+                    mod.lstm_step(dtype, h_prev, w, gt, cs, ho, w_scale=sc)
+            prev = cur
+        return hseq.cpu(), c.cpu()
+
+    pair_h, pair_c = run(ops, DEV, True)
+    single_h, single_c = run(ops, DEV, False)
+    ref_h, ref_c = run(F, "cpu", True)
+    assert torch.equal(pair_h, single_h) and torch.equal(pair_c, single_c)
+    assert float((pair_h - ref_h).abs().max()) < 2e-5 and float((pair_c - ref_c).abs().max()) < 2e-5
+
+
 def test_small_lstm_kernels():
     g = torch.Generator().manual_seed(4)
     m = 300

@@ -39,9 +39,9 @@ def test_forward_matches_golden(golden_dir, kind, precision):
                 assert float((out[k] - ref[k]).abs().max()) < 2e-5, k
         else:
             assert out["motion"].shape[2:] == (43, 6)
-    n_steps = fake_ops.CALLS.count("lstm_step")
+    n_steps = fake_ops.CALLS.count("lstm_step_pair")
     t = out["motion"].shape[1]
-    assert n_steps == (1 if kind == "disco" else 2) * CFG["n_layer"] * 2 * t          # one launch per layer, direction and step
+    assert n_steps == (1 if kind == "disco" else 2) * CFG["n_layer"] * t              # one launch per layer and step (both directions)
 
 
 @pytest.mark.parametrize("kind", ["disco", "camn"])

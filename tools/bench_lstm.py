@@ -46,7 +46,7 @@ def main():
         frames = motion.shape[0] * motion.shape[1]
         line = {"model": kind, "batch": batch, "frames_per_clip": int(motion.shape[1]), "ms_per_step": ms, "value": frames / (ms * 1e-3),
                 "unit": "motion-frames/s (15 fps)", "dtype": "f16x3", "launch": "hipGraph replay", "graph_capture_s": t_capture,
-                "lstm_step_launches": (1 if kind == "disco" else 2) * 4 * 2 * int(motion.shape[1])}
+                "lstm_step_pair_launches": (1 if kind == "disco" else 2) * 4 * int(motion.shape[1])}
         if not args.no_cpu:
             torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
             sd = weights(kind)
