@@ -253,6 +253,27 @@ int emage_lstm_step_pair(int dtype, const float* h_prev0, const float* h_prev1, 
                          float* cstate0, float* cstate1, int ldc, float* h_out0, float* h_out1, int ld_hout,
                          int B, int H, void* stream);
 
+/*
+ * emage_lstm_layer — the whole recurrence of one bidirectional nn.LSTM layer in ONE launch per <= n_CU / (2 * H/16) * 64 clips
+ * (D:190-195,252; C:204-218,261-268): persistent blocks keep their W_hh slice (both split-fp16 planes) and their cell state in
+ * registers for all T steps and exchange h_t through the layer output with agent-scope release / acquire (csrc/lstmseq.hip).
+ * Bit-identical to T emage_lstm_step_pair launches with zero initial state.  dtype: EMAGE_F16X3 only; H = 256 or 512.
+ *   gates_x  (B, T, >= 8H) fp32: the input projection of every step incl. both biases, columns dir * 4H + 4u + g
+ *            (row strides ld_gx_b per clip, ld_gx_t per step, in floats)
+ *   w_hh0/1  the directions' recurrent weights packed like emage_gemm's F16X3 W operand (rows 4u + g), scales w_scale0/1
+ *   hseq     (B, T, >= 2H) fp32 out: h_t of the forward direction in columns [0, H), of the backward one in [H, 2H)
+ *   sync     scratch of emage_lstm_layer_sync_words(B, H) 32-bit words (zeroed by the call, on the stream).  After the
+ *            stream has been synchronised, word EMAGE_LSTM_SYNC_ERROR_WORD of each EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH-word
+ *            record is non-zero if a block gave up waiting for its group (~1 s: blocks not co-resident) — the output
+ *            is then invalid; the Python layer raises.
+ */
+#define EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH 544
+#define EMAGE_LSTM_SYNC_ERROR_WORD 512
+int emage_lstm_layer_sync_words(int B, int H);
+int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, int ld_gx_t, const void* w_hh0, const void* w_hh1,
+                     float w_scale0, float w_scale1, float a_scale, float* hseq, long ld_h_b, int ld_h_t,
+                     int B, int T, int H, unsigned* sync, int sync_words, void* stream);
+
 /* DisCo's content blend (D:244-247): out = softmax(sel[:, 0:2])[0] * c1 + softmax(...)[1] * c2, rows of C channels. */
 int emage_softmax2_mix(const float* sel, int ld_sel, const float* c1, int ld1, const float* c2, int ld2,
                        float* out, int ldo, int M, int C, void* stream);

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 
 F32, BF16, F16X3 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -35,6 +35,8 @@ SIGNATURES = {
     "emage_velocity_to_position": [_p, _i, _i, _p, _i, _f, _p, _i, _i, _p],
     "emage_lstm_step": [_i, _p, _i, _p, _f, _f, _p, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_lstm_step_pair": [_i, _p, _p, _i, _i, _p, _p, _f, _f, _f, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p],
+    "emage_lstm_layer_sync_words": [_i, _i],
+    "emage_lstm_layer": [_i, _p, _l, _i, _p, _p, _f, _f, _f, _p, _l, _i, _i, _i, _i, _p, _i, _p],
     "emage_softmax2_mix": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_lstm_inputs": [_p, _p, _i, _p, _l, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "emage_rot6d_scatter": [_p, _i, _p, _p, _i, _i, _p],

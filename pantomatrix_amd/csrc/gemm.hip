@@ -9,6 +9,8 @@
 
 #include "gemm_tile.h"
 
+namespace emage_dev { extern int g_lstm_layer_dbg; }   // csrc/lstmseq.hip
+
 namespace {
 
 using namespace emage_dev;
@@ -325,5 +327,6 @@ extern "C" int emage_set_tuning(int key, int value) {
     if (key == 0) { g_force_config = value; return 0; }
     if (key == 1) { g_debug_skip = value; return 0; }
     if (key == 2) { g_variant = value; return 0; }
+    if (key == 3) { emage_dev::g_lstm_layer_dbg = value; return 0; }     // csrc/lstmseq.hip: A/B and timing ablations
     return EMAGE_EINVAL;
 }

@@ -1,0 +1,297 @@
+// emage_lstm_layer — the whole recurrence of ONE bidirectional nn.LSTM layer (all time steps, both directions) in one launch
+// (models/disco_audio/modeling_disco_audio.py:190-195,252; models/camn_audio/modeling_camn_audio.py:204-218,261-268).
+//
+// The per-step form (lstm.hip) pays a launch and a cold W_hh stream from L2 for ~1.3 us of MFMA work per step.  Here the
+// recurrent weights never move after the prologue:
+//   * a block owns 16 hidden units (64 gate rows i,f,g,o interleaved per unit) of one direction and 64 clips of the batch;
+//     its 4 waves hold their 16 x H slice of W_hh — both fp16 planes of the split-f16 form — in REGISTERS (128 VGPRs at
+//     H = 512) for the whole sequence; the cell state of the block's (clip, unit) pairs lives in registers too;
+//   * per step: wait until the H/16 blocks of the group (same direction, same clips) have published h_{t-1}, stage the
+//     64 x H slice of h_{t-1} into LDS as fp16 hi / lo planes (split once per block, in the packed-weight chunk order, XOR-
+//     swizzled rows: conflict-free writes and reads), 3 MFMAs per product as in emage_gemm's X3 form — same operand
+//     roles, same order of the three terms, K ascending: BIT-IDENTICAL to the emage_lstm_step sequence — then the LSTM
+//     cell in registers, h_t written into the (B, T, 2H) layer output, which is also the exchange buffer of the next step;
+//   * group barrier = one arrival counter per (direction, 64-clip slice) (the blocks of a group can sit on any XCD; with
+//     8 groups the launch order puts each group on one XCD).  The exchange uses agent-scope ACCESSES, not fences: h_t is
+//     stored write-through (`sc1`), the stores are drained (`s_waitcnt vmcnt(0)`) ahead of the block's relaxed agent-scope
+//     atomic add; readers poll with agent-scope loads and read h_{t-1} with `sc1` buffer loads.  (Release / acquire FENCES at
+//     agent scope cost a whole-L2 write-back / invalidate per wave and step — `buffer_wbl2` / `buffer_inv` — and made the
+//     first version slower than one launch per step: 30-34 us per step against 10, profiles/r02_lstm_layer_breakdown.json.)
+//     Blocks must be co-resident (one per CU: 128 KB of LDS), so
+//     a launch covers at most n_CU / (2 * H/16) slices of 64 clips; larger batches are walked in sequential launches.
+//     The polling loop is bounded: a block that waits longer than ~1 s raises the error word and every block leaves
+//     (the host checks the word) — a lost block can never hang the device.
+#include "common.h"
+#include <math.h>
+#include "gemm_tile.h"
+
+namespace {
+
+using namespace emage_dev;
+
+struct SeqArgs {
+    const float* gx; long ld_gx_b; int ld_gx_t;        // gates_x[b][t][dir * 4H + 4u + g]: the input projection incl. both biases
+    float* hseq; long ld_h_b; int ld_h_t;              // layer output [b][t][dir * H + u]
+    const unsigned char* w[2]; float os[2]; float a_scale;
+    unsigned* sync;                                    // this launch's record: arrival counter of group g at word 32 g (one 128-B line each), error word at 32 * 16
+    int B, T, slices;
+    int dbg;                                           // emage_set_tuning key 3 (tools): timing-only
+                                                       // ablations (wrong results): 2 = no MFMA phase, 4 = no h load / staging, 8 = no group barrier; 16 = two staging phases instead of one (same bits)
+};
+
+constexpr unsigned SPIN_LIMIT = 1u << 20;
+constexpr int MAX_GROUPS = 16;                         // 2 directions x at most 8 slices of 64 clips per launch
+static_assert(EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH == 32 * (MAX_GROUPS + 1), "sync record layout");
+
+__device__ __forceinline__ int swz4(int row) { return (-(row >> 2)) & 3; }
+
+// LDS hand-over inside a step: the staging writes of this wave are done (lgkmcnt) and every wave has arrived — a raw s_barrier,
+// NOT __syncthreads(): its workgroup-release fence would also drain the global loads still in flight for the next K half
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int H, int HALVES>
+__global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
+    constexpr int KT = H / 32, WPG = H / 16;           // K-tiles; blocks per group
+    constexpr unsigned PLANE = KT * 64 * 64;           // one fp16 plane of the 64 x H slice: [kt][row][4 chunks of 16 B]
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    int* s_flag = (int*)(smem + 2 * PLANE);
+
+    const int groups = 2 * p.slices;
+    const int g = blockIdx.x % groups, j = blockIdx.x / groups;
+    const int dir = g / p.slices, slice = g - dir * p.slices;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+    const int b_base = slice * 64;
+    const int unit = j * 16 + wave * 4 + fg;           // the hidden unit whose 4 gates this lane ends up with
+    unsigned* const cnt = p.sync + 32 * g;
+    unsigned* const err = p.sync + 32 * MAX_GROUPS;
+
+    // this wave's 16 gate rows of W_hh, both planes, all K: the first MFMA operand (row = lane & 15, k-chunk = lane >> 4)
+    f16x8 wh[KT], wl[KT];
+    {
+        const unsigned char* wrow = p.w[dir] + (long)(j * 64 + wave * 16 + fr) * (H * 4) + fg * 16;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            wh[kt] = *(const f16x8*)(wrow + kt * 128);
+            wl[kt] = *(const f16x8*)(wrow + kt * 128 + 64);
+        }
+    }
+    const float os = p.os[dir], as = p.a_scale;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int st_row = lane >> 2, st_g = lane & 3;
+
+    // the input projection of a step is fetched one step ahead (it does not depend on the recurrence): its HBM latency hides
+    // behind the previous step instead of sitting on the serial path
+    auto load_gx = [&](int step, float4 (&dst)[4]) {
+        const int tt = dir ? p.T - 1 - step : step;
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            const int b = b_base + fb * 16 + fr;
+            dst[fb] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < p.B) dst[fb] = *(const float4*)(p.gx + (long)b * p.ld_gx_b + (long)tt * p.ld_gx_t + dir * 4 * H + 4 * unit);
+        }
+    };
+    float4 rv[4];
+    load_gx(0, rv);
+
+    for (int s = 0; s < p.T; ++s) {
+        const int t = dir ? p.T - 1 - s : s;
+        float4 rvn[4];
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) rvn[fb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s == 0 && p.T > 1) load_gx(1, rvn);
+        f32x4 acc[4];
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) acc[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if (s > 0) {
+            if (p.dbg & 8) {
+                __syncthreads();
+            } else {
+            if (tid == 0) {
+                const unsigned target = (unsigned)WPG * (unsigned)s;
+                unsigned it = 0;
+                int bad = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    ++it;
+                    if (it > SPIN_LIMIT || ((it & 63u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { bad = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (bad) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_flag = bad;
+            }
+            __syncthreads();
+            if (*s_flag) return;
+            }
+
+            // stage h_{t-1}[b_base .. +64][dir * H .. +H] as split fp16 planes
+            const int tp = dir ? t + 1 : t - 1;
+            const float* hp = p.hseq + (long)b_base * p.ld_h_b + (long)tp * p.ld_h_t + dir * H;      // row 0 of the block's slice at step tp
+            // rows past the batch end lie beyond num_records: the buffer load returns zeros for them, no branch per load
+            const int rows_in = p.B - b_base < 64 ? p.B - b_base : 64;
+            const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hp, 0, (int)((long)(rows_in - 1) * p.ld_h_b * 4) + H * 4, 0x00020000);
+            // staging role: iteration `it` of this wave moves rows 16 * (it & 3) + (lane >> 2), chunk lane & 3 of K-tile
+            // kt_of(it); with HALVES = 2 (A/B only: measured equal, 9.5 vs 9.4 us per step) iterations [0, KT/2) cover the first K half, the rest the
+            // second, and the MFMAs of the first half run while the second half is still arriving
+            constexpr int KH = KT / HALVES;                 // K-tiles per staging phase
+            auto kt_of = [&](int it) { return (it / KH) * KH + wave * (KH / 4) + ((it % KH) >> 2); };
+            u32x4 c0[KT], c1[KT];
+            if (!(p.dbg & 4)) {
+#pragma unroll
+                for (int it = 0; it < KT; ++it) {
+                    const int row = 16 * (it & 3) + st_row, kt = kt_of(it);
+                    const int off = (int)((long)row * p.ld_h_b * 4) + (kt * 32 + st_g * 4) * 4;         // < 2^31: checked by the host entry
+                    c0[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 16));      // aux 16 = sc1: agent-coherent reads
+                    c1[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 64, 0, 16));
+                }
+            }
+            if (s + 1 < p.T) load_gx(s + 1, rvn);          // behind the h loads in the queue, lands during this step
+#pragma unroll
+            for (int half = 0; half < HALVES; ++half) {
+                if (!(p.dbg & 4)) {
+#pragma unroll
+                    for (int i2 = 0; i2 < KH; ++i2) {
+                        const int it = half * KH + i2;
+                        const int row = 16 * (it & 3) + st_row, kt = kt_of(it);
+                        f16x8 hi, lo;
+                        split_f16(c0[it], c1[it], as, hi, lo);
+                        const unsigned off = kt * 4096 + row * 64 + ((st_g ^ swz4(row)) << 4);
+                        *(f16x8*)(smem + off) = hi;
+                        *(f16x8*)(smem + PLANE + off) = lo;
+                    }
+                }
+                lds_barrier();
+                if (!(p.dbg & 2)) {
+#pragma unroll
+                    for (int k2 = 0; k2 < KH; ++k2) {
+                        const int kt = half * KH + k2;
+                        f16x8 ah[4], al[4];
+#pragma unroll
+                        for (int fb = 0; fb < 4; ++fb) {
+                            const int row = fb * 16 + fr;
+                            const unsigned off = kt * 4096 + row * 64 + ((fg ^ swz4(row)) << 4);
+                            ah[fb] = *(const f16x8*)(smem + off);
+                            al[fb] = *(const f16x8*)(smem + PLANE + off);
+                        }
+                        // small terms first, the order of emage_gemm's X3 K-loop; consecutive MFMAs never share an accumulator
+#pragma unroll
+                        for (int fb = 0; fb < 4; ++fb) acc[fb] = mma_f16(wl[kt], ah[fb], acc[fb]);
+#pragma unroll
+                        for (int fb = 0; fb < 4; ++fb) acc[fb] = mma_f16(wh[kt], al[fb], acc[fb]);
+#pragma unroll
+                        for (int fb = 0; fb < 4; ++fb) acc[fb] = mma_f16(wh[kt], ah[fb], acc[fb]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) acc[fb] = acc[fb] * os;
+        }
+
+        // the LSTM cell (gate order i, f, g, o), arithmetic of gemm_tile.h's EPI_LSTM
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            const int b = b_base + fb * 16 + fr;
+            const float gi = sigmoid_f(acc[fb][0] + rv[fb].x), gf = sigmoid_f(acc[fb][1] + rv[fb].y);
+            const float gg = tanhf(acc[fb][2] + rv[fb].z), go = sigmoid_f(acc[fb][3] + rv[fb].w);
+            const float cn = gf * c[fb] + gi * gg;
+            c[fb] = cn;
+            if (b < p.B) {
+                float* dst = p.hseq + (long)b * p.ld_h_b + (long)t * p.ld_h_t + dir * H + unit;
+                __hip_atomic_store(dst, go * tanhf(cn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
+            }
+        }
+
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) rv[fb] = rvn[fb];
+
+        if (s + 1 < p.T) {                              // publish h_t to the group
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's h stores have reached the agent coherence point
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int max_slices_for(int H);
+}
+namespace emage_dev { int g_lstm_layer_dbg = 0; }   // emage_set_tuning key 3 (gemm.hip)
+namespace {
+
+int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return v;
+    }();
+    return n;
+}
+
+int max_slices_for(int H) {                            // co-resident blocks: one per CU, 2 * H/16 per slice of 64 clips
+    int m = device_cus() / (2 * (H / 16));
+    return m > MAX_GROUPS / 2 ? MAX_GROUPS / 2 : m;
+}
+
+template <int H, int HALVES>
+int launch_seq(SeqArgs a, int B, int max_slices, unsigned* sync, hipStream_t s) {
+    constexpr int KT = H / 32, WPG = H / 16;
+    constexpr size_t LDS = 2 * (size_t)KT * 64 * 64 + 128;
+    static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (configured != hipSuccess) return (int)configured;
+    const float* gx = a.gx;
+    float* hseq = a.hseq;
+    int chunk = 0;
+    for (int b0 = 0; b0 < B; b0 += 64 * max_slices, ++chunk) {
+        const int nb = B - b0 < 64 * max_slices ? B - b0 : 64 * max_slices;
+        a.gx = gx + (long)b0 * a.ld_gx_b;
+        a.hseq = hseq + (long)b0 * a.ld_h_b;
+        a.B = nb;
+        a.slices = (nb + 63) / 64;
+        a.sync = sync + chunk * EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH;
+        hipLaunchKernelGGL((lstm_seq_kernel<H, HALVES>), dim3(2 * a.slices * WPG), dim3(256), LDS, s, a);
+        const int rc = launch_status();
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int emage_lstm_layer_sync_words(int B, int H) {
+    if (B <= 0 || (H != 256 && H != 512)) return EMAGE_EINVAL;
+    const int max_slices = max_slices_for(H);
+    if (max_slices < 1) return EMAGE_EINVAL;
+    const int launches = (B + 64 * max_slices - 1) / (64 * max_slices);
+    return launches * EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH;
+}
+
+extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, int ld_gx_t, const void* w_hh0, const void* w_hh1,
+                                float w_scale0, float w_scale1, float a_scale, float* hseq, long ld_h_b, int ld_h_t,
+                                int B, int T, int H, unsigned* sync, int sync_words, void* stream) {
+    if (dtype != EMAGE_F16X3 || !gates_x || !w_hh0 || !w_hh1 || !hseq || !sync || B <= 0 || T <= 0) return EMAGE_EINVAL;
+    if (H != 256 && H != 512) return EMAGE_EINVAL;
+    if (!(a_scale > 0.f && w_scale0 > 0.f && w_scale1 > 0.f)) return EMAGE_EINVAL;
+    if (ld_gx_t % 4 || ld_gx_t < 8 * H || ld_gx_b % 4 || ld_h_t % 4 || ld_h_t < 2 * H || ld_h_b % 4) return EMAGE_EINVAL;
+    if (((uintptr_t)gates_x | (uintptr_t)w_hh0 | (uintptr_t)w_hh1 | (uintptr_t)hseq) & 15 || ((uintptr_t)sync & 3)) return EMAGE_EINVAL;
+    if (64 * ld_h_b * 4 + 4096 >= (1L << 31)) return EMAGE_EINVAL;                    // a block's 64 clip rows are addressed with 32-bit buffer offsets
+    const int need = emage_lstm_layer_sync_words(B, H);
+    if (need < 0 || sync_words < need) return EMAGE_EINVAL;
+    const int max_slices = max_slices_for(H);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sync, 0, (size_t)need * sizeof(unsigned), s);
+    if (e != hipSuccess) return (int)e;
+    SeqArgs a{};
+    a.gx = gates_x; a.ld_gx_b = ld_gx_b; a.ld_gx_t = ld_gx_t;
+    a.hseq = hseq; a.ld_h_b = ld_h_b; a.ld_h_t = ld_h_t;
+    a.w[0] = (const unsigned char*)w_hh0; a.w[1] = (const unsigned char*)w_hh1;
+    a.os[0] = 1.f / (a_scale * w_scale0); a.os[1] = 1.f / (a_scale * w_scale1);
+    a.a_scale = a_scale;
+    a.T = T;
+    a.dbg = emage_dev::g_lstm_layer_dbg;
+    if (a.dbg & 16) return H == 512 ? launch_seq<512, 2>(a, B, max_slices, sync, s) : launch_seq<256, 2>(a, B, max_slices, sync, s);   // A/B: two staging phases (measured equal)
+    return H == 512 ? launch_seq<512, 1>(a, B, max_slices, sync, s) : launch_seq<256, 1>(a, B, max_slices, sync, s);
+}

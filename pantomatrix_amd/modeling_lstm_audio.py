@@ -38,6 +38,8 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         super().__init__(config)
         self._dt = F16X3
         self.pose_rep = getattr(config, "pose_rep", "smplx")
+        self.persistent_lstm = True            # one launch per LSTM layer (csrc/lstmseq.hip) instead of one per time step; same bits
+        self._sync = {}                        # scratch of the persistent recurrences, see _lstm_sync
 
     def set_precision(self, precision: str):
         if precision == "bf16":
@@ -113,24 +115,50 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         return cx.gemm(h, name + ".fc2", out=out, out_f32=out_f32)[0]
 
     def _bilstm(self, cx, name, x, b, t, n_layer):
-        """nn.LSTM(bidirectional=True, batch_first=True), eval: x (B*T, Cp) -> (B*T, 2H) [forward | backward]."""
+        """nn.LSTM(bidirectional=True, batch_first=True), eval: x (B*T, Cp) -> (B*T, 2H) [forward | backward].
+        f16x3 with H in {256, 512}: the recurrence of a layer is ONE persistent launch (`ops.lstm_layer`, csrc/lstmseq.hip);
+        otherwise (exact-fp32 mode, other sizes, `persistent_lstm = False`) one launch per time step — the same bits."""
         hid = self.config.hidden_size
-        zeros = torch.zeros(b, hid, dtype=torch.float32, device=cx.dev)
+        persistent = self.persistent_lstm and ops.lstm_layer_supported(cx.gdt, hid)
+        zeros = None if persistent else torch.zeros(b, hid, dtype=torch.float32, device=cx.dev)
         for k in range(n_layer):
             gx, _ = cx.gemm(x, f"{name}.ih.{k}")                                     # (B*T, 8H): all steps, both directions
             hseq = torch.empty(b * t, 2 * hid, dtype=torch.float32, device=cx.dev)
-            g3, h3 = gx.view(b, t, 8 * hid), hseq.view(b, t, 2 * hid)
-            cstate = torch.zeros(2, b, hid, dtype=torch.float32, device=cx.dev)
+            g3, h3 = gx.view(b, t, -1), hseq.view(b, t, 2 * hid)
             w0, w1 = cx.pk.w[f"{name}.hh.{k}.0"], cx.pk.w[f"{name}.hh.{k}.1"]
+            if persistent:
+                sync = self._lstm_sync(name, k, b, hid, cx.dev)
+                ops.lstm_layer(cx.gdt, g3, (w0["w"], w1["w"]), (w0["ws"], w1["ws"]), h3, sync)
+                x = hseq
+                continue
+            cstate = torch.zeros(2, b, hid, dtype=torch.float32, device=cx.dev)
             prev = [zeros, zeros]
             for s in range(t):                                                       # step s of the forward direction runs beside
                 sf, sb = s, t - 1 - s                                                # step t-1-s of the backward one, in ONE launch
                 cur = [h3[:, sf, :hid], h3[:, sb, hid:]]
                 ops.lstm_step_pair(cx.gdt, (prev[0], w0["w"], g3[:, sf, :4 * hid], cstate[0], cur[0], w0["ws"]),
-                                   (prev[1], w1["w"], g3[:, sb, 4 * hid:], cstate[1], cur[1], w1["ws"]))
+                                   (prev[1], w1["w"], g3[:, sb, 4 * hid:8 * hid], cstate[1], cur[1], w1["ws"]))
                 prev = cur
             x = hseq
         return x
+
+    def _lstm_sync(self, name, k, b, hid, dev):
+        """Scratch of the persistent recurrence, one tensor per (LSTM, layer, batch): allocated once (stable under graph replay)."""
+        key = (name, k, b, str(dev))
+        if key not in self._sync:
+            self._sync[key] = ops.lstm_layer_sync(b, hid, dev)
+        return self._sync[key]
+
+    def _checked(self, result):
+        """End of an eager forward: surface a lost block of the persistent recurrence (under graph capture the runner checks)."""
+        if self._sync and not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self.check_kernels()
+        return result
+
+    def check_kernels(self):
+        """Raise if a persistent-recurrence launch reported a lost block since the last call (synchronises the device)."""
+        for s in self._sync.values():
+            ops.lstm_layer_check(s)
 
     def _lstm_head(self, cx, name, out_name, in_fea, b, t, out=None, out_f32=None):
         hid = self.config.hidden_size
@@ -193,7 +221,7 @@ class DiscoAudioModel(_LstmAudioModel):
         out = {"motion": motion.view(b, t, c.pose_dims),
                "motion_axis_angle": self._axis_angle(cx, motion, b, t) if return_axis_angle else None,
                "audio_fea_c": in_fea[:, :af].reshape(b, t, af), "audio_fea_r": in_fea[:, af:2 * af].reshape(b, t, af)}
-        return out
+        return self._checked(out)
 
 
 class CamnAudioModel(_LstmAudioModel):
@@ -233,5 +261,5 @@ class CamnAudioModel(_LstmAudioModel):
         self._lstm_head(cx, "body_motion_decoder", "body_out", wide[:, :_rup(cin)], b, t,
                         out=wide[:, cin:cin + c.body_dims], out_f32=motion[:, :c.body_dims])
         self._lstm_head(cx, "hands_motion_decoder", "hands_out", wide, b, t, out=motion[:, c.body_dims:])
-        return {"motion": motion.view(b, t, c.pose_dims // 6, 6),
-                "motion_axis_angle": self._axis_angle(cx, motion, b, t) if return_axis_angle else None}
+        return self._checked({"motion": motion.view(b, t, c.pose_dims // 6, 6),
+                              "motion_axis_angle": self._axis_angle(cx, motion, b, t) if return_axis_angle else None})

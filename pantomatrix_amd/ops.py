@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, F16X3, check
+from ._lib import F32, BF16, F16X3, check, EmageKernelError
 
 _LIBRARY = torch.library.Library("emage", "DEF")
 
@@ -424,6 +424,47 @@ def lstm_step_pair(dtype, fwd, bwd, *, a_scale=None):
     _dev(fwd[0])
     _lstm_step_pair(dtype, fwd[0], bwd[0], fwd[1], bwd[1], fwd[2], bwd[2], fwd[3], bwd[3], fwd[4], bwd[4], float(fwd[5]), float(bwd[5]),
                     float(A_SCALE_F16X3 if a_scale is None else a_scale))
+
+
+LSTM_SYNC_WORDS_PER_LAUNCH, LSTM_SYNC_ERROR_WORD = 544, 512      # include/emage_hip.h
+
+
+def lstm_layer_supported(dtype, hidden):
+    """Whether `lstm_layer` (the persistent recurrence) takes this layer: split-f16 precision, H = 256 or 512."""
+    return dtype == F16X3 and hidden in (256, 512)
+
+
+def lstm_layer_sync(b, hidden, device):
+    """The int32 scratch tensor `lstm_layer` needs for a batch of b clips (arrival counters + error words)."""
+    n = _lib.load().emage_lstm_layer_sync_words(int(b), int(hidden))
+    if n <= 0:
+        raise EmageKernelError(f"lstm_layer: unsupported batch / hidden size ({b}, {hidden})")
+    return torch.zeros(n, dtype=torch.int32, device=device)
+
+
+@_op("lstm_layer", "(int dtype, Tensor gates_x, Tensor w_hh0, Tensor w_hh1, float w_scale0, float w_scale1, float a_scale, Tensor(a!) hseq, "
+                   "Tensor(b!) sync) -> ()")
+def _lstm_layer(dtype, gates_x, w_hh0, w_hh1, w_scale0, w_scale1, a_scale, hseq, sync):
+    b, t, h2 = hseq.shape
+    assert gates_x.dim() == 3 and gates_x.shape[0] == b and gates_x.shape[1] == t and gates_x.stride(2) == 1 and hseq.stride(2) == 1
+    check(_lib.load().emage_lstm_layer(dtype, _ptr(gates_x), gates_x.stride(0), gates_x.stride(1), _ptr(w_hh0), _ptr(w_hh1), w_scale0, w_scale1, a_scale,
+                                       _ptr(hseq), hseq.stride(0), hseq.stride(1), b, t, h2 // 2, _ptr(sync), sync.numel(), _stream()), "lstm_layer")
+
+
+def lstm_layer(dtype, gates_x, w_hh, w_scale, hseq, sync, *, a_scale=None):
+    """The whole recurrence of one bidirectional LSTM layer (zero initial state) in one launch per <= 256 clips:
+    gates_x (B, T, 8H) fp32 (input projection incl. biases, columns dir * 4H + 4u + g), w_hh / w_scale the two directions'
+    packed recurrent weights, hseq (B, T, 2H) fp32 out.  Bit-identical to T `lstm_step_pair` launches.  `sync` from
+    `lstm_layer_sync`; call `lstm_layer_check(sync)` once the stream is synchronised."""
+    _dev(gates_x)
+    _lstm_layer(dtype, gates_x, w_hh[0], w_hh[1], float(w_scale[0]), float(w_scale[1]), float(A_SCALE_F16X3 if a_scale is None else a_scale), hseq, sync)
+    return hseq
+
+
+def lstm_layer_check(sync):
+    """Raise if a block of an `lstm_layer` launch gave up waiting for its group (reads the error words: synchronises)."""
+    if bool(sync.view(-1, LSTM_SYNC_WORDS_PER_LAUNCH)[:, LSTM_SYNC_ERROR_WORD].any()):
+        raise EmageKernelError("emage_lstm_layer: a block timed out waiting for its group (blocks not co-resident?); the layer output is invalid")
 
 
 @_op("softmax2_mix", "(Tensor sel, Tensor c1, Tensor c2, Tensor(a!) out) -> ()")

@@ -54,6 +54,7 @@ class ClipRunner:
         self.out = out
         self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)
         self.frames_out = int(out[0].shape[1])
+        self._checked_replays = 0
 
     def _step(self):
         codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
@@ -125,6 +126,7 @@ class LstmClipRunner:
         self.out = out
         self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)
         self.frames_out = int(out[0].shape[1])
+        self._checked_replays = 0
 
     def _step(self):
         o = self.model.forward(self.audio, self.speaker_id)
@@ -143,4 +145,11 @@ class LstmClipRunner:
         for h, d in zip(self.host, self.out):
             h.copy_(d, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
+        if self.graph is not None and self._checked_replays < 2:     # the persistent recurrence's error words: first replays, then `check()`
+            self._checked_replays += 1
+            self.model.check_kernels()
         return tuple(h.numpy() for h in self.host)
+
+    def check(self):
+        """Raise if a persistent-recurrence launch of a replay reported a lost block (synchronises)."""
+        self.model.check_kernels()

@@ -296,6 +296,37 @@ def lstm_step_pair(dtype, fwd, bwd, *, a_scale=None):
     CALLS.append("lstm_step_pair")
 
 
+def lstm_layer_supported(dtype, hidden):
+    return dtype == F16X3 and hidden in (256, 512)
+
+
+def lstm_layer_sync(b, hidden, device):
+    return torch.zeros(((b + 255) // 256) * 544, dtype=torch.int32)
+
+
+def lstm_layer_check(sync):
+    assert not bool(sync.any())
+
+
+def lstm_layer(dtype, gates_x, w_hh, w_scale, hseq, sync, *, a_scale=None):
+    """The persistent recurrence == T paired steps from a zero state (csrc/lstmseq.hip is bit-identical to that sequence)."""
+    assert lstm_layer_supported(dtype, hseq.shape[2] // 2) and sync.dtype == torch.int32
+    b, t, h2 = hseq.shape
+    hid = h2 // 2
+    mark = len(CALLS)
+    cstate = torch.zeros(2, b, hid)
+    prev = [torch.zeros(b, hid), torch.zeros(b, hid)]
+    for s in range(t):
+        sf, sb = s, t - 1 - s
+        cur = [hseq[:, sf, :hid], hseq[:, sb, hid:]]
+        lstm_step_pair(dtype, (prev[0], w_hh[0], gates_x[:, sf, :4 * hid], cstate[0], cur[0], w_scale[0]),
+                       (prev[1], w_hh[1], gates_x[:, sb, 4 * hid:8 * hid], cstate[1], cur[1], w_scale[1]), a_scale=a_scale)
+        prev = cur
+    del CALLS[mark:]
+    CALLS.append("lstm_layer")
+    return hseq
+
+
 def softmax2_mix(sel, c1, c2, out):
     CALLS.append("softmax2_mix")
     w = torch.softmax(sel[:, :2], dim=1)
@@ -332,7 +363,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

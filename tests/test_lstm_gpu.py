@@ -82,6 +82,79 @@ def test_lstm_step_pair_kernel(dtype):
     assert float((pair_h - ref_h).abs().max()) < 2e-5 and float((pair_c - ref_c).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("b,t,hid", [(2, 5, 512), (130, 4, 512), (256, 6, 512), (300, 3, 512), (70, 5, 256)])
+def test_lstm_layer_kernel(b, t, hid):
+    """The persistent recurrence (one launch per layer, W_hh and the cell state in registers, group barriers through
+    agent-scope atomics) against T paired step launches from a zero state: the same bits, incl. ragged 64-clip slices and a
+    batch that needs two launches; and against the CPU restatement."""
+    g = torch.Generator().manual_seed(b + t)
+    wp, ws, wraw = [], [], []
+    for _ in range(2):
+        w = torch.randn(4 * hid, hid, generator=g) / hid ** 0.5
+        p, s = ops.split_f16_weights(w)
+        wp.append(p.to(DEV))
+        ws.append(s)
+    gx = torch.randn(b, t, 8 * hid, generator=g)
+    gxd = gx.to(DEV)
+
+    hseq = torch.full((b, t, 2 * hid), float("nan"), device=DEV)
+    sync = ops.lstm_layer_sync(b, hid, DEV)
+    ops.lstm_layer(F16X3, gxd, wp, ws, hseq, sync)
+    torch.cuda.synchronize()
+    ops.lstm_layer_check(sync)
+
+    def steps(mod, dev):
+        gxx = gx.to(dev)
+        c, ref = torch.zeros(2, b, hid, device=dev), torch.zeros(b, t, 2 * hid, device=dev)
+        prev = [torch.zeros(b, hid, device=dev), torch.zeros(b, hid, device=dev)]
+        for s in range(t):
+            sf, sb = s, t - 1 - s
+            cur = [ref[:, sf, :hid], ref[:, sb, hid:]]
+            mod.lstm_step_pair(F16X3, (prev[0], wp[0].to(dev), gxx[:, sf, :4 * hid], c[0], cur[0], ws[0]),
+                               (prev[1], wp[1].to(dev), gxx[:, sb, 4 * hid:], c[1], cur[1], ws[1]))
+            prev = cur
+        return ref.cpu()
+
+    got = hseq.cpu()
+    assert torch.equal(got, steps(ops, DEV))
+    if b <= 130:
+        assert float((got - steps(F, "cpu")).abs().max()) < 2e-5
+
+
+def test_lstm_layer_long_sequence_and_replay():
+    """415 steps (the CaMN length) at the full 256-clip batch, twice on the same buffers: every group barrier of a long
+    launch holds, the scratch counters are re-armed by the call, results repeat bit for bit."""
+    g = torch.Generator().manual_seed(3)
+    b, t, hid = 256, 415, 512
+    wp, ws = [], []
+    for _ in range(2):
+        p, s = ops.split_f16_weights(torch.randn(4 * hid, hid, generator=g) / hid ** 0.5)
+        wp.append(p.to(DEV))
+        ws.append(s)
+    gx = torch.randn(b, t, 8 * hid, generator=g).to(DEV)
+    sync = ops.lstm_layer_sync(b, hid, DEV)
+    outs = []
+    for _ in range(2):
+        hseq = torch.empty(b, t, 2 * hid, device=DEV)
+        ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
+        torch.cuda.synchronize()
+        ops.lstm_layer_check(sync)
+        outs.append(hseq)
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+    # spot-check the last forward step and the last backward step of a few clips against per-step launches of those clips
+    sel = torch.tensor([0, 63, 64, 200, 255], device=DEV)
+    ref = torch.empty(len(sel), t, 2 * hid, device=DEV)
+    c = torch.zeros(2, len(sel), hid, device=DEV)
+    prev = [torch.zeros(len(sel), hid, device=DEV), torch.zeros(len(sel), hid, device=DEV)]
+    gsel = gx[sel].contiguous()
+    for s in range(t):
+        sf, sb = s, t - 1 - s
+        cur = [ref[:, sf, :hid], ref[:, sb, hid:]]
+        ops.lstm_step_pair(F16X3, (prev[0], wp[0], gsel[:, sf, :4 * hid], c[0], cur[0], ws[0]), (prev[1], wp[1], gsel[:, sb, 4 * hid:], c[1], cur[1], ws[1]))
+        prev = cur
+    assert torch.equal(outs[0][sel], ref)
+
+
 def test_small_lstm_kernels():
     g = torch.Generator().manual_seed(4)
     m = 300

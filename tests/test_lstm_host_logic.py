@@ -39,9 +39,25 @@ def test_forward_matches_golden(golden_dir, kind, precision):
                 assert float((out[k] - ref[k]).abs().max()) < 2e-5, k
         else:
             assert out["motion"].shape[2:] == (43, 6)
-    n_steps = fake_ops.CALLS.count("lstm_step_pair")
     t = out["motion"].shape[1]
-    assert n_steps == (1 if kind == "disco" else 2) * CFG["n_layer"] * t              # one launch per layer and step (both directions)
+    n_lstm = (1 if kind == "disco" else 2) * CFG["n_layer"]
+    if precision == "f16x3":        # one persistent launch per LSTM layer
+        assert fake_ops.CALLS.count("lstm_layer") == n_lstm and "lstm_step_pair" not in fake_ops.CALLS
+    else:                           # exact-fp32 mode: one launch per layer and step (both directions)
+        assert fake_ops.CALLS.count("lstm_step_pair") == n_lstm * t and "lstm_layer" not in fake_ops.CALLS
+
+
+def test_per_step_recurrence_switch():
+    """`persistent_lstm = False` routes the f16x3 recurrence through one paired launch per step: the same result."""
+    audio, spk, motion = inputs(with_seed_motion=True)
+    outs = []
+    for persistent in (True, False):
+        model = product("disco")
+        model.persistent_lstm = persistent
+        with fake_ops.installed(), torch.no_grad():
+            outs.append(model(audio, spk, seed_frames=CFG["seed_frames"], seed_motion=motion)["motion"])
+            assert ("lstm_layer" in fake_ops.CALLS) == persistent and ("lstm_step_pair" in fake_ops.CALLS) != persistent
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("kind", ["disco", "camn"])

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--models", default="disco,camn")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--per-step", action="store_true", help="one launch per time step instead of the persistent recurrence (A/B; same bits)")
+    ap.add_argument("--layer-only", action="store_true", help="also time one bare lstm_layer launch at the model's size")
     args = ap.parse_args()
     from pantomatrix_amd import synthetic
     from pantomatrix_amd.runtime import LstmClipRunner
@@ -32,6 +34,7 @@ def main():
             continue
         n = int(seconds * 16000)
         model = product(kind, "f16x3", dev)
+        model.persistent_lstm = not args.per_step
         audio = synthetic.synthetic_audio(batch, n, seed=5).to(dev)
         t0 = time.time()
         runner = LstmClipRunner(model, batch, n)
@@ -46,7 +49,39 @@ def main():
         frames = motion.shape[0] * motion.shape[1]
         line = {"model": kind, "batch": batch, "frames_per_clip": int(motion.shape[1]), "ms_per_step": ms, "value": frames / (ms * 1e-3),
                 "unit": "motion-frames/s (15 fps)", "dtype": "f16x3", "launch": "hipGraph replay", "graph_capture_s": t_capture,
-                "lstm_step_pair_launches": (1 if kind == "disco" else 2) * 4 * int(motion.shape[1])}
+                "recurrence": "one launch per step" if args.per_step else "persistent (one launch per layer)",
+                "lstm_layers": (1 if kind == "disco" else 2) * 4, "steps_per_layer": int(motion.shape[1])}
+        if args.layer_only and not args.per_step:
+            from pantomatrix_amd import ops
+            from pantomatrix_amd._lib import F16X3
+            hid, tt = 512, int(motion.shape[1])
+            g = torch.Generator().manual_seed(1)
+            wp, ws = [], []
+            for _ in range(2):
+                p_, s_ = ops.split_f16_weights(torch.randn(4 * hid, hid, generator=g) / hid ** 0.5)
+                wp.append(p_.to(dev))
+                ws.append(s_)
+            gx = torch.randn(batch, tt, 8 * hid, generator=g).to(dev)
+            hseq = torch.empty(batch, tt, 2 * hid, device=dev)
+            sync = ops.lstm_layer_sync(batch, hid, dev)
+            from pantomatrix_amd import _lib
+            lib = _lib.load()
+            names = {0: "shipped", 16: "two staging phases", 2: "no MFMA phase", 4: "no h load / staging", 8: "no group barrier",
+                     14: "skeleton: cell + h store only"}
+            line["lstm_layer_us_per_step"] = {}
+            for dbg in (0, 16, 2, 4, 8, 14):
+                lib.emage_set_tuning(3, dbg)
+                ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
+                e1.record()
+                torch.cuda.synchronize()
+                ops.lstm_layer_check(sync)
+                line["lstm_layer_us_per_step"][names[dbg]] = round(1e3 * e0.elapsed_time(e1) / 3 / tt, 2)
+            lib.emage_set_tuning(3, 0)
         if not args.no_cpu:
             torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
             sd = weights(kind)
