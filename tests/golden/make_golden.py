@@ -51,6 +51,17 @@ def golden_b64(model, vq):
                         **{f"index_{p}": idx[p].numpy().astype(np.int16) for p in common.PARTS})
 
 
+def golden_long(model, vq):
+    """A clip of many windows: 310 frames = 5 full 64-frame windows (stride 60) + a 10-frame tail, so the seed chain
+    (last 4 frames of window w -> first 4 of window w+1) is exercised four times and ends in a T+1 audio memory."""
+    a = synthetic.synthetic_audio(1, synthetic.samples_for_frames(310))
+    lat, pred, idx = ref_infer_clip(model, vq, a)
+    np.savez_compressed(os.path.join(HERE, "infer_310f_b1.npz"),
+                        poses=pred["motion_axis_angle"].numpy(), expressions=pred["expression"].numpy(),
+                        trans=pred["trans"].numpy(), rec_face=lat["rec_face"].numpy(),
+                        **{f"index_{p}": idx[p].numpy() for p in common.PARTS})
+
+
 def golden_vq_api(acfg, vqc, gc):
     """EmageVQModel.spilt_inputs / map2index / map2latent (M:97-124) and EmageVQVAEConv.forward (M:42-46, P:144-156:
     straight-through latents, embedding_loss, perplexity) on seeded rot-6D motion — the calls train_emage_audio.py:149-150
@@ -81,11 +92,17 @@ def main():
     torch.set_num_threads(8)
     acfg, vqc, gc = common.cfg_dicts(vae_layer=2)
     model, vq = rh.build_reference(acfg, vqc, gc, seed=0)
+    if "--only-long" in sys.argv:
+        golden_long(model, vq)
+        print("wrote infer_310f_b1.npz")
+        return
     if "--only-new" in sys.argv:             # round-2 additions only (the round-1 fixtures are unchanged)
+        golden_long(model, vq)
         golden_b64(model, vq)
         golden_vq_api(acfg, vqc, gc)
         print("wrote infer_128f_b64.npz, vq_api.npz")
         return
+    golden_long(model, vq)
     golden_b64(model, vq)
     golden_vq_api(acfg, vqc, gc)
 
