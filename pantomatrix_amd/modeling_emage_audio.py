@@ -36,6 +36,9 @@ _PRECISION_NAMES = {v: k for k, v in _PRECISIONS.items()}
 _WAV_TAPS = spec.WAV_KERNEL
 
 
+_NARROW = 32          # WavEncoder width of DisCo / CaMN's first blocks: half a 64-channel operand row (see _Packed.conv_pairs)
+
+
 def _rup(x, m=64):
     return (x + m - 1) // m * m
 
@@ -270,6 +273,40 @@ class _Packed:
             w = torch.nn.functional.pad(w, (0, cp - cin))
         wp, wsc = self._operand(w.reshape(cout, k * cp))
         self.w[key] = dict(w=wp, b=b.contiguous(), n=cout, cp=cp, taps=k, k_real=k * cin, ws=wsc)
+
+    def conv_pairs(self, key, w, b, slope, stride, pad):
+        """A Conv1d over NARROW rows (Cin = 32) as a convolution over PAIRS of positions: the (L, 32) activation rows of a
+        sequence are, in memory, (L/2, 64) rows [x[2p] | x[2p+1]], so a 64-channel kernel (slab / implicit GEMM) runs it
+        without the 2x zero padding of K (and, for stride 1, of N: the output pair [y[2p] | y[2p+1]] is one 64-wide row).
+          stride 1:  out pair p, half ho  <-  in pair p+q, half hi  through tap 2q + hi - ho + pad   (q = -4..4 for k = 15)
+          stride 2s: out row p            <-  in pair s*p + q, half hi through tap 2q + hi           (pad must be 0)
+        w (Cout, Cin, k) / b / slope are the folded conv; entry: w (N, taps_p * 64) packed, n, taps, pad, stride in pair units."""
+        cout, cin, k = w.shape
+        assert cin * 2 == 64
+        if stride == 1:
+            qs = sorted({q for q in range(-k, k + 1) for hi in (0, 1) for ho in (0, 1) if 0 <= 2 * q + hi - ho + pad < k})
+            wp = torch.zeros(2, cout, len(qs), 2, cin, dtype=torch.float32, device=w.device)
+            for ho in (0, 1):
+                for hi in (0, 1):
+                    for j, q in enumerate(qs):
+                        tau = 2 * q + hi - ho + pad
+                        if 0 <= tau < k:
+                            wp[ho, :, j, hi, :] = w[:, :, tau]
+            wp = wp.reshape(2 * cout, len(qs) * 2 * cin)
+            b, slope = torch.cat([b, b]), torch.cat([slope, slope])
+            ent = dict(n=2 * cout, taps=len(qs), pad=-qs[0], stride=1)
+        else:
+            assert stride % 2 == 0 and pad == 0
+            nq = (k + 1) // 2
+            wp = torch.zeros(cout, nq, 2, cin, dtype=torch.float32, device=w.device)
+            for q in range(nq):
+                for hi in (0, 1):
+                    if 2 * q + hi < k:
+                        wp[:, q, hi, :] = w[:, :, 2 * q + hi]
+            wp = wp.reshape(cout, nq * 2 * cin)
+            ent = dict(n=cout, taps=nq, pad=0, stride=stride // 2)
+        wpk, wsc = self._operand(wp)
+        self.w[key] = dict(w=wpk, b=b.float().contiguous(), slope=slope.float().contiguous(), cp=2 * cin, k_real=k * cin, ws=wsc, **ent)
 
     def norm(self, key, name):
         self.w[key] = dict(g=self.f32(name + ".weight"), b=self.f32(name + ".bias"))
@@ -557,11 +594,11 @@ class _WavEncoderMixin:
     def _wav_blocks(self):
         raise NotImplementedError
 
-    def _wav_clip_chunk(self, cx, n_seq, lens):
+    def _wav_clip_chunk(self, cx, n_seq, lens, width=None):
         """Sequences per launch so that the largest intermediate (block 0's (seq * L0, n_enc*2q) output) stays below the
         2 GiB a kernel operand may span (32-bit buffer offsets, include/emage_hip.h: emage_gemm)."""
         es = 2 if cx.tdt == torch.bfloat16 else 4
-        per_seq = lens[0] * cx.pk.w["wav_in"]["w"].shape[0] * es
+        per_seq = lens[0] * (width or cx.pk.w["wav_in"]["w"].shape[0]) * es
         return max(1, min(n_seq, ((1 << 31) - (1 << 20)) // per_seq))
 
     def _pack_wav_encoders(self, pk, encoders):
@@ -582,6 +619,23 @@ class _WavEncoderMixin:
                     pk.w[base + ".conv1"]["slope"] = torch.cat([torch.full((cout,), 0.01, device=pk.device),
                                                                 torch.ones(n1 - cout, device=pk.device)]).contiguous()
                 pk.conv(base + ".conv2", base + ".conv2", fold_bn=base + ".bn2")
+                dev = pk.device
+                lrelu, ident = (lambda n: torch.full((n,), 0.01, device=dev)), (lambda n: torch.ones(n, device=dev))
+                if cout == _NARROW:                              # conv2 (stride 1, Cout -> Cout) over position pairs
+                    w, b = pk.folded(base + ".conv2", base + ".bn2")
+                    pk.conv_pairs(base + ".conv2.pairs", w, b, lrelu(cout), 1, _WAV_TAPS // 2)
+                if i > 0 and cin == _NARROW:                     # conv1 (+ shortcut conv) reading narrow rows
+                    w1, b1 = pk.folded(base + ".conv1", base + ".bn1")
+                    if not ds:
+                        pk.conv_pairs(base + ".conv1.pairs", w1, b1, lrelu(cout), stride, pad)
+                    else:
+                        wd, bd = pk.folded(base + ".downsample.0", base + ".downsample.1")
+                        if cout == _NARROW:                      # two launches: both results must be contiguous narrow tensors
+                            pk.conv_pairs(base + ".conv1.pairs", w1, b1, lrelu(cout), stride, pad)
+                            pk.conv_pairs(base + ".downsample.pairs", wd, bd, ident(cout), stride, pad)
+                        else:
+                            pk.conv_pairs(base + ".conv1.pairs", torch.cat([w1, wd], 0), torch.cat([b1, bd]),
+                                          torch.cat([lrelu(cout), ident(cout)]), stride, pad)
         pk.w["wav_in"] = dict(w=torch.cat(w0, 0).float().contiguous(), b=torch.cat(b0).float().contiguous(),
                               slope=torch.cat(s0).float().contiguous())
 
@@ -653,6 +707,86 @@ class _WavEncoderMixin:
                 x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
                                m=b * lout, out=out, n_store=0 if out is not None else _rup(cout))
                 x = x[:, :cout] if x.shape[1] != cout else x
+            lin = lout
+        return x
+
+    # ---- narrow (32-channel) blocks as convolutions over position pairs (DisCo / CaMN) ------------------------------------
+    def _wav_pairs_ok(self, lens):
+        """The pair form needs the slab kernel, a narrow first block, and an even frame count wherever rows are paired."""
+        blocks = self._wav_blocks()
+        if not (self.slab_convs and blocks[0][1] == _NARROW and ops.conv_slab_supported(2 * _NARROW, _WAV_TAPS, 1)):
+            return False
+        for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
+            if cout == _NARROW and lens[i] % 2:
+                return False
+            if i > 0 and cin == _NARROW and stride > 1 and (stride % 2 or pad):
+                return False
+        return True
+
+    def _wav_first_layer_pairs(self, cx, audio, lens):
+        """Block 0's conv1 and shortcut of the (single) narrow encoder as two contiguous (B*L0, 32) tensors."""
+        blocks = self._wav_blocks()
+        q, w_in = blocks[0][1], cx.pk.w["wav_in"]
+        outs = []
+        for r in (slice(0, q), slice(q, 2 * q)):
+            y = cx.lo(audio.shape[0] * lens[0], q)
+            ops.wav_conv_in(cx.dt, audio, w_in["w"][r], w_in["b"][r], w_in["slope"][r], y, lens[0], blocks[0][2], blocks[0][3])
+            outs.append(y)
+        return outs
+
+    def _wav_encoder_chain_pairs(self, cx, enc, y1, sc, b, lens, dest=None):
+        """`_wav_encoder_chain` for an encoder whose first blocks are 32 channels wide: those blocks' rows are read and
+        written as (L/2, 64) pair rows by the 64-channel kernels (`_Packed.conv_pairs`) instead of zero-padded to 64
+        channels — a quarter of the padded path's MFMA work and half its activation bytes."""
+        blocks = self._wav_blocks()
+        k = _WAV_TAPS
+        pairs = lambda t: t.view(-1, 2 * _NARROW)
+
+        def slab_pairs(a, key, res, l):
+            e = cx.pk.w[key]
+            out = cx.lo(a.shape[0], _NARROW)
+            ops.conv_slab(cx.gdt, pairs(a), e["w"], e["b"], e["slope"], None if res is None else pairs(res), pairs(out),
+                          nseq=b, l=l // 2, taps=e["taps"], pad=e["pad"], w_scale=e.get("ws", 1.0))
+            return out
+
+        x, lin = None, None
+        for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
+            base = f"{enc}.feat_extractor.{i}"
+            lout = lens[i]
+            if i > 0:
+                if cin != _NARROW:                                   # wide input: the regular forms
+                    ent = cx.pk.w[base + ".conv1"]
+                    if not ds and ops.conv_slab_supported(cout, k, stride) and cin == cout:
+                        y = cx.lo(b * lout, cout)
+                        ops.conv_slab(cx.gdt, x, ent["w"], ent["b"], ent["slope"], None, y, nseq=b, l=lout, taps=k, pad=pad, w_scale=ent.get("ws", 1.0))
+                    else:
+                        y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout, n_store=_rup(ent["n"]))
+                    y1, sc = (y[:, :cout], y[:, cout:2 * cout]) if ds else (y[:, :cout], x)
+                elif not ds:                                         # 32 -> 32, stride 1
+                    y1, sc = slab_pairs(x, base + ".conv1.pairs", None, lout), x
+                else:                                                # strided, reading pair rows
+                    e1 = cx.pk.w[base + ".conv1.pairs"]
+                    cv = (e1["stride"], 0, lin // 2, lout)
+                    if cout == _NARROW:
+                        y1, _ = cx.gemm(pairs(x), None, w=e1, slope=e1["slope"], conv=cv, m=b * lout)
+                        ed = cx.pk.w[base + ".downsample.pairs"]
+                        sc, _ = cx.gemm(pairs(x), None, w=ed, slope=ed["slope"], conv=cv, m=b * lout)
+                    else:
+                        y, _ = cx.gemm(pairs(x), None, w=e1, slope=e1["slope"], conv=cv, m=b * lout)
+                        y1, sc = y[:, :cout], y[:, cout:2 * cout]
+            last = i == len(blocks) - 1
+            out = dest if (last and dest is not None and dest.shape[0] == b * lout) else None
+            if cout == _NARROW:
+                x = slab_pairs(y1, base + ".conv2.pairs", sc, lout)
+            else:
+                c2 = cx.pk.w[base + ".conv2"]
+                if ops.conv_slab_supported(cout, k, 1):
+                    x = out if out is not None else cx.lo(b * lout, cout)
+                    ops.conv_slab(cx.gdt, y1, c2["w"], c2["b"], cx.pk.slope(0.01, cout), sc, x, nseq=b, l=lout, taps=k, pad=k // 2, w_scale=c2.get("ws", 1.0))
+                else:
+                    x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
+                                   m=b * lout, out=out, n_store=0 if out is not None else _rup(cout))
+                    x = x[:, :cout] if x.shape[1] != cout else x
             lin = lout
         return x
 

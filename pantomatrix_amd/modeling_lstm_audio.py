@@ -38,6 +38,7 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         super().__init__(config)
         self._dt = F16X3
         self.pose_rep = getattr(config, "pose_rep", "smplx")
+        self.pair_convs = True                 # WavEncoder: 32-channel blocks through the 64-channel kernels on position pairs (A/B switch)
         self.persistent_lstm = True            # one launch per LSTM layer (csrc/lstmseq.hip) instead of one per time step; same bits
         self._sync = {}                        # scratch of the persistent recurrences, see _lstm_sync
 
@@ -85,11 +86,16 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         t = lens[-1]
         if dest is None:
             dest = torch.empty(b * t, self.config.audio_f, dtype=torch.float32, device=cx.dev)
-        step = self._wav_clip_chunk(cx, b, lens)
+        pair_rows = self.pair_convs and self._wav_pairs_ok(lens)       # 32-channel blocks as 64-channel convolutions over position pairs
+        step = self._wav_clip_chunk(cx, b, lens, width=32 if pair_rows else None)
         for c0 in range(0, b, step):
             n = min(step, b - c0)
-            y0 = self._wav_first_layer(cx, audio[c0:c0 + n], lens)
-            self._wav_encoder_chain(cx, "audio_encoder", 0, y0, n, lens, dest=dest[c0 * t:(c0 + n) * t])
+            if pair_rows:
+                y1, sc = self._wav_first_layer_pairs(cx, audio[c0:c0 + n], lens)
+                self._wav_encoder_chain_pairs(cx, "audio_encoder", y1, sc, n, lens, dest=dest[c0 * t:(c0 + n) * t])
+            else:
+                y0 = self._wav_first_layer(cx, audio[c0:c0 + n], lens)
+                self._wav_encoder_chain(cx, "audio_encoder", 0, y0, n, lens, dest=dest[c0 * t:(c0 + n) * t])
         return dest, t
 
     def _seed_src_map(self, t, seed_motion):

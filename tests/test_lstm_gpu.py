@@ -236,3 +236,24 @@ def test_graph_runner_matches_eager():
         motion, aa = runner(audio.to(DEV))
         assert np.array_equal(motion, eager["motion"].reshape(4, -1, 258).cpu().numpy())
         assert np.array_equal(aa, eager["motion_axis_angle"].cpu().numpy())
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_pair_rows_route_matches_padded_route(precision):
+    """The narrow WavEncoder blocks on (L/2, 64) pair rows (two first-layer launches, 64-channel slab / implicit-GEMM
+    kernels with re-packed weights) against the zero-padded route and the CPU oracle, on a clip whose frame counts are even."""
+    audio, spk, _ = inputs(bs=3, frames=34)
+    audio = audio[:, :30000]
+    outs = []
+    for pair in (True, False):
+        model = product("disco", precision, DEV)
+        model.pair_convs = pair
+        assert model._wav_pairs_ok(model._wav_lengths(audio.shape[1]))
+        o = model(audio.to(DEV), spk.to(DEV))
+        outs.append({k: o[k].cpu() for k in ("motion", "audio_fea_c", "audio_fea_r")})
+    for k in outs[0]:
+        assert float((outs[0][k] - outs[1][k]).abs().max()) < 2e-5, k
+    ref = run_oracle("disco", weights("disco"), audio, spk, None)
+    for k in ("audio_fea_c", "audio_fea_r"):
+        assert float((outs[0][k] - ref[k]).abs().max()) < 2e-5, k
+    assert float((outs[0]["motion"].reshape(3, -1, 258) - ref["motion"].reshape(3, -1, 258)).abs().max()) < 5e-5

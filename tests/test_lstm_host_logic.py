@@ -47,6 +47,55 @@ def test_forward_matches_golden(golden_dir, kind, precision):
         assert fake_ops.CALLS.count("lstm_step_pair") == n_lstm * t and "lstm_layer" not in fake_ops.CALLS
 
 
+def test_narrow_blocks_run_as_position_pairs():
+    """The 32-channel WavEncoder blocks go through the 64-channel kernels on (L/2, 64) pair rows (`_Packed.conv_pairs`):
+    the same features as the zero-padded route (`pair_convs = False`) up to fp32 summation order, no padded launches."""
+    audio, spk, _ = inputs()
+    audio = audio[:, :30000]                       # 6638 / 1104 / 1104 frames after blocks 0-2: even, like the 8.5 s and 28 s clips
+    outs, calls = [], []
+    for pair in (True, False):
+        model = product("camn")
+        model.pair_convs = pair
+        with fake_ops.installed(), torch.no_grad():
+            lens = model._wav_lengths(audio.shape[1])
+            assert model._wav_pairs_ok(lens) and lens[:3] == [6638, 1104, 1104]
+            outs.append(model(audio, spk, seed_frames=CFG["seed_frames"])["motion"])
+            calls.append(list(fake_ops.CALLS))
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5
+    # pair route: 2 first-layer launches, conv2 of blocks 0-2 + conv1 of block 2 as slabs (4) + the wide blocks' 4 slabs
+    assert calls[0].count("wav_conv_in") == 2 and calls[0].count("conv_slab") == 8
+    assert calls[1].count("wav_conv_in") == 1 and calls[1].count("conv_slab") == 4
+    odd = product("camn")                          # an odd frame count anywhere in the narrow blocks: the padded route, silently
+    assert not odd._wav_pairs_ok(odd._wav_lengths(inputs()[0].shape[1]))
+
+
+def test_pair_weights_equal_the_convolution():
+    """`conv_pairs` against torch's conv1d on random narrow rows: stride 1 (pad 7) and stride 6 (pad 0)."""
+    import torch.nn.functional as F
+    from pantomatrix_amd import modeling_emage_audio as M
+    from pantomatrix_amd._lib import F32
+    g = torch.Generator().manual_seed(4)
+    pk = M._Packed({}, torch.device("cpu"), F32)
+    x = torch.randn(3, 32, 40, generator=g)                                   # (seq, C, L), L even
+    for stride, pad, cout in ((1, 7, 32), (6, 0, 32), (6, 0, 128)):
+        w, b = 0.1 * torch.randn(cout, 32, 15, generator=g), torch.randn(cout, generator=g)
+        pk.conv_pairs("t", w, b, torch.ones(cout), stride, pad)
+        e = pk.w["t"]
+        ref = F.conv1d(x, w, b, stride=stride, padding=pad)                  # (seq, cout, Lout)
+        rows = x.permute(0, 2, 1).reshape(3, 20, 64)                          # pair rows
+        wp = e["w"].view(e["n"], e["taps"], 64)
+        lout = ref.shape[2] // (2 if stride == 1 else 1)
+        got = torch.zeros(3, lout, e["n"])
+        for p in range(lout):
+            for j in range(e["taps"]):
+                r = e["stride"] * p + j - e["pad"]
+                if 0 <= r < 20:
+                    got[:, p] += rows[:, r] @ wp[:, j].T
+        got = got + e["b"]
+        got = got.reshape(3, -1, cout).permute(0, 2, 1) if stride == 1 else got.permute(0, 2, 1)
+        assert float((got - ref).abs().max()) < 1e-4
+
+
 def test_per_step_recurrence_switch():
     """`persistent_lstm = False` routes the f16x3 recurrence through one paired launch per step: the same result."""
     audio, spk, motion = inputs(with_seed_motion=True)
