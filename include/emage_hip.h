@@ -169,6 +169,12 @@ int emage_wav_block0(int dtype, const float* wav, long ldw, int Lw, int nwin, lo
 int emage_attention(int dtype, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int vt_rows,
                     void* out, int ldo, int B, int H, int Tq, int Tk, int hd, void* stream);
 
+/* emage_attention with the attention-probability dropout of a TRAINING forward (nn.MultiheadAttention in train mode,
+ * torch's scaled_dot_product_attention math path): softmax(.) * pmask, then P V.  pmask: (B, H, Tq, Tk) fp32, the
+ * factors bernoulli / (1 - p).  dtype EMAGE_F32 or EMAGE_F16X3. */
+int emage_attention_dropout(int dtype, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int vt_rows,
+                            void* out, int ldo, int B, int H, int Tq, int Tk, int hd, const float* pmask, void* stream);
+
 /*
  * K5 — LayerNorm(C, eps) over rows (post-norm of every transformer sub-layer):
  *   y = (x - mean) * rsqrt(var + eps) * gamma + beta (+ add[m][:])
@@ -294,6 +300,50 @@ int emage_lstm_inputs(const float* speaker_table, const int64_t* speaker_id, int
  * rot6d: (M, ld) fp32; slot_of_joint: n_joints ints on the device; axis_angle: (M, n_joints*3).
  */
 int emage_rot6d_scatter(const float* rot6d, int ld, const int* slot_of_joint, float* axis_angle, int M, int n_joints, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Train-mode forward (train_emage_audio.py:130-204): what differs from the inference path.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/*
+ * nn.BatchNorm1d in training mode, statistics: per-channel batch mean and BIASED variance over the M rows (all clips x all
+ * positions) of a channels-last fp32 tensor x (M, ldx), float64 accumulation; running_mean / running_var (either may be
+ * NULL) are updated in place as torch does: r = (1 - momentum) * r + momentum * {mean, UNBIASED variance}
+ * (processing_emage_audio.py:262-294 with nn.BatchNorm1d semantics; nn.SyncBatchNorm at world size 1).
+ * workspace: emage_bn_stats_workspace_bytes(M, C) bytes, 8-byte aligned.
+ */
+long emage_bn_stats_workspace_bytes(int M, int C);
+int emage_bn_stats(const float* x, int ldx, int M, int C, void* workspace, long workspace_bytes,
+                   float* mean, float* var, float* running_mean, float* running_var, float momentum, void* stream);
+
+/*
+ * The normalisation with what follows it in BasicBlock.forward (P:283-294):
+ *   out = LeakyReLU((x - mean) / sqrt(var + eps) * gamma + beta + shortcut, slope)
+ * shortcut: none (sc NULL) | sc raw (sc_mean NULL) | sc batch-normalised with its own statistics (the downsample branch).
+ */
+int emage_bn_apply(const float* x, int ldx, const float* mean, const float* var, const float* gamma, const float* beta,
+                   const float* sc, int ld_sc, const float* sc_mean, const float* sc_var, const float* sc_gamma, const float* sc_beta,
+                   float eps, float slope, float* out, int ldo, int M, int C, void* stream);
+
+/*
+ * out = a * mask (+ b): nn.Dropout with a given mask and the residual add that follows it in nn.Transformer*Layer.
+ * mask_t_rows = T > 0: the mask is stored (T, M / T, C) — the (T, B, d) layout the reference's layers see — while the
+ * rows of a / b / out run (B, T); 0: same row order.
+ */
+int emage_mul_add(const float* a, int lda, const float* mask, int ld_mask, int mask_t_rows, const float* b, int ldb,
+                  float* out, int ldo, int M, int C, void* stream);
+
+/*
+ * The losses of train_emage_audio.py:106-130, accumulated into a float64 device scalar: loss[0] += weight * value.
+ *   emage_mse_loss: value = mean((pred - target)^2) over the (M, C) fp32 views           (F.mse_loss, T:108-111)
+ *   emage_nll_loss: value = mean over rows of -log_softmax(logits[m])[index[m]]           (NLLLoss(log_softmax), T:113-128)
+ * workspace: EMAGE_LOSS_WORKSPACE_BYTES bytes, 8-byte aligned.  An index outside [0, K) contributes nothing and sets the
+ * last 8-byte slot of the workspace non-zero (torch raises there; the Python layer checks it).
+ */
+#define EMAGE_LOSS_WORKSPACE_BYTES 8192
+int emage_mse_loss(const float* pred, int ld_pred, const float* target, int ld_target, int M, int C, float weight,
+                   double* loss, void* workspace, void* stream);
+int emage_nll_loss(const float* logits, int ld, const int64_t* index, int M, int K, float weight, double* loss, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

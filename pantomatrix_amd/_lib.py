@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 
 F32, BF16, F16X3 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -25,6 +25,13 @@ SIGNATURES = {
     "emage_conv_slab": [_i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p],
     "emage_wav_block0": [_i, _p, _l, _i, _i, _l, _i, _p, _p, _f, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _i, _i, _f, _f, _p],
     "emage_attention": [_i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "emage_attention_dropout": [_i, _p, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "emage_bn_stats_workspace_bytes": [_i, _i],
+    "emage_bn_stats": [_p, _i, _i, _i, _p, _l, _p, _p, _p, _p, _f, _p],
+    "emage_bn_apply": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _i, _i, _p],
+    "emage_mse_loss": [_p, _i, _p, _i, _i, _i, _f, _p, _p, _p],
+    "emage_nll_loss": [_p, _i, _p, _i, _i, _f, _p, _p, _p],
+    "emage_mul_add": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p],
     "emage_pack_motion": [_i, _p, _p, _l, _p, _p, _l, _i, _p, _i, _i, _i, _i, _i, _p],
@@ -41,7 +48,7 @@ SIGNATURES = {
     "emage_lstm_inputs": [_p, _p, _i, _p, _l, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "emage_rot6d_scatter": [_p, _i, _p, _p, _i, _i, _p],
 }
-RESTYPES = {}
+RESTYPES = {"emage_bn_stats_workspace_bytes": _l}
 
 _lib = None
 

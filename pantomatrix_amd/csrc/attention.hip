@@ -42,16 +42,28 @@ int dispatch(AttnArgs& a, int hd, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int emage_attention(int dtype, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int vt_rows,
-                               void* out, int ldo, int B, int H, int Tq, int Tk, int hd, void* stream) {
+static int attention_impl(int dtype, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int vt_rows,
+                          void* out, int ldo, int B, int H, int Tq, int Tk, int hd, const float* pmask, void* stream) {
     if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || Tk > 128 || vt_rows < H * hd) return EMAGE_EINVAL;
     if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3) return EMAGE_EINVAL;
+    if (pmask && dtype == EMAGE_BF16) return EMAGE_EINVAL;                 // the training forward runs in the fp32-storage modes
     const int epc = dtype == EMAGE_BF16 ? 8 : 4;
     if (ldq % epc || ldk % epc || ldo % 4 || ldvt % 32 || ldvt < ((Tk + 31) / 32) * 32) return EMAGE_EINVAL;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) return EMAGE_EINVAL;
     if ((long)B * Tq * ldq * 4 >= (1L << 31) || (long)B * Tk * ldk * 4 >= (1L << 31) || (long)B * vt_rows * ldvt * 4 >= (1L << 31)) return EMAGE_EINVAL;
-    AttnArgs a{q, k, vt, out, ldq, ldk, ldvt, vt_rows, ldo, B, H, Tq, Tk, 1.0f / sqrtf((float)hd)};
+    AttnArgs a{q, k, vt, out, ldq, ldk, ldvt, vt_rows, ldo, B, H, Tq, Tk, 1.0f / sqrtf((float)hd), pmask};
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EMAGE_F16X3) return dispatch<float, true>(a, hd, s);     // float32 tensors, split-f16 MFMA
     return dtype == EMAGE_BF16 ? dispatch<bf16_t, false>(a, hd, s) : dispatch<float, false>(a, hd, s);
+}
+
+extern "C" int emage_attention(int dtype, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int vt_rows,
+                               void* out, int ldo, int B, int H, int Tq, int Tk, int hd, void* stream) {
+    return attention_impl(dtype, q, ldq, k, ldk, vt, ldvt, vt_rows, out, ldo, B, H, Tq, Tk, hd, nullptr, stream);
+}
+
+extern "C" int emage_attention_dropout(int dtype, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int vt_rows,
+                                       void* out, int ldo, int B, int H, int Tq, int Tk, int hd, const float* pmask, void* stream) {
+    if (!pmask) return EMAGE_EINVAL;
+    return attention_impl(dtype, q, ldq, k, ldk, vt, ldvt, vt_rows, out, ldo, B, H, Tq, Tk, hd, pmask, stream);
 }

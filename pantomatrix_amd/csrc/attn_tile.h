@@ -10,6 +10,7 @@ struct AttnArgs {
     const void* q; const void* k; const void* vt; void* out;
     int ldq, ldk, ldvt, vt_rows, ldo, B, H, Tq, Tk;
     float scale;
+    const float* pmask;       // optional (B, H, Tq, Tk) fp32 factor on the probabilities: the attention dropout of a training forward
 };
 
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
@@ -201,7 +202,14 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
 #pragma unroll
         for (int c = 0; c < NPC; ++c) {
             const f32x4 v = sc[c];
-            pc[c] = __builtin_bit_cast(uint4, f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv});
+            f32x4 pv = {v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+            if (p.pmask) {                    // wave-uniform; train-mode forward only: dropout(softmax(.)) before P V, as torch does
+                const float* pm = p.pmask + (((long)b * p.H + h) * p.Tq + min(q0 + fr, p.Tq - 1)) * p.Tk + c * 16 + fg * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c * 16 + fg * 4 + r < p.Tk) pv[r] *= pm[r];
+            }
+            pc[c] = __builtin_bit_cast(uint4, pv);
         }
     }
 

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "attention.hip", "vq.hip", "elementwise.hip", "motion.hip", "wavconv.hip", "convslab.hip", "lstm.hip", "lstmseq.hip", "version.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "vq.hip", "elementwise.hip", "motion.hip", "wavconv.hip", "convslab.hip", "lstm.hip", "lstmseq.hip", "train.hip", "version.hip"]
 LIB = os.path.join(HERE, "libemage_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 

@@ -246,6 +246,107 @@ def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
     _attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd)
 
 
+@_op("attention_dropout", "(int dtype, Tensor q, Tensor k, Tensor vt, int vt_rows, Tensor(a!) out, int b, int h, int tq, int tk, int hd, Tensor pmask) -> ()")
+def _attention_dropout(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd, pmask):
+    assert pmask.dtype == torch.float32 and pmask.is_contiguous() and tuple(pmask.shape) == (b, h, tq, tk)
+    check(_lib.load().emage_attention_dropout(dtype, _ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(vt), vt.shape[-1], vt_rows, _ptr(out), _ld(out),
+                                              b, h, tq, tk, hd, _ptr(pmask), _stream()), "attention_dropout")
+
+
+def attention_dropout(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd, pmask):
+    """`attention` of a TRAINING forward: the probabilities are multiplied by pmask (B, H, Tq, Tk) fp32 before P V
+    (nn.MultiheadAttention's attention-probability dropout; the mask holds bernoulli / (1 - p))."""
+    _dev(q)
+    _attention_dropout(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd, pmask)
+
+
+@_op("bn_stats", "(Tensor x, Tensor(a!) mean, Tensor(b!) var, Tensor(c!)? running_mean, Tensor(d!)? running_var, float momentum, Tensor(e!) workspace) -> ()")
+def _bn_stats(x, mean, var, running_mean, running_var, momentum, workspace):
+    m, c = x.shape
+    check(_lib.load().emage_bn_stats(_ptr(x), _ld(x), m, c, _ptr(workspace), workspace.numel() * workspace.element_size(), _ptr(mean), _ptr(var),
+                                     _ptr(running_mean), _ptr(running_var), momentum, _stream()), "bn_stats")
+
+
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
+    """nn.BatchNorm1d (training) statistics of a channels-last fp32 (M, C) view: returns (mean, biased var) and updates
+    the running buffers in place as torch does (unbiased variance, momentum)."""
+    _dev(x)
+    m, c = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    nbytes = _lib.load().emage_bn_stats_workspace_bytes(m, c)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
+    mean, var = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
+    _bn_stats(x, mean, var, running_mean, running_var, float(momentum), ws)
+    return mean, var
+
+
+@_op("bn_apply", "(Tensor x, Tensor mean, Tensor var, Tensor gamma, Tensor beta, Tensor? sc, Tensor? sc_mean, Tensor? sc_var, Tensor? sc_gamma, "
+                 "Tensor? sc_beta, float eps, float slope, Tensor(a!) out) -> ()")
+def _bn_apply(x, mean, var, gamma, beta, sc, sc_mean, sc_var, sc_gamma, sc_beta, eps, slope, out):
+    m, c = x.shape
+    check(_lib.load().emage_bn_apply(_ptr(x), _ld(x), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), _ptr(sc), _ld(sc) if sc is not None else 0,
+                                     _ptr(sc_mean), _ptr(sc_var), _ptr(sc_gamma), _ptr(sc_beta), eps, slope, _ptr(out), _ld(out), m, c, _stream()), "bn_apply")
+
+
+def bn_apply(x, stats, gamma, beta, out, *, slope=1.0, sc=None, sc_bn=None, eps=1e-5):
+    """out = LeakyReLU(bn(x) + shortcut, slope) on fp32 (M, C) views; stats = (mean, var); sc = raw shortcut rows, or with
+    sc_bn = (mean, var, gamma, beta) a shortcut that is batch-normalised itself (BasicBlock's downsample branch)."""
+    _dev(x)
+    sm, sv, sg, sb = sc_bn if sc_bn is not None else (None, None, None, None)
+    _bn_apply(x, stats[0], stats[1], gamma, beta, sc, sm, sv, sg, sb, float(eps), float(slope), out)
+    return out
+
+
+@_op("mul_add", "(Tensor a, Tensor mask, int mask_t_rows, Tensor? b, Tensor(a!) out) -> ()")
+def _mul_add(a, mask, mask_t_rows, b, out):
+    m, c = a.shape
+    check(_lib.load().emage_mul_add(_ptr(a), _ld(a), _ptr(mask), _ld(mask), mask_t_rows, _ptr(b), _ld(b) if b is not None else 0, _ptr(out), _ld(out),
+                                    m, c, _stream()), "mul_add")
+
+
+def mul_add(a, mask, b=None, out=None, *, mask_t_rows=0):
+    """out = a * mask (+ b) on fp32 (M, C) views: dropout with a given mask, and the residual add behind it.  mask_t_rows = T:
+    the mask rows are stored (T, B) while a / b / out run (B, T)."""
+    _dev(a)
+    assert mask.dtype == torch.float32 and mask.dim() == 2 and mask.shape == a.shape and mask.stride(1) == 1
+    out = torch.empty_like(a) if out is None else out
+    _mul_add(a, mask, int(mask_t_rows), b, out)
+    return out
+
+
+LOSS_WORKSPACE_BYTES = 8192      # include/emage_hip.h
+
+
+@_op("mse_loss", "(Tensor pred, Tensor target, float weight, Tensor(a!) loss, Tensor(b!) workspace) -> ()")
+def _mse_loss(pred, target, weight, loss, workspace):
+    m, c = pred.shape
+    check(_lib.load().emage_mse_loss(_ptr(pred), _ld(pred), _ptr(target), _ld(target), m, c, weight, _ptr(loss), _ptr(workspace), _stream()), "mse_loss")
+
+
+@_op("nll_loss", "(Tensor logits, Tensor index, float weight, Tensor(a!) loss, Tensor(b!) workspace) -> ()")
+def _nll_loss(logits, index, weight, loss, workspace):
+    m, k = logits.shape
+    check(_lib.load().emage_nll_loss(_ptr(logits), _ld(logits), _ptr(index), m, k, weight, _ptr(loss), _ptr(workspace), _stream()), "nll_loss")
+
+
+def loss_workspace(device):
+    return torch.zeros(LOSS_WORKSPACE_BYTES // 8, dtype=torch.float64, device=device)
+
+
+def mse_loss(pred, target, weight, loss, workspace):
+    """loss[0] += weight * mean((pred - target)^2): fp32 (M, C) views, `loss` a float64 device scalar (F.mse_loss)."""
+    _dev(pred)
+    assert pred.shape == target.shape and pred.dtype == target.dtype == torch.float32 and loss.dtype == torch.float64
+    _mse_loss(pred, target, float(weight), loss, workspace)
+
+
+def nll_loss(logits, index, weight, loss, workspace):
+    """loss[0] += weight * mean_m(-log_softmax(logits[m])[index[m]]): logits fp32 (M, K), index int64 (M,) (NLLLoss(log_softmax))."""
+    _dev(logits)
+    assert logits.dtype == torch.float32 and index.dtype == torch.int64 and index.numel() == logits.shape[0] and index.is_contiguous()
+    _nll_loss(logits, index, float(weight), loss, workspace)
+
+
 @_op("layernorm", "(int dtype, Tensor x, Tensor gamma, Tensor beta, float eps, Tensor? add, Tensor(a!)? y_f32, Tensor(b!)? y) -> ()")
 def _layernorm(dtype, x, gamma, beta, eps, add, y_f32, y):
     m, c = x.shape

@@ -115,6 +115,73 @@ def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
     torch.as_strided(out, (b * tq, h * hd), (out.stride(0), 1))[:] = o.to(TD[dtype])
 
 
+def loss_workspace(device):
+    return torch.zeros(1024, dtype=torch.float64)
+
+
+def mse_loss(pred, target, weight, loss, workspace):
+    CALLS.append("mse_loss")
+    loss += weight * ((pred - target) ** 2).double().mean()
+
+
+def nll_loss(logits, index, weight, loss, workspace):
+    CALLS.append("nll_loss")
+    lp = torch.log_softmax(logits, dim=1)
+    loss += weight * (-lp.gather(1, index.view(-1, 1)).double().mean())
+
+
+def attention_dropout(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd, pmask):
+    CALLS.append("attention_dropout")
+    tp = vt.shape[-1]
+    assert dtype != BF16 and tuple(pmask.shape) == (b, h, tq, tk)
+    qf = torch.as_strided(q, (b * tq, h * hd), (q.stride(0), 1)).float().view(b, tq, h, hd).transpose(1, 2)
+    kf = torch.as_strided(k, (b * tk, h * hd), (k.stride(0), 1)).float().view(b, tk, h, hd).transpose(1, 2)
+    v_all = torch.as_strided(vt, (b, h * hd, tp), (vt_rows * tp, tp, 1)).float()
+    vf = v_all[:, :, :tk].reshape(b, h, hd, tk).transpose(2, 3)
+    p = torch.softmax((qf @ kf.transpose(-1, -2)) * (1.0 / math.sqrt(hd)), dim=-1) * pmask
+    o = (p @ vf).transpose(1, 2).reshape(b * tq, h * hd)
+    torch.as_strided(out, (b * tq, h * hd), (out.stride(0), 1))[:] = o.to(TD[dtype])
+
+
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1):
+    CALLS.append("bn_stats")
+    m = x.shape[0]
+    xd = x.double()
+    mean = xd.mean(0)
+    var = ((xd - mean) ** 2).mean(0)
+    if running_mean is not None:
+        running_mean.copy_((1 - momentum) * running_mean + momentum * mean.float())
+    if running_var is not None:
+        running_var.copy_((1 - momentum) * running_var + momentum * (var * m / max(m - 1, 1)).float())
+    return mean.float(), var.float()
+
+
+def bn_apply(x, stats, gamma, beta, out, *, slope=1.0, sc=None, sc_bn=None, eps=1e-5):
+    CALLS.append("bn_apply")
+    v = (x - stats[0]) / torch.sqrt(stats[1] + eps) * gamma + beta
+    if sc is not None:
+        r = sc
+        if sc_bn is not None:
+            r = (sc - sc_bn[0]) / torch.sqrt(sc_bn[1] + eps) * sc_bn[2] + sc_bn[3]
+        v = v + r
+    out.copy_(torch.nn.functional.leaky_relu(v, slope))
+    return out
+
+
+def mul_add(a, mask, b=None, out=None, *, mask_t_rows=0):
+    CALLS.append("mul_add")
+    m, c = a.shape
+    mk = mask
+    if mask_t_rows:
+        mk = mask.view(mask_t_rows, m // mask_t_rows, c).transpose(0, 1).reshape(m, c)
+    v = a * mk
+    if b is not None:
+        v = v + b
+    out = torch.empty_like(a) if out is None else out
+    out.copy_(v)
+    return out
+
+
 def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
     CALLS.append("layernorm")
     assert x.dtype == TD[dtype] and (add is None or add.dtype == TD[dtype])
@@ -363,7 +430,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

@@ -12,7 +12,7 @@ def _declared():
     text = open(os.path.join(ROOT, "include", "emage_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(?:int|size_t|const char\*)\s+(emage_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"(?:int|long|size_t|const char\*)\s+(emage_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         protos[m.group(1)] = args
     return protos

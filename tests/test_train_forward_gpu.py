@@ -1,0 +1,118 @@
+"""The train-mode forward on the MI355X (pantomatrix_amd/training.py: batch-statistics BatchNorm, dropout with the
+reference's masks) against the CPU training oracle and, through the three forwards of a step and the oracle's loss
+functions, against the losses of the REAL reference step in tests/golden/train_step_b2.npz."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+import train_common as tc
+from oracle import emage_train_oracle as tro
+from pantomatrix_amd import ops, synthetic, training
+from pantomatrix_amd.configuration_emage_audio import EmageAudioConfig
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_bn_kernels():
+    g = torch.Generator().manual_seed(0)
+    m, c = 5000, 192
+    x = (torch.randn(m, 256, generator=g) * 3 + 1.5).to(DEV)[:, 32:32 + c]          # a strided view
+    rm, rv = torch.randn(c, generator=g).to(DEV), (torch.rand(c, generator=g) + 0.5).to(DEV)
+    rm0, rv0 = rm.clone(), rv.clone()
+    mean, var = ops.bn_stats(x, rm, rv, 0.1)
+    xd = x.double()
+    assert float((mean.double() - xd.mean(0)).abs().max()) < 1e-6 and float((var.double() - xd.var(0, unbiased=False)).abs().max()) < 1e-5
+    assert float((rm - (0.9 * rm0 + 0.1 * xd.mean(0).float())).abs().max()) < 1e-6
+    assert float((rv - (0.9 * rv0 + 0.1 * xd.var(0, unbiased=True).float())).abs().max()) < 1e-5
+    gamma, beta = torch.randn(c, generator=g).to(DEV), torch.randn(c, generator=g).to(DEV)
+    sc = torch.randn(m, c, generator=g).to(DEV)
+    out = torch.empty(m, c, device=DEV)
+    ops.bn_apply(x, (mean, var), gamma, beta, out, slope=0.01, sc=sc, sc_bn=(mean, var, beta, gamma))
+    bn = lambda t, w, b: (t - mean) / torch.sqrt(var + 1e-5) * w + b
+    ref = torch.nn.functional.leaky_relu(bn(x, gamma, beta) + bn(sc, beta, gamma), 0.01)
+    assert float((out - ref).abs().max()) < 1e-5
+    ops.bn_apply(x, (mean, var), gamma, beta, out, slope=1.0, sc=sc)
+    assert float((out - (bn(x, gamma, beta) + sc)).abs().max()) < 1e-5
+
+
+def test_mul_add_and_attention_dropout():
+    g = torch.Generator().manual_seed(1)
+    b, t, c = 3, 7, 40
+    a, res = torch.randn(b * t, c, generator=g).to(DEV), torch.randn(b * t, c, generator=g).to(DEV)
+    mask_tb = (torch.rand(t, b, c, generator=g) > 0.1).float().to(DEV) / 0.9
+    got = ops.mul_add(a, mask_tb.view(t * b, c), res, mask_t_rows=t)
+    want = a * mask_tb.permute(1, 0, 2).reshape(b * t, c) + res
+    assert torch.equal(got, want)
+    assert torch.equal(ops.mul_add(a, want), a * want)
+    import fake_ops as F
+    from pantomatrix_amd._lib import F16X3, F32
+    bsz, h, tq, tk, hd = 2, 4, 64, 65, 192
+    for dtype in (F32, F16X3):
+        q = torch.randn(bsz * tq, h * hd, generator=g)
+        k = torch.randn(bsz * tk, h * hd, generator=g)
+        vt = torch.zeros(bsz, h * hd, 96)
+        vt[:, :, :tk] = torch.randn(bsz, h * hd, tk, generator=g)
+        pm = (torch.rand(bsz, h, tq, tk, generator=g) > 0.1).float() / 0.9
+        ref = torch.empty(bsz * tq, h * hd)
+        F.attention_dropout(dtype, q, k, vt, h * hd, ref, bsz, h, tq, tk, hd, pm)
+        out = torch.empty(bsz * tq, h * hd, device=DEV)
+        ops.attention_dropout(dtype, q.to(DEV), k.to(DEV), vt.to(DEV), h * hd, out, bsz, h, tq, tk, hd, pm.to(DEV))
+        assert float((out.cpu() - ref).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_train_forward_matches_oracle(precision):
+    (audio, spk, motion, mask), ref, masks, ref_stats = tc.oracle_forward(seed=7)
+    model, _ = common.product_models(precision=precision, device=DEV)
+    fwd = training.TrainForward(model)
+    out, stats = fwd(audio, spk, motion, mask, masks)
+    for k in ref:
+        err = float((out[k].cpu() - ref[k]).abs().max())
+        print(f"{precision} train forward {k}: max|err| {err:.2e}")
+        assert err < 3e-4, (k, err)
+    for k, v in ref_stats.items():
+        got = stats[k].cpu()
+        assert (int(got) == int(v)) if k.endswith("num_batches_tracked") else float((got - v).abs().max()) < 1e-5 * max(1.0, float(v.abs().max())), k
+
+
+def test_three_forwards_of_a_step_give_the_reference_losses(golden_dir):
+    """train_emage_audio.py:132-172 — the seed / audio / mask passes of one step with the reference's mask schedule and
+    generator draws (replayed by the oracle, which records every mask), run on the GPU; the six losses computed from the
+    GPU outputs equal the REAL reference's (tests/golden/train_step_b2.npz)."""
+    from test_train_oracle import train_batch
+    g = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    acfg, _, _ = common.cfg_dicts()
+    cfg = EmageAudioConfig(**acfg)
+    _, vq = common.oracle_models()
+    sd = synthetic.audio_model_state(cfg, 0)
+    model, _ = common.product_models(precision="f16x3", device=DEV)
+    fwd = training.TrainForward(model)
+    calls = []
+    orig = tro.forward_train
+
+    def spy(sd_, audio, spk, motion, mask, use_audio=True, p=tro.DROPOUT_P, new_stats=None):
+        masks = []
+        before = {k: v.clone() for k, v in (new_stats or {}).items()}
+        with tc.recorded_masks(masks):
+            out = orig(sd_, audio, spk, motion, mask, use_audio=use_audio, p=p, new_stats=new_stats)
+        gpu_out, _ = fwd(audio, spk, motion, mask, masks, use_audio=use_audio, new_stats=before)
+        calls.append(max(float((gpu_out[k].cpu() - out[k].detach()).abs().max()) for k in out))
+        return {k: gpu_out[k].cpu() for k in out}                  # the losses below are computed from the GPU's outputs
+
+    tro.forward_train = spy
+    try:
+        torch.manual_seed(int(g["seed"]))
+        with torch.no_grad():
+            losses = tro.train_step_losses(sd, vq, cfg, train_batch(), int(g["iteration"]))
+    finally:
+        tro.forward_train = orig
+    assert len(calls) == 3 and max(calls) < 3e-4, calls
+    losses = losses[0] if isinstance(losses, tuple) else losses
+    for k in ("rec_seed", "cls_seed", "rec_audio", "cls_audio", "rec_mask", "cls_mask", "all"):
+        got, want = float(losses[k]), float(g["loss_" + k])
+        print(f"loss {k}: GPU forward {got:.6f}  reference {want:.6f}")
+        assert abs(got - want) < 2e-4 * max(1.0, abs(want)), k

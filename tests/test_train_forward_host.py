@@ -1,0 +1,66 @@
+"""Host logic of the train-mode forward (pantomatrix_amd/training.py) on CPU stand-ins of the kernels: the order in which the
+dropout masks are consumed, the BatchNorm bookkeeping, the un-folded WavEncoder — against oracle/emage_train_oracle.py, which
+is pinned to the reference's training step (tests/test_train_oracle.py)."""
+import pytest
+import torch
+
+import common
+import fake_ops
+import train_common as tc
+from oracle import emage_train_oracle as tro
+from pantomatrix_amd import training
+
+
+def test_recorder_is_transparent():
+    """Recording the masks does not change the oracle: same outputs as the plain run with the same seed."""
+    (audio, spk, motion, mask), out, masks, ns = tc.oracle_forward(seed=3)
+    import common as c
+    from pantomatrix_amd import synthetic
+    from pantomatrix_amd.configuration_emage_audio import EmageAudioConfig
+    sd = synthetic.audio_model_state(EmageAudioConfig(**c.cfg_dicts()[0]), 0)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        ref = tro.forward_train(sd, audio, spk, motion, mask)
+    assert len(masks) == training.dropout_mask_count()
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+
+
+@pytest.mark.parametrize("precision,use_audio", [("fp32", True), ("f16x3", True), ("fp32", False)])
+def test_train_forward_host_logic(precision, use_audio):
+    (audio, spk, motion, mask), ref, masks, ref_stats = tc.oracle_forward(seed=7, use_audio=use_audio)
+    model, _ = common.product_models(precision=precision)
+    fwd = training.TrainForward(model)
+    with fake_ops.installed(), torch.no_grad():
+        out, stats = fwd(audio, spk, motion, mask, masks, use_audio=use_audio)
+        assert "bn_stats" in fake_ops.CALLS and "attention_dropout" in fake_ops.CALLS and "attention" not in fake_ops.CALLS
+    for k in ref:
+        err = float((out[k] - ref[k]).abs().max())
+        assert err < 2e-4, (k, err)
+    assert set(stats) == set(ref_stats)
+    for k, v in ref_stats.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(stats[k]) == int(v)
+        else:
+            assert float((stats[k] - v).abs().max()) < 1e-5 * max(1.0, float(v.abs().max())), k
+
+
+def test_running_stats_chain_and_mask_checks():
+    """Two forwards of one step: the second starts from the first one's running buffers (three forwards per step in
+    train_emage_audio.py:138-172); wrong mask counts / shapes are refused."""
+    (audio, spk, motion, mask), _, masks1, ns = tc.oracle_forward(seed=1)
+    _, ref2, masks2, ns = tc.oracle_forward(seed=2, new_stats=ns)
+    model, _ = common.product_models(precision="fp32")
+    fwd = training.TrainForward(model)
+    with fake_ops.installed(), torch.no_grad():
+        _, stats = fwd(audio, spk, motion, mask, masks1)
+        out2, stats = fwd(audio, spk, motion, mask, masks2, new_stats=stats)
+        with pytest.raises(RuntimeError, match="masks given"):
+            fwd(audio, spk, motion, mask, masks1[:-1])
+        with pytest.raises(RuntimeError, match="the reference draws"):
+            fwd(audio, spk, motion, mask, masks1[1:] + masks1[:1])
+    for k in ref2:
+        assert float((out2[k] - ref2[k]).abs().max()) < 2e-4, k
+    key = "audio_encoder_face.feat_extractor.0.bn1"
+    assert int(stats[key + ".num_batches_tracked"]) == int(ns[key + ".num_batches_tracked"])
+    assert float((stats[key + ".running_var"] - ns[key + ".running_var"]).abs().max()) < 1e-5

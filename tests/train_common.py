@@ -1,0 +1,43 @@
+"""Shared pieces of the train-mode forward tests: the oracle run with its dropout masks RECORDED (the oracle issues the
+reference's generator draws; a recorded mask is exactly the tensor torch multiplies with), product-side drivers."""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+import common
+from oracle import emage_train_oracle as tro
+from pantomatrix_amd import synthetic
+from pantomatrix_amd.configuration_emage_audio import EmageAudioConfig
+
+
+@contextlib.contextmanager
+def recorded_masks(store):
+    """Inside: every dropout of the training oracle appends its mask (values 0 or 1 / (1 - p), the logical shape the
+    reference's module sees) to `store`; the oracle's result is unchanged bit for bit (x * mask is what F.dropout returns)."""
+    saved = tro._drop
+
+    def _drop(x, p):
+        if p <= 0:
+            return x
+        m = F.dropout(torch.ones_like(x), p, training=True)           # ones_like keeps x's memory format: the same draws in the same order
+        store.append(m)
+        return x * m
+
+    tro._drop = _drop
+    try:
+        yield store
+    finally:
+        tro._drop = saved
+
+
+def oracle_forward(seed, use_audio=True, new_stats=None, batch=2):
+    cfg = EmageAudioConfig(**common.cfg_dicts()[0])
+    sd = synthetic.audio_model_state(cfg, 0)
+    audio, spk, motion, mask = common.window_inputs(batch)
+    masks = []
+    torch.manual_seed(seed)
+    with torch.no_grad(), recorded_masks(masks):
+        ns = {} if new_stats is None else new_stats
+        out = tro.forward_train(sd, audio, spk, motion, mask, use_audio=use_audio, new_stats=ns)
+    return (audio, spk, motion, mask), out, masks, ns
