@@ -284,9 +284,9 @@ def targets(vq, motion_aa, expressions, trans, foot_contact):
     """Top of train_val_fn (T:146-152): axis-angle -> rot-6D, the frozen VQ-VAEs' code indices and quantised latents, and the
     337-channel motion the model is conditioned on — all on the device (`vq` is the product EmageVQModel)."""
     bs, t, jc = motion_aa.shape
-    dev = vq.device
+    dev = vq.vq_model_face.device
     aa = motion_aa.to(device=dev, dtype=torch.float32).reshape(bs * t * (jc // 3), 3).contiguous()
-    rot6d = ops.axis_angle_to_rot6d(aa).view(bs, t, jc // 3 * 6)
+    rot6d = ops.axis_angle_to_rot6d(aa).reshape(bs, t, jc // 3 * 6)
     expressions, trans, foot_contact = (x.to(device=dev, dtype=torch.float32) for x in (expressions, trans, foot_contact))
     index = vq.map2index(rot6d, expressions, tar_contact=foot_contact, tar_trans=trans)
     latent = vq.map2latent(rot6d, expressions, tar_contact=foot_contact, tar_trans=trans)

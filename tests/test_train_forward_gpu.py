@@ -116,3 +116,37 @@ def test_three_forwards_of_a_step_give_the_reference_losses(golden_dir):
         got, want = float(losses[k]), float(g["loss_" + k])
         print(f"loss {k}: GPU forward {got:.6f}  reference {want:.6f}")
         assert abs(got - want) < 2e-4 * max(1.0, abs(want)), k
+
+
+def test_loss_kernels():
+    g = torch.Generator().manual_seed(2)
+    m, c = 130, 256
+    pred, tgt = torch.randn(m, 300, generator=g)[:, :c].to(DEV), torch.randn(m, c, generator=g).to(DEV)
+    idx = torch.randint(0, c, (m,), generator=g).to(DEV)
+    ws = ops.loss_workspace(DEV)
+    acc = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ops.mse_loss(pred, tgt, 3.0, acc, ws)
+    ops.nll_loss(pred, idx, 0.5, acc, ws)
+    want = 3.0 * torch.nn.functional.mse_loss(pred, tgt).double() + 0.5 * torch.nn.functional.nll_loss(torch.log_softmax(pred, 1), idx).double()
+    assert abs(float(acc) - float(want)) < 1e-5 * abs(float(want))
+    assert float(ws[-1]) == 0.0
+    ops.nll_loss(pred, torch.full((m,), c, dtype=torch.long, device=DEV), 1.0, acc, ws)       # class index out of range: flagged
+    torch.cuda.synchronize()
+    assert ws.view(torch.int32)[-2].item() != 0
+
+
+def test_step_losses_on_device(golden_dir):
+    """The whole loss side of a training step on the GPU — targets through the HIP VQ models, three train-mode forwards, the
+    loss kernels — with the draws of the reference's generator: the six losses of tests/golden/train_step_b2.npz."""
+    g = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    batch, ref, masks, random_mask, ref_stats = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    got, stats = training.step_losses(training.TrainForward(model), vq, {k: v.to(DEV) for k, v in batch.items()}, int(g["iteration"]),
+                                      masks, random_mask.to(DEV))
+    for k in ("rec_seed", "cls_seed", "rec_audio", "cls_audio", "rec_mask", "cls_mask", "all"):
+        want = float(g["loss_" + k])
+        print(f"loss {k}: on device {got[k]:.6f}  reference {want:.6f}")
+        assert abs(got[k] - want) < 2e-4 * max(1.0, abs(want)), k
+    for k, v in ref_stats.items():
+        if not k.endswith("num_batches_tracked"):
+            assert float((stats[k].cpu() - v).abs().max()) < 1e-5 * max(1.0, float(v.abs().max())), k

@@ -64,3 +64,22 @@ def test_running_stats_chain_and_mask_checks():
     key = "audio_encoder_face.feat_extractor.0.bn1"
     assert int(stats[key + ".num_batches_tracked"]) == int(ns[key + ".num_batches_tracked"])
     assert float((stats[key + ".running_var"] - ns[key + ".running_var"]).abs().max()) < 1e-5
+
+
+def test_step_losses_host_logic(golden_dir):
+    """training.step_losses (targets through the product VQ model, three forwards, the two loss kernels) on the CPU stand-ins:
+    the oracle's losses for the same draws — which are the REAL reference's (tests/golden/train_step_b2.npz)."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    batch, ref, masks, random_mask, ref_stats = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
+    model, vq = common.product_models(precision="fp32")
+    fwd = training.TrainForward(model)
+    with fake_ops.installed(), torch.no_grad():
+        got, stats = training.step_losses(fwd, vq, batch, int(g["iteration"]), masks, random_mask)
+        assert fake_ops.CALLS.count("mse_loss") == 12 and fake_ops.CALLS.count("nll_loss") == 12
+    for k in ("rec_seed", "cls_seed", "rec_audio", "cls_audio", "rec_mask", "cls_mask", "all"):
+        assert abs(got[k] - ref[k]) < 2e-4 * max(1.0, abs(ref[k])), (k, got[k], ref[k])
+        assert abs(got[k] - float(g["loss_" + k])) < 2e-4 * max(1.0, abs(float(g["loss_" + k]))), k
+    key = "audio_encoder_body.feat_extractor.5.downsample.1.running_mean"
+    assert float((stats[key] - ref_stats[key]).abs().max()) < 1e-5
