@@ -345,6 +345,39 @@ int emage_mse_loss(const float* pred, int ld_pred, const float* target, int ld_t
                    double* loss, void* workspace, void* stream);
 int emage_nll_loss(const float* logits, int ld, const int64_t* index, int M, int K, float weight, double* loss, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Backward building blocks of the training step (first functional versions: fp32 VALU code with float64 reductions; the
+ * contractions of the Linear layers — dX = dY W, dW = dY^T X — are emage_gemm launches on transposed operands).
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* out (N, ld_out) = in (M, ld_in) transposed, fp32. */
+int emage_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int M, int N, void* stream);
+
+/* out[c] (+)= sum_m x[m][c] (* y[m][c] when y is given): bias / LayerNorm-affine gradients.  float64 block partials added in
+ * block order (deterministic); workspace: ceil(M / 2048) * C * 8 bytes. */
+int emage_col_sum(const float* x, int ldx, const float* y, int ldy, int M, int C, float* out, int accumulate,
+                  void* workspace, long workspace_bytes, void* stream);
+
+/* out = dy * (y > 0 ? 1 : slope): LeakyReLU / ReLU backward from the saved OUTPUT y of the activation. */
+int emage_act_backward(const float* dy, int ld_dy, const float* y, int ld_y, float slope, float* out, int ldo, int M, int C, void* stream);
+
+/* nn.LayerNorm backward for input rows x (M, C): dx, and dy_xhat = dy * (x - mean) * rstd (column sums of dy_xhat / dy are
+ * the weight / bias gradients: emage_col_sum). */
+int emage_layernorm_backward(const float* x, int ldx, const float* gamma, const float* dy, int ld_dy, float eps,
+                             float* dx, int ld_dx, float* dy_xhat, int ld_t, int M, int C, void* stream);
+
+/* Backward of emage_attention / emage_attention_dropout (same operand layouts; pmask may be NULL): dq (B*Tq, .), dk, dv (B*Tk, .)
+ * in row layout with head h at columns [h*hd, (h+1)*hd).  The probabilities are recomputed. */
+int emage_attention_backward(const float* q, int ldq, const float* k, int ldk, const float* vt, int ldvt, int vt_rows, const float* pmask,
+                             const float* d_out, int ld_do, float* dq, int ld_dq, float* dk, int ld_dk, float* dv, int ld_dv,
+                             int B, int H, int Tq, int Tk, int hd, void* stream);
+
+/* Gradients of the two losses w.r.t. their predictions: grad = weight * 2 (pred - target) / (M C);
+ * grad = weight * (softmax(logits) - onehot(index)) / M. */
+int emage_mse_loss_grad(const float* pred, int ld_pred, const float* target, int ld_target, int M, int C, float weight,
+                        float* grad, int ld_grad, void* stream);
+int emage_nll_loss_grad(const float* logits, int ld, const int64_t* index, int M, int K, float weight, float* grad, int ld_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

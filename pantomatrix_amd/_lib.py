@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 
 F32, BF16, F16X3 = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -31,6 +31,13 @@ SIGNATURES = {
     "emage_bn_apply": [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _i, _i, _p],
     "emage_mse_loss": [_p, _i, _p, _i, _i, _i, _f, _p, _p, _p],
     "emage_nll_loss": [_p, _i, _p, _i, _i, _f, _p, _p, _p],
+    "emage_transpose_f32": [_p, _i, _p, _i, _i, _i, _p],
+    "emage_col_sum": [_p, _i, _p, _i, _i, _i, _p, _i, _p, _l, _p],
+    "emage_act_backward": [_p, _i, _p, _i, _f, _p, _i, _i, _i, _p],
+    "emage_layernorm_backward": [_p, _i, _p, _p, _i, _f, _p, _i, _p, _i, _i, _i, _p],
+    "emage_attention_backward": [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "emage_mse_loss_grad": [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p],
+    "emage_nll_loss_grad": [_p, _i, _p, _i, _i, _f, _p, _i, _p],
     "emage_mul_add": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p],

@@ -217,3 +217,244 @@ extern "C" int emage_nll_loss(const float* logits, int ld, const int64_t* index,
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, s, (const double*)workspace, blocks, (double)weight / (double)M, loss);
     return launch_status();
 }
+
+// =====================================================================================================================
+// Backward building blocks of the training step (first, functional versions: plain fp32 VALU code, float64 reductions;
+// the contractions of the Linear layers go through emage_gemm with transposed operands, see pantomatrix_amd/training.py)
+// =====================================================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, int M, int N) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, n = n0 + tx;
+        tile[r][tx] = (m < M && n < N) ? in[(long)m * ldi + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, m = m0 + tx;
+        if (n < N && m < M) out[(long)n * ldo + m] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy, int M, int C,
+                                                              double* __restrict__ partial) {
+    __shared__ double red[STAT_ROWS][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const long r0 = (long)blockIdx.x * STAT_CHUNK;
+    const long r1 = r0 + STAT_CHUNK < M ? r0 + STAT_CHUNK : M;
+    double s = 0.0;
+    if (c < C)
+        for (long r = r0 + rl; r < r1; r += STAT_ROWS) s += y ? (double)(x[r * ldx + c] * y[r * ldy + c]) : (double)x[r * ldx + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double a = 0.0;
+        for (int i = 0; i < STAT_ROWS; ++i) a += red[i][cl];
+        partial[(long)blockIdx.x * C + c] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void col_sum_finalize_kernel(const double* __restrict__ partial, int chunks, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = 0; i < chunks; ++i) s += partial[(long)i * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// dpre = dy * (y > 0 ? 1 : slope): backward of LeakyReLU / ReLU from the saved OUTPUT (same sign as the pre-activation)
+__global__ __launch_bounds__(256) void act_backward_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy, float slope,
+                                                           float* __restrict__ out, int ldo, int M, int C) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / C;
+        const int c = (int)(i - m * C);
+        out[m * ldo + c] = dy[m * ldd + c] * (y[m * ldy + c] > 0.f ? 1.f : slope);
+    }
+}
+
+// LayerNorm backward, one wave per row: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; also t = dy * xhat
+// (its column sums are d gamma; the column sums of dy are d beta)
+__global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ dy, int ldd,
+                                                                 float eps, float* __restrict__ dx, int ldo, float* __restrict__ dyxhat, int ldt, int M, int C) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* xr = x + m * ldx;
+    const float* dr = dy + m * ldd;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mu; v += d * d; }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / C + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mu) * rstd, g = dr[c] * gamma[c];
+        sg += g;
+        sgx += g * xh;
+    }
+    for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o); sgx += __shfl_xor(sgx, o); }
+    const float mg = sg / C, mgx = sgx / C;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mu) * rstd, g = dr[c] * gamma[c];
+        dx[m * ldo + c] = rstd * (g - mg - xh * mgx);
+        dyxhat[m * ldt + c] = dr[c] * xh;
+    }
+}
+
+struct AttnBwdArgs {
+    const float* q; const float* k; const float* vt; const float* pmask; const float* d_out;
+    float* dq; float* dk; float* dv;
+    int ldq, ldk, ldvt, vt_rows, ld_do, ld_dq, ld_dk, ld_dv, B, H, Tq, Tk, HD;
+    float scale;
+};
+
+// one block per (batch, head): recomputes P = softmax(scale Q K^T), then dV = (P*mask)^T dO, dP = (dO V^T) * mask,
+// dS = P * (dP - rowsum(dP * P)) * scale, dQ = dS K, dK = dS^T Q.  P and dS live in LDS (Tq * Tk floats each).
+__global__ __launch_bounds__(256) void attention_backward_kernel(AttnBwdArgs p) {
+    extern __shared__ float lds[];
+    float* P = lds;
+    float* dS = lds + p.Tq * p.Tk;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int Tq = p.Tq, Tk = p.Tk, HD = p.HD;
+    const float* Q = p.q + (long)b * Tq * p.ldq + h * HD;
+    const float* K = p.k + (long)b * Tk * p.ldk + h * HD;
+    const float* VT = p.vt + ((long)b * p.vt_rows + h * HD) * p.ldvt;           // VT[d * ldvt + j]
+    const float* dO = p.d_out + (long)b * Tq * p.ld_do + h * HD;
+    const float* MK = p.pmask ? p.pmask + ((long)b * p.H + h) * Tq * Tk : nullptr;
+    const int n_pairs = Tq * Tk;
+    for (int e = threadIdx.x; e < n_pairs; e += blockDim.x) {
+        const int i = e / Tk, j = e - i * Tk;
+        float s = 0.f, dp = 0.f;
+        for (int d = 0; d < HD; ++d) {
+            s = fmaf(Q[(long)i * p.ldq + d], K[(long)j * p.ldk + d], s);
+            dp = fmaf(dO[(long)i * p.ld_do + d], VT[(long)d * p.ldvt + j], dp);
+        }
+        P[e] = s * p.scale;
+        dS[e] = MK ? dp * MK[e] : dp;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Tq; i += blockDim.x) {
+        float mx = -INFINITY;
+        for (int j = 0; j < Tk; ++j) mx = fmaxf(mx, P[i * Tk + j]);
+        float sum = 0.f;
+        for (int j = 0; j < Tk; ++j) { const float e = expf(P[i * Tk + j] - mx); P[i * Tk + j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        float dsum = 0.f;
+        for (int j = 0; j < Tk; ++j) { P[i * Tk + j] *= inv; dsum = fmaf(dS[i * Tk + j], P[i * Tk + j], dsum); }
+        for (int j = 0; j < Tk; ++j) dS[i * Tk + j] = P[i * Tk + j] * (dS[i * Tk + j] - dsum) * p.scale;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < Tq * HD; e += blockDim.x) {                 // dQ[i][d] = sum_j dS[i][j] K[j][d]
+        const int i = e / HD, d = e - i * HD;
+        float a = 0.f;
+        for (int j = 0; j < Tk; ++j) a = fmaf(dS[i * Tk + j], K[(long)j * p.ldk + d], a);
+        p.dq[((long)b * Tq + i) * p.ld_dq + h * HD + d] = a;
+    }
+    for (int e = threadIdx.x; e < Tk * HD; e += blockDim.x) {                 // dK[j][d] = sum_i dS[i][j] Q[i][d];  dV[j][d] = sum_i P[i][j] mask[i][j] dO[i][d]
+        const int j = e / HD, d = e - j * HD;
+        float a = 0.f, c = 0.f;
+        for (int i = 0; i < Tq; ++i) {
+            a = fmaf(dS[i * Tk + j], Q[(long)i * p.ldq + d], a);
+            const float pm = MK ? P[i * Tk + j] * MK[i * Tk + j] : P[i * Tk + j];
+            c = fmaf(pm, dO[(long)i * p.ld_do + d], c);
+        }
+        p.dk[((long)b * Tk + j) * p.ld_dk + h * HD + d] = a;
+        p.dv[((long)b * Tk + j) * p.ld_dv + h * HD + d] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ target, int ldt, float scale,
+                                                       float* __restrict__ out, int ldo, int M, int C) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / C;
+        const int c = (int)(i - m * C);
+        out[m * ldo + c] = scale * (pred[m * ldp + c] - target[m * ldt + c]);
+    }
+}
+
+// out[m][k] = scale * (softmax(logits[m])[k] - [k == index[m]]): one wave per row
+__global__ __launch_bounds__(256) void nll_grad_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ index, float scale,
+                                                       float* __restrict__ out, int ldo, int M, int K) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* x = logits + m * ld;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, x[k]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float se = 0.f;
+    for (int k = lane; k < K; k += 64) se += expf(x[k] - mx);
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    const int64_t t = index[m];
+    for (int k = lane; k < K; k += 64) out[m * ldo + k] = scale * (expf(x[k] - mx) / se - (k == t ? 1.f : 0.f));
+}
+
+}  // namespace
+
+extern "C" int emage_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int M, int N, void* stream) {
+    if (!in || !out || M <= 0 || N <= 0 || ld_in < N || ld_out < M) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, ld_in, out, ld_out, M, N);
+    return launch_status();
+}
+
+extern "C" int emage_col_sum(const float* x, int ldx, const float* y, int ldy, int M, int C, float* out, int accumulate,
+                             void* workspace, long workspace_bytes, void* stream) {
+    if (!x || !out || !workspace || M <= 0 || C <= 0 || ldx < C || (y && ldy < C) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
+    const int chunks = (M + STAT_CHUNK - 1) / STAT_CHUNK;
+    if (workspace_bytes < (long)chunks * C * (long)sizeof(double)) return EMAGE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, y, ldy, M, C, (double*)workspace);
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C, out, accumulate);
+    return launch_status();
+}
+
+extern "C" int emage_act_backward(const float* dy, int ld_dy, const float* y, int ld_y, float slope, float* out, int ldo, int M, int C, void* stream) {
+    if (!dy || !y || !out || M <= 0 || C <= 0 || ld_dy < C || ld_y < C || ldo < C) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(act_backward_kernel, dim3(grid_for((long)M * C)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, y, ld_y, slope, out, ldo, M, C);
+    return launch_status();
+}
+
+extern "C" int emage_layernorm_backward(const float* x, int ldx, const float* gamma, const float* dy, int ld_dy, float eps,
+                                        float* dx, int ld_dx, float* dy_xhat, int ld_t, int M, int C, void* stream) {
+    if (!x || !gamma || !dy || !dx || !dy_xhat || M <= 0 || C <= 0 || ldx < C || ld_dy < C || ld_dx < C || ld_t < C) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(layernorm_backward_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, dy, ld_dy, eps, dx, ld_dx, dy_xhat, ld_t, M, C);
+    return launch_status();
+}
+
+extern "C" int emage_attention_backward(const float* q, int ldq, const float* k, int ldk, const float* vt, int ldvt, int vt_rows, const float* pmask,
+                                        const float* d_out, int ld_do, float* dq, int ld_dq, float* dk, int ld_dk, float* dv, int ld_dv,
+                                        int B, int H, int Tq, int Tk, int hd, void* stream) {
+    if (!q || !k || !vt || !d_out || !dq || !dk || !dv || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || hd <= 0 || vt_rows < H * hd || ldvt < Tk) return EMAGE_EINVAL;
+    const size_t lds = (size_t)2 * Tq * Tk * sizeof(float);
+    if (lds > 144 * 1024) return EMAGE_EINVAL;
+    static const hipError_t configured = hipFuncSetAttribute((const void*)attention_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (configured != hipSuccess) return (int)configured;
+    AttnBwdArgs a{q, k, vt, pmask, d_out, dq, dk, dv, ldq, ldk, ldvt, vt_rows, ld_do, ld_dq, ld_dk, ld_dv, B, H, Tq, Tk, hd, 1.0f / sqrtf((float)hd)};
+    hipLaunchKernelGGL(attention_backward_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+extern "C" int emage_mse_loss_grad(const float* pred, int ld_pred, const float* target, int ld_target, int M, int C, float weight,
+                                   float* grad, int ld_grad, void* stream) {
+    if (!pred || !target || !grad || M <= 0 || C <= 0 || ld_pred < C || ld_target < C || ld_grad < C) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(grid_for((long)M * C)), dim3(256), 0, (hipStream_t)stream, pred, ld_pred, target, ld_target,
+                       (float)(2.0 * (double)weight / ((double)M * C)), grad, ld_grad, M, C);
+    return launch_status();
+}
+
+extern "C" int emage_nll_loss_grad(const float* logits, int ld, const int64_t* index, int M, int K, float weight, float* grad, int ld_grad, void* stream) {
+    if (!logits || !index || !grad || M <= 0 || K <= 0 || ld < K || ld_grad < K) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(nll_grad_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, index, (float)((double)weight / M), grad, ld_grad, M, K);
+    return launch_status();
+}

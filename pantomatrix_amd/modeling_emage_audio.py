@@ -198,6 +198,7 @@ class _Packed:
         self.p, self.device, self.dt = params, device, dt
         self.tdt = ops.TORCH_DTYPE[dt]
         self.w = {}
+        self.origin = {}     # key -> [(weight name, bias name, row slice of that parameter)] in stacking order (training: gradient unpacking)
         # per-column LeakyReLU slope vectors, built once here (before any stream fork can race on them):
         # 0 = ReLU, 0.01 / 0.1 / 0.2 = the reference's LeakyReLU slopes
         self._slopes = {v: torch.full((4096,), v, dtype=torch.float32, device=device) for v in (0.0, 0.01, 0.1, 0.2)}
@@ -234,6 +235,8 @@ class _Packed:
         k_real = ws[0].shape[1]
         w, kp, wsc = self._pack_mat(torch.cat(ws, 0).float())
         self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc)
+        self.origin[key] = [(nm + ".weight", nm + ".bias", rows[i] if rows is not None else slice(0, self.p[nm + ".weight"].shape[0]))
+                            for i, nm in enumerate(names)]
 
     def in_proj(self, key, names, parts):
         """Row blocks of packed in_proj weights: parts e.g. "qkv", "q", "kv"; several layers stack as
@@ -241,10 +244,12 @@ class _Packed:
         d = self.p[names[0] + ".in_proj_weight"].shape[1]
         sl = {"q": slice(0, d), "k": slice(d, 2 * d), "v": slice(2 * d, 3 * d)}
         ws, bs = [], []
+        self.origin[key] = []
         for part in parts:
             for nm in names:
                 ws.append(self.p[nm + ".in_proj_weight"][sl[part]])
                 bs.append(self.p[nm + ".in_proj_bias"][sl[part]])
+                self.origin[key].append((nm + ".in_proj_weight", nm + ".in_proj_bias", sl[part]))
         k_real = ws[0].shape[1]
         w, kp, wsc = self._pack_mat(torch.cat(ws, 0).float())
         self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc)

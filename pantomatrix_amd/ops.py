@@ -347,6 +347,107 @@ def nll_loss(logits, index, weight, loss, workspace):
     _nll_loss(logits, index, float(weight), loss, workspace)
 
 
+# ---- backward building blocks (include/emage_hip.h) --------------------------------------------------------------------
+@_op("transpose", "(Tensor x, Tensor(a!) out) -> ()")
+def _transpose(x, out):
+    m, n = x.shape
+    check(_lib.load().emage_transpose_f32(_ptr(x), _ld(x), _ptr(out), _ld(out), m, n, _stream()), "transpose")
+
+
+def transpose(x, out=None):
+    """(M, N) fp32 view -> contiguous (N, M)."""
+    _dev(x)
+    m, n = x.shape
+    out = torch.empty(n, m, dtype=torch.float32, device=x.device) if out is None else out
+    _transpose(x, out)
+    return out
+
+
+@_op("col_sum", "(Tensor x, Tensor? y, Tensor(a!) out, bool accumulate, Tensor(b!) workspace) -> ()")
+def _col_sum(x, y, out, accumulate, workspace):
+    m, c = x.shape
+    check(_lib.load().emage_col_sum(_ptr(x), _ld(x), _ptr(y), _ld(y) if y is not None else 0, m, c, _ptr(out), int(accumulate), _ptr(workspace),
+                                    workspace.numel() * 8, _stream()), "col_sum")
+
+
+def col_sum(x, y=None, out=None, accumulate=False):
+    """out[c] (+)= sum_m x[m, c] (* y[m, c]) over fp32 (M, C) views."""
+    _dev(x)
+    m, c = x.shape
+    out = torch.zeros(c, dtype=torch.float32, device=x.device) if out is None else out
+    ws = torch.empty(((m + 2047) // 2048) * c, dtype=torch.float64, device=x.device)
+    _col_sum(x, y, out, accumulate, ws)
+    return out
+
+
+@_op("act_backward", "(Tensor dy, Tensor y, float slope, Tensor(a!) out) -> ()")
+def _act_backward(dy, y, slope, out):
+    m, c = dy.shape
+    check(_lib.load().emage_act_backward(_ptr(dy), _ld(dy), _ptr(y), _ld(y), slope, _ptr(out), _ld(out), m, c, _stream()), "act_backward")
+
+
+def act_backward(dy, y, slope, out=None):
+    """dy * (y > 0 ? 1 : slope) from the activation's saved output."""
+    _dev(dy)
+    out = torch.empty(dy.shape, dtype=torch.float32, device=dy.device) if out is None else out
+    _act_backward(dy, y, float(slope), out)
+    return out
+
+
+@_op("layernorm_backward", "(Tensor x, Tensor gamma, Tensor dy, float eps, Tensor(a!) dx, Tensor(b!) dy_xhat) -> ()")
+def _layernorm_backward(x, gamma, dy, eps, dx, dy_xhat):
+    m, c = x.shape
+    check(_lib.load().emage_layernorm_backward(_ptr(x), _ld(x), _ptr(gamma), _ptr(dy), _ld(dy), eps, _ptr(dx), _ld(dx), _ptr(dy_xhat), _ld(dy_xhat),
+                                               m, c, _stream()), "layernorm_backward")
+
+
+def layernorm_backward(x, gamma, dy, eps=1e-5):
+    """-> (dx, dgamma, dbeta) of LayerNorm(x) * gamma + beta for fp32 (M, C) rows."""
+    _dev(x)
+    dx, t = torch.empty(x.shape, dtype=torch.float32, device=x.device), torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _layernorm_backward(x, gamma, dy, float(eps), dx, t)
+    return dx, col_sum(t), col_sum(dy)
+
+
+@_op("attention_backward", "(Tensor q, Tensor k, Tensor vt, int vt_rows, Tensor? pmask, Tensor d_out, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) dv, "
+                           "int b, int h, int tq, int tk, int hd) -> ()")
+def _attention_backward(q, k, vt, vt_rows, pmask, d_out, dq, dk, dv, b, h, tq, tk, hd):
+    check(_lib.load().emage_attention_backward(_ptr(q), _ld(q), _ptr(k), _ld(k), _ptr(vt), vt.shape[-1], vt_rows, _ptr(pmask), _ptr(d_out), _ld(d_out),
+                                               _ptr(dq), _ld(dq), _ptr(dk), _ld(dk), _ptr(dv), _ld(dv), b, h, tq, tk, hd, _stream()), "attention_backward")
+
+
+def attention_backward(q, k, vt, vt_rows, pmask, d_out, dq, dk, dv, b, h, tq, tk, hd):
+    """Backward of `attention` / `attention_dropout` (fp32 operands, same layouts): fills dq (B*Tq, >= h*hd), dk, dv (B*Tk, >= h*hd)."""
+    _dev(q)
+    _attention_backward(q, k, vt, vt_rows, pmask, d_out, dq, dk, dv, b, h, tq, tk, hd)
+
+
+@_op("mse_loss_grad", "(Tensor pred, Tensor target, float weight, Tensor(a!) grad) -> ()")
+def _mse_loss_grad(pred, target, weight, grad):
+    m, c = pred.shape
+    check(_lib.load().emage_mse_loss_grad(_ptr(pred), _ld(pred), _ptr(target), _ld(target), m, c, weight, _ptr(grad), _ld(grad), _stream()), "mse_loss_grad")
+
+
+@_op("nll_loss_grad", "(Tensor logits, Tensor index, float weight, Tensor(a!) grad) -> ()")
+def _nll_loss_grad(logits, index, weight, grad):
+    m, k = logits.shape
+    check(_lib.load().emage_nll_loss_grad(_ptr(logits), _ld(logits), _ptr(index), m, k, weight, _ptr(grad), _ld(grad), _stream()), "nll_loss_grad")
+
+
+def mse_loss_grad(pred, target, weight):
+    _dev(pred)
+    g = torch.empty(pred.shape, dtype=torch.float32, device=pred.device)
+    _mse_loss_grad(pred, target, float(weight), g)
+    return g
+
+
+def nll_loss_grad(logits, index, weight):
+    _dev(logits)
+    g = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
+    _nll_loss_grad(logits, index, float(weight), g)
+    return g
+
+
 @_op("layernorm", "(int dtype, Tensor x, Tensor gamma, Tensor beta, float eps, Tensor? add, Tensor(a!)? y_f32, Tensor(b!)? y) -> ()")
 def _layernorm(dtype, x, gamma, beta, eps, add, y_f32, y):
     m, c = x.shape

@@ -52,13 +52,83 @@ class _Masks:
         return m.to(device=self.dev, dtype=torch.float32).contiguous()
 
 
+class _Token:
+    """Stands for a logical (rows, cols) tensor that exists only in pieces (a projection whose V columns are stored transposed)."""
+
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class _Tape:
+    """Reverse-mode bookkeeping of one forward: backward closures in launch order, gradient buffers keyed by the forward tensor
+    (or token) they belong to, column-slice views routed into their parent's buffer.  Gradients are fp32 (rows, cols)."""
+
+    def __init__(self, dev):
+        self.dev, self.nodes, self.g, self.views, self.keep = dev, [], {}, {}, []
+
+    def node(self, fn):
+        self.nodes.append(fn)
+
+    def view(self, parent, view, c0):
+        self.views[id(view)] = (parent, c0, view.shape[1])
+        self.keep.append(view)
+
+    def buffer(self, t):
+        """The zero-initialised, tape-owned gradient buffer of `t` (created on first use)."""
+        e = self.g.get(id(t))
+        if e is None:
+            e = [torch.zeros(tuple(t.shape), dtype=torch.float32, device=self.dev), True]
+            self.g[id(t)] = e
+            self.keep.append(t)
+        elif not e[1]:
+            e[0], e[1] = e[0].clone(), True
+        return e[0]
+
+    def add(self, t, g, cols=None):
+        """grad(t)[:, :cols] += g.  The first gradient of a tensor is kept by reference (never modified in place afterwards)."""
+        if id(t) in self.views:
+            parent, c0, n = self.views[id(t)]
+            dst = self.buffer(parent)[:, c0:c0 + (n if cols is None else cols)]
+            ops.add(F32, dst, g, out=dst)
+            return
+        e = self.g.get(id(t))
+        if cols is not None and cols != t.shape[1]:
+            dst = self.buffer(t)[:, :cols]
+            ops.add(F32, dst, g, out=dst)
+        elif e is None:
+            self.g[id(t)] = [g, False]
+            self.keep.append(t)
+        elif e[1]:
+            ops.add(F32, e[0], g, out=e[0])
+        else:
+            s = torch.empty(tuple(e[0].shape), dtype=torch.float32, device=self.dev)
+            ops.add(F32, e[0], g, out=s)
+            e[0], e[1] = s, True
+
+    def get(self, t):
+        if id(t) in self.views:                          # a column block of its parent's gradient
+            parent, c0, n = self.views[id(t)]
+            e = self.g.get(id(parent))
+            return None if e is None else e[0][:, c0:c0 + n]
+        e = self.g.get(id(t))
+        return None if e is None else e[0]
+
+    def run(self):
+        for fn in reversed(self.nodes):
+            fn()
+        self.nodes = []
+
+
 class TrainForward:
-    """Callable train-mode forward of an `EmageAudioModel` (f16x3 or fp32 precision)."""
+    """Callable train-mode forward of an `EmageAudioModel` (f16x3 or fp32 precision), with `backward()` for the part of the
+    network behind the convolutional front ends."""
 
     def __init__(self, model):
         if model.precision == "bf16":
             raise ValueError("the training forward runs in the fp32-storage precisions (f16x3 / fp32)")
         self.model = model
+        self.tape = None
+        self.param_grads = {}
 
     # ---- packing of what the inference pack does not hold: un-folded WavEncoder convolutions ----------------------------
     def _train_pack(self, pk):
@@ -133,64 +203,207 @@ class TrainForward:
             x, lin = out, lout
         return x, lens[-1]
 
-    # ---- transformer pieces, train mode ---------------------------------------------------------------------------------------
+    # ---- differentiable pieces: each wrapper launches the forward op and, when a tape is attached, records its backward -----------
+    def _lin(self, cx, x, key, slope=None, out=None, need_dx=True):
+        """y = act(x W^T + b) through emage_gemm (one fp32 output used both as the next operand and as the result)."""
+        y, _ = cx.gemm(x, key, slope=slope, out=out)
+        if self.tape is not None:
+            self.tape.node(lambda: self._lin_backward(cx, x, key, slope, y, y, need_dx))
+        return y
+
+    def _lin_kv(self, cx, x, key, n_first, t_rows, b):
+        """A projection whose last columns are emitted transposed (V^T for emage_attention): returns (first n_first columns as
+        rows, the V^T buffer, a token standing for the logical (M, N) output in the tape)."""
+        n = cx.pk.w[key]["n"]
+        first = cx.lo(x.shape[0], n_first)
+        vt = cx.vt_buffer(b, n - n_first, t_rows)
+        cx.gemm(x, key, out=first, out_t=vt, t_col0=n_first, t_rows=t_rows)
+        token = _Token((x.shape[0], n))
+        if self.tape is not None:
+            self.tape.node(lambda: self._lin_backward(cx, x, key, None, token, None, True))
+        return first, vt, token
+
+    def _lin_backward(self, cx, x, key, slope, y_id, y, need_dx):
+        tape = self.tape
+        dy = tape.get(y_id)
+        if dy is None:
+            return
+        ent = cx.pk.w[key]
+        n, k = ent["n"], ent["k_real"]
+        m = dy.shape[0]
+        dpre = dy if slope is None else ops.act_backward(dy, y, slope)
+        if dpre.shape[1] != n or dpre.stride(1) != 1:
+            raise RuntimeError(f"{key}: gradient of shape {tuple(dpre.shape)} for an output of {n} columns")
+        w32 = torch.cat([self._param(wn)[rs] for wn, _bn, rs in cx.pk.origin[key]], 0).float().contiguous()            # (N, K)
+        mp = _rup(m)
+        dpre_t = torch.zeros(n, mp, dtype=torch.float32, device=cx.dev)
+        ops.transpose(dpre, dpre_t)
+        x_t = torch.zeros(k, mp, dtype=torch.float32, device=cx.dev)
+        ops.transpose(x[:, :k], x_t)
+        dw = torch.empty(n, k, dtype=torch.float32, device=cx.dev)
+        ops.gemm(F32, dpre_t, x_t, None, None, None, dw, None, None, n=k, cp=mp)                                          # dW = dpre^T x
+        db = ops.col_sum(dpre)
+        r0 = 0
+        for wn, bn, rs in cx.pk.origin[key]:
+            rows = rs.stop - rs.start
+            self._param_grad(wn, rs, dw[r0:r0 + rows])
+            self._param_grad(bn, rs, db[r0:r0 + rows])
+            r0 += rows
+        if need_dx:
+            np_ = _rup(n)
+            if np_ != n:
+                raise RuntimeError(f"{key}: {n} output columns (not a multiple of 64) — pad before the backward contraction")
+            w_t = ops.transpose(w32)                                                                                    # (K, N)
+            dx = torch.empty(m, k, dtype=torch.float32, device=cx.dev)
+            ops.gemm(F32, dpre, w_t, None, None, None, dx, None, None, n=k, cp=n)                                        # dX = dpre W
+            tape.add(x, dx, cols=k)
+
+    def _param(self, name):
+        return self.model._flat_params()[name].detach().to(self.model.device)
+
+    def _param_grad(self, name, rows, g):
+        full = self.param_grads.get(name)
+        if full is None:
+            full = torch.zeros_like(self._param(name), dtype=torch.float32)
+            self.param_grads[name] = full
+        dst = full[rows]
+        dst += g.reshape(dst.shape)                    # parameter-sized accumulation across the forwards of a step
+
+    def _add(self, cx, a, bb, mod_b=0, grad_b=True):
+        out = cx.lo(*a.shape)
+        ops.add(cx.dt, a, bb, out=out, mod_b=mod_b)
+        if self.tape is not None:
+            def bw():
+                g = self.tape.get(out)
+                if g is None:
+                    return
+                self.tape.add(a, g)
+                if grad_b and not mod_b:
+                    self.tape.add(bb, g)
+            self.tape.node(bw)
+        return out
+
+    def _mul_add(self, a, mask, res=None, t_rows=0):
+        out = ops.mul_add(a, mask, res, mask_t_rows=t_rows)
+        if self.tape is not None:
+            def bw():
+                g = self.tape.get(out)
+                if g is None:
+                    return
+                self.tape.add(a, ops.mul_add(g, mask, None, mask_t_rows=t_rows))
+                if res is not None:
+                    self.tape.add(res, g)
+            self.tape.node(bw)
+        return out
+
+    def _layernorm(self, cx, key, s_in):
+        n = cx.pk.w[key]
+        y = cx.lo(*s_in.shape)
+        ops.layernorm(cx.dt, s_in, n["g"], n["b"], 1e-5, None, None, y)
+        if self.tape is not None:
+            def bw():
+                g = self.tape.get(y)
+                if g is None:
+                    return
+                dx, dg, db = ops.layernorm_backward(s_in, n["g"], g)
+                self._param_grad(key + ".weight", slice(None), dg)
+                self._param_grad(key + ".bias", slice(None), db)
+                self.tape.add(s_in, dx)
+            self.tape.node(bw)
+        return y
+
     def _drop_add(self, cx, o, masks, t, res=None):
         """res + dropout(o) with the mask the reference draws on the (T, B, C) tensor."""
         m, c = o.shape
         mk = masks.take((t, m // t, c)).view(m, c)
-        return ops.mul_add(o, mk, res, mask_t_rows=t)
+        return self._mul_add(o, mk, res, t_rows=t)
 
-    def _mha(self, cx, masks, q, k, vt, vt_rows, b, tq, tk):
+    def _mha(self, cx, masks, q_src, k_src, v_src, k_rows, vt, vt_rows, b, tq, tk):
+        """Attention with probability dropout.  *_src = (tensor-or-token the operand is a column block of, first column); q / k
+        operand views are built here.  k_rows: the row buffer holding the keys."""
         d, h = self.model.config.hidden_size, spec.N_HEAD
+        q = q_src[2]
+        k = k_rows
+        pm = masks.take((b, h, tq, tk))
         att = cx.lo(b * tq, d)
-        ops.attention_dropout(cx.gdt, q, k, vt, vt_rows, att, b, h, tq, tk, d // h, masks.take((b, h, tq, tk)))
+        ops.attention_dropout(cx.gdt, q, k, vt, vt_rows, att, b, h, tq, tk, d // h, pm)
+        if self.tape is not None:
+            def bw():
+                g = self.tape.get(att)
+                if g is None:
+                    return
+                gq = self.tape.buffer(q_src[0])[:, q_src[1]:q_src[1] + d]
+                gk = self.tape.buffer(k_src[0])[:, k_src[1]:k_src[1] + d]
+                gv = self.tape.buffer(v_src[0])[:, v_src[1]:v_src[1] + d]
+                ops.attention_backward(q, k, vt, vt_rows, pm, g, gq, gk, gv, b, h, tq, tk, d // h)
+            self.tape.node(bw)
         return att
 
     def _self_attn(self, cx, masks, name, x, b, t):
         d = self.model.config.hidden_size
-        qk = cx.lo(b * t, 2 * d)
-        vt = cx.vt_buffer(b, d, t)
-        cx.gemm(x, name + ".sa.qkv", out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
-        att = self._mha(cx, masks, qk[:, :d], qk[:, d:], vt, d, b, t, t)
-        o, _ = cx.gemm(att, name + ".sa.out")
+        qk, vt, tok = self._lin_kv(cx, x, name + ".sa.qkv", 2 * d, t, b)
+        att = self._mha(cx, masks, (tok, 0, qk[:, :d]), (tok, d), (tok, 2 * d), qk[:, d:], vt, d, b, t, t)
+        o = self._lin(cx, att, name + ".sa.out")
         return self._drop_add(cx, o, masks, t, res=x)
 
     def _ffn(self, cx, masks, name, x, t):
-        f, _ = cx.gemm(x, name + ".ff1", slope=0.0)
+        f = self._lin(cx, x, name + ".ff1", slope=0.0)
         f = self._drop_add(cx, f, masks, t)
-        o, _ = cx.gemm(f, name + ".ff2")
+        o = self._lin(cx, f, name + ".ff2")
         return self._drop_add(cx, o, masks, t, res=x)
 
     def _encoder_layer(self, cx, masks, name, x, b, t):
-        ln = self.model._ln
-        x = ln(cx, name + ".norm1", self._self_attn(cx, masks, name, x, b, t))
-        return ln(cx, name + ".norm2", self._ffn(cx, masks, name, x, t))
+        x = self._layernorm(cx, name + ".norm1", self._self_attn(cx, masks, name, x, b, t))
+        return self._layernorm(cx, name + ".norm2", self._ffn(cx, masks, name, x, t))
 
-    def _decoder_layer(self, cx, masks, name, x, b, t, mem_k, mem_vt, vt_rows, tk):
-        ln = self.model._ln
-        x = ln(cx, name + ".norm1", self._self_attn(cx, masks, name, x, b, t))
-        q, _ = cx.gemm(x, name + ".ca.q")
-        att = self._mha(cx, masks, q, mem_k, mem_vt, vt_rows, b, t, tk)
-        o, _ = cx.gemm(att, name + ".ca.out")
-        x = ln(cx, name + ".norm2", self._drop_add(cx, o, masks, t, res=x))
-        return ln(cx, name + ".norm3", self._ffn(cx, masks, name, x, t))
+    def _decoder_layer(self, cx, masks, name, x, b, t, mem, vt_rows, tk):
+        """mem = (keys as rows, V^T buffer view, token of the K/V projection, first K column, first V column)."""
+        d = self.model.config.hidden_size
+        mem_k, mem_vt, tok, kc, vc = mem
+        x = self._layernorm(cx, name + ".norm1", self._self_attn(cx, masks, name, x, b, t))
+        q = self._lin(cx, x, name + ".ca.q")
+        att = self._mha(cx, masks, (q, 0, q), (tok, kc), (tok, vc), mem_k, mem_vt, vt_rows, b, t, tk)
+        o = self._lin(cx, att, name + ".ca.out")
+        x = self._layernorm(cx, name + ".norm2", self._drop_add(cx, o, masks, t, res=x))
+        return self._layernorm(cx, name + ".norm3", self._ffn(cx, masks, name, x, t))
+
+    def _memory(self, cx, key, mem_rows, b, tk, n_layers):
+        """K / V projection of a cross-attention memory for n_layers layers: per layer the tuple `_decoder_layer` takes."""
+        d = self.model.config.hidden_size
+        k, vt, tok = self._lin_kv(cx, mem_rows, key, n_layers * d, tk, b)
+        return [(k[:, i * d:(i + 1) * d], vt[:, i * d:], tok, i * d, n_layers * d + i * d) for i in range(n_layers)]
 
     def _ppe(self, cx, masks, x, b, t):
         """PeriodicPositionalEncoding.forward (P:341-343): dropout(x + pe[:, :T]) on (B*T, d) rows."""
         m, d = x.shape
-        y = cx.lo(m, d)
-        ops.add(cx.dt, x, cx.pk.w["pe"][:t], out=y, mod_b=t)
-        return ops.mul_add(y, masks.take((b, t, d)).view(m, d))
+        y = self._add(cx, x, cx.pk.w["pe"][:t], mod_b=t)
+        return self._mul_add(y, masks.take((b, t, d)).view(m, d))
+
+    def _speaker(self, cx, key, name, sid):
+        rows = ops.gather_rows(cx.pk.w[key], sid, F32)
+        if self.tape is not None:
+            def bw():
+                g = self.tape.get(rows)
+                if g is None:
+                    return
+                if cx.pk.w[key].shape[0] != 1:
+                    raise NotImplementedError("speaker-embedding gradient for more than one speaker row")
+                self._param_grad(name, slice(None), ops.col_sum(g))
+            self.tape.node(bw)
+        return rows
 
     # ---- the forward --------------------------------------------------------------------------------------------------------
-    def __call__(self, audio, speaker_id, masked_motion, mask, dropout_masks, use_audio=True, new_stats=None):
+    def __call__(self, audio, speaker_id, masked_motion, mask, dropout_masks, use_audio=True, new_stats=None, tape=False):
         """-> (dict of the 8 (B, T, 256) fp32 outputs, new_stats).  `new_stats` carries the BatchNorm running buffers from one
-        forward of a step to the next (as oracle.emage_train_oracle.forward_train does); it is not written into the model."""
+        forward of a step to the next (as oracle.emage_train_oracle.forward_train does); it is not written into the model.
+        tape=True keeps what `backward()` needs (see there)."""
         model = self.model
         c = model.config
         cx = _Ctx(model._engine())
         pk, dev = cx.pk, cx.dev
         self._train_pack(pk)
+        self.tape = _Tape(dev) if tape else None
+        self._cx = cx
         new_stats = {} if new_stats is None else new_stats
         masks = _Masks(dropout_masks, dev)
         b, t, cm = masked_motion.shape
@@ -201,13 +414,19 @@ class TrainForward:
         motion3 = masked_motion.to(device=dev, dtype=torch.float32).contiguous()
         mask3 = mask.to(device=dev, dtype=torch.float32).contiguous()
 
-        # masked motion -> spatial hints (M:267-273)
+        # masked motion -> spatial hints (M:267-273); the tape starts behind the motion encoder (its backward is not written yet)
         x0 = ops.pack_motion(cx.dt, motion3, mask3, pk.w["mask_emb"], _rup(cm))
         hint, _ = _conv_encoder(cx, "motion_encoder", x0, t, spec.MOTION_ENC_LAYERS, mf, False)
-        hh, _ = cx.gemm(hint, "bodyhints.fc1", slope=0.1)
+        hh = self._lin(cx, hint, "bodyhints.fc1", slope=0.1, need_dx=False)
         memcat = cx.lo(m, af + mf)                                                   # [audio2face | body_hint_face] (M:288)
-        cx.gemm(hh[:, :d], "bodyhints_face.fc2", out=memcat[:, af:])
-        hint_body, _ = cx.gemm(hh[:, d:], "bodyhints_body.fc2")
+        hh_face, hh_body = hh[:, :d], hh[:, d:]
+        hint_face = memcat[:, af:]
+        if self.tape is not None:
+            self.tape.view(hh, hh_face, 0)
+            self.tape.view(hh, hh_body, d)
+            self.tape.view(memcat, hint_face, af)
+        self._lin(cx, hh_face, "bodyhints_face.fc2", out=hint_face)
+        hint_body = self._lin(cx, hh_body, "bodyhints_body.fc2")
 
         # the two WavEncoders, batch statistics (M:275-281)
         a_face, ta = self._wav_encoder(cx, "audio_encoder_face", 0, audio, b, new_stats)
@@ -217,64 +436,75 @@ class TrainForward:
         memcat[:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)                # M:278-281: the FACE features are trimmed to T
 
         sid = speaker_id.to(dev).reshape(b, 1).expand(b, t)
-        spk_body = ops.gather_rows(pk.w["spk_body"], sid, F32)
-        spk_face = ops.gather_rows(pk.w["spk_face"], sid, F32)
+        spk_body = self._speaker(cx, "spk_body", "speaker_embedding_body.weight", sid)
+        spk_face = self._speaker(cx, "spk_face", "speaker_embedding_face.weight", sid)
         out = {}
 
         # face branch (M:288-294)
-        mem_face, _ = cx.gemm(memcat, "audio_face_motion_proj")
+        mem_face = self._lin(cx, memcat, "audio_face_motion_proj")
         face = self._ppe(cx, masks, spk_face, b, t)
-        fkk, fvt = model._memory_kv(cx, "face.kv_all", mem_face, b, t, nf)
+        fmem = self._memory(cx, "face.kv_all", mem_face, b, t, nf)
         for i in range(nf):
-            face = self._decoder_layer(cx, masks, f"face_motion_decoder.layers.{i}", face, b, t, fkk[:, i * d:(i + 1) * d], fvt[:, i * d:], nf * d, t)
-        rec_lo, out["rec_face"] = cx.gemm(face, "face_out_proj", want="both")
-        hc, _ = cx.gemm(rec_lo, "face_cls.fc1", slope=0.1)
-        _, out["cls_face"] = cx.gemm(hc, "face_cls.fc2", want="f32")
+            face = self._decoder_layer(cx, masks, f"face_motion_decoder.layers.{i}", face, b, t, fmem[i], nf * d, t)
+        out["rec_face"] = self._lin(cx, face, "face_out_proj")
+        out["cls_face"] = self._lin(cx, self._lin(cx, out["rec_face"], "face_cls.fc1", slope=0.1), "face_cls.fc2")
 
         # body branch (M:297-312)
-        x, _ = cx.gemm(hint_body, "moton_proj")
-        x = self._ppe(cx, masks, x, b, t)
-        xs = cx.lo(m, d)
-        ops.add(cx.dt, x, spk_body, out=xs)
-        x = self._encoder_layer(cx, masks, "motion_self_encoder.layers.0", xs, b, t)
-        mem_body, _ = cx.gemm(a_body, "audio_body_motion_proj")                      # M:303
-        xs = cx.lo(m, d)
-        ops.add(cx.dt, x, spk_body, out=xs)
-        base = self._ppe(cx, masks, xs, b, t)                                        # M:304-305
+        x = self._ppe(cx, masks, self._lin(cx, hint_body, "moton_proj"), b, t)
+        x = self._encoder_layer(cx, masks, "motion_self_encoder.layers.0", self._add(cx, x, spk_body), b, t)
+        mem_body = self._lin(cx, a_body, "audio_body_motion_proj", need_dx=False)    # M:303
+        base = self._ppe(cx, masks, self._add(cx, x, spk_body), b, t)               # M:304-305
         x = base
-        bk, bvt = model._memory_kv(cx, "cross.kv_all", mem_body, b, ta, nc)
+        bmem = self._memory(cx, "cross.kv_all", mem_body, b, ta, nc)
         for i in range(nc):
-            x = self._decoder_layer(cx, masks, f"audio_motion_cross_attn.layers.{i}", x, b, t, bk[:, i * d:(i + 1) * d], bvt[:, i * d:], nc * d, ta)
-        fea = cx.lo(m, d)
-        if use_audio:
-            ops.add(cx.dt, base, x, out=fea)                                         # motion_fea + cross (M:310-312)
-        else:
-            fea.copy_(base)                                                          # cross * 0 (M:311)
+            x = self._decoder_layer(cx, masks, f"audio_motion_cross_attn.layers.{i}", x, b, t, bmem[i], nc * d, ta)
+        fea = self._add(cx, base, x) if use_audio else base                          # motion_fea + cross; cross * 0 without audio (M:310-312)
 
         # part latents, refinement layers, heads (M:315-330)
         parts = ("upper", "hands", "lower")
         others = {"upper": ("hands", "lower"), "hands": ("upper", "lower"), "lower": ("upper", "hands")}
-        hl, _ = cx.gemm(fea, "motion2latent.fc1", slope=0.1)
-        lat = {p: cx.gemm(hl[:, i * d:(i + 1) * d], f"motion2latent_{p}.fc2")[0] for i, p in enumerate(parts)}
+        hl = self._lin(cx, fea, "motion2latent.fc1", slope=0.1)
+        lat = {}
+        for i, p in enumerate(parts):
+            hv = hl[:, i * d:(i + 1) * d]
+            if self.tape is not None:
+                self.tape.view(hl, hv, i * d)
+            lat[p] = self._lin(cx, hv, f"motion2latent_{p}.fc2")
         refine = {}
         for p in parts:
-            tgt, mem_lo = cx.lo(m, d), cx.lo(m, d)
-            ops.add(cx.dt, lat[p], spk_body, out=tgt)
-            ops.add(cx.dt, lat[others[p][0]], lat[others[p][1]], out=mem_lo)
+            tgt = self._add(cx, lat[p], spk_body)
+            mem_lo = self._add(cx, lat[others[p][0]], lat[others[p][1]])
             name = f"body_motion_decoder_{p}.layers.0"
-            k1, vt1 = model._memory_kv(cx, name + ".ca.kv", mem_lo, b, t, 1)
-            refine[p] = self._decoder_layer(cx, masks, name, tgt, b, t, k1, vt1, d, t)
-        rec_los = {}
+            refine[p] = self._decoder_layer(cx, masks, name, tgt, b, t, self._memory(cx, name + ".ca.kv", mem_lo, b, t, 1)[0], d, t)
         for p in parts:
-            sum_lo = cx.lo(m, d)
-            ops.add(cx.dt, lat[p], refine[p], out=sum_lo)
-            rec_los[p], out[f"rec_{p}"] = cx.gemm(sum_lo, f"motion_out_proj_{p}", want="both")
+            out[f"rec_{p}"] = self._lin(cx, self._add(cx, lat[p], refine[p]), f"motion_out_proj_{p}")
         for p in parts:
-            hc, _ = cx.gemm(rec_los[p], f"motion_cls_{p}.fc1", slope=0.1)
-            _, out[f"cls_{p}"] = cx.gemm(hc, f"motion_cls_{p}.fc2", want="f32")
+            out[f"cls_{p}"] = self._lin(cx, self._lin(cx, out[f"rec_{p}"], f"motion_cls_{p}.fc1", slope=0.1), f"motion_cls_{p}.fc2")
         if masks.i != len(masks.masks):
             raise RuntimeError(f"dropout_masks: {len(masks.masks)} masks given, the forward consumed {masks.i}")
+        self._out2d = out
         return {key: out[key].view(b, t, -1) for key in OUT_KEYS}, new_stats
+
+    # ---- backward through everything behind the motion encoder and the WavEncoders ------------------------------------------------
+    def backward(self, index_gt, latent_gt):
+        """Gradients of `rec_loss + cls_loss` (T:106-130) of the LAST forward (called with tape=True) w.r.t. every parameter of the
+        MAGE transformer stack, the projections, MLP heads and speaker embeddings; they ACCUMULATE in `self.param_grads` (name ->
+        fp32 tensor of the parameter's shape) across the forwards of a step, like `loss_all.backward()` in the reference (T:174).
+        The contractions are emage_gemm launches in exact-fp32 mode on transposed operands; the convolutional front ends
+        (motion encoder, WavEncoders with their BatchNorms, mask embedding) are not differentiated yet."""
+        if self.tape is None:
+            raise RuntimeError("backward() needs the forward to be run with tape=True")
+        cfg, tape, out = self.model.config, self.tape, self._out2d
+        for q in ("upper", "lower", "hands", "face"):
+            pred = out[f"rec_{q}"]
+            tape.add(pred, ops.mse_loss_grad(pred, latent_gt[q].reshape(pred.shape).to(pred.device), getattr(cfg, "l" + q[0])))
+            logits = out[f"cls_{q}"]
+            cw = getattr(cfg, "c" + q[0])
+            if cw != 0:
+                tape.add(logits, ops.nll_loss_grad(logits, index_gt[q].reshape(-1).contiguous().to(logits.device), cw))
+        tape.run()
+        self.tape = None
+        return self.param_grads
 
 
 # ======================================================================================

@@ -115,6 +115,73 @@ def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
     torch.as_strided(out, (b * tq, h * hd), (out.stride(0), 1))[:] = o.to(TD[dtype])
 
 
+def transpose(x, out=None):
+    CALLS.append("transpose")
+    r = x.t().contiguous()
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def col_sum(x, y=None, out=None, accumulate=False):
+    CALLS.append("col_sum")
+    s = (x.double() * (y.double() if y is not None else 1.0)).sum(0).float()
+    if out is None:
+        return s
+    out.copy_(out + s if accumulate else s)
+    return out
+
+
+def act_backward(dy, y, slope, out=None):
+    CALLS.append("act_backward")
+    r = dy * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def layernorm_backward(x, gamma, dy, eps=1e-5):
+    CALLS.append("layernorm_backward")
+    mu = x.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(((x - mu) ** 2).mean(1, keepdim=True) + eps)
+    xh = (x - mu) * rstd
+    g = dy * gamma
+    dx = rstd * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    return dx, (dy * xh).sum(0), dy.sum(0)
+
+
+def attention_backward(q, k, vt, vt_rows, pmask, d_out, dq, dk, dv, b, h, tq, tk, hd):
+    CALLS.append("attention_backward")
+    tp = vt.shape[-1]
+    qf = torch.as_strided(q, (b * tq, h * hd), (q.stride(0), 1)).view(b, tq, h, hd).transpose(1, 2)
+    kf = torch.as_strided(k, (b * tk, h * hd), (k.stride(0), 1)).view(b, tk, h, hd).transpose(1, 2)
+    vf = torch.as_strided(vt, (b, h * hd, tp), (vt_rows * tp, tp, 1))[:, :, :tk].reshape(b, h, hd, tk).transpose(2, 3)
+    do = torch.as_strided(d_out, (b * tq, h * hd), (d_out.stride(0), 1)).view(b, tq, h, hd).transpose(1, 2)
+    scale = 1.0 / math.sqrt(hd)
+    p = torch.softmax((qf @ kf.transpose(-1, -2)) * scale, dim=-1)
+    mk = pmask if pmask is not None else torch.ones_like(p)
+    d_v = (p * mk).transpose(-1, -2) @ do
+    dp = (do @ vf.transpose(-1, -2)) * mk
+    ds = p * (dp - (dp * p).sum(-1, keepdim=True)) * scale
+    d_q, d_k = ds @ kf, ds.transpose(-1, -2) @ qf
+    for dst, src, t in ((dq, d_q, tq), (dk, d_k, tk), (dv, d_v, tk)):
+        torch.as_strided(dst, (b * t, h * hd), (dst.stride(0), 1))[:] = src.transpose(1, 2).reshape(b * t, h * hd)
+
+
+def mse_loss_grad(pred, target, weight):
+    CALLS.append("mse_loss_grad")
+    return (2.0 * weight / pred.numel()) * (pred - target)
+
+
+def nll_loss_grad(logits, index, weight):
+    CALLS.append("nll_loss_grad")
+    g = torch.softmax(logits, dim=1)
+    g[torch.arange(logits.shape[0]), index] -= 1.0
+    return g * (weight / logits.shape[0])
+
+
 def loss_workspace(device):
     return torch.zeros(1024, dtype=torch.float64)
 
@@ -430,7 +497,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

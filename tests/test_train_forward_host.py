@@ -83,3 +83,54 @@ def test_step_losses_host_logic(golden_dir):
         assert abs(got[k] - float(g["loss_" + k])) < 2e-4 * max(1.0, abs(float(g["loss_" + k]))), k
     key = "audio_encoder_body.feat_extractor.5.downsample.1.running_mean"
     assert float((stats[key] - ref_stats[key]).abs().max()) < 1e-5
+
+
+def _oracle_grads(seed, use_audio=True):
+    """Autograd gradients of rec_loss + cls_loss of ONE train-mode forward of the oracle (same draws as oracle_forward(seed))."""
+    from pantomatrix_amd import synthetic
+    from pantomatrix_amd.configuration_emage_audio import EmageAudioConfig
+    cfg = EmageAudioConfig(**common.cfg_dicts()[0])
+    sd = synthetic.audio_model_state(cfg, 0)
+    keys = tro.trainable_keys(sd)
+    work = dict(sd)
+    for k in keys:
+        work[k] = sd[k].detach().clone().requires_grad_(True)
+    audio, spk, motion, mask = common.window_inputs(2)
+    g = torch.Generator().manual_seed(99)
+    latent = {q: torch.randn(2, motion.shape[1], 256, generator=g) for q in ("face", "upper", "hands", "lower")}
+    index = {q: torch.randint(0, 256, (2, motion.shape[1]), generator=g) for q in ("face", "upper", "hands", "lower")}
+    masks = []
+    torch.manual_seed(seed)
+    with tc.recorded_masks(masks):
+        pred = tro.forward_train(work, audio, spk, motion, mask, use_audio=use_audio)
+    loss = tro.rec_loss(pred, latent, cfg) + tro.cls_loss(pred, index, cfg)
+    loss.backward()
+    grads = {k: work[k].grad for k in keys if work[k].grad is not None}
+    return (audio, spk, motion, mask), masks, index, latent, grads
+
+
+FRONT_END = ("audio_encoder_face.", "audio_encoder_body.", "motion_encoder.", "mask_embedding")
+
+
+@pytest.mark.parametrize("use_audio", [True, False])
+def test_backward_host_logic(use_audio):
+    """The tape-driven backward (training.TrainForward.backward) on the CPU stand-ins against torch autograd through the
+    training oracle: every parameter behind the convolutional front ends — the 16 transformer layers, projections, MLP heads,
+    speaker embeddings."""
+    (audio, spk, motion, mask), masks, index, latent, ref = _oracle_grads(seed=4, use_audio=use_audio)
+    model, _ = common.product_models(precision="fp32")
+    fwd = training.TrainForward(model)
+    with fake_ops.installed(), torch.no_grad():
+        fwd(audio, spk, motion, mask, masks, use_audio=use_audio, tape=True)
+        grads = fwd.backward(index, latent)
+    covered = [k for k in ref if not k.startswith(FRONT_END)]
+    assert len(covered) > 300
+    gmax = max(float(ref[k].abs().max()) for k in covered)
+    missing = [k for k in covered if k not in grads and float(ref[k].abs().max()) > 1e-7 * gmax]
+    assert not missing, missing[:8]
+    for k in covered:
+        if k not in grads:
+            continue
+        err = float((grads[k] - ref[k]).abs().max())
+        assert err <= 2e-4 * float(ref[k].abs().max()) + 1e-6 * gmax, (k, err, float(ref[k].abs().max()))
+    assert not [k for k in grads if k.startswith(FRONT_END)]
