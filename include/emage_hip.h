@@ -378,6 +378,11 @@ int emage_mse_loss_grad(const float* pred, int ld_pred, const float* target, int
                         float* grad, int ld_grad, void* stream);
 int emage_nll_loss_grad(const float* logits, int ld, const int64_t* index, int M, int K, float weight, float* grad, int ld_grad, void* stream);
 
+/* torch.optim.Adam (no amsgrad) on one flat fp32 tensor of n elements, in place (train_emage_audio.py:258-265): step is the
+ * 1-based step count of this parameter. */
+int emage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

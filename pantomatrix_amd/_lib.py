@@ -38,6 +38,7 @@ SIGNATURES = {
     "emage_attention_backward": [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_mse_loss_grad": [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p],
     "emage_nll_loss_grad": [_p, _i, _p, _i, _i, _f, _p, _i, _p],
+    "emage_adam_step": [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _p],
     "emage_mul_add": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p],

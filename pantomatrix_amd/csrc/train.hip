@@ -458,3 +458,29 @@ extern "C" int emage_nll_loss_grad(const float* logits, int ld, const int64_t* i
     hipLaunchKernelGGL(nll_grad_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, index, (float)((double)weight / M), grad, ld_grad, M, K);
     return launch_status();
 }
+
+// torch.optim.Adam (no amsgrad, weight decay folded into the gradient when non-zero), one flat tensor per call (T:258-265):
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+namespace {
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                                   float b1, float b2, float step_size, float inv_sqrt_bias2, float eps, float weight_decay) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (weight_decay != 0.f) gi += weight_decay * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bias2 + eps);
+    }
+}
+}  // namespace
+
+extern "C" int emage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return EMAGE_EINVAL;
+    const double bias1 = 1.0 - pow((double)beta1, step), bias2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, beta1, beta2,
+                       (float)((double)lr / bias1), (float)(1.0 / sqrt(bias2)), eps, weight_decay);
+    return launch_status();
+}

@@ -448,6 +448,21 @@ def nll_loss_grad(logits, index, weight):
     return g
 
 
+@_op("adam_step", "(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, int step, float lr, float beta1, float beta2, float eps, "
+                  "float weight_decay) -> ()")
+def _adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay):
+    check(_lib.load().emage_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), step, lr, beta1, beta2, eps, weight_decay,
+                                      _stream()), "adam_step")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam's update of one contiguous fp32 parameter tensor, in place (param, exp_avg, exp_avg_sq)."""
+    _dev(param)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
+    _adam_step(param, grad, exp_avg, exp_avg_sq, int(step), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay))
+
+
 @_op("layernorm", "(int dtype, Tensor x, Tensor gamma, Tensor beta, float eps, Tensor? add, Tensor(a!)? y_f32, Tensor(b!)? y) -> ()")
 def _layernorm(dtype, x, gamma, beta, eps, add, y_f32, y):
     m, c = x.shape

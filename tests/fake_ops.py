@@ -182,6 +182,15 @@ def nll_loss_grad(logits, index, weight):
     return g * (weight / logits.shape[0])
 
 
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    CALLS.append("adam_step")
+    g = grad + weight_decay * param if weight_decay else grad
+    exp_avg.copy_(beta1 * exp_avg + (1 - beta1) * g)
+    exp_avg_sq.copy_(beta2 * exp_avg_sq + (1 - beta2) * g * g)
+    b1, b2 = 1 - beta1 ** step, 1 - beta2 ** step
+    param.copy_(param - (lr / b1) * exp_avg / (exp_avg_sq.sqrt() / math.sqrt(b2) + eps))
+
+
 def loss_workspace(device):
     return torch.zeros(1024, dtype=torch.float64)
 
@@ -497,7 +506,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

@@ -150,3 +150,101 @@ def test_step_losses_on_device(golden_dir):
     for k, v in ref_stats.items():
         if not k.endswith("num_batches_tracked"):
             assert float((stats[k].cpu() - v).abs().max()) < 1e-5 * max(1.0, float(v.abs().max())), k
+
+
+def test_backward_kernels():
+    """Each backward building block against torch autograd / the CPU stand-in."""
+    import fake_ops as F
+    g = torch.Generator().manual_seed(6)
+    m, c = 130, 768
+    x = torch.randn(m, 800, generator=g)[:, :c]
+    assert torch.equal(ops.transpose(x.to(DEV)).cpu(), x.t().contiguous())
+    y = torch.randn(m, c, generator=g)
+    got = ops.col_sum(x.to(DEV), y.to(DEV)).cpu()
+    assert float((got - (x.double() * y.double()).sum(0).float()).abs().max()) < 1e-4
+    acc = torch.ones(c, device=DEV)
+    ops.col_sum(x.to(DEV), None, out=acc, accumulate=True)
+    assert float((acc.cpu() - (1 + x.double().sum(0)).float()).abs().max()) < 1e-4
+    assert torch.equal(ops.act_backward(x.contiguous().to(DEV), y.to(DEV), 0.1).cpu(), F.act_backward(x.contiguous(), y, 0.1))
+    # LayerNorm
+    xs = x.contiguous().clone().requires_grad_(True)
+    gamma, beta = torch.randn(c, generator=g).requires_grad_(True), torch.randn(c, generator=g).requires_grad_(True)
+    dy = torch.randn(m, c, generator=g)
+    torch.nn.functional.layer_norm(xs, (c,), gamma, beta, 1e-5).backward(dy)
+    dx, dg, db = ops.layernorm_backward(xs.detach().to(DEV), gamma.detach().to(DEV), dy.to(DEV))
+    assert float((dx.cpu() - xs.grad).abs().max()) < 2e-5 and float((dg.cpu() - gamma.grad).abs().max()) < 2e-4 and float((db.cpu() - beta.grad).abs().max()) < 2e-4
+    # attention (with probability dropout), Tk != Tq
+    b, h, tq, tk, hd = 2, 4, 64, 65, 192
+    q = torch.randn(b * tq, h * hd, generator=g)
+    k = torch.randn(b * tk, 2 * h * hd, generator=g)[:, h * hd:]           # a strided key view
+    vt = torch.zeros(b, h * hd, 96)
+    vt[:, :, :tk] = torch.randn(b, h * hd, tk, generator=g)
+    pm = (torch.rand(b, h, tq, tk, generator=g) > 0.1).float() / 0.9
+    d_out = torch.randn(b * tq, h * hd, generator=g)
+    ref = [torch.zeros(b * tq, h * hd), torch.zeros(b * tk, h * hd), torch.zeros(b * tk, h * hd)]
+    F.attention_backward(q, k, vt, h * hd, pm, d_out, *ref, b, h, tq, tk, hd)
+    got = [torch.zeros(b * tq, h * hd, device=DEV), torch.zeros(b * tk, 3 * h * hd, device=DEV), torch.zeros(b * tk, h * hd, device=DEV)]
+    ops.attention_backward(q.to(DEV), k.to(DEV), vt.to(DEV), h * hd, pm.to(DEV), d_out.to(DEV), got[0], got[1][:, h * hd:2 * h * hd], got[2], b, h, tq, tk, hd)
+    for a, r in zip((got[0], got[1][:, h * hd:2 * h * hd], got[2]), ref):
+        assert float((a.cpu() - r).abs().max()) < 1e-4 * max(1.0, float(r.abs().max()))
+    assert float(got[1][:, :h * hd].abs().max()) == 0.0
+    # loss gradients
+    pred, tgt = torch.randn(m, 256, generator=g), torch.randn(m, 256, generator=g)
+    idx = torch.randint(0, 256, (m,), generator=g)
+    assert float((ops.mse_loss_grad(pred.to(DEV), tgt.to(DEV), 3.0).cpu() - F.mse_loss_grad(pred, tgt, 3.0)).abs().max()) < 1e-7
+    assert float((ops.nll_loss_grad(pred.to(DEV), idx.to(DEV), 0.5).cpu() - F.nll_loss_grad(pred, idx, 0.5)).abs().max()) < 1e-7
+
+
+def test_backward_matches_autograd_on_device():
+    """TrainForward.backward on the GPU against torch autograd through the training oracle (one forward, random targets):
+    every parameter behind the convolutional front ends."""
+    from test_train_forward_host import FRONT_END, _oracle_grads
+    (audio, spk, motion, mask), masks, index, latent, ref = _oracle_grads(seed=4)
+    model, _ = common.product_models(precision="f16x3", device=DEV)
+    fwd = training.TrainForward(model)
+    fwd(audio, spk, motion, mask, masks, tape=True)
+    grads = fwd.backward(index, latent)
+    covered = [k for k in ref if not k.startswith(FRONT_END)]
+    gmax = max(float(ref[k].abs().max()) for k in covered)
+    worst = 0.0
+    for k in covered:
+        if k not in grads:
+            assert float(ref[k].abs().max()) <= 1e-7 * gmax, k
+            continue
+        err = float((grads[k].cpu() - ref[k]).abs().max())
+        worst = max(worst, err / (float(ref[k].abs().max()) + 1e-3 * gmax))
+        assert err <= 1e-3 * float(ref[k].abs().max()) + 1e-5 * gmax, (k, err, float(ref[k].abs().max()))
+    print(f"backward on device: {len(covered)} parameters, worst relative error {worst:.2e}")
+
+
+def test_step_gradients_match_the_reference(golden_dir):
+    """Three forwards + three backwards of one training step on the GPU (the reference's draws): per-parameter gradient norm and
+    first entry of every covered parameter equal the REAL reference's (tests/golden/train_step_b2.npz)."""
+    from test_train_forward_host import FRONT_END
+    g = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    batch, _, masks, random_mask, _ = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    fwd = training.TrainForward(model)
+    cfg = model.config
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    index, latent, masked_motion = training.targets(vq, batch["motion"], batch["expressions"], batch["trans"], batch["foot_contact"])
+    spk = torch.zeros(masked_motion.shape[0], 1, dtype=torch.long, device=DEV)
+    seed_mask = torch.ones_like(masked_motion)
+    seed_mask[:, :cfg.seed_frames] = 0
+    stats = {}
+    for mask, use_audio, mk in ((seed_mask, True, masks[0]), (random_mask.to(DEV), True, masks[1]), (random_mask.to(DEV), False, masks[2])):
+        _, stats = fwd(batch["audio"], spk, masked_motion, mask, mk, use_audio=use_audio, new_stats=stats, tape=True)
+        grads = fwd.backward(index, latent)
+    names = [str(n) for n in g["grad_names"]]
+    gmax = float(np.max(g["grad_norms"]))
+    checked = 0
+    for n, norm, first, shadowed in zip(names, g["grad_norms"], g["grad_first"], g["shadowed"]):
+        if n.startswith(FRONT_END) or shadowed:
+            continue
+        assert n in grads, n
+        gn = float(grads[n].norm())
+        assert abs(gn - float(norm)) <= 5e-3 * float(norm) + 1e-6 * gmax, (n, gn, float(norm))
+        assert abs(float(grads[n].reshape(-1)[0]) - float(first)) <= 5e-3 * float(grads[n].abs().max()) + 1e-6 * gmax, n
+        checked += 1
+    print(f"{checked} parameter gradients equal the reference's (norm and first entry)")
+    assert checked > 300
