@@ -378,6 +378,26 @@ int emage_mse_loss_grad(const float* pred, int ld_pred, const float* target, int
                         float* grad, int ld_grad, void* stream);
 int emage_nll_loss_grad(const float* logits, int ld, const int64_t* index, int M, int K, float weight, float* grad, int ld_grad, void* stream);
 
+/*
+ * Conv1d backward through emage_gemm: dW (N, taps*C) = dY^T (N, M) x im2col(X)^T, dX = col2im(dY W).
+ *   emage_im2col_t: out[(tap*C + c)][m] = X[seq*Lin + l*stride - pad + tap][c] (0 outside the sequence), m = seq*Lout + l,
+ *                   out is (taps*C, ld_out >= nseq*Lout) fp32 with the tail columns left untouched (pre-zeroed by the caller)
+ *   emage_col2im:   dx[seq*Lin + r][c] = sum of dcol[seq*Lout + l][tap*C + c] over the (l, tap) that read input position r
+ */
+int emage_im2col_t(const float* x, int ldx, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq,
+                   float* out, long ld_out, void* stream);
+int emage_col2im(const float* dcol, long ld, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq, float* dx, int ldx, void* stream);
+
+/* nn.BatchNorm1d (training) backward on channels-last rows: dgamma = sum dy * xhat, dbeta = sum dy (float64 sums),
+ * dx = gamma * rstd * (dy - dbeta / M - xhat * dgamma / M).  workspace as for emage_bn_stats. */
+int emage_bn_backward(const float* x, int ldx, const float* mean, const float* var, const float* gamma, float eps, const float* dy, int ld_dy,
+                      float* dx, int ld_dx, float* dgamma, float* dbeta, int M, int C, void* workspace, long workspace_bytes, void* stream);
+
+/* Weight gradient of emage_wav_conv_in (Cin = 1): dw[c][tap] = sum_m dy[m][c] * wav[seq][l*stride - pad + tap]. */
+long emage_wav_conv_in_backward_workspace_bytes(int M, int C, int taps);
+int emage_wav_conv_in_backward(const float* dy, int ld_dy, const float* wav, long ldw, int L, int B, int Lout, int C, int taps, int stride, int pad,
+                               float* dw, void* workspace, long workspace_bytes, void* stream);
+
 /* torch.optim.Adam (no amsgrad) on one flat fp32 tensor of n elements, in place (train_emage_audio.py:258-265): step is the
  * 1-based step count of this parameter. */
 int emage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,

@@ -38,6 +38,11 @@ SIGNATURES = {
     "emage_attention_backward": [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_mse_loss_grad": [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p],
     "emage_nll_loss_grad": [_p, _i, _p, _i, _i, _f, _p, _i, _p],
+    "emage_im2col_t": [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p],
+    "emage_col2im": [_p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    "emage_bn_backward": [_p, _i, _p, _p, _p, _f, _p, _i, _p, _i, _p, _p, _i, _i, _p, _l, _p],
+    "emage_wav_conv_in_backward_workspace_bytes": [_i, _i, _i],
+    "emage_wav_conv_in_backward": [_p, _i, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p],
     "emage_adam_step": [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _p],
     "emage_mul_add": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
@@ -56,7 +61,7 @@ SIGNATURES = {
     "emage_lstm_inputs": [_p, _p, _i, _p, _l, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "emage_rot6d_scatter": [_p, _i, _p, _p, _i, _i, _p],
 }
-RESTYPES = {"emage_bn_stats_workspace_bytes": _l}
+RESTYPES = {"emage_bn_stats_workspace_bytes": _l, "emage_wav_conv_in_backward_workspace_bytes": _l}
 
 _lib = None
 

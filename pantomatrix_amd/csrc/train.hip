@@ -484,3 +484,179 @@ extern "C" int emage_adam_step(float* param, const float* grad, float* exp_avg, 
                        (float)((double)lr / bias1), (float)(1.0 / sqrt(bias2)), eps, weight_decay);
     return launch_status();
 }
+
+// ---- convolution / BatchNorm backward pieces --------------------------------------------------------------------------------------
+namespace {
+
+// colT[(tap * C + c)][m] = X[seq * Lin + l * stride - pad + tap][c] (0 outside the sequence), m = seq * Lout + l; rows m >= M stay 0.
+// One 32 x 32 (m, c) tile per block and tap through LDS: coalesced reads along c, coalesced writes along m.
+__global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__ x, int ldx, int C, int taps, int stride, int pad, int Lin, int Lout, int M,
+                                                       float* __restrict__ out, long ld_out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ctiles = (C + 31) / 32;
+    const int tap = blockIdx.y / ctiles, c0 = (blockIdx.y % ctiles) * 32, m0 = blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (m < M && c < C) {
+            const int seq = m / Lout, l = m - seq * Lout, pos = l * stride - pad + tap;
+            if (pos >= 0 && pos < Lin) v = x[((long)seq * Lin + pos) * ldx + c];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, m = m0 + tx;
+        if (c < C && m < M) out[((long)tap * C + c) * ld_out + m] = tile[tx][r];
+    }
+}
+
+// dx[seq * Lin + r][c] = sum over taps with (r + pad - tap) = l * stride, 0 <= l < Lout, of dcol[seq * Lout + l][tap * C + c]
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, long ld, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq,
+                                                     float* __restrict__ dx, int ldx) {
+    const long total = (long)nseq * Lin * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / C;
+        const int c = (int)(i - row * C);
+        const int seq = (int)(row / Lin), r = (int)(row - (long)seq * Lin);
+        float s = 0.f;
+        for (int tap = 0; tap < taps; ++tap) {
+            const int q = r + pad - tap;
+            if (q < 0 || q % stride) continue;
+            const int l = q / stride;
+            if (l < Lout) s += dcol[((long)seq * Lout + l) * ld + tap * C + c];
+        }
+        dx[row * ldx + c] = s;
+    }
+}
+
+// BatchNorm (training) backward: sums of dy and dy * xhat per channel (float64 partials), then
+// dx = gamma * rstd * (dy - sum_dy / M - xhat * sum_dyxhat / M); dgamma = sum_dyxhat, dbeta = sum_dy
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                             const float* __restrict__ dy, int ldd, int M, int C, double* __restrict__ partial) {
+    __shared__ double red[2][STAT_ROWS][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const long r0 = (long)blockIdx.x * STAT_CHUNK;
+    const long r1 = r0 + STAT_CHUNK < M ? r0 + STAT_CHUNK : M;
+    double s = 0.0, sx = 0.0;
+    if (c < C) {
+        const float mu = mean[c], rstd = 1.0f / sqrtf(var[c] + eps);
+        for (long r = r0 + rl; r < r1; r += STAT_ROWS) {
+            const float d = dy[r * ldd + c];
+            s += (double)d;
+            sx += (double)(d * ((x[r * ldx + c] - mu) * rstd));
+        }
+    }
+    red[0][rl][cl] = s;
+    red[1][rl][cl] = sx;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < STAT_ROWS; ++i) { a += red[0][i][cl]; b += red[1][i][cl]; }
+        partial[((long)blockIdx.x * 2 + 0) * C + c] = a;
+        partial[((long)blockIdx.x * 2 + 1) * C + c] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int chunks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int i = 0; i < chunks; ++i) { s += partial[((long)i * 2 + 0) * C + c]; sx += partial[((long)i * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)sx;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                           const float* __restrict__ gamma, const float* __restrict__ dy, int ldd,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta, float* __restrict__ dx, int ldo, int M, int C) {
+    const long total = (long)M * C;
+    const float inv_m = 1.0f / (float)M;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / C;
+        const int c = (int)(i - m * C);
+        const float rstd = 1.0f / sqrtf(var[c] + eps);
+        const float xh = (x[m * ldx + c] - mean[c]) * rstd;
+        dx[m * ldo + c] = gamma[c] * rstd * (dy[m * ldd + c] - dbeta[c] * inv_m - xh * dgamma[c] * inv_m);
+    }
+}
+
+// first WavEncoder layer (Cin = 1): dW[c][tap] = sum_m dy[m][c] * wav[seq][l * stride - pad + tap]; float64 block partials
+constexpr int WIN_CHUNK = 1024;
+__global__ __launch_bounds__(256) void wav_in_dw_partial_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ wav, long ldw, int L,
+                                                                int Lout, int M, int C, int taps, int stride, int pad, double* __restrict__ partial) {
+    const long r0 = (long)blockIdx.x * WIN_CHUNK;
+    const long r1 = r0 + WIN_CHUNK < M ? r0 + WIN_CHUNK : M;
+    for (int e = threadIdx.x; e < C * taps; e += blockDim.x) {
+        const int c = e / taps, tap = e - c * taps;
+        double s = 0.0;
+        for (long m = r0; m < r1; ++m) {
+            const int seq = (int)(m / Lout), l = (int)(m - (long)seq * Lout), pos = l * stride - pad + tap;
+            if (pos >= 0 && pos < L) s += (double)(dy[m * ldd + c] * wav[(long)seq * ldw + pos]);
+        }
+        partial[(long)blockIdx.x * C * taps + e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wav_in_dw_finalize_kernel(const double* __restrict__ partial, int chunks, int n, float* __restrict__ dw) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int i = 0; i < chunks; ++i) s += partial[(long)i * n + e];
+    dw[e] = (float)s;
+}
+
+}  // namespace
+
+extern "C" int emage_im2col_t(const float* x, int ldx, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq,
+                              float* out, long ld_out, void* stream) {
+    if (!x || !out || C <= 0 || taps <= 0 || stride <= 0 || pad < 0 || Lin <= 0 || Lout <= 0 || nseq <= 0 || ldx < C) return EMAGE_EINVAL;
+    const long M = (long)nseq * Lout;
+    if (ld_out < M || M >= (1L << 31)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)((M + 31) / 32), (unsigned)(taps * ((C + 31) / 32))), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, C, taps, stride, pad, Lin, Lout, (int)M, out, ld_out);
+    return launch_status();
+}
+
+extern "C" int emage_col2im(const float* dcol, long ld, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq, float* dx, int ldx, void* stream) {
+    if (!dcol || !dx || C <= 0 || taps <= 0 || stride <= 0 || pad < 0 || Lin <= 0 || Lout <= 0 || nseq <= 0 || ldx < C || ld < (long)taps * C) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long)nseq * Lin * C)), dim3(256), 0, (hipStream_t)stream, dcol, ld, C, taps, stride, pad, Lin, Lout, nseq, dx, ldx);
+    return launch_status();
+}
+
+extern "C" int emage_bn_backward(const float* x, int ldx, const float* mean, const float* var, const float* gamma, float eps, const float* dy, int ld_dy,
+                                 float* dx, int ld_dx, float* dgamma, float* dbeta, int M, int C, void* workspace, long workspace_bytes, void* stream) {
+    if (!x || !mean || !var || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || ldx < C || ld_dy < C || ld_dx < C) return EMAGE_EINVAL;
+    if (workspace_bytes < emage_bn_stats_workspace_bytes(M, C) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
+    const int chunks = (M + STAT_CHUNK - 1) / STAT_CHUNK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, mean, var, eps, dy, ld_dy, M, C, (double*)workspace);
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C, dgamma, dbeta);
+    rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long)M * C)), dim3(256), 0, s, x, ldx, mean, var, eps, gamma, dy, ld_dy, dgamma, dbeta, dx, ld_dx, M, C);
+    return launch_status();
+}
+
+extern "C" long emage_wav_conv_in_backward_workspace_bytes(int M, int C, int taps) {
+    if (M <= 0 || C <= 0 || taps <= 0) return EMAGE_EINVAL;
+    return (long)((M + WIN_CHUNK - 1) / WIN_CHUNK) * C * taps * (long)sizeof(double);
+}
+
+extern "C" int emage_wav_conv_in_backward(const float* dy, int ld_dy, const float* wav, long ldw, int L, int B, int Lout, int C, int taps, int stride, int pad,
+                                          float* dw, void* workspace, long workspace_bytes, void* stream) {
+    if (!dy || !wav || !dw || !workspace || B <= 0 || L <= 0 || Lout <= 0 || C <= 0 || taps <= 0 || stride <= 0 || ld_dy < C || ldw < L) return EMAGE_EINVAL;
+    const long M = (long)B * Lout;
+    if (M >= (1L << 31) || workspace_bytes < emage_wav_conv_in_backward_workspace_bytes((int)M, C, taps) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
+    const int chunks = (int)((M + WIN_CHUNK - 1) / WIN_CHUNK);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wav_in_dw_partial_kernel, dim3(chunks), dim3(256), 0, s, dy, ld_dy, wav, ldw, L, Lout, (int)M, C, taps, stride, pad, (double*)workspace);
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(wav_in_dw_finalize_kernel, dim3((C * taps + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C * taps, dw);
+    return launch_status();
+}

@@ -448,6 +448,70 @@ def nll_loss_grad(logits, index, weight):
     return g
 
 
+@_op("im2col_t", "(Tensor x, int c, int taps, int stride, int pad, int lin, int lout, int nseq, Tensor(a!) out) -> ()")
+def _im2col_t(x, c, taps, stride, pad, lin, lout, nseq, out):
+    check(_lib.load().emage_im2col_t(_ptr(x), _ld(x), c, taps, stride, pad, lin, lout, nseq, _ptr(out), out.stride(0), _stream()), "im2col_t")
+
+
+def im2col_t(x, c, taps, stride, pad, lin, lout, nseq, mp):
+    """-> (taps*c, mp) fp32, columns m = seq*lout + l (zero beyond nseq*lout): the transposed im2col of channels-last rows x."""
+    _dev(x)
+    out = torch.zeros(taps * c, mp, dtype=torch.float32, device=x.device)
+    _im2col_t(x, c, taps, stride, pad, lin, lout, nseq, out)
+    return out
+
+
+@_op("col2im", "(Tensor dcol, int c, int taps, int stride, int pad, int lin, int lout, int nseq, Tensor(a!) dx) -> ()")
+def _col2im(dcol, c, taps, stride, pad, lin, lout, nseq, dx):
+    check(_lib.load().emage_col2im(_ptr(dcol), dcol.stride(0), c, taps, stride, pad, lin, lout, nseq, _ptr(dx), _ld(dx), _stream()), "col2im")
+
+
+def col2im(dcol, c, taps, stride, pad, lin, lout, nseq):
+    """dcol (nseq*lout, taps*c) -> dx (nseq*lin, c): the adjoint of im2col."""
+    _dev(dcol)
+    dx = torch.empty(nseq * lin, c, dtype=torch.float32, device=dcol.device)
+    _col2im(dcol, c, taps, stride, pad, lin, lout, nseq, dx)
+    return dx
+
+
+@_op("bn_backward", "(Tensor x, Tensor mean, Tensor var, Tensor gamma, float eps, Tensor dy, Tensor(a!) dx, Tensor(b!) dgamma, Tensor(c!) dbeta, "
+                    "Tensor(d!) workspace) -> ()")
+def _bn_backward(x, mean, var, gamma, eps, dy, dx, dgamma, dbeta, workspace):
+    m, c = x.shape
+    check(_lib.load().emage_bn_backward(_ptr(x), _ld(x), _ptr(mean), _ptr(var), _ptr(gamma), eps, _ptr(dy), _ld(dy), _ptr(dx), _ld(dx), _ptr(dgamma),
+                                        _ptr(dbeta), m, c, _ptr(workspace), workspace.numel() * 8, _stream()), "bn_backward")
+
+
+def bn_backward(x, stats, gamma, dy, eps=1e-5):
+    """Training-mode BatchNorm backward on fp32 (M, C) views -> (dx, dgamma, dbeta); stats = (mean, biased var) of the forward."""
+    _dev(x)
+    m, c = x.shape
+    nbytes = _lib.load().emage_bn_stats_workspace_bytes(m, c)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
+    dx = torch.empty(m, c, dtype=torch.float32, device=x.device)
+    dg, db = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
+    _bn_backward(x, stats[0], stats[1], gamma, float(eps), dy, dx, dg, db, ws)
+    return dx, dg, db
+
+
+@_op("wav_conv_in_backward", "(Tensor dy, Tensor wav, int lout, int taps, int stride, int pad, Tensor(a!) dw, Tensor(b!) workspace) -> ()")
+def _wav_conv_in_backward(dy, wav, lout, taps, stride, pad, dw, workspace):
+    b, l = wav.shape
+    check(_lib.load().emage_wav_conv_in_backward(_ptr(dy), _ld(dy), _ptr(wav), wav.stride(0), l, b, lout, dy.shape[1], taps, stride, pad, _ptr(dw),
+                                                 _ptr(workspace), workspace.numel() * 8, _stream()), "wav_conv_in_backward")
+
+
+def wav_conv_in_backward(dy, wav, lout, taps, stride, pad):
+    """Weight gradient (C, taps) of the first WavEncoder layer for output gradient dy (B*lout, C) and the waveform wav (B, L)."""
+    _dev(dy)
+    m, c = dy.shape
+    nbytes = _lib.load().emage_wav_conv_in_backward_workspace_bytes(m, c, taps)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dy.device)
+    dw = torch.empty(c, taps, dtype=torch.float32, device=dy.device)
+    _wav_conv_in_backward(dy, wav, lout, taps, stride, pad, dw, ws)
+    return dw
+
+
 @_op("adam_step", "(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, int step, float lr, float beta1, float beta2, float eps, "
                   "float weight_decay) -> ()")
 def _adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay):

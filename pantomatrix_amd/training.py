@@ -188,20 +188,119 @@ class TrainForward:
             y1 = torch.empty(rows, _rup(cout), dtype=torch.float32, device=cx.dev) if _rup(cout) != cout else torch.empty(rows, cout, dtype=torch.float32, device=cx.dev)
             if y1.shape[1] != cout:
                 y1.zero_()
-            ops.bn_apply(c1, self._bn(cx, base + ".bn1", c1, new_stats), g1, b1, y1[:, :cout], slope=0.01)
+            st1 = self._bn(cx, base + ".bn1", c1, new_stats)
+            ops.bn_apply(c1, st1, g1, b1, y1[:, :cout], slope=0.01)
             c2, _ = cx.gemm(y1, base + ".conv2.raw", conv=(1, k // 2, lout, lout), m=rows, n_store=_rup(cout))
             c2 = c2[:, :cout]
             g2, b2 = cx.pk.w[base + ".bn2.affine"]
             st2 = self._bn(cx, base + ".bn2", c2, new_stats)                           # P:287-288, before the downsample branch (P:289-290)
             out = torch.empty(rows, cout, dtype=torch.float32, device=cx.dev)
+            cds, std = None, None
             if ds:
                 cds = y[:, cout:2 * cout]
                 gd, bd = cx.pk.w[base + ".downsample.1.affine"]
-                ops.bn_apply(c2, st2, g2, b2, out, slope=0.01, sc=cds, sc_bn=(*self._bn(cx, base + ".downsample.1", cds, new_stats), gd, bd))
+                std = self._bn(cx, base + ".downsample.1", cds, new_stats)
+                ops.bn_apply(c2, st2, g2, b2, out, slope=0.01, sc=cds, sc_bn=(*std, gd, bd))
             else:
                 ops.bn_apply(c2, st2, g2, b2, out, slope=0.01, sc=x[:, :cout])
+            if self.tape is not None:
+                saved = dict(i=i, base=base, geom=(cin, cout, stride, pad, ds), x_prev=x, lin=lin, lout=lout, b=b, audio=audio, c1=c1, st1=st1,
+                             y1=y1[:, :cout], c2=c2, st2=st2, cds=cds, std=std, out=out)
+                self.tape.node(lambda sv=saved: self._wav_block_backward(cx, sv))
             x, lin = out, lout
         return x, lens[-1]
+
+    def _conv_backward(self, cx, x, cin, origins, dy, taps, stride, pad, lin, lout, nseq, need_dx):
+        """Conv1d backward on channels-last rows through emage_gemm (exact fp32): x (nseq*lin, >= cin) the layer input, dy (nseq*lout, N)
+        the gradient of its pre-activation output; origins = [(weight name, bias name)] of the convolutions stacked along N.
+        Accumulates the parameter gradients; returns dx (nseq*lin, cin) when asked."""
+        ws = [self._param(wn).float() for wn, _ in origins]                      # (Cout_i, Cin, k)
+        n = sum(w.shape[0] for w in ws)
+        m = dy.shape[0]
+        mp = _rup(m)
+        dy_t = torch.zeros(n, mp, dtype=torch.float32, device=cx.dev)
+        ops.transpose(dy, dy_t)
+        col_t = ops.im2col_t(x, cin, taps, stride, pad, lin, lout, nseq, mp)     # (taps*cin, mp)
+        dw = torch.empty(n, taps * cin, dtype=torch.float32, device=cx.dev)
+        ops.gemm(F32, dy_t, col_t, None, None, None, dw, None, None, n=taps * cin, cp=mp)
+        db = ops.col_sum(dy)
+        r0 = 0
+        for (wn, bn), w in zip(origins, ws):
+            rows = w.shape[0]
+            self._param_grad(wn, slice(None), dw[r0:r0 + rows].view(rows, taps, cin).permute(0, 2, 1))
+            self._param_grad(bn, slice(None), db[r0:r0 + rows])
+            r0 += rows
+        if not need_dx:
+            return None
+        if n % 64:
+            raise RuntimeError(f"convolution backward: {n} output channels (not a multiple of 64)")
+        wflat = torch.cat([w.permute(0, 2, 1).reshape(w.shape[0], taps * cin) for w in ws], 0).contiguous()        # (N, taps*cin), taps major
+        dcol = torch.empty(m, taps * cin, dtype=torch.float32, device=cx.dev)
+        ops.gemm(F32, dy, ops.transpose(wflat), None, None, None, dcol, None, None, n=taps * cin, cp=n)
+        return ops.col2im(dcol, cin, taps, stride, pad, lin, lout, nseq)
+
+    def _bn_backward(self, name, x, stats, dy):
+        gamma = self._param(name + ".weight").float()
+        dx, dg, db = ops.bn_backward(x, stats, gamma, dy)
+        self._param_grad(name + ".weight", slice(None), dg)
+        self._param_grad(name + ".bias", slice(None), db)
+        return dx
+
+    def _wav_block_backward(self, cx, sv):
+        """BasicBlock.forward (P:283-294) backwards: LeakyReLU, bn2 / the (batch-normalised) shortcut, conv2, LeakyReLU, bn1, conv1 (+ shortcut conv)."""
+        tape = self.tape
+        d_out = tape.get(sv["out"])
+        if d_out is None:
+            return
+        cin, cout, stride, pad, ds = sv["geom"]
+        base, k, b, lin, lout = sv["base"], _WAV_TAPS, sv["b"], sv["lin"], sv["lout"]
+        dv = ops.act_backward(d_out, sv["out"], 0.01)
+        dc2 = self._bn_backward(base + ".bn2", sv["c2"], sv["st2"], dv)
+        if ds:
+            dcds = self._bn_backward(base + ".downsample.1", sv["cds"], sv["std"], dv)
+        else:
+            tape.add(sv["x_prev"], dv, cols=cout)
+        dy1 = self._conv_backward(cx, sv["y1"], cout, [(base + ".conv2.weight", base + ".conv2.bias")], dc2, k, 1, k // 2, lout, lout, b, True)
+        dc1 = self._bn_backward(base + ".bn1", sv["c1"], sv["st1"], ops.act_backward(dy1, sv["y1"], 0.01))
+        origins = [(base + ".conv1.weight", base + ".conv1.bias")]
+        dys = dc1
+        if ds:
+            origins.append((base + ".downsample.0.weight", base + ".downsample.0.bias"))
+            dys = torch.cat([dc1, dcds], 1)
+        if sv["i"] == 0:
+            dw = ops.wav_conv_in_backward(dys, sv["audio"], lout, k, stride, pad)          # (2*cout, k): conv1 rows, then the shortcut conv's
+            db = ops.col_sum(dys)
+            for j, (wn, bn) in enumerate(origins):
+                self._param_grad(wn, slice(None), dw[j * cout:(j + 1) * cout].view(cout, 1, k))
+                self._param_grad(bn, slice(None), db[j * cout:(j + 1) * cout])
+        else:
+            tape.add(sv["x_prev"], self._conv_backward(cx, sv["x_prev"], cin, origins, dys, k, stride, pad, lin, lout, b, True), cols=cin)
+
+    # ---- motion pre-encoder (VQEncoderV6, P:213-235), tape-aware ----------------------------------------------------------------------
+    def _conv3(self, cx, x, key, t, b, cin, slope=None, res=None):
+        y, _ = cx.conv3(x, key, t, slope=slope, res=res, n_store=_rup(cx.pk.w[key]["n"]))
+        if self.tape is not None:
+            def bw():
+                g = self.tape.get(y)
+                if g is None:
+                    return
+                if res is not None:
+                    self.tape.add(res, g)
+                dpre = g if slope is None else ops.act_backward(g, y, slope)
+                dx = self._conv_backward(cx, x, cin, [(key + ".weight", key + ".bias")], dpre, 3, 1, 1, t, t, b, True)
+                self.tape.add(x, dx, cols=cin)
+            self.tape.node(bw)
+        return y
+
+    def _motion_encoder(self, cx, x0, t, b, cin0):
+        h, cin = x0, cin0
+        for i in range(spec.MOTION_ENC_LAYERS):
+            p = f"motion_encoder.main.{3 * i}"
+            h = self._conv3(cx, h, p, t, b, cin, slope=0.2)
+            cin = cx.pk.w[p]["n"]
+            r = self._conv3(cx, h, f"motion_encoder.main.{3 * i + 2}.model.0", t, b, cin, slope=0.2)
+            h = self._conv3(cx, r, f"motion_encoder.main.{3 * i + 2}.model.2", t, b, cin, res=h)
+        return h
 
     # ---- differentiable pieces: each wrapper launches the forward op and, when a tape is attached, records its backward -----------
     def _lin(self, cx, x, key, slope=None, out=None, need_dx=True):
@@ -414,10 +513,16 @@ class TrainForward:
         motion3 = masked_motion.to(device=dev, dtype=torch.float32).contiguous()
         mask3 = mask.to(device=dev, dtype=torch.float32).contiguous()
 
-        # masked motion -> spatial hints (M:267-273); the tape starts behind the motion encoder (its backward is not written yet)
+        # masked motion -> spatial hints (M:267-273)
         x0 = ops.pack_motion(cx.dt, motion3, mask3, pk.w["mask_emb"], _rup(cm))
-        hint, _ = _conv_encoder(cx, "motion_encoder", x0, t, spec.MOTION_ENC_LAYERS, mf, False)
-        hh = self._lin(cx, hint, "bodyhints.fc1", slope=0.1, need_dx=False)
+        if self.tape is not None:
+            def bw_mask_embedding():                                                 # x0 = mask ? mask_embedding : motion (M:267-268)
+                g = self.tape.get(x0)
+                if g is not None:
+                    self._param_grad("mask_embedding", slice(None), ops.col_sum(g[:, :cm], mask3.view(m, cm)))
+            self.tape.node(bw_mask_embedding)
+        hint = self._motion_encoder(cx, x0, t, b, cm)
+        hh = self._lin(cx, hint, "bodyhints.fc1", slope=0.1)
         memcat = cx.lo(m, af + mf)                                                   # [audio2face | body_hint_face] (M:288)
         hh_face, hh_body = hh[:, :d], hh[:, d:]
         hint_face = memcat[:, af:]
@@ -434,6 +539,15 @@ class TrainForward:
         if ta < t:
             raise RuntimeError(f"Sizes of tensors must match: audio features {ta} frames vs motion {t} frames")
         memcat[:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)                # M:278-281: the FACE features are trimmed to T
+        if self.tape is not None:
+            def bw_face_features():
+                g = self.tape.get(memcat)
+                if g is None:
+                    return
+                ga = torch.zeros(b, ta, af, dtype=torch.float32, device=dev)
+                ga[:, :t] = g[:, :af].reshape(b, t, af)
+                self.tape.add(a_face, ga.view(b * ta, af))
+            self.tape.node(bw_face_features)
 
         sid = speaker_id.to(dev).reshape(b, 1).expand(b, t)
         spk_body = self._speaker(cx, "spk_body", "speaker_embedding_body.weight", sid)
@@ -452,7 +566,7 @@ class TrainForward:
         # body branch (M:297-312)
         x = self._ppe(cx, masks, self._lin(cx, hint_body, "moton_proj"), b, t)
         x = self._encoder_layer(cx, masks, "motion_self_encoder.layers.0", self._add(cx, x, spk_body), b, t)
-        mem_body = self._lin(cx, a_body, "audio_body_motion_proj", need_dx=False)    # M:303
+        mem_body = self._lin(cx, a_body, "audio_body_motion_proj")                   # M:303
         base = self._ppe(cx, masks, self._add(cx, x, spk_body), b, t)               # M:304-305
         x = base
         bmem = self._memory(cx, "cross.kv_all", mem_body, b, ta, nc)
@@ -487,11 +601,10 @@ class TrainForward:
 
     # ---- backward through everything behind the motion encoder and the WavEncoders ------------------------------------------------
     def backward(self, index_gt, latent_gt):
-        """Gradients of `rec_loss + cls_loss` (T:106-130) of the LAST forward (called with tape=True) w.r.t. every parameter of the
-        MAGE transformer stack, the projections, MLP heads and speaker embeddings; they ACCUMULATE in `self.param_grads` (name ->
-        fp32 tensor of the parameter's shape) across the forwards of a step, like `loss_all.backward()` in the reference (T:174).
-        The contractions are emage_gemm launches in exact-fp32 mode on transposed operands; the convolutional front ends
-        (motion encoder, WavEncoders with their BatchNorms, mask embedding) are not differentiated yet."""
+        """Gradients of `rec_loss + cls_loss` (T:106-130) of the LAST forward (called with tape=True) w.r.t. every trainable parameter
+        that takes part in it; they ACCUMULATE in `self.param_grads` (name -> fp32 tensor of the parameter's shape) across the
+        forwards of a step, like `loss_all.backward()` in the reference (T:174).  Every contraction (Linear and Conv1d, dX and dW) is
+        an emage_gemm launch in exact-fp32 mode on transposed / im2col operands."""
         if self.tape is None:
             raise RuntimeError("backward() needs the forward to be run with tape=True")
         cfg, tape, out = self.model.config, self.tape, self._out2d
@@ -554,3 +667,52 @@ def step_losses(fwd: TrainForward, vq, batch, iteration, dropout_masks, random_m
     res = {k: float(v) for k, v in out.items()}
     res["all"] = sum(res.values())
     return res, stats
+
+
+class Trainer:
+    """One optimisation step of train_emage_audio.py:132-180 on the device: the three train-mode forwards with their backward
+    passes (gradients accumulate like `loss_all.backward()`), torch.optim.Adam with the reference's settings (lr 1.5e-4 constant,
+    betas .9 / .999, eps 1e-8, no weight decay: configs/emage_audio.yaml:63-78), the BatchNorm running buffers.  Parameters that
+    take no part in the forward (the deep-copied template layers, M:246-262) get no gradient and stay untouched, as in torch.
+    `grad_hook(param_grads)` runs between backward and the update: the place of the gradient all-reduce of a multi-GPU run
+    (`pantomatrix_amd.dist.GradientBuckets`)."""
+
+    def __init__(self, model, vq, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.fwd, self.vq = TrainForward(model), vq
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.state = {}                                   # name -> dict(step, exp_avg, exp_avg_sq)
+
+    def step(self, batch, iteration, dropout_masks, random_mask, grad_hook=None):
+        fwd, model = self.fwd, self.fwd.model
+        cfg = model.config
+        index, latent, masked_motion = targets(self.vq, batch["motion"], batch["expressions"], batch["trans"], batch["foot_contact"])
+        bs = masked_motion.shape[0]
+        speaker_id = torch.zeros(bs, 1, dtype=torch.long, device=masked_motion.device)
+        seed_mask = torch.ones_like(masked_motion)
+        seed_mask[:, :cfg.seed_frames] = 0
+        fwd.param_grads = {}
+        stats, out = {}, {}
+        ws = ops.loss_workspace(masked_motion.device)
+        for tag, mask, use_audio, masks in (("seed", seed_mask, True, dropout_masks[0]), ("audio", random_mask, True, dropout_masks[1]),
+                                            ("mask", random_mask, False, dropout_masks[2])):
+            pred, stats = fwd(batch["audio"], speaker_id, masked_motion, mask, masks, use_audio=use_audio, new_stats=stats, tape=True)
+            out["rec_" + tag], out["cls_" + tag] = losses(cfg, pred, index, latent, ws)
+            fwd.backward(index, latent)
+        grads = fwd.param_grads
+        if grad_hook is not None:
+            grad_hook(grads)
+        params = model._flat_params()                     # detached views of the nn.Parameters: updated in place
+        for name, g in grads.items():
+            p = params[name]
+            st = self.state.get(name)
+            if st is None:
+                st = self.state[name] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+            st["step"] += 1
+            ops.adam_step(p, g.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"], self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay)
+        for name, v in stats.items():                     # BatchNorm running statistics after the three forwards
+            if name in params:
+                params[name].copy_(v.to(params[name].dtype))
+        model.invalidate_packed()                         # the MFMA operand copies are rebuilt from the updated parameters
+        res = {k: float(v) for k, v in out.items()}
+        res["all"] = sum(res.values())
+        return res

@@ -119,7 +119,7 @@ def transpose(x, out=None):
     CALLS.append("transpose")
     r = x.t().contiguous()
     if out is not None:
-        out.copy_(r)
+        out[:, :r.shape[1]].copy_(r)              # `out` may be wider (zero-padded contraction length)
         return out
     return r
 
@@ -180,6 +180,47 @@ def nll_loss_grad(logits, index, weight):
     g = torch.softmax(logits, dim=1)
     g[torch.arange(logits.shape[0]), index] -= 1.0
     return g * (weight / logits.shape[0])
+
+
+def _im2col(x, c, taps, stride, pad, lin, lout, nseq):
+    xs = x[:, :c].reshape(nseq, lin, c)
+    xp = torch.nn.functional.pad(xs, (0, 0, pad, max(0, (lout - 1) * stride - pad + taps - lin)))
+    idx = (torch.arange(lout) * stride).view(lout, 1) + torch.arange(taps).view(1, taps)          # padded positions
+    return xp[:, idx]                                                                              # (nseq, lout, taps, c)
+
+
+def im2col_t(x, c, taps, stride, pad, lin, lout, nseq, mp):
+    CALLS.append("im2col_t")
+    col = _im2col(x, c, taps, stride, pad, lin, lout, nseq).reshape(nseq * lout, taps * c)
+    out = torch.zeros(taps * c, mp)
+    out[:, :nseq * lout] = col.t()
+    return out
+
+
+def col2im(dcol, c, taps, stride, pad, lin, lout, nseq):
+    CALLS.append("col2im")
+    d = dcol.reshape(nseq, lout, taps, c)
+    width = max(lin + 2 * pad, (lout - 1) * stride + taps)
+    dxp = torch.zeros(nseq, width, c)
+    for tap in range(taps):
+        dxp[:, tap:tap + (lout - 1) * stride + 1:stride] += d[:, :, tap]
+    return dxp[:, pad:pad + lin].reshape(nseq * lin, c).contiguous()
+
+
+def bn_backward(x, stats, gamma, dy, eps=1e-5):
+    CALLS.append("bn_backward")
+    m = x.shape[0]
+    rstd = 1.0 / torch.sqrt(stats[1] + eps)
+    xh = (x - stats[0]) * rstd
+    dg, db = (dy.double() * xh.double()).sum(0).float(), dy.double().sum(0).float()
+    return gamma * rstd * (dy - db / m - xh * dg / m), dg, db
+
+
+def wav_conv_in_backward(dy, wav, lout, taps, stride, pad):
+    CALLS.append("wav_conv_in_backward")
+    b, l = wav.shape
+    col = _im2col(wav.reshape(b * l, 1), 1, taps, stride, pad, l, lout, b).reshape(b * lout, taps)
+    return (dy.double().t() @ col.double()).float()
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
@@ -506,7 +547,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 
