@@ -68,7 +68,7 @@ def finalize():
 # a ring all-reduce is bound per link, so few large messages beat many small ones) issued in backward order so the
 # first buckets overlap the rest of the backward; SyncBatchNorm's per-channel statistics of both WavEncoders travel as
 # ONE small all-reduce per block pair instead of one per BatchNorm.  Backend "nccl" == RCCL on ROCm, "gloo" in tests.
-# The HIP backward that feeds these buckets is not built yet; this is its exchange layer, tested on CPU.
+# `gradient_allreduce_hook` plugs them into `pantomatrix_amd.training.Trainer.step` between the backward and Adam.
 # ----------------------------------------------------------------------------------------------------------------------
 EMAGE_BUCKET_PREFIXES = (
     # backward order of EmageAudioModel (M:315-330 run last in forward, so their gradients are ready first)
@@ -128,6 +128,28 @@ class GradientBuckets:
             world = dist.get_world_size(self.group)
             for b in self.flat:
                 b.div_(world)
+
+
+def gradient_allreduce_hook(model, device=None, group=None):
+    """The `grad_hook` of `training.Trainer.step` for a multi-GPU run: the step's gradients go into the four backward-ordered
+    bucket messages, are summed over ranks (RCCL / gloo) and averaged (the DDP average, train_emage_audio.py:251), and come
+    back in place.  Every rank runs the same forwards, so every rank holds the same gradient names."""
+    plan, _unused = emage_bucket_plan([(k, v) for k, v in model._flat_params().items() if v.is_floating_point()])
+    buckets = GradientBuckets(plan, device=device if device is not None else model.device, group=group)
+
+    def hook(param_grads):
+        for b in buckets.flat:
+            b.zero_()
+        for name, g in param_grads.items():
+            buckets.grads[name].copy_(g)
+        for i in range(len(buckets.flat)):
+            buckets.reduce(i)
+        buckets.wait()
+        for name, g in param_grads.items():
+            g.copy_(buckets.grads[name])
+
+    hook.buckets = buckets
+    return hook
 
 
 def sync_batch_stats(sums, sq_sums, count, group=None):

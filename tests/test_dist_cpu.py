@@ -98,3 +98,57 @@ def test_training_exchange_on_two_gloo_ranks():
         allx = np.concatenate([x0[i], x1[i]])
         assert np.allclose(m0[i], allx.mean(0), atol=1e-5) and np.allclose(v0[i], allx.var(0), atol=1e-4)
         assert np.array_equal(m0[i], m1[i])
+
+
+def _trainer_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import common
+    import fake_ops
+    import train_common as tc
+    from pantomatrix_amd import dist as pd
+    from pantomatrix_amd import training
+    assert pd.init("gloo") is not None
+    torch.set_num_threads(2)
+    model, vq = common.product_models(precision="fp32")
+    batch, _, masks, random_mask, _ = tc.oracle_step(seed=20 + rank, iteration=0)          # each rank: its own draws (its own shard of the data)
+    hook = pd.gradient_allreduce_hook(model, device="cpu")
+    seen = {}
+
+    def spy(grads):
+        seen["local"] = {k: v.clone() for k, v in grads.items() if k.startswith(("face_out_proj", "audio_encoder_body.feat_extractor.5.conv2", "mask_embedding"))}
+        hook(grads)
+        seen["avg"] = {k: grads[k].clone() for k in seen["local"]}
+
+    trainer = training.Trainer(model, vq)
+    with fake_ops.installed(), torch.no_grad():
+        trainer.step(batch, 0, masks, random_mask, grad_hook=spy)
+    after = {k: model._flat_params()[k].clone() for k in ("face_out_proj.weight", "mask_embedding")}
+    q.put((rank, {k: v.numpy() for k, v in seen["local"].items()}, {k: v.numpy() for k, v in seen["avg"].items()},
+           {k: v.numpy() for k, v in after.items()}, [b.numel() for b in hook.buckets.flat]))
+    pd.finalize()
+
+
+def test_two_rank_training_step_averages_gradients():
+    """training.Trainer.step on two gloo ranks (CPU stand-ins of the kernels) with `gradient_allreduce_hook`: after the exchange
+    both ranks hold the mean of the two local gradients, in the four bucket messages, and apply the same Adam update."""
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, loc0, avg0, after0, sizes0), (_, loc1, avg1, after1, sizes1) = res
+    assert sizes0 == sizes1 and len(sizes0) == 4
+    for k in loc0:
+        assert not np.array_equal(loc0[k], loc1[k])                                   # different data on the two ranks
+        np.testing.assert_allclose(avg0[k], 0.5 * (loc0[k] + loc1[k]), rtol=1e-6, atol=1e-9)
+        np.testing.assert_array_equal(avg0[k], avg1[k])
+    for k in after0:
+        np.testing.assert_array_equal(after0[k], after1[k])                            # replicas stay in step

@@ -226,7 +226,7 @@ def test_conv_and_bn_backward_kernels():
     dev = [t.to(DEV) for t in (p, mm, vv)]
     ops.adam_step(dev[0], gr.to(DEV), dev[1], dev[2], 3)
     for a, b in zip(dev, ref):
-        assert float((a.cpu() - b).abs().max()) < 1e-7
+        assert float((a.cpu() - b).abs().max()) < 5e-7
 
 
 def test_backward_matches_autograd_on_device():

@@ -1,0 +1,5 @@
+#!/bin/bash
+O=gpurun_out/c27; mkdir -p $O
+cd "$GRAFT_REPO_ROOT"
+timeout 1500 python -m pytest tests/test_train_forward_gpu.py -x -q -s -k "conv_and_bn or backward_matches or training_step" > $O/pytest_train.txt 2>&1; echo "train tests rc=$?" | tee -a $O/summary.txt
+tail -30 $O/pytest_train.txt
