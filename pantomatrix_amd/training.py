@@ -59,6 +59,16 @@ class _Token:
         self.shape = shape
 
 
+def _accumulate(dst, g, out=None):
+    """out (default dst) = dst + g on fp32 (rows, cols) views: emage_add where its 16-byte granularity allows, torch otherwise
+    (the 337-column motion rows)."""
+    out = dst if out is None else out
+    if g.shape[1] % 4 == 0 and all(t.stride(0) % 4 == 0 and t.data_ptr() % 8 == 0 for t in (dst, g, out)):
+        ops.add(F32, dst, g, out=out)
+    else:
+        torch.add(dst, g, out=out)
+
+
 class _Tape:
     """Reverse-mode bookkeeping of one forward: backward closures in launch order, gradient buffers keyed by the forward tensor
     (or token) they belong to, column-slice views routed into their parent's buffer.  Gradients are fp32 (rows, cols)."""
@@ -89,20 +99,20 @@ class _Tape:
         if id(t) in self.views:
             parent, c0, n = self.views[id(t)]
             dst = self.buffer(parent)[:, c0:c0 + (n if cols is None else cols)]
-            ops.add(F32, dst, g, out=dst)
+            _accumulate(dst, g)
             return
         e = self.g.get(id(t))
         if cols is not None and cols != t.shape[1]:
             dst = self.buffer(t)[:, :cols]
-            ops.add(F32, dst, g, out=dst)
+            _accumulate(dst, g)
         elif e is None:
             self.g[id(t)] = [g, False]
             self.keep.append(t)
         elif e[1]:
-            ops.add(F32, e[0], g, out=e[0])
+            _accumulate(e[0], g)
         else:
             s = torch.empty(tuple(e[0].shape), dtype=torch.float32, device=self.dev)
-            ops.add(F32, e[0], g, out=s)
+            _accumulate(e[0], g, out=s)
             e[0], e[1] = s, True
 
     def get(self, t):
@@ -221,13 +231,14 @@ class TrainForward:
         dy_t = torch.zeros(n, mp, dtype=torch.float32, device=cx.dev)
         ops.transpose(dy, dy_t)
         col_t = ops.im2col_t(x, cin, taps, stride, pad, lin, lout, nseq, mp)     # (taps*cin, mp)
-        dw = torch.empty(n, taps * cin, dtype=torch.float32, device=cx.dev)
-        ops.gemm(F32, dy_t, col_t, None, None, None, dw, None, None, n=taps * cin, cp=mp)
+        kc = taps * cin
+        dw = torch.empty(n, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]          # 16-byte row pitch for emage_gemm's stores
+        ops.gemm(F32, dy_t, col_t, None, None, None, dw, None, None, n=kc, cp=mp)
         db = ops.col_sum(dy)
         r0 = 0
         for (wn, bn), w in zip(origins, ws):
             rows = w.shape[0]
-            self._param_grad(wn, slice(None), dw[r0:r0 + rows].view(rows, taps, cin).permute(0, 2, 1))
+            self._param_grad(wn, slice(None), dw[r0:r0 + rows].reshape(rows, taps, cin).permute(0, 2, 1))
             self._param_grad(bn, slice(None), db[r0:r0 + rows])
             r0 += rows
         if not need_dx:
@@ -235,8 +246,8 @@ class TrainForward:
         if n % 64:
             raise RuntimeError(f"convolution backward: {n} output channels (not a multiple of 64)")
         wflat = torch.cat([w.permute(0, 2, 1).reshape(w.shape[0], taps * cin) for w in ws], 0).contiguous()        # (N, taps*cin), taps major
-        dcol = torch.empty(m, taps * cin, dtype=torch.float32, device=cx.dev)
-        ops.gemm(F32, dy, ops.transpose(wflat), None, None, None, dcol, None, None, n=taps * cin, cp=n)
+        dcol = torch.empty(m, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
+        ops.gemm(F32, dy, ops.transpose(wflat), None, None, None, dcol, None, None, n=kc, cp=n)
         return ops.col2im(dcol, cin, taps, stride, pad, lin, lout, nseq)
 
     def _bn_backward(self, name, x, stats, dy):
