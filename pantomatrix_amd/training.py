@@ -623,9 +623,9 @@ class TrainForward:
             pred = out[f"rec_{q}"]
             tape.add(pred, ops.mse_loss_grad(pred, latent_gt[q].reshape(pred.shape).to(pred.device), getattr(cfg, "l" + q[0])))
             logits = out[f"cls_{q}"]
-            cw = getattr(cfg, "c" + q[0])
-            if cw != 0:
-                tape.add(logits, ops.nll_loss_grad(logits, index_gt[q].reshape(-1).contiguous().to(logits.device), cw))
+            # cf = 0 in the reference's config: the face classifier's loss is evaluated and multiplied by 0 (T:113-128), its
+            # parameters receive exact-zero gradients and an Adam state — kept that way
+            tape.add(logits, ops.nll_loss_grad(logits, index_gt[q].reshape(-1).contiguous().to(logits.device), getattr(cfg, "c" + q[0])))
         tape.run()
         self.tape = None
         return self.param_grads
