@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=56)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--full-step", action="store_true", help="whole optimisation steps (training.Trainer.step: + backward, Adam) instead of the forward side")
     args = ap.parse_args()
     import common
     from pantomatrix_amd import training
@@ -52,8 +53,12 @@ def main():
     ta = model._wav_lengths(batch["audio"].shape[1])[-1]
     random_mask = (torch.rand(b, t, 337, device=dev) < 0.5).float()
 
+    trainer = training.Trainer(model, vq) if args.full_step else None
+
     def step():
         masks = [draw_masks(b, t, c.hidden_size, 2 * c.hidden_size, 4, ta, dev) for _ in range(3)]
+        if trainer is not None:
+            return trainer.step(batch, 0, masks, random_mask), None
         return training.step_losses(fwd, vq, batch, 0, masks, random_mask)
 
     step()
@@ -63,9 +68,12 @@ def main():
         losses, _ = step()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"what": "forward side of one EMAGE training step (targets + 3 train-mode forwards + 6 losses), eager, one stream",
-                      "config": {"workload": "BASELINE config 3", "clips_per_gpu": b, "frames_per_clip": t}, "dtype": args.precision,
-                      "ms_per_step_forward_side": ms, "clip_windows_per_s": b / (ms * 1e-3), "losses": {k: round(v, 4) for k, v in losses.items()}}))
+    what = ("one whole EMAGE optimisation step (targets, 3 x (train-mode forward, losses, backward), Adam), eager, one stream; backward "
+            "contractions in exact-fp32 MFMA" if args.full_step else
+            "forward side of one EMAGE training step (targets + 3 train-mode forwards + 6 losses), eager, one stream")
+    print(json.dumps({"what": what, "config": {"workload": "BASELINE config 3", "clips_per_gpu": b, "frames_per_clip": t}, "dtype": args.precision,
+                      "ms_per_step": ms, "clip_windows_per_s": b / (ms * 1e-3), "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                      "losses": {k: round(v, 4) for k, v in losses.items()}}))
 
 
 if __name__ == "__main__":
