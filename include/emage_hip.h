@@ -393,6 +393,13 @@ int emage_col2im(const float* dcol, long ld, int C, int taps, int stride, int pa
 int emage_bn_backward(const float* x, int ldx, const float* mean, const float* var, const float* gamma, float eps, const float* dy, int ld_dy,
                       float* dx, int ld_dx, float* dgamma, float* dbeta, int M, int C, void* workspace, long workspace_bytes, void* stream);
 
+/* The two halves of emage_bn_backward on their own: nn.SyncBatchNorm all-reduces the per-channel sums between them
+ * (train_emage_audio.py:248); `count` is the GLOBAL number of rows behind mean / var. */
+int emage_bn_backward_sums(const float* x, int ldx, const float* mean, const float* var, float eps, const float* dy, int ld_dy,
+                           float* sum_dy_xhat, float* sum_dy, int M, int C, void* workspace, long workspace_bytes, void* stream);
+int emage_bn_backward_apply(const float* x, int ldx, const float* mean, const float* var, const float* gamma, float eps, const float* dy, int ld_dy,
+                            const float* sum_dy_xhat, const float* sum_dy, long count, float* dx, int ld_dx, int M, int C, void* stream);
+
 /* Weight gradient of emage_wav_conv_in (Cin = 1): dw[c][tap] = sum_m dy[m][c] * wav[seq][l*stride - pad + tap]. */
 long emage_wav_conv_in_backward_workspace_bytes(int M, int C, int taps);
 int emage_wav_conv_in_backward(const float* dy, int ld_dy, const float* wav, long ldw, int L, int B, int Lout, int C, int taps, int stride, int pad,

@@ -660,3 +660,41 @@ extern "C" int emage_wav_conv_in_backward(const float* dy, int ld_dy, const floa
     hipLaunchKernelGGL(wav_in_dw_finalize_kernel, dim3((C * taps + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C * taps, dw);
     return launch_status();
 }
+
+// The two halves of emage_bn_backward on their own — nn.SyncBatchNorm's backward all-reduces the two per-channel sums between them
+// (train_emage_audio.py:248): `count` is then the GLOBAL number of rows the statistics were taken over.
+extern "C" int emage_bn_backward_sums(const float* x, int ldx, const float* mean, const float* var, float eps, const float* dy, int ld_dy,
+                                      float* sum_dy_xhat, float* sum_dy, int M, int C, void* workspace, long workspace_bytes, void* stream) {
+    if (!x || !mean || !var || !dy || !sum_dy_xhat || !sum_dy || !workspace || M <= 0 || C <= 0 || ldx < C || ld_dy < C) return EMAGE_EINVAL;
+    if (workspace_bytes < emage_bn_stats_workspace_bytes(M, C) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
+    const int chunks = (M + STAT_CHUNK - 1) / STAT_CHUNK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, mean, var, eps, dy, ld_dy, M, C, (double*)workspace);
+    const int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C, sum_dy_xhat, sum_dy);
+    return launch_status();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void bn_bwd_apply_n_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                             const float* __restrict__ gamma, const float* __restrict__ dy, int ldd,
+                                                             const float* __restrict__ sdx, const float* __restrict__ sd, float inv_n, float* __restrict__ dx, int ldo, int M, int C) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / C;
+        const int c = (int)(i - m * C);
+        const float rstd = 1.0f / sqrtf(var[c] + eps);
+        const float xh = (x[m * ldx + c] - mean[c]) * rstd;
+        dx[m * ldo + c] = gamma[c] * rstd * (dy[m * ldd + c] - sd[c] * inv_n - xh * sdx[c] * inv_n);
+    }
+}
+}  // namespace
+
+extern "C" int emage_bn_backward_apply(const float* x, int ldx, const float* mean, const float* var, const float* gamma, float eps, const float* dy, int ld_dy,
+                                       const float* sum_dy_xhat, const float* sum_dy, long count, float* dx, int ld_dx, int M, int C, void* stream) {
+    if (!x || !mean || !var || !gamma || !dy || !sum_dy_xhat || !sum_dy || !dx || M <= 0 || C <= 0 || count < M || ldx < C || ld_dy < C || ld_dx < C) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_n_kernel, dim3(grid_for((long)M * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, mean, var, eps, gamma, dy, ld_dy,
+                       sum_dy_xhat, sum_dy, 1.0f / (float)count, dx, ld_dx, M, C);
+    return launch_status();
+}

@@ -152,20 +152,34 @@ def gradient_allreduce_hook(model, device=None, group=None):
     return hook
 
 
-def sync_batch_stats(sums, sq_sums, count, group=None):
+def sync_batch_stats(sums, sq_sums, count, group=None, return_counts=False):
     """SyncBatchNorm's exchange (train_emage_audio.py:248): per-channel sum and sum of squares of several BatchNorm layers
     plus their element counts, summed over ranks in ONE all-reduce.  sums / sq_sums: lists of (C_i,) tensors, count: list
-    of numbers.  Returns (means, biased variances) lists over the GLOBAL batch."""
+    of numbers.  Returns (means, biased variances) lists over the GLOBAL batch (and the global counts when asked)."""
     flat = torch.cat([torch.cat([s.reshape(-1), q.reshape(-1), torch.as_tensor([float(c)], dtype=s.dtype, device=s.device)])
                       for s, q, c in zip(sums, sq_sums, count)])
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    means, variances, off = [], [], 0
+    means, variances, counts, off = [], [], [], 0
     for s in sums:
         c = s.numel()
         tot_s, tot_q, n = flat[off:off + c], flat[off + c:off + 2 * c], flat[off + 2 * c]
         mean = tot_s / n
         means.append(mean)
         variances.append(tot_q / n - mean * mean)
+        counts.append(n)
         off += 2 * c + 1
-    return means, variances
+    return (means, variances, counts) if return_counts else (means, variances)
+
+
+def sum_over_group(tensors, group=None):
+    """Element-wise sum over ranks of a list of small tensors in ONE all-reduce (SyncBatchNorm's backward sums); in place."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensors
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view(t.shape))
+        off += t.numel()
+    return tensors

@@ -494,6 +494,39 @@ def bn_backward(x, stats, gamma, dy, eps=1e-5):
     return dx, dg, db
 
 
+@_op("bn_backward_sums", "(Tensor x, Tensor mean, Tensor var, float eps, Tensor dy, Tensor(a!) sum_dy_xhat, Tensor(b!) sum_dy, Tensor(c!) workspace) -> ()")
+def _bn_backward_sums(x, mean, var, eps, dy, sum_dy_xhat, sum_dy, workspace):
+    m, c = x.shape
+    check(_lib.load().emage_bn_backward_sums(_ptr(x), _ld(x), _ptr(mean), _ptr(var), eps, _ptr(dy), _ld(dy), _ptr(sum_dy_xhat), _ptr(sum_dy), m, c,
+                                             _ptr(workspace), workspace.numel() * 8, _stream()), "bn_backward_sums")
+
+
+@_op("bn_backward_apply", "(Tensor x, Tensor mean, Tensor var, Tensor gamma, float eps, Tensor dy, Tensor sum_dy_xhat, Tensor sum_dy, int count, Tensor(a!) dx) -> ()")
+def _bn_backward_apply(x, mean, var, gamma, eps, dy, sum_dy_xhat, sum_dy, count, dx):
+    m, c = x.shape
+    check(_lib.load().emage_bn_backward_apply(_ptr(x), _ld(x), _ptr(mean), _ptr(var), _ptr(gamma), eps, _ptr(dy), _ld(dy), _ptr(sum_dy_xhat), _ptr(sum_dy),
+                                              count, _ptr(dx), _ld(dx), m, c, _stream()), "bn_backward_apply")
+
+
+def bn_backward_sums(x, stats, dy, eps=1e-5):
+    """-> (sum_m dy * xhat, sum_m dy) per channel over THIS rank's rows (SyncBatchNorm all-reduces them before `bn_backward_apply`)."""
+    _dev(x)
+    m, c = x.shape
+    nbytes = _lib.load().emage_bn_stats_workspace_bytes(m, c)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
+    sdx, sd = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
+    _bn_backward_sums(x, stats[0], stats[1], float(eps), dy, sdx, sd, ws)
+    return sdx, sd
+
+
+def bn_backward_apply(x, stats, gamma, dy, sums, count, eps=1e-5):
+    """dx of training-mode BatchNorm from (global) sums over `count` rows."""
+    _dev(x)
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _bn_backward_apply(x, stats[0], stats[1], gamma, float(eps), dy, sums[0], sums[1], int(count), dx)
+    return dx
+
+
 @_op("wav_conv_in_backward", "(Tensor dy, Tensor wav, int lout, int taps, int stride, int pad, Tensor(a!) dw, Tensor(b!) workspace) -> ()")
 def _wav_conv_in_backward(dy, wav, lout, taps, stride, pad, dw, workspace):
     b, l = wav.shape

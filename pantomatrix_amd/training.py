@@ -133,12 +133,17 @@ class TrainForward:
     """Callable train-mode forward of an `EmageAudioModel` (f16x3 or fp32 precision), with `backward()` for the part of the
     network behind the convolutional front ends."""
 
-    def __init__(self, model):
+    def __init__(self, model, sync_bn=False, group=None):
+        """sync_bn: BatchNorm statistics (forward) and their gradient sums (backward) are taken over all ranks of `group`, the
+        behaviour of nn.SyncBatchNorm the reference converts its model to (train_emage_audio.py:248); torch.distributed must be
+        initialised."""
         if model.precision == "bf16":
             raise ValueError("the training forward runs in the fp32-storage precisions (f16x3 / fp32)")
         self.model = model
+        self.sync_bn, self.group, self._bn_count = sync_bn, group, {}
         self.tape = None
         self.param_grads = {}
+        self._pcache = None
 
     # ---- packing of what the inference pack does not hold: un-folded WavEncoder convolutions ----------------------------
     def _train_pack(self, pk):
@@ -165,10 +170,20 @@ class TrainForward:
     # ---- BatchNorm bookkeeping ----------------------------------------------------------------------------------------------
     def _bn(self, cx, name, x, new_stats):
         """Batch statistics of conv output `x` (M, C) for BatchNorm `name`; the running buffers advance in `new_stats`."""
-        params = self.model._flat_params()
+        params = self._params()
         rm = new_stats.get(name + ".running_mean", params[name + ".running_mean"]).detach().to(cx.dev, torch.float32).clone()
         rv = new_stats.get(name + ".running_var", params[name + ".running_var"]).detach().to(cx.dev, torch.float32).clone()
-        stats = ops.bn_stats(x, rm, rv, BN_MOMENTUM)
+        if self.sync_bn:                                   # nn.SyncBatchNorm (T:248): statistics over the GLOBAL batch, one small all-reduce
+            from . import dist as pdist
+            mean_l, var_l = ops.bn_stats(x, None, None, BN_MOMENTUM)
+            rows = float(x.shape[0])
+            (mean,), (var,), (n,) = pdist.sync_batch_stats([mean_l * rows], [(var_l + mean_l * mean_l) * rows], [rows], group=self.group, return_counts=True)
+            stats = (mean.contiguous(), var.clamp_min(0).contiguous())
+            rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * stats[0])
+            rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * stats[1] * (n / (n - 1)))
+            self._bn_count[name] = int(round(float(n)))
+        else:
+            stats = ops.bn_stats(x, rm, rv, BN_MOMENTUM)
         new_stats[name + ".running_mean"], new_stats[name + ".running_var"] = rm, rv
         nbt = new_stats.get(name + ".num_batches_tracked", params.get(name + ".num_batches_tracked", torch.zeros((), dtype=torch.long)))
         new_stats[name + ".num_batches_tracked"] = nbt.detach().clone() + 1
@@ -252,7 +267,13 @@ class TrainForward:
 
     def _bn_backward(self, name, x, stats, dy):
         gamma = self._param(name + ".weight").float()
-        dx, dg, db = ops.bn_backward(x, stats, gamma, dy)
+        if self.sync_bn:                                   # local sums -> parameter gradients (averaged later with all the others);
+            from . import dist as pdist                    # their sum over ranks -> the input gradient
+            dg, db = ops.bn_backward_sums(x, stats, dy)
+            tot = pdist.sum_over_group([dg.clone(), db.clone()], group=self.group)
+            dx = ops.bn_backward_apply(x, stats, gamma, dy, tot, self._bn_count[name])
+        else:
+            dx, dg, db = ops.bn_backward(x, stats, gamma, dy)
         self._param_grad(name + ".weight", slice(None), dg)
         self._param_grad(name + ".bias", slice(None), db)
         return dx
@@ -368,8 +389,16 @@ class TrainForward:
             ops.gemm(F32, dpre, w_t, None, None, None, dx, None, None, n=k, cp=n)                                        # dX = dpre W
             tape.add(x, dx, cols=k)
 
+    def _params(self):
+        """name -> detached parameter / buffer view, built once per forward (walking the module tree per lookup costs more than
+        the launches it feeds)."""
+        if self._pcache is None:
+            dev = self.model.device
+            self._pcache = {k: v.detach().to(dev) for k, v in self.model._flat_params().items()}
+        return self._pcache
+
     def _param(self, name):
-        return self.model._flat_params()[name].detach().to(self.model.device)
+        return self._params()[name]
 
     def _param_grad(self, name, rows, g):
         full = self.param_grads.get(name)
@@ -514,6 +543,7 @@ class TrainForward:
         self._train_pack(pk)
         self.tape = _Tape(dev) if tape else None
         self._cx = cx
+        self._pcache = None
         new_stats = {} if new_stats is None else new_stats
         masks = _Masks(dropout_masks, dev)
         b, t, cm = masked_motion.shape
@@ -688,8 +718,8 @@ class Trainer:
     `grad_hook(param_grads)` runs between backward and the update: the place of the gradient all-reduce of a multi-GPU run
     (`pantomatrix_amd.dist.GradientBuckets`)."""
 
-    def __init__(self, model, vq, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        self.fwd, self.vq = TrainForward(model), vq
+    def __init__(self, model, vq, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, sync_bn=False, group=None):
+        self.fwd, self.vq = TrainForward(model, sync_bn=sync_bn, group=group), vq
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.state = {}                                   # name -> dict(step, exp_avg, exp_avg_sq)
 
@@ -724,6 +754,7 @@ class Trainer:
             if name in params:
                 params[name].copy_(v.to(params[name].dtype))
         model.invalidate_packed()                         # the MFMA operand copies are rebuilt from the updated parameters
+        fwd._pcache = None
         res = {k: float(v) for k, v in out.items()}
         res["all"] = sum(res.values())
         return res

@@ -216,6 +216,19 @@ def bn_backward(x, stats, gamma, dy, eps=1e-5):
     return gamma * rstd * (dy - db / m - xh * dg / m), dg, db
 
 
+def bn_backward_sums(x, stats, dy, eps=1e-5):
+    CALLS.append("bn_backward_sums")
+    xh = (x - stats[0]) / torch.sqrt(stats[1] + eps)
+    return (dy.double() * xh.double()).sum(0).float(), dy.double().sum(0).float()
+
+
+def bn_backward_apply(x, stats, gamma, dy, sums, count, eps=1e-5):
+    CALLS.append("bn_backward_apply")
+    rstd = 1.0 / torch.sqrt(stats[1] + eps)
+    xh = (x - stats[0]) * rstd
+    return gamma * rstd * (dy - sums[1] / count - xh * sums[0] / count)
+
+
 def wav_conv_in_backward(dy, wav, lout, taps, stride, pad):
     CALLS.append("wav_conv_in_backward")
     b, l = wav.shape
@@ -547,7 +560,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

@@ -43,7 +43,7 @@ def oracle_forward(seed, use_audio=True, new_stats=None, batch=2):
     return (audio, spk, motion, mask), out, masks, ns
 
 
-def oracle_step(seed, iteration):
+def oracle_step(seed, iteration, bs=2):
     """tro.train_step_losses with every forward's dropout masks and the random motion mask recorded:
     -> (batch, loss dict of floats, [masks of forward 1, 2, 3], random_mask, BatchNorm buffers)."""
     from test_train_oracle import train_batch
@@ -65,7 +65,18 @@ def oracle_step(seed, iteration):
     try:
         torch.manual_seed(seed)
         with torch.no_grad():
-            losses, stats = tro.train_step_losses(sd, vq, cfg, train_batch(), iteration)
+            losses, stats = tro.train_step_losses(sd, vq, cfg, train_batch(bs=bs), iteration)
     finally:
         tro.forward_train = orig
-    return train_batch(), {k: float(v) for k, v in losses.items()}, per_forward, motion_masks[1], stats
+    return train_batch(bs=bs), {k: float(v) for k, v in losses.items()}, per_forward, motion_masks[1], stats
+
+
+def shard_masks(masks, lo, hi, batch):
+    """The slice [lo, hi) of the clips out of a forward's dropout masks: the batch axis is 0 for (B, T, d) / (B, H, Tq, Tk), 1 for (T, B, C)."""
+    out = []
+    for m in masks:
+        if m.shape[0] == batch and m.dim() in (3, 4) and not (m.dim() == 3 and m.shape[1] == batch and m.shape[0] != batch):
+            out.append(m[lo:hi].contiguous())
+        else:
+            out.append(m[:, lo:hi].contiguous())
+    return out
