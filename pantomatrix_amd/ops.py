@@ -333,6 +333,13 @@ def loss_workspace(device):
     return torch.zeros(LOSS_WORKSPACE_BYTES // 8, dtype=torch.float64, device=device)
 
 
+def loss_check(workspace):
+    """Raise if an `nll_loss` call on this workspace met a class index outside [0, K) (torch's NLLLoss raises there); reads one
+    word from the device, so call it where the losses are read back anyway."""
+    if int(workspace.view(torch.int32)[-2]) != 0:
+        raise EmageKernelError("nll_loss: class index out of range")
+
+
 def mse_loss(pred, target, weight, loss, workspace):
     """loss[0] += weight * mean((pred - target)^2): fp32 (M, C) views, `loss` a float64 device scalar (F.mse_loss)."""
     _dev(pred)

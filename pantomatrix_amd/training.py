@@ -706,6 +706,7 @@ def step_losses(fwd: TrainForward, vq, batch, iteration, dropout_masks, random_m
         pred, stats = fwd(batch["audio"], speaker_id, masked_motion, mask, masks, use_audio=use_audio, new_stats=stats)
         out["rec_" + tag], out["cls_" + tag] = losses(cfg, pred, index, latent, ws)
     res = {k: float(v) for k, v in out.items()}
+    ops.loss_check(ws)
     res["all"] = sum(res.values())
     return res, stats
 
@@ -756,5 +757,6 @@ class Trainer:
         model.invalidate_packed()                         # the MFMA operand copies are rebuilt from the updated parameters
         fwd._pcache = None
         res = {k: float(v) for k, v in out.items()}
+        ops.loss_check(ws)
         res["all"] = sum(res.values())
         return res

@@ -249,6 +249,10 @@ def loss_workspace(device):
     return torch.zeros(1024, dtype=torch.float64)
 
 
+def loss_check(workspace):
+    assert int(workspace.view(torch.int32)[-2]) == 0
+
+
 def mse_loss(pred, target, weight, loss, workspace):
     CALLS.append("mse_loss")
     loss += weight * ((pred - target) ** 2).double().mean()
@@ -560,7 +564,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 
