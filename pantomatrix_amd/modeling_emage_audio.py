@@ -125,8 +125,8 @@ class _EmageModule(torch.nn.Module):
 
     def train(self, mode=True):
         if mode:
-            raise NotImplementedError("training through the HIP path is not built yet (SURVEY.md §8f row 1); "
-                                      "the accelerated modules run eval-mode inference only")
+            raise NotImplementedError("these modules' forward() is the eval-mode forward; the training step (train-mode forward, "
+                                      "backward, Adam) on the HIP kernels is pantomatrix_amd.training.Trainer")
         return super().train(False)
 
     def set_precision(self, precision: str):
