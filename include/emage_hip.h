@@ -301,6 +301,9 @@ int emage_lstm_inputs(const float* speaker_table, const int64_t* speaker_id, int
  */
 int emage_rot6d_scatter(const float* rot6d, int ld, const int* slot_of_joint, float* axis_angle, int M, int n_joints, void* stream);
 
+/* counter[0] += number of non-finite values in the contiguous fp32 array x[0 .. n): the runners' end-of-batch health check. */
+int emage_count_nonfinite(const float* x, long n, int* counter, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Train-mode forward (train_emage_audio.py:130-204): what differs from the inference path.
  * ------------------------------------------------------------------------------------------------------------------ */

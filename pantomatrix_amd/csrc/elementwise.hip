@@ -130,3 +130,23 @@ extern "C" int emage_cast_pad(int dtype, const float* src, int lds, void* out, i
     else return EMAGE_EINVAL;
     return launch_status();
 }
+
+// counter[0] += number of non-finite values among x[0 .. n): the end-of-batch health check of the runners (an activation beyond the
+// split-fp16 range, |x| >= 4094, becomes inf / NaN and reaches the outputs; this makes it an error instead of a silent result)
+namespace {
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ x, long n, int* __restrict__ counter) {
+    int bad = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned u = __builtin_bit_cast(unsigned, x[i]);
+        bad += (u & 0x7f800000u) == 0x7f800000u;
+    }
+    if (bad) atomicAdd(counter, bad);
+}
+}  // namespace
+
+extern "C" int emage_count_nonfinite(const float* x, long n, int* counter, void* stream) {
+    if (!x || !counter || n <= 0) return EMAGE_EINVAL;
+    long g = (n + 255) / 256;
+    hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, (hipStream_t)stream, x, n, counter);
+    return launch_status();
+}

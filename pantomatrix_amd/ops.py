@@ -552,6 +552,18 @@ def wav_conv_in_backward(dy, wav, lout, taps, stride, pad):
     return dw
 
 
+@_op("count_nonfinite", "(Tensor x, Tensor(a!) counter) -> ()")
+def _count_nonfinite(x, counter):
+    check(_lib.load().emage_count_nonfinite(_ptr(x), x.numel(), _ptr(counter), _stream()), "count_nonfinite")
+
+
+def count_nonfinite(x, counter):
+    """counter (int32, 1 element) += number of inf / NaN values in the contiguous fp32 tensor x."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and counter.dtype == torch.int32
+    _count_nonfinite(x, counter)
+
+
 @_op("adam_step", "(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, int step, float lr, float beta1, float beta2, float eps, "
                   "float weight_decay) -> ()")
 def _adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay):

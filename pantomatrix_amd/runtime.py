@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
+
 
 class ClipRunner:
     def __init__(self, model, vq_model, batch: int, n_samples: int, use_graph: bool = True, warmup: int = 2,
@@ -42,6 +44,8 @@ class ClipRunner:
         self.audio = torch.zeros(batch, n_samples, dtype=torch.float32, device=dev)
         self.speaker_id = torch.zeros(batch, 1, dtype=torch.long, device=dev)
         self.ref_trans = torch.zeros(1, 3, device=dev)
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.nonfinite_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
         self.graph = None
         for _ in range(max(1, warmup)):            # packs weights, warms the allocator, validates shapes
             out = self._step()
@@ -59,7 +63,11 @@ class ClipRunner:
     def _step(self):
         codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
         pred = self.vq.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
-        return pred["motion_axis_angle"], pred["expression"], pred["trans"]
+        out = pred["motion_axis_angle"], pred["expression"], pred["trans"]
+        self.nonfinite.zero_()                       # health check: inf / NaN in the results (e.g. an activation beyond the f16x3 range)
+        for t in out:
+            ops.count_nonfinite(t, self.nonfinite)
+        return out
 
     def run_device(self, audio=None, speaker_id=None):
         """Launch one batch on the current stream; returns device tensors (poses (B,T,165), expressions (B,T,100),
@@ -84,7 +92,9 @@ class ClipRunner:
         if self.sub == 1:
             self.run_device(audio, speaker_id)
             self._to_host(self.host)
+            self.nonfinite_host.copy_(self.nonfinite, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
+            self._raise_if_nonfinite()
             return tuple(h.numpy() for h in self.host)
         main = torch.cuda.current_stream(self.device)
         start = torch.cuda.Event()
@@ -96,9 +106,18 @@ class ClipRunner:
                 child.run_device(None if audio is None else audio[i * n:(i + 1) * n],
                                  None if speaker_id is None else speaker_id[i * n:(i + 1) * n])
                 child._to_host(tuple(h[i * n:(i + 1) * n] for h in self.host))
+                child.nonfinite_host.copy_(child.nonfinite, non_blocking=True)
         for s in self.streams:
             s.synchronize()
+        for child in self.children:
+            child._raise_if_nonfinite()
         return tuple(h.numpy() for h in self.host)
+
+    def _raise_if_nonfinite(self):
+        n = int(self.nonfinite_host[0])
+        if n:
+            raise FloatingPointError(f"{n} non-finite values in the generated motion (precision {self.model.precision!r}): in f16x3 an activation beyond "
+                                     "|x| < 4094 overflows the fp16 planes — run this checkpoint with set_precision('fp32')")
 
 
 class LstmClipRunner:

@@ -236,6 +236,11 @@ def wav_conv_in_backward(dy, wav, lout, taps, stride, pad):
     return (dy.double().t() @ col.double()).float()
 
 
+def count_nonfinite(x, counter):
+    CALLS.append("count_nonfinite")
+    counter += int((~torch.isfinite(x)).sum())
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     CALLS.append("adam_step")
     g = grad + weight_decay * param if weight_decay else grad
@@ -564,7 +569,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["count_nonfinite", "loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

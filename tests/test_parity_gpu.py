@@ -194,6 +194,23 @@ def test_clip_runner_graph_equals_eager(precision):
     assert e[0].shape == (4, 120, 165)
 
 
+def test_clip_runner_raises_on_overflow_of_the_split_fp16_range():
+    """An activation beyond the fp16 planes' range (|x| >= 4094 in f16x3) becomes inf / NaN; the runner's end-of-batch health
+    check turns that into an error instead of handing back poisoned motion — and the same checkpoint runs in fp32 mode."""
+    from pantomatrix_amd.runtime import ClipRunner
+    n = synthetic.samples_for_frames(128)
+    a = synthetic.synthetic_audio(2, n).to(DEV)
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    sd = model.state_dict()
+    sd["moton_proj.bias"] = sd["moton_proj.bias"] + 6000.0                  # pushes the body stream out of range
+    model.load_state_dict(sd)
+    with pytest.raises(FloatingPointError, match="non-finite"):
+        ClipRunner(model, vq, 2, n, use_graph=True)(a)
+    model.set_precision("fp32")
+    poses, _, _ = ClipRunner(model, vq, 2, n, use_graph=False)(a)
+    assert np.isfinite(poses).all()
+
+
 def test_clip_runner_sub_batches_match():
     """Splitting the batch into stream-parallel groups changes scheduling only: results equal the single-group run."""
     from pantomatrix_amd.runtime import ClipRunner
