@@ -72,6 +72,7 @@ class _EmageModule(torch.nn.Module):
         self.concurrent = True                 # issue independent launch chains on side streams (streams.py)
         self.hoist_audio = True                # inference(): waveform-only features of all full windows in one pass
         self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
+        self.health_counter = None             # optional int32 device counter of non-finite logits / latents met by infer_codes (runtime.ClipRunner)
         self.slab_convs = True                 # WavEncoder: LDS-resident-slab convolutions + fused block 0 (A/B switch; same bits)
         self._templates = {}                   # cached default motion / mask of inference() per (batch, length, device)
         self._spec = type(self)._spec_fn(config)
@@ -1095,11 +1096,14 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             if route is None:
                 continue
             dst = codes[p][:, col0:col0 + t]
+            src = net[f"cls_{p}" if route == "cls" else f"rec_{p}"].reshape(bs * t, -1)
+            if self.health_counter is not None:      # the quantiser turns a NaN logit / latent into a valid-looking code: count them here
+                ops.count_nonfinite(src.contiguous(), self.health_counter)
             if route == "cls":
-                ops.argmax_logsoftmax(net[f"cls_{p}"].reshape(bs * t, -1), out=dst)
+                ops.argmax_logsoftmax(src, out=dst)
             else:
                 part = getattr(vq_model, f"vq_model_{p}")
-                part._nearest(_Ctx(part._engine()), net[f"rec_{p}"].reshape(bs * t, -1), out=dst)
+                part._nearest(_Ctx(part._engine()), src, out=dst)
 
     def inference(self, audio, speaker_id, vq_model, masked_motion=None, mask=None):
         """EmageAudioModel.inference (M:343-490): sliding 64-frame windows with 4 seed frames carried over

@@ -61,10 +61,16 @@ class ClipRunner:
         self._checked_replays = 0
 
     def _step(self):
-        codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
+        # health check: inf / NaN among the network outputs the codes are taken from (the quantiser would launder them into valid
+        # codes) and among the results — e.g. an activation beyond the f16x3 range
+        self.nonfinite.zero_()
+        self.model.health_counter = self.nonfinite
+        try:
+            codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
+        finally:
+            self.model.health_counter = None
         pred = self.vq.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
         out = pred["motion_axis_angle"], pred["expression"], pred["trans"]
-        self.nonfinite.zero_()                       # health check: inf / NaN in the results (e.g. an activation beyond the f16x3 range)
         for t in out:
             ops.count_nonfinite(t, self.nonfinite)
         return out
@@ -116,7 +122,7 @@ class ClipRunner:
     def _raise_if_nonfinite(self):
         n = int(self.nonfinite_host[0])
         if n:
-            raise FloatingPointError(f"{n} non-finite values in the generated motion (precision {self.model.precision!r}): in f16x3 an activation beyond "
+            raise FloatingPointError(f"{n} non-finite values among the network outputs / the generated motion (precision {self.model.precision!r}): in f16x3 an activation beyond "
                                      "|x| < 4094 overflows the fp16 planes — run this checkpoint with set_precision('fp32')")
 
 
