@@ -140,6 +140,8 @@ class LstmClipRunner:
         self.model, self.device = model, dev
         self.audio = torch.zeros(batch, n_samples, dtype=torch.float32, device=dev)
         self.speaker_id = torch.zeros(batch, 1, dtype=torch.long, device=dev)
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.nonfinite_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
         self.graph = None
         for _ in range(max(1, warmup)):
             out = self._step()
@@ -156,7 +158,11 @@ class LstmClipRunner:
     def _step(self):
         o = self.model.forward(self.audio, self.speaker_id)
         b = self.audio.shape[0]
-        return o["motion"].reshape(b, o["motion"].shape[1], -1), o["motion_axis_angle"]
+        out = o["motion"].reshape(b, o["motion"].shape[1], -1), o["motion_axis_angle"]
+        self.nonfinite.zero_()                       # health check, as in ClipRunner: inf / NaN in the generated motion raises
+        for t in out:
+            ops.count_nonfinite(t.contiguous(), self.nonfinite)
+        return out
 
     def __call__(self, audio=None, speaker_id=None):
         if audio is not None:
@@ -169,7 +175,11 @@ class LstmClipRunner:
             self.out = self._step()
         for h, d in zip(self.host, self.out):
             h.copy_(d, non_blocking=True)
+        self.nonfinite_host.copy_(self.nonfinite, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
+        if int(self.nonfinite_host[0]):
+            raise FloatingPointError(f"{int(self.nonfinite_host[0])} non-finite values in the generated motion (precision {self.model.precision!r}): in f16x3 an "
+                                     "activation beyond |x| < 4094 overflows the fp16 planes — run this checkpoint with set_precision('fp32')")
         if self.graph is not None and self._checked_replays < 2:     # the persistent recurrence's error words: first replays, then `check()`
             self._checked_replays += 1
             self.model.check_kernels()
