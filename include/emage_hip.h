@@ -413,6 +413,10 @@ int emage_wav_conv_in_backward(const float* dy, int ld_dy, const float* wav, lon
 int emage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* emage_adam_step with the 1-based step count read from device memory (`step`: one int32), for a step captured in a hipGraph. */
+int emage_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const int* step,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 
 F32, BF16, F16X3 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "emage_wav_conv_in_backward_workspace_bytes": [_i, _i, _i],
     "emage_wav_conv_in_backward": [_p, _i, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p],
     "emage_count_nonfinite": [_p, _l, _p, _p],
+    "emage_adam_step_dev": [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _p],
     "emage_adam_step": [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _p],
     "emage_mul_add": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],

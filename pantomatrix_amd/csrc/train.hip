@@ -698,3 +698,30 @@ extern "C" int emage_bn_backward_apply(const float* x, int ldx, const float* mea
                        sum_dy_xhat, sum_dy, 1.0f / (float)count, dx, ld_dx, M, C);
     return launch_status();
 }
+
+// emage_adam_step with the step count read from device memory (a captured hipGraph replays with fixed kernel arguments: the count
+// must advance on the device); the same arithmetic as emage_adam_step.
+namespace {
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                                       const int* __restrict__ step, float lr, float b1, float b2, float eps, float weight_decay) {
+    const int t = *step;
+    const double bias1 = 1.0 - pow((double)b1, t), bias2 = 1.0 - pow((double)b2, t);
+    const float step_size = (float)((double)lr / bias1), inv_sqrt_bias2 = (float)(1.0 / sqrt(bias2));
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (weight_decay != 0.f) gi += weight_decay * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bias2 + eps);
+    }
+}
+}  // namespace
+
+extern "C" int emage_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const int* step,
+                                   float lr, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n <= 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay);
+    return launch_status();
+}

@@ -571,12 +571,24 @@ def _adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, we
                                       _stream()), "adam_step")
 
 
+@_op("adam_step_dev", "(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor step, float lr, float beta1, float beta2, float eps, "
+                      "float weight_decay) -> ()")
+def _adam_step_dev(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay):
+    check(_lib.load().emage_adam_step_dev(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), _ptr(step), lr, beta1, beta2, eps,
+                                          weight_decay, _stream()), "adam_step_dev")
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
-    """torch.optim.Adam's update of one contiguous fp32 parameter tensor, in place (param, exp_avg, exp_avg_sq)."""
+    """torch.optim.Adam's update of one contiguous fp32 parameter tensor, in place (param, exp_avg, exp_avg_sq).  `step`: the
+    1-based step count as a Python int, or a one-element int32 device tensor (read by the kernel: for hipGraph-captured steps)."""
     _dev(param)
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == param.numel()
-    _adam_step(param, grad, exp_avg, exp_avg_sq, int(step), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay))
+    if torch.is_tensor(step):
+        assert step.dtype == torch.int32 and step.numel() == 1
+        _adam_step_dev(param, grad, exp_avg, exp_avg_sq, step, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay))
+    else:
+        _adam_step(param, grad, exp_avg, exp_avg_sq, int(step), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay))
 
 
 @_op("layernorm", "(int dtype, Tensor x, Tensor gamma, Tensor beta, float eps, Tensor? add, Tensor(a!)? y_f32, Tensor(b!)? y) -> ()")

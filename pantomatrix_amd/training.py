@@ -724,7 +724,9 @@ class Trainer:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.state = {}                                   # name -> dict(step, exp_avg, exp_avg_sq)
 
-    def step(self, batch, iteration, dropout_masks, random_mask, grad_hook=None):
+    def _device_step(self, batch, dropout_masks, random_mask, grad_hook=None, step_counter=None):
+        """Everything of a step that runs on the device; returns (dict of float64 device loss scalars, loss workspace).  With
+        `step_counter` (one int32 on the device) Adam reads the step count from it — what a captured graph needs."""
         fwd, model = self.fwd, self.fwd.model
         cfg = model.config
         index, latent, masked_motion = targets(self.vq, batch["motion"], batch["expressions"], batch["trans"], batch["foot_contact"])
@@ -750,13 +752,66 @@ class Trainer:
             if st is None:
                 st = self.state[name] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
             st["step"] += 1
-            ops.adam_step(p, g.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"], self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay)
+            ops.adam_step(p, g.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"] if step_counter is None else step_counter,
+                          self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay)
         for name, v in stats.items():                     # BatchNorm running statistics after the three forwards
             if name in params:
                 params[name].copy_(v.to(params[name].dtype))
-        model.invalidate_packed()                         # the MFMA operand copies are rebuilt from the updated parameters
-        fwd._pcache = None
+        return out, ws
+
+    def step(self, batch, iteration, dropout_masks, random_mask, grad_hook=None):
+        out, ws = self._device_step(batch, dropout_masks, random_mask, grad_hook)
+        self.fwd.model.invalidate_packed()                # the MFMA operand copies are rebuilt from the updated parameters
+        self.fwd._pcache = None
         res = {k: float(v) for k, v in out.items()}
         ops.loss_check(ws)
+        res["all"] = sum(res.values())
+        return res
+
+    # ---- the step as ONE hipGraph -------------------------------------------------------------------------------------------------
+    def capture(self, batch, dropout_masks, random_mask):
+        """Capture the whole step — re-packing the MFMA operands from the current parameters, targets, three forwards with their
+        backward passes, Adam, BatchNorm buffers — into one hipGraph over the GIVEN tensors: `batch`, `dropout_masks`,
+        `random_mask` become the graph's input buffers (refill them in place between replays: the randomness stays outside the
+        captured region), the parameters its state.  `replay()` then runs a step at device speed instead of the ~10^4 Python-level
+        launches of `step()`.  Needs the model in "fp32" precision (packing split-fp16 operands reads each weight's scale back to
+        the host) and a single process (no SyncBatchNorm exchange inside a capture).  One eager warm-up step is run and undone."""
+        fwd, model = self.fwd, self.fwd.model
+        if model.precision != "fp32" or fwd.sync_bn:
+            raise RuntimeError("Trainer.capture: needs precision 'fp32' and sync_bn=False")
+        dev = model.device
+        params = model._flat_params()
+        saved = {k: v.clone() for k, v in params.items()}
+        self._device_step(batch, dropout_masks, random_mask)          # warm-up: lazy initialisation inside the library / the allocator
+        torch.cuda.synchronize(dev)
+        for k, v in saved.items():
+            params[k].copy_(v)
+        for st in self.state.values():                                 # the moments live OUTSIDE the graph's memory (created by the warm-up step)
+            st["exp_avg"].zero_()
+            st["exp_avg_sq"].zero_()
+            st["step"] = 0
+        for fm in dropout_masks:
+            for mk in fm:
+                if not (mk.is_cuda and mk.dtype == torch.float32 and mk.is_contiguous()):
+                    raise RuntimeError("Trainer.capture: dropout masks must be contiguous fp32 tensors on the device (they are the graph's input buffers)")
+        self._step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+            model.invalidate_packed()                                  # so that the packing of the current parameters is part of the graph
+            fwd._pcache = None
+            self._step_counter.add_(1)
+            self._graph_out, self._graph_ws = self._device_step(batch, dropout_masks, random_mask, step_counter=self._step_counter)
+        for st in self.state.values():
+            st["step"] = 0
+        return self
+
+    def replay(self):
+        """One captured step on the current contents of the captured input buffers -> the loss dict of `step()`."""
+        self._graph.replay()
+        n = int(self._step_counter)
+        for st in self.state.values():
+            st["step"] = n
+        res = {k: float(v) for k, v in self._graph_out.items()}
+        ops.loss_check(self._graph_ws)
         res["all"] = sum(res.values())
         return res

@@ -243,6 +243,7 @@ def count_nonfinite(x, counter):
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
     CALLS.append("adam_step")
+    step = int(step)
     g = grad + weight_decay * param if weight_decay else grad
     exp_avg.copy_(beta1 * exp_avg + (1 - beta1) * g)
     exp_avg_sq.copy_(beta2 * exp_avg_sq + (1 - beta2) * g * g)

@@ -277,3 +277,30 @@ def test_training_step_matches_the_reference(golden_dir):
     print(f"training step on the GPU: {checked} parameters: gradient norms and post-Adam sums equal the reference's")
     assert checked > 440
     assert torch.equal(params["transformer_en_layer.linear1.weight"], before["transformer_en_layer.linear1.weight"])
+
+
+def test_captured_training_step_equals_the_eager_step(golden_dir):
+    """Trainer.capture / replay (the whole step as one hipGraph: operand re-packing, targets, three forwards + backwards, Adam with
+    the step count on the device, BatchNorm buffers) against two eager Trainer.step calls on a twin model with the same masks:
+    the same parameters after step 1 and after step 2."""
+    g = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    batch, _, masks, random_mask, _ = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    masks = [[m.to(DEV).contiguous() for m in fm] for fm in masks]
+    random_mask = random_mask.to(DEV)
+    model_e, vq = common.product_models(precision="fp32", device=DEV)
+    model_g, _ = common.product_models(precision="fp32", device=DEV)
+    eager, graphed = training.Trainer(model_e, vq), training.Trainer(model_g, vq)
+    graphed.capture(batch, masks, random_mask)
+    keys = ("face_out_proj.weight", "audio_encoder_body.feat_extractor.0.conv1.weight", "audio_motion_cross_attn.layers.7.linear2.bias",
+            "mask_embedding", "audio_encoder_face.feat_extractor.3.bn1.running_var", "motion_encoder.main.0.weight")
+    for step in (1, 2):
+        le = eager.step(batch, 0, masks, random_mask)
+        lg = graphed.replay()
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 1e-6 * max(1.0, abs(le[k])), (step, k, le[k], lg[k])
+        pe, pg = model_e._flat_params(), model_g._flat_params()
+        for k in keys:
+            assert float((pe[k] - pg[k]).abs().max()) <= 1e-7 * max(1.0, float(pe[k].abs().max())), (step, k)
+    want = float(g["loss_all"])
+    assert abs(eager.state["face_out_proj.weight"]["step"] - 2) == 0 and graphed.state["face_out_proj.weight"]["step"] == 2

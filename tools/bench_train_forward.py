@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=56)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--graph", action="store_true", help="with --full-step: the step captured as one hipGraph (Trainer.capture / replay; precision fp32)")
     ap.add_argument("--full-step", action="store_true", help="whole optimisation steps (training.Trainer.step: + backward, Adam) instead of the forward side")
     args = ap.parse_args()
     import common
@@ -54,13 +55,25 @@ def main():
     random_mask = (torch.rand(b, t, 337, device=dev) < 0.5).float()
 
     trainer = training.Trainer(model, vq) if args.full_step else None
+    if args.graph:
+        static_masks = [draw_masks(b, t, c.hidden_size, 2 * c.hidden_size, 4, ta, dev) for _ in range(3)]
+        trainer.capture(batch, static_masks, random_mask)
 
-    def step():
+        def step():
+            for fm in static_masks:                                   # fresh dropout masks, drawn on the device into the graph's input buffers
+                for mk in fm:
+                    mk.copy_((torch.rand(mk.shape, device=dev) >= 0.1).float() / 0.9)
+            return trainer.replay(), None
+    else:
+        step = None
+
+    def eager_step():
         masks = [draw_masks(b, t, c.hidden_size, 2 * c.hidden_size, 4, ta, dev) for _ in range(3)]
         if trainer is not None:
             return trainer.step(batch, 0, masks, random_mask), None
         return training.step_losses(fwd, vq, batch, 0, masks, random_mask)
 
+    step = step or eager_step
     step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -68,7 +81,8 @@ def main():
         losses, _ = step()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
-    what = ("one whole EMAGE optimisation step (targets, 3 x (train-mode forward, losses, backward), Adam), eager, one stream; backward "
+    what = ("one whole EMAGE optimisation step (targets, 3 x (train-mode forward, losses, backward), Adam), "
+            + ("ONE hipGraph replay (+ drawing the dropout masks)" if args.graph else "eager, one stream") + "; backward "
             "contractions in exact-fp32 MFMA" if args.full_step else
             "forward side of one EMAGE training step (targets + 3 train-mode forwards + 6 losses), eager, one stream")
     print(json.dumps({"what": what, "config": {"workload": "BASELINE config 3", "clips_per_gpu": b, "frames_per_clip": t}, "dtype": args.precision,
