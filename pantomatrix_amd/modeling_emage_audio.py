@@ -510,6 +510,7 @@ class EmageVQModel(torch.nn.Module):
         self.vq_model_hands = hands_model
         self.vq_model_lower = lower_model
         self.global_motion = global_model
+        self._templates = {}                       # device index tensors of the joint partition, per device
 
     def _models(self):
         return (self.vq_model_face, self.vq_model_upper, self.vq_model_hands, self.vq_model_lower, self.global_motion)
@@ -522,13 +523,16 @@ class EmageVQModel(torch.nn.Module):
     def spilt_inputs(self, smplx_body_rot6d, expression, tar_contact=None, tar_trans=None):     # (sic) M:97-108
         bs, t, j6 = smplx_body_rot6d.shape
         r = smplx_body_rot6d.reshape(bs, t, j6 // 6, 6)
-        up = [j for j in range(55) if self.joint_mask_upper[j]]
-        lo = [j for j in range(55) if self.joint_mask_lower[j]]
         dev = smplx_body_rot6d.device
+        key = ("joint_index", str(dev))
+        if key not in self._templates:               # device index tensors, built once (never inside a graph capture)
+            self._templates[key] = tuple(torch.tensor([j for j in range(55) if mk[j]], dtype=torch.long, device=dev)
+                                         for mk in (self.joint_mask_upper, self.joint_mask_lower))
+        up, lo = self._templates[key]
         face = torch.cat([r[:, :, 22], expression], dim=2)
-        upper = r[:, :, up].reshape(bs, t, 78)
+        upper = r.index_select(2, up).reshape(bs, t, 78)
         hands = r[:, :, 25:55].reshape(bs, t, 180)
-        lower = r[:, :, lo].reshape(bs, t, 54)
+        lower = r.index_select(2, lo).reshape(bs, t, 54)
         tar_contact = torch.zeros(bs, t, 4, device=dev) if tar_contact is None else tar_contact
         tar_trans = torch.zeros(bs, t, 3, device=dev) if tar_trans is None else tar_trans
         return dict(face=face, upper=upper, hands=hands, lower=torch.cat([lower, tar_trans, tar_contact], dim=2))
