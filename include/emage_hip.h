@@ -340,8 +340,8 @@ int emage_mul_add(const float* a, int lda, const float* mask, int ld_mask, int m
  * The losses of train_emage_audio.py:106-130, accumulated into a float64 device scalar: loss[0] += weight * value.
  *   emage_mse_loss: value = mean((pred - target)^2) over the (M, C) fp32 views           (F.mse_loss, T:108-111)
  *   emage_nll_loss: value = mean over rows of -log_softmax(logits[m])[index[m]]           (NLLLoss(log_softmax), T:113-128)
- * workspace: EMAGE_LOSS_WORKSPACE_BYTES bytes, 8-byte aligned.  An index outside [0, K) contributes nothing and sets the
- * last 8-byte slot of the workspace non-zero (torch raises there; the Python layer checks it).
+ * workspace: EMAGE_LOSS_WORKSPACE_BYTES bytes, 8-byte aligned, zeroed once by the caller.  An index outside [0, K) contributes
+ * nothing and sets the last 8-byte slot of the workspace non-zero (sticky; torch raises there; the Python layer checks it).
  */
 #define EMAGE_LOSS_WORKSPACE_BYTES 8192
 int emage_mse_loss(const float* pred, int ld_pred, const float* target, int ld_target, int M, int C, float weight,

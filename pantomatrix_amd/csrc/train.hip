@@ -208,9 +208,8 @@ extern "C" int emage_nll_loss(const float* logits, int ld, const int64_t* index,
     if (!logits || !index || !loss || !workspace || M <= 0 || K <= 0 || ld < K || ((uintptr_t)workspace & 7) || ((uintptr_t)loss & 7)) return EMAGE_EINVAL;
     const int blocks = loss_grid(M);
     hipStream_t s = (hipStream_t)stream;
-    int* bad = (int*)((double*)workspace + (LOSS_BLOCKS - 1));                 // last workspace slot: out-of-range class index seen
-    hipError_t e = hipMemsetAsync(bad, 0, sizeof(double), s);
-    if (e != hipSuccess) return (int)e;
+    int* bad = (int*)((double*)workspace + (LOSS_BLOCKS - 1));                 // last workspace slot: out-of-range class index seen (sticky:
+                                                                               // the caller hands in a zeroed workspace, ops.loss_workspace)
     hipLaunchKernelGGL(nll_partial_kernel, dim3(blocks), dim3(256), 0, s, logits, ld, index, M, K, (double*)workspace, bad);
     int rc = launch_status();
     if (rc) return rc;
