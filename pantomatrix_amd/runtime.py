@@ -127,11 +127,11 @@ class ClipRunner:
 
 
 class LstmClipRunner:
-    """One DisCo / CaMN forward (WavEncoder, input projections, thousands of `emage_lstm_step` launches, output MLPs,
-    rot-6D -> axis-angle) captured as ONE hipGraph for a fixed (batch, audio length): the recurrence is one small launch
-    per time step and direction, so replaying a graph instead of issuing ~10 us Python calls per launch is what makes the
-    sequential part run at device speed.  `__call__(audio)` returns (motion (B,T,pose_dims), axis_angle (B,T,165)) as
-    numpy arrays (views of pinned buffers, valid until the next call)."""
+    """One DisCo / CaMN forward (WavEncoder, input projections, one persistent `emage_lstm_layer` launch per LSTM layer — or, in
+    the exact-fp32 mode, one `emage_lstm_step_pair` launch per time step —, output MLPs, rot-6D -> axis-angle) captured as ONE
+    hipGraph for a fixed (batch, audio length).  `__call__(audio)` returns (motion (B,T,pose_dims), axis_angle (B,T,165)) as numpy
+    arrays (views of pinned buffers, valid until the next call); inf / NaN in them, or a lost block of the persistent recurrence,
+    raises."""
 
     def __init__(self, model, batch: int, n_samples: int, use_graph: bool = True, warmup: int = 1):
         dev = model.device
