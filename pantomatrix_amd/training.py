@@ -26,8 +26,8 @@ from __future__ import annotations
 import torch
 
 from . import ops, spec
-from ._lib import BF16, F32
-from .modeling_emage_audio import OUT_KEYS, _Ctx, _WAV_TAPS, _conv_encoder, _rup
+from ._lib import F32
+from .modeling_emage_audio import OUT_KEYS, _Ctx, _WAV_TAPS, _rup
 
 BN_MOMENTUM = 0.1          # nn.BatchNorm1d default
 DROPOUT_P = 0.1            # PeriodicPositionalEncoding (P:329) and nn.Transformer*Layer defaults
@@ -210,9 +210,9 @@ class TrainForward:
                 y, _ = cx.gemm(x, base + ".conv1.raw", conv=(stride, pad, lin, lout), m=rows, n_store=_rup(ent["n"]))
             c1 = y[:, :cout]
             g1, b1 = cx.pk.w[base + ".bn1.affine"]
-            y1 = torch.empty(rows, _rup(cout), dtype=torch.float32, device=cx.dev) if _rup(cout) != cout else torch.empty(rows, cout, dtype=torch.float32, device=cx.dev)
+            y1 = torch.empty(rows, _rup(cout), dtype=torch.float32, device=cx.dev)
             if y1.shape[1] != cout:
-                y1.zero_()
+                y1.zero_()                                 # padded channels feed conv2's contraction: they must be zero
             st1 = self._bn(cx, base + ".bn1", c1, new_stats)
             ops.bn_apply(c1, st1, g1, b1, y1[:, :cout], slope=0.01)
             c2, _ = cx.gemm(y1, base + ".conv2.raw", conv=(1, k // 2, lout, lout), m=rows, n_store=_rup(cout))

@@ -245,3 +245,15 @@ def test_trainer_step_host_logic(golden_dir):
         assert float((params[k] - new_sd[k]).abs().max()) < 1e-5 * max(1.0, float(new_sd[k].abs().max())), k
     assert not torch.equal(params["transformer_en_layer.linear1.weight"], params["transformer_en_layer.linear1.weight"] * 0) and \
         torch.equal(params["transformer_en_layer.linear1.weight"], sd["transformer_en_layer.linear1.weight"])
+
+
+def test_capture_preconditions():
+    """Trainer.capture refuses what cannot be captured (split-fp16 packing reads scales back to the host; the SyncBatchNorm exchange)."""
+    model, vq = common.product_models(precision="f16x3")
+    with pytest.raises(RuntimeError, match="fp32"):
+        training.Trainer(model, vq).capture({}, [[], [], []], None)
+    model.set_precision("fp32")
+    with pytest.raises(RuntimeError, match="sync_bn"):
+        training.Trainer(model, vq, sync_bn=True).capture({}, [[], [], []], None)
+    with pytest.raises(ValueError, match="fp32-storage"):
+        training.TrainForward(common.product_models(precision="bf16")[0])
