@@ -29,6 +29,19 @@ def main():
     path = os.path.join(HERE, "lstm_models.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: v.shape for k, v in out.items()})
+    # a clip whose WavEncoder frame counts are even after blocks 0-2 (6638 / 1104 / 1104, like the 8.5 s and 28 s clips of the
+    # BASELINE configs): the product runs its 32-channel blocks as convolutions over position pairs there
+    even = {}
+    for kind in ("disco", "camn"):
+        model = rh.build_reference_lstm_model(kind, CFG, weights(kind))
+        audio, spk, motion = inputs(with_seed_motion=True)
+        audio = audio[:, :30000]
+        with torch.no_grad():
+            ref = model(audio, spk, seed_frames=CFG["seed_frames"], seed_motion=motion)
+        even[f"{kind}_motion"] = ref["motion"].reshape(2, -1, 258).numpy()
+        even[f"{kind}_axis_angle"] = ref["motion_axis_angle"].numpy()
+    np.savez_compressed(os.path.join(HERE, "lstm_models_even.npz"), **even)
+    print("wrote lstm_models_even.npz", {k: v.shape for k, v in even.items()})
 
 
 if __name__ == "__main__":

@@ -69,6 +69,22 @@ def test_narrow_blocks_run_as_position_pairs():
     assert not odd._wav_pairs_ok(odd._wav_lengths(inputs()[0].shape[1]))
 
 
+@pytest.mark.parametrize("kind", ["disco", "camn"])
+def test_pair_rows_route_matches_reference_golden(golden_dir, kind):
+    """The pair-rows route against the REAL reference (tests/golden/lstm_models_even.npz: a clip with even frame counts after
+    WavEncoder blocks 0-2, seed motion longer than the audio frames)."""
+    g = np.load(os.path.join(golden_dir, "lstm_models_even.npz"))
+    audio, spk, motion = inputs(with_seed_motion=True)
+    audio = audio[:, :30000]
+    model = product(kind)
+    with fake_ops.installed(), torch.no_grad():
+        assert model._wav_pairs_ok(model._wav_lengths(audio.shape[1]))
+        out = model(audio, spk, seed_frames=CFG["seed_frames"], seed_motion=motion)
+        assert fake_ops.CALLS.count("wav_conv_in") == 2
+    np.testing.assert_allclose(out["motion"].reshape(2, -1, 258).numpy(), g[f"{kind}_motion"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(out["motion_axis_angle"].numpy(), g[f"{kind}_axis_angle"], atol=1e-3, rtol=0)
+
+
 def test_pair_weights_equal_the_convolution():
     """`conv_pairs` against torch's conv1d on random narrow rows: stride 1 (pad 7) and stride 6 (pad 0)."""
     import torch.nn.functional as F
