@@ -43,7 +43,20 @@ def oracle_forward(seed, use_audio=True, new_stats=None, batch=2):
     return (audio, spk, motion, mask), out, masks, ns
 
 
+_STEP_CACHE = {}
+
+
 def oracle_step(seed, iteration, bs=2):
+    """Cached per (seed, iteration, bs): several tests replay the same reference step; callers must not modify the tensors in place
+    (they move copies to the device / slice them)."""
+    key = (seed, iteration, bs)
+    if key not in _STEP_CACHE:
+        _STEP_CACHE[key] = _oracle_step(seed, iteration, bs)
+    batch, losses, masks, random_mask, stats = _STEP_CACHE[key]
+    return dict(batch), dict(losses), [list(m) for m in masks], random_mask, dict(stats)
+
+
+def _oracle_step(seed, iteration, bs=2):
     """tro.train_step_losses with every forward's dropout masks and the random motion mask recorded:
     -> (batch, loss dict of floats, [masks of forward 1, 2, 3], random_mask, BatchNorm buffers)."""
     from test_train_oracle import train_batch
