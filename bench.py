@@ -90,6 +90,24 @@ def timed_steps(step, steps, warmup, barrier, reduce_max):
     return reduce_max(time.perf_counter() - t0), out
 
 
+def timed_pipeline(pipe, audio, steps, warmup, barrier, reduce_max):
+    """The same timed region with `pipe.depth` batches in flight (runtime.ClipPipeline): exactly `steps` batches are submitted
+    AND collected (results on the host, health-checked) between the two barriers."""
+    for _ in range(warmup):
+        pipe.submit(audio)
+    pipe.drain()
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        r = pipe.submit(audio)
+        out = r if r is not None else out
+    rest = pipe.drain()
+    out = rest[-1] if rest else out
+    barrier()
+    return reduce_max(time.perf_counter() - t0), out
+
+
 def result_line(precision, elapsed, steps, warmup, world, frames_per_step, batch, frames_in, launch):
     return {
         "metric": METRIC,
@@ -361,6 +379,9 @@ def build(precision, device, args):
     model.hoist_audio = not args.no_hoist
     model.slab_convs = not args.no_slab_convs
     for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
+        part.split_acts = not args.no_split_acts
+    model.h2_residual = args.h2_residual
+    for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.concurrent = not args.no_concurrent
     n_samples = synthetic.samples_for_frames(args.frames)
     runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph, main_priority=args.main_priority)
@@ -385,6 +406,10 @@ def main():
     ap.add_argument("--main-priority", action="store_true", help="experiment: capture the clip graph on a high-priority stream")
     ap.add_argument("--gemm-variant", type=int, default=-1, help="experiments: emage_set_tuning key 2 (tile-heuristic variant)")
     ap.add_argument("--gemm-dbg", type=int, default=0, help="experiments: emage_set_tuning key 1 mask (8: sc1 result stores, 16: nt)")
+    ap.add_argument("--no-split-acts", action="store_true", help="A/B: float32 activations split inside every GEMM (EMAGE_F16X3) instead of pre-split EMAGE_H2 storage")
+    ap.add_argument("--pipeline", type=int, default=1, help="also time the step with this many batches in flight (runtime.ClipPipeline)")
+    ap.add_argument("--h2-residual", action="store_true", help="A/B: EMAGE_H2 residual stream read from the H2 images (no float32 twins)")
+    ap.add_argument("--h2-variant", type=int, default=0, help="experiments: emage_set_tuning key 5 (EMAGE_H2 tile-heuristic variant)")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
@@ -409,9 +434,10 @@ def main():
     from pantomatrix_amd import dist as pdist
     from pantomatrix_amd import synthetic
 
-    if args.gemm_dbg or args.gemm_variant >= 0:
+    if args.gemm_dbg or args.gemm_variant >= 0 or args.h2_variant:
         from pantomatrix_amd import _lib
         _lib.load().emage_set_tuning(1, args.gemm_dbg)
+        _lib.load().emage_set_tuning(5, args.h2_variant)
         if args.gemm_variant >= 0:
             _lib.load().emage_set_tuning(2, args.gemm_variant)
     log(f"rank {rank}/{world}: building the {args.precision} models on {dev} and capturing the clip graph")
@@ -442,6 +468,14 @@ def main():
     result["pcie_inclusive"] = {"value": frames_per_step * world * args.steps / el_pcie, "ms_per_step": 1e3 * el_pcie / args.steps,
                                 "h2d_bytes_per_step": audio_host.numel() * 4,
                                 "note": "audio batch copied pinned-host -> HBM inside every timed step; `value` above is HBM-resident"}
+
+    if args.pipeline > 1:
+        from pantomatrix_amd.runtime import ClipPipeline
+        pipe = ClipPipeline(model, vq, args.batch, n_samples, depth=args.pipeline, use_graph=not args.no_graph)
+        el_p, out_p = timed_pipeline(pipe, audio, args.steps, args.warmup, barrier, reduce_max)
+        assert np.array_equal(out_p[0], poses), "pipelined batches must reproduce the one-at-a-time result bit for bit"
+        result["pipelined"] = {"depth": args.pipeline, "value": frames_per_step * world * args.steps / el_p, "ms_per_step": 1e3 * el_p / args.steps}
+        del pipe
 
     if rank == 0 and not args.no_roofline:
         records, _marker_ms = profile_kernels(runner, model, vq)

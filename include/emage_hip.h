@@ -38,6 +38,7 @@ extern "C" {
 #define EMAGE_F32 0
 #define EMAGE_BF16 1
 #define EMAGE_F16X3 2
+#define EMAGE_H2 3
 
 #define EMAGE_EINVAL (-1)   /* unsupported size / alignment / null pointer */
 

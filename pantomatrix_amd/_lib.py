@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 
-F32, BF16, F16X3 = 0, 1, 2
+F32, BF16, F16X3, H2 = 0, 1, 2, 3
 ABI_VERSION = 10
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long

@@ -16,7 +16,7 @@ namespace {
 
 using namespace emage_dev;
 
-template <typename T, int HD, int NT, bool X3>
+template <typename T, int HD, int NT, bool X3, bool H2OUT = false>
 __global__ __launch_bounds__(64 * QW * DS, 1) void attn_kernel(AttnArgs p) {
     const int qtiles = (p.Tq + 15) >> 4;
     const int qgroups = (qtiles + QW - 1) / QW;
@@ -26,17 +26,17 @@ __global__ __launch_bounds__(64 * QW * DS, 1) void attn_kernel(AttnArgs p) {
     const int h = bid % p.H;
     const int b = bid / p.H;
     if (qt >= qtiles) return;                 // no barriers below: surplus waves simply leave
-    attn_tile<T, HD, NT, DS, X3>(p, b, h, qt, wave % DS);
+    attn_tile<T, HD, NT, DS, X3, H2OUT>(p, b, h, qt, wave % DS);
 }
 
-template <typename T, bool X3>
+template <typename T, bool X3, bool H2OUT = false>
 int dispatch(AttnArgs& a, int hd, hipStream_t s) {
     if (hd != 192) return EMAGE_EINVAL;
     const int qtiles = (a.Tq + 15) / 16;
     const int grid = a.B * a.H * ((qtiles + QW - 1) / QW);
-    if (a.Tk <= 32) hipLaunchKernelGGL((attn_kernel<T, 192, 2, X3>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
-    else if (a.Tk <= 64) hipLaunchKernelGGL((attn_kernel<T, 192, 4, X3>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<T, 192, 8, X3>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
+    if (a.Tk <= 32) hipLaunchKernelGGL((attn_kernel<T, 192, 2, X3, H2OUT>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
+    else if (a.Tk <= 64) hipLaunchKernelGGL((attn_kernel<T, 192, 4, X3, H2OUT>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
+    else hipLaunchKernelGGL((attn_kernel<T, 192, 8, X3, H2OUT>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
     return launch_status();
 }
 
@@ -45,8 +45,9 @@ int dispatch(AttnArgs& a, int hd, hipStream_t s) {
 static int attention_impl(int dtype, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int vt_rows,
                           void* out, int ldo, int B, int H, int Tq, int Tk, int hd, const float* pmask, void* stream) {
     if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || Tk > 128 || vt_rows < H * hd) return EMAGE_EINVAL;
-    if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3) return EMAGE_EINVAL;
-    if (pmask && dtype == EMAGE_BF16) return EMAGE_EINVAL;                 // the training forward runs in the fp32-storage modes
+    if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3 && dtype != EMAGE_H2) return EMAGE_EINVAL;
+    if (pmask && (dtype == EMAGE_BF16 || dtype == EMAGE_H2)) return EMAGE_EINVAL;
+    if (dtype == EMAGE_H2 && ldo % 8) return EMAGE_EINVAL;                  // out is an EMAGE_H2 image; q / k / vt are float32                 // the training forward runs in the fp32-storage modes
     const int epc = dtype == EMAGE_BF16 ? 8 : 4;
     if (ldq % epc || ldk % epc || ldo % 4 || ldvt % 32 || ldvt < ((Tk + 31) / 32) * 32) return EMAGE_EINVAL;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) return EMAGE_EINVAL;
@@ -54,6 +55,7 @@ static int attention_impl(int dtype, const void* q, int ldq, const void* k, int 
     AttnArgs a{q, k, vt, out, ldq, ldk, ldvt, vt_rows, ldo, B, H, Tq, Tk, 1.0f / sqrtf((float)hd), pmask};
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EMAGE_F16X3) return dispatch<float, true>(a, hd, s);     // float32 tensors, split-f16 MFMA
+    if (dtype == EMAGE_H2) return dispatch<float, true, true>(a, hd, s);  // the same arithmetic, output as an EMAGE_H2 image
     return dtype == EMAGE_BF16 ? dispatch<bf16_t, false>(a, hd, s) : dispatch<float, false>(a, hd, s);
 }
 

@@ -2,6 +2,7 @@
 // transformer-layer kernel runs it for its (clip, head) between two projection tiles).
 #pragma once
 #include "common.h"
+#include "h2.h"
 #include <math.h>
 
 namespace emage_dev {
@@ -63,7 +64,9 @@ constexpr int DS = 1;    // waves per query tile: with DS = 2 each wave recomput
                          // of P V (two shorter waves per SIMD).  Measured: 16.0 us vs 13.3 us with DS = 1 — not a win.
 
 // softmax(Q K^T * scale) V for query tile qt (16 queries) of (batch b, head h); one wave64 (wave `dpart` of the DSP that share that tile: each recomputes the scores and owns NDT / DSP of the output d tiles).
-template <typename T, int HD, int NT, int DSP = DS, bool X3 = false>
+// H2OUT (split-f16 form only): the output is written as an EMAGE_H2 image (csrc/h2.h) — V^T rows are fetched in a permuted order
+// so that a lane ends with 8 consecutive d of its query from each PAIR of d tiles (one 32-byte group).
+template <typename T, int HD, int NT, int DSP = DS, bool X3 = false, bool H2OUT = false>
 __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const int h, const int qt, const int dpart) {
     constexpr int EPC = Elem<T>::EPC;
     static_assert(!X3 || (EPC == 4 && NT % 2 == 0), "split-f16 attention: fp32 operands, key tiles pair up");
@@ -105,8 +108,12 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
         for (int nt = 0; nt < NT; ++nt) load_k(nt, kf[nt]);
     }
     // V^T chunk c of d-tile dt: keys {32c + 4g + r} U {32c + 16 + 4g + r} (bf16) / {16c + 4g + r} (fp32), r = 0..3
-    const int voff = ((b * p.vt_rows + h * HD + fr) * p.ldvt + fg * 4) * ES;
+    static_assert(!H2OUT || (X3 && DSP == 1 && (HD / 16) % 2 == 0), "h2 output: split-f16 form, one wave per query tile, d tiles pair up");
+    // d row of (d tile dt, operand row fr): natural 16 dt + fr; H2OUT: 32 (dt >> 1) + 8 (fr >> 2) + 4 (dt & 1) + (fr & 3)
+    const int vrow0 = H2OUT ? 8 * (fr >> 2) + (fr & 3) : fr;
+    const int voff = ((b * p.vt_rows + h * HD + vrow0) * p.ldvt + fg * 4) * ES;
     const int vstep = 16 * p.ldvt * ES;
+    auto vsoff = [&](int dt) { return H2OUT ? (32 * (dt >> 1) + 4 * (dt & 1)) * p.ldvt * ES : dt * vstep; };
     static_assert(NDT % DSP == 0, "d tiles split evenly over the DSP waves");
     constexpr int NDW = NDT / DSP;            // d tiles per wave
     constexpr int VT_ = PRE ? NDW : 1;
@@ -115,11 +122,11 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
 #pragma unroll
         for (int c = 0; c < NPC; ++c) {
             if constexpr (EPC == 8) {
-                const uint2 lo = bload64(rv, voff, dt * vstep + c * 64);
-                const uint2 hi = bload64(rv, voff, dt * vstep + c * 64 + 32);
+                const uint2 lo = bload64(rv, voff, vsoff(dt) + c * 64);
+                const uint2 hi = bload64(rv, voff, vsoff(dt) + c * 64 + 32);
                 dst[c] = make_uint4(lo.x, lo.y, hi.x, hi.y);
             } else {
-                dst[c] = bload128(rv, voff, dt * vstep + c * 64);
+                dst[c] = bload128(rv, voff, vsoff(dt) + c * 64);
             }
         }
     };
@@ -223,6 +230,7 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
 #pragma unroll
         for (int c = 0; c < NPC / 2; ++c) ps[c] = split_chunks(pc[2 * c], pc[2 * c + 1], ATT_P_SCALE);
     }
+    f32x4 held = {0.f, 0.f, 0.f, 0.f};            // H2OUT: the even d tile of a pair
 #pragma unroll
     for (int dw = 0; dw < NDW; ++dw) {
         const int dt = dt0 + dw;
@@ -236,6 +244,14 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
         } else {
 #pragma unroll
             for (int c = 0; c < NPC; ++c) acc = Elem<T>::mma(vf[PRE ? dw : 0][c], pc[c], acc);
+        }
+        if constexpr (H2OUT) {
+            if ((dw & 1) == 0) { held = acc; continue; }
+            if (qq < p.Tq) {
+                const float v8[8] = {held[0], held[1], held[2], held[3], acc[0], acc[1], acc[2], acc[3]};
+                h2_store8((h2_t*)p.out + ((long)b * p.Tq + qq) * p.ldo + h * HD + 32 * (dt >> 1) + 8 * fg, v8);
+            }
+            continue;
         }
         if (qq < p.Tq) {
             if constexpr (EPC == 8) {

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "attention.hip", "vq.hip", "elementwise.hip", "motion.hip", "wavconv.hip", "convslab.hip", "lstm.hip", "lstmseq.hip", "train.hip", "version.hip"]
+SOURCES = ["gemm.hip", "gemm_h2.hip", "attention.hip", "vq.hip", "elementwise.hip", "motion.hip", "wavconv.hip", "convslab.hip", "lstm.hip", "lstmseq.hip", "train.hip", "version.hip"]
 LIB = os.path.join(HERE, "libemage_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
@@ -21,7 +21,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_tile.h"), os.path.join(HERE, "attn_tile.h"), os.path.join(HERE, "ln_row.h"), os.path.join(HERE, "rot_math.h"),
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_tile.h"), os.path.join(HERE, "h2_tile.h"), os.path.join(HERE, "h2.h"), os.path.join(HERE, "attn_tile.h"), os.path.join(HERE, "ln_row.h"), os.path.join(HERE, "rot_math.h"),
                                                         os.path.join(HERE, "..", "..", "include", "emage_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -13,12 +13,27 @@ template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         const T* __restrict__ add, int ldadd,
-                                                        float* __restrict__ yf, T* __restrict__ y, int ldy, int M, int C) {
+                                                        float* __restrict__ yf, T* __restrict__ y, int ldy, int M, int C,
+                                                        h2_t* __restrict__ yh = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
     layernorm_row<T, MAXV>(x + (long)row * ldx, gamma, beta, eps, add ? add + (long)row * ldadd : nullptr,
-                           yf ? yf + (long)row * ldy : nullptr, y ? y + (long)row * ldy : nullptr, C, lane);
+                           yf ? yf + (long)row * ldy : nullptr, y ? y + (long)row * ldy : nullptr, C, lane,
+                           yh ? yh + (long)row * ldy : nullptr);
+}
+
+// ---- EMAGE_H2 storage (csrc/h2.h): 4 logical columns at a 4-aligned column n of a row ----
+template <typename T> __device__ __forceinline__ float4 ldv4(const T* p, int n) { return Vec4<T>::load(p); }
+template <> __device__ __forceinline__ float4 ldv4<h2_t>(const h2_t* p, int n) {
+    float v[4];
+    h2_load4(p, n, v);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+template <typename T> __device__ __forceinline__ void stv4(T* p, int n, float4 v) { Vec4<T>::store(p, v); }
+template <> __device__ __forceinline__ void stv4<h2_t>(h2_t* p, int n, float4 v) {
+    const float t[4] = {v.x, v.y, v.z, v.w};
+    h2_store4(p, n, t);
 }
 
 // out[m] = a[m] + b[m % mod_b] (+ c[m % mod_c]); operand k is fp32 when bit k of f32_mask is set, else T
@@ -32,14 +47,14 @@ __global__ __launch_bounds__(256) void add_kernel(const void* __restrict__ a, in
         const int m = (int)(i / nv), n = 4 * (int)(i - (long)m * nv);
         auto ld = [&](const void* p, int ldp, int mod, int bit) {
             const long r = mod ? m % mod : m;
-            return (f32_mask >> bit) & 1 ? Vec4<float>::load((const float*)p + r * ldp + n) : Vec4<T>::load((const T*)p + r * ldp + n);
+            return (f32_mask >> bit) & 1 ? Vec4<float>::load((const float*)p + r * ldp + n) : ldv4<T>((const T*)p + r * ldp + n, n);
         };
         float4 v = ld(a, lda, 0, 0);
         const float4 w = ld(b, ldb, mod_b, 1);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         if (c) { const float4 u = ld(c, ldc, mod_c, 2); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
         if (of) Vec4<float>::store(of + (long)m * ldo + n, v);
-        if (o) Vec4<T>::store(o + (long)m * ldo + n, v);
+        if (o) stv4<T>(o + (long)m * ldo + n, n, v);
     }
 }
 
@@ -76,6 +91,44 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
     }
 }
 
+// EMAGE_H2 forms: one thread per group of 8 logical columns (32 bytes)
+__global__ __launch_bounds__(256) void pack_motion_h2_kernel(const float* __restrict__ motion, const float* __restrict__ mask, long ldb,
+                                                             const float* __restrict__ emb, const float* __restrict__ seed, long ld_seed, int pre,
+                                                             h2_t* __restrict__ out, int ldo, int n_store, int B, int Tn, int C) {
+    const int ng = n_store >> 3;
+    const long total = (long)B * Tn * ng;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / ng), n0 = 8 * (int)(i - (long)m * ng);
+        const int b = m / Tn, t = m - b * Tn;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = n0 + e;
+            v[e] = 0.f;
+            if (n < C) {
+                const long src = (long)b * ldb + (long)t * C + n;
+                const float mk = mask[src], mv = motion[src];
+                if (seed && t < pre) v[e] = mk == 0.0f ? mv : seed[(long)b * ld_seed + (long)t * C + n];
+                else v[e] = mk == 1.0f ? emb[n] : mv;
+            }
+        }
+        h2_store8(out + (long)m * ldo + n0, v);
+    }
+}
+
+// src may alias out (same row stride): each thread reads its 8 values before it writes their 32 bytes
+__global__ __launch_bounds__(256) void cast_pad_h2_kernel(const float* src, int lds, h2_t* out, int ldo, int n_store, int M, int C) {
+    const int ng = n_store >> 3;
+    const long total = (long)M * ng;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / ng), n0 = 8 * (int)(i - (long)m * ng);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = n0 + e < C ? src[(long)m * lds + n0 + e] : 0.f;
+        h2_store8(out + (long)m * ldo + n0, v);
+    }
+}
+
 inline int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -91,8 +144,11 @@ extern "C" int emage_layernorm(int dtype, const void* x, int ldx, const float* g
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((M + 3) / 4), block(256);
     if (dtype == EMAGE_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16_t, 4>), grid, block, 0, s, (const bf16_t*)x, ldx, gamma, beta, eps, (const bf16_t*)add, ldadd, y_f32, (bf16_t*)y, ldy, M, C);
-    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, eps, (const float*)add, ldadd, y_f32, (float*)y, ldy, M, C);
-    else return EMAGE_EINVAL;
+    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, eps, (const float*)add, ldadd, y_f32, (float*)y, ldy, M, C, (h2_t*)nullptr);
+    else if (dtype == EMAGE_H2) {      // x / add / y_f32 float32 (the fp32 residual stream), y the EMAGE_H2 copy for the next contraction
+        if (ldy % 8) return EMAGE_EINVAL;
+        hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, eps, (const float*)add, ldadd, y_f32, (float*)nullptr, ldy, M, C, (h2_t*)y);
+    } else return EMAGE_EINVAL;
     return launch_status();
 }
 
@@ -104,7 +160,10 @@ extern "C" int emage_add(int dtype, const void* a, int lda, const void* b, int l
     const dim3 grid(grid_for((long)M * C / 4)), block(256);
     if (dtype == EMAGE_BF16) hipLaunchKernelGGL((add_kernel<bf16_t>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask, out_f32, (bf16_t*)out, ldo, M, C);
     else if (dtype == EMAGE_F32) hipLaunchKernelGGL((add_kernel<float>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask | 7, out_f32, (float*)out, ldo, M, C);
-    else return EMAGE_EINVAL;
+    else if (dtype == EMAGE_H2) {      // operands with a clear f32_mask bit and `out` are EMAGE_H2 images: rows start on a 32-byte group
+        if (lda % 8 || ldb % 8 || ldo % 8 || (c && ldc % 8)) return EMAGE_EINVAL;
+        hipLaunchKernelGGL((add_kernel<h2_t>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask, out_f32, (h2_t*)out, ldo, M, C);
+    } else return EMAGE_EINVAL;
     return launch_status();
 }
 
@@ -117,7 +176,10 @@ extern "C" int emage_pack_motion(int dtype, const float* motion, const float* ma
     const dim3 grid(grid_for((long)B * T * n_store)), block(256);
     if (dtype == EMAGE_BF16) hipLaunchKernelGGL((pack_motion_kernel<bf16_t>), grid, block, 0, s, motion, mask, ldb, mask_embedding, seed, ld_seed, pre, (bf16_t*)out, ldo, n_store, B, T, C);
     else if (dtype == EMAGE_F32) hipLaunchKernelGGL((pack_motion_kernel<float>), grid, block, 0, s, motion, mask, ldb, mask_embedding, seed, ld_seed, pre, (float*)out, ldo, n_store, B, T, C);
-    else return EMAGE_EINVAL;
+    else if (dtype == EMAGE_H2) {
+        if (n_store % 8 || ldo % 8 || ((uintptr_t)out & 15)) return EMAGE_EINVAL;
+        hipLaunchKernelGGL(pack_motion_h2_kernel, dim3(grid_for((long)B * T * n_store / 8)), block, 0, s, motion, mask, ldb, mask_embedding, seed, ld_seed, pre, (h2_t*)out, ldo, n_store, B, T, C);
+    } else return EMAGE_EINVAL;
     return launch_status();
 }
 
@@ -127,7 +189,10 @@ extern "C" int emage_cast_pad(int dtype, const float* src, int lds, void* out, i
     const dim3 grid(grid_for((long)M * n_store)), block(256);
     if (dtype == EMAGE_BF16) hipLaunchKernelGGL((cast_pad_kernel<bf16_t>), grid, block, 0, s, src, lds, (bf16_t*)out, ldo, n_store, M, C);
     else if (dtype == EMAGE_F32) hipLaunchKernelGGL((cast_pad_kernel<float>), grid, block, 0, s, src, lds, (float*)out, ldo, n_store, M, C);
-    else return EMAGE_EINVAL;
+    else if (dtype == EMAGE_H2) {      // fp32 -> EMAGE_H2; in place when src == out and lds == ldo
+        if (n_store % 8 || ldo % 8 || ((uintptr_t)out & 15) || ((const void*)src == out && lds != ldo)) return EMAGE_EINVAL;
+        hipLaunchKernelGGL(cast_pad_h2_kernel, dim3(grid_for((long)M * n_store / 8)), block, 0, s, src, lds, (h2_t*)out, ldo, n_store, M, C);
+    } else return EMAGE_EINVAL;
     return launch_status();
 }
 

@@ -9,7 +9,11 @@
 
 #include "gemm_tile.h"
 
-namespace emage_dev { extern int g_lstm_layer_dbg; }   // csrc/lstmseq.hip
+namespace emage_dev {
+extern int g_lstm_layer_dbg;                        // csrc/lstmseq.hip
+extern int g_h2_force_config, g_h2_variant;         // csrc/gemm_h2.hip
+int gemm_h2_dispatch(GemmArgs& a, hipStream_t s);   // csrc/gemm_h2.hip: the EMAGE_H2 (pre-split operands) tile kernels
+}
 
 namespace {
 
@@ -298,13 +302,18 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
                           float a_scale, float w_scale, void* stream) {
     const int epc = dtype == EMAGE_BF16 ? 8 : 4;
     if (!A || !W || M <= 0 || N <= 0 || taps <= 0 || Cp <= 0 || Cp % 64 != 0) return EMAGE_EINVAL;
-    if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3) return EMAGE_EINVAL;
+    if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3 && dtype != EMAGE_H2) return EMAGE_EINVAL;
+    if (dtype == EMAGE_H2) {       // 32-byte groups of 8 logical columns: every row of every h2 operand starts on a group
+        if (lda % 8 || (res && ldr % (res_is_f32 ? 4 : 8)) || (res && ((uintptr_t)res & 15))) return EMAGE_EINVAL;
+        if (out && (ldo % 8 || ((uintptr_t)out & 15) || ldo < ((((out_t ? t_col0 : N) > n_store ? (out_t ? t_col0 : N) : n_store) + 7) & ~7))) return EMAGE_EINVAL;
+        if ((bias && ((uintptr_t)bias & 15)) || (slope && ((uintptr_t)slope & 15))) return EMAGE_EINVAL;
+    }
     if (lda % epc != 0 || lda < Cp) return EMAGE_EINVAL;                 // 16-byte aligned operand rows
     if (((uintptr_t)A | (uintptr_t)W) & 15) return EMAGE_EINVAL;
     if (Lout <= 0 || Lin <= 0 || M % Lout != 0 || stride <= 0) return EMAGE_EINVAL;
     if (!out && !out_f32 && !out_t) return EMAGE_EINVAL;
     if (out_t && (t_rows <= 0 || M % t_rows != 0 || t_ld < t_rows || t_col0 < 0 || t_col0 > N)) return EMAGE_EINVAL;
-    if (dtype == EMAGE_F16X3 && !(a_scale > 0.f && w_scale > 0.f)) return EMAGE_EINVAL;
+    if ((dtype == EMAGE_F16X3 || dtype == EMAGE_H2) && !(a_scale > 0.f && w_scale > 0.f)) return EMAGE_EINVAL;
     {   // operands are addressed through 32-bit buffer offsets: each must span less than 2 GiB (the host splits larger batches)
         const long es = dtype == EMAGE_BF16 ? 2 : 4;
         const long a_span = ((((long)(M / Lout)) * Lin - 1) * lda + Cp + (long)pad * lda) * es;
@@ -315,10 +324,13 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.ldf = ldf; a.res_is_f32 = res_is_f32; a.res_first = res_first; a.n_store = out ? n_store : 0;
     a.t_col0 = out_t ? t_col0 : N; a.t_rows = t_rows > 0 ? t_rows : 1; a.t_ld = t_ld;
     a.dbg = g_debug_skip;
+    a.trace = nullptr; a.cstate = nullptr; a.ldc = 0;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
-    a.a_scale = dtype == EMAGE_F16X3 ? a_scale : 1.f;
-    a.o_scale = dtype == EMAGE_F16X3 ? 1.f / (a_scale * w_scale) : 1.f;
+    const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2;
+    a.a_scale = split ? a_scale : 1.f;
+    a.o_scale = split ? 1.f / (a_scale * w_scale) : 1.f;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == EMAGE_H2) return gemm_h2_dispatch(a, s);
     if (dtype == EMAGE_F16X3) return dispatch<float, true>(a, s);
     return dtype == EMAGE_BF16 ? dispatch<bf16_t, false>(a, s) : dispatch<float, false>(a, s);
 }
@@ -328,5 +340,7 @@ extern "C" int emage_set_tuning(int key, int value) {
     if (key == 1) { g_debug_skip = value; return 0; }
     if (key == 2) { g_variant = value; return 0; }
     if (key == 3) { emage_dev::g_lstm_layer_dbg = value; return 0; }     // csrc/lstmseq.hip: A/B and timing ablations
+    if (key == 4) { emage_dev::g_h2_force_config = value; return 0; }    // csrc/gemm_h2.hip: fixed EMAGE_H2 tile configuration
+    if (key == 5) { emage_dev::g_h2_variant = value; return 0; }         // csrc/gemm_h2.hip: dispatch-heuristic variant (A/B runs)
     return EMAGE_EINVAL;
 }

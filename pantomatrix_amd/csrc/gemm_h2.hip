@@ -1,0 +1,131 @@
+// emage_gemm, EMAGE_H2 mode: Linear / Conv1d as implicit GEMM over PRE-SPLIT operands (h2.h) — the parity-green split-fp16
+// MFMA arithmetic of EMAGE_F16X3 (hi*hi + hi*lo + lo*hi, fp32 accumulate) with the activation split done ONCE by the producer
+// instead of by every consuming wave at every K-tile.  Tile routine: h2_tile.h.
+#include "common.h"
+#include <utility>
+#include "h2_tile.h"
+
+namespace emage_dev {
+int g_h2_force_config = -1;      // EMAGE_TOOLS builds only (emage_set_tuning key 4): fixed tile configuration for sweeps
+int g_h2_variant = 0;            // tools: dispatch-heuristic variant for A/B runs (emage_set_tuning key 5)
+unsigned long long* g_h2_trace = nullptr;   // tools: device buffer of (waves x 512) s_memtime stamps (emage_h2_set_trace)
+}
+
+namespace {
+
+using namespace emage_dev;
+
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV, bool TRACE>
+__global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) void gemm_h2_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[h2_smem_bytes<BM, BN, NS>()];
+    // XCD-aware tile order (gemm.hip): each XCD walks a contiguous run of tiles
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE>(p, tile_m * BM, tile_n * BN, smem);
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false, bool TRACE = false>
+int launch_h2(GemmArgs& a, hipStream_t s) {
+    if (a.out_t && a.t_col0 % BN != 0) return EMAGE_EINVAL;      // a tile is either row-major or transposed
+    a.tiles_m = (a.M + BM - 1) / BM;
+    const int ncols = a.n_store > a.N ? a.n_store : a.N;
+    a.tiles_n = (ncols + BN - 1) / BN;
+    a.trace = TRACE ? g_h2_trace : nullptr;
+    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE>), dim3(a.tiles_m * a.tiles_n), dim3((WM * WN + NLW) * 64), 0, s, a);
+    return launch_status();
+}
+
+// Tile configurations (id: block tile, compute-wave grid [wave tile], ring depth, loader waves, register-pipelined K-loop)
+int run_config(int cfg, GemmArgs& a, hipStream_t s) {
+    switch (cfg) {
+        //                       BM   BN  WM WN NS NLW PIPE  PRE  OCC
+        case 100: return launch_h2<64, 192, 4, 2, 2, 0, false>(a, s);              // 8 waves 16x96 (the F16X3 shape)
+        case 101: return launch_h2<64, 192, 4, 2, 3, 0, false>(a, s);
+        case 102: return launch_h2<64, 192, 2, 4, 3, 0, false>(a, s);              // 8 waves 32x48
+        case 103: return launch_h2<64, 192, 2, 2, 3, 0, true>(a, s);               // 4 waves 32x96, pipelined
+        case 104: return launch_h2<64, 192, 2, 2, 4, 0, true>(a, s);
+        case 105: return launch_h2<64, 192, 2, 2, 3, 4, true>(a, s);               // 4 compute + 4 loader waves
+        case 106: return launch_h2<64, 192, 2, 2, 3, 4, false>(a, s);
+        case 107: return launch_h2<64, 192, 2, 4, 3, 4, false>(a, s);              // 8 compute (32x48) + 4 loaders
+        case 108: return launch_h2<128, 96, 4, 1, 3, 0, true>(a, s);               // 4 waves 32x96
+        case 109: return launch_h2<128, 96, 4, 1, 3, 4, true>(a, s);
+        case 110: return launch_h2<128, 96, 4, 2, 3, 4, false>(a, s);              // 8 compute 32x48 + 4 loaders
+        case 111: return launch_h2<128, 128, 2, 2, 3, 0, true>(a, s);              // 4 waves 64x64
+        case 112: return launch_h2<128, 128, 4, 2, 2, 0, false>(a, s);             // 8 waves 32x64
+        case 113: return launch_h2<128, 128, 4, 2, 3, 0, false>(a, s);
+        case 115: return launch_h2<128, 192, 2, 2, 3, 0, true>(a, s);              // 4 waves 64x96
+        case 116: return launch_h2<128, 192, 4, 2, 3, 0, false>(a, s);             // 8 waves 32x96
+        case 118: return launch_h2<128, 256, 2, 2, 3, 0, true>(a, s);              // 4 waves 64x128
+        case 119: return launch_h2<128, 256, 4, 2, 2, 0, false>(a, s);             // 8 waves 32x128
+        case 120: return launch_h2<64, 64, 2, 2, 3, 0, false, false, 2>(a, s);     // small grids: 4 waves 32x32
+        case 121: return launch_h2<64, 64, 2, 2, 3, 0, true, false, 2>(a, s);
+        case 122: return launch_h2<64, 128, 2, 2, 3, 0, true>(a, s);               // 4 waves 32x64
+        case 123: return launch_h2<128, 64, 4, 1, 3, 0, true>(a, s);               // 4 waves 32x64
+        case 124: return launch_h2<64, 96, 2, 2, 3, 0, true, false, 2>(a, s);      // 4 waves 32x48
+        case 125: return launch_h2<64, 192, 2, 2, 3, 0, true, true>(a, s);         // 103 + residual prefetch
+        case 126: return launch_h2<64, 192, 2, 2, 3, 4, false, true>(a, s);        // 106 + residual prefetch
+        case 127: return launch_h2<128, 96, 4, 1, 3, 0, true, true>(a, s);         // 108 + residual prefetch
+        case 128: return launch_h2<64, 192, 4, 2, 3, 0, false, true>(a, s);        // 101 + residual prefetch
+        case 129: return launch_h2<128, 96, 4, 1, 4, 0, true, true>(a, s);
+        case 130: return launch_h2<64, 64, 2, 2, 2, 0, false, false, 3>(a, s);
+        case 131: return launch_h2<128, 128, 4, 2, 3, 4, false>(a, s);             // 8 compute 32x64 + 4 loaders
+        case 132: return launch_h2<128, 192, 4, 2, 3, 4, false>(a, s);             // 8 compute 32x96 + 4 loaders
+        // DMA issue interleaved with the MFMAs (DILV)
+        case 140: return launch_h2<64, 192, 4, 2, 2, 0, false, false, 1, true>(a, s);
+        case 141: return launch_h2<64, 192, 4, 2, 3, 0, false, false, 1, true>(a, s);
+        case 142: return launch_h2<64, 192, 2, 4, 3, 0, false, false, 1, true>(a, s);
+        case 143: return launch_h2<64, 192, 2, 2, 3, 0, true, false, 1, true>(a, s);
+        case 144: return launch_h2<64, 192, 4, 2, 3, 0, true, false, 1, true>(a, s);      // 8 waves, pipelined fragments + interleaved DMA
+        case 145: return launch_h2<128, 128, 4, 2, 3, 0, false, false, 1, true>(a, s);
+        case 146: return launch_h2<128, 128, 4, 2, 3, 0, true, false, 1, true>(a, s);
+        case 147: return launch_h2<128, 192, 4, 2, 3, 0, false, false, 1, true>(a, s);
+        case 148: return launch_h2<128, 192, 4, 2, 3, 0, true, false, 1, true>(a, s);
+        case 149: return launch_h2<128, 256, 4, 2, 2, 0, false, false, 1, true>(a, s);
+        case 150: return launch_h2<64, 64, 2, 2, 2, 0, false, false, 3, true>(a, s);
+        case 151: return launch_h2<64, 64, 2, 2, 3, 0, false, false, 2, true>(a, s);
+        case 152: return launch_h2<128, 64, 4, 2, 3, 0, false, false, 1, true>(a, s);     // 8 waves 32x32
+        case 153: return launch_h2<64, 128, 2, 4, 3, 0, false, false, 1, true>(a, s);     // 8 waves 32x32
+        case 155: return launch_h2<64, 192, 4, 2, 4, 0, false, false, 1, true>(a, s);
+        case 156: return launch_h2<128, 128, 2, 4, 3, 0, false, false, 1, true>(a, s);    // 8 waves 64x32
+        // instrumented twins (TRACE) of 101 / 103 / 105 / 141
+        case 201: return launch_h2<64, 192, 4, 2, 3, 0, false, false, 1, false, true>(a, s);
+        case 203: return launch_h2<64, 192, 2, 2, 3, 0, true, false, 1, false, true>(a, s);
+        case 205: return launch_h2<64, 192, 2, 2, 3, 4, true, false, 1, false, true>(a, s);
+        case 241: return launch_h2<64, 192, 4, 2, 3, 0, false, false, 1, true, true>(a, s);
+        default: break;
+    }
+    return EMAGE_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int emage_h2_set_trace(void* buf) { emage_dev::g_h2_trace = (unsigned long long*)buf; return 0; }
+
+namespace emage_dev {
+
+// called by emage_gemm (gemm.hip) for dtype EMAGE_H2 after the common argument checks
+int gemm_h2_dispatch(GemmArgs& a, hipStream_t s) {
+    if (g_h2_force_config >= 0) return run_config(g_h2_force_config, a, s);
+    // measured on MI355X (tools/bench_gemm_h2.py, profiles/r03_h2_sweep*.txt).  Wide outputs: 8-wave 64x192 / 128x256 tiles; everything
+    // else: 64x64 tiles, three resident blocks per CU (their barriers de-synchronise, which hides each block's DMA / LDS phases
+    // behind the others' MFMAs better than one fat block per CU does at M = 4096)
+    const int ncols = a.n_store > a.N ? a.n_store : a.N;
+    const int v = g_h2_variant;
+    if ((v & 1) && ncols < 1024 && ncols % 192 == 0 && a.M >= 2048 && !a.out_t) return run_config(101, a, s);       // one 8-wave block per CU
+    if ((v & 4) && ncols < 1024 && ncols % 192 == 0 && a.M >= 2048 && !a.out_t) return run_config(124, a, s);       // 64x96, two 4-wave blocks per CU
+    if (ncols >= 1024 && a.M >= 1024) {
+        const long t128x256 = (long)((a.M + 127) / 128) * ((ncols + 255) / 256);
+        if (!(v & 2) && t128x256 >= 512 && ncols % 256 == 0 && (!a.out_t || a.t_col0 % 256 == 0)) return run_config(119, a, s);
+        if (ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return run_config(100, a, s);
+        if (!a.out_t || a.t_col0 % 128 == 0) return run_config(113, a, s);
+    }
+    if (a.out_t && a.t_col0 % 64 != 0) return EMAGE_EINVAL;
+    return run_config((v & 8) ? 130 : 120, a, s);
+}
+
+}  // namespace emage_dev

@@ -17,6 +17,7 @@ struct GemmArgs {
     int dbg;
     float a_scale, o_scale;   // split-f16 mode: A is multiplied by a_scale before the hi/lo split, accumulators by o_scale after the K-loop
     float* cstate; int ldc;   // EPI_LSTM: the (M, N/4) cell state, updated in place
+    unsigned long long* trace;   // tools builds: per-wave s_memtime stamps of one block (h2_tile.h TRACE), else NULL
 };
 
 // Epilogue kinds of gemm_pipe_tile.  EPI_LSTM (emage_lstm_step): the contraction is h_{t-1} W_hh^T with the gate rows of

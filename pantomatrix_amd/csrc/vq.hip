@@ -1,6 +1,7 @@
 // Codebook kernels: fp32 L2 nearest-neighbour arg-min (K6), classifier log-softmax arg-max (K8),
 // codebook row gather (K7).  Index outputs are int64 and follow torch's first-extremum tie rule.
 #include "common.h"
+#include "h2.h"
 #include <math.h>
 
 namespace {
@@ -250,6 +251,20 @@ __global__ __launch_bounds__(256) void gather_rows(const float* __restrict__ tab
         out[(long)row * ldo + j] = Elem<T>::to(j < D ? table[k * D + j] : 0.f);
 }
 
+// EMAGE_H2 output (csrc/h2.h): one thread per group of 8 columns
+__global__ __launch_bounds__(128) void gather_rows_h2(const float* __restrict__ table, const int64_t* __restrict__ idx, IdxView iv,
+                                                      emage_dev::h2_t* __restrict__ out, int ldo, int n_store, int N, int K, int D) {
+    const int row = blockIdx.x;
+    long k = idx[idx_at(iv, row)];
+    k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+    for (int g = threadIdx.x; g < (n_store >> 3); g += blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 8 * g + e < D ? table[k * D + 8 * g + e] : 0.f;
+        emage_dev::h2_store8(out + (long)row * ldo + 8 * g, v);
+    }
+}
+
 }  // namespace
 
 extern "C" int emage_vq_argmin_f32(const float* z, int ldz, const float* codebook, int64_t* idx, int idx_rows, long idx_ld,
@@ -283,6 +298,9 @@ extern "C" int emage_gather_rows(const float* table, const int64_t* idx, int idx
     const IdxView iv{idx_rows, idx_ld, idx_tstride};
     if (dtype == EMAGE_BF16) hipLaunchKernelGGL((gather_rows<bf16_t>), dim3(N), dim3(128), 0, s, table, idx, iv, (bf16_t*)out, ldo, n_store, N, K, D);
     else if (dtype == EMAGE_F32) hipLaunchKernelGGL((gather_rows<float>), dim3(N), dim3(128), 0, s, table, idx, iv, (float*)out, ldo, n_store, N, K, D);
-    else return EMAGE_EINVAL;
+    else if (dtype == EMAGE_H2) {
+        if (n_store % 8 || ldo % 8 || ((uintptr_t)out & 15)) return EMAGE_EINVAL;
+        hipLaunchKernelGGL(gather_rows_h2, dim3(N), dim3(128), 0, s, table, idx, iv, (emage_dev::h2_t*)out, ldo, n_store, N, K, D);
+    } else return EMAGE_EINVAL;
     return launch_status();
 }

@@ -27,7 +27,7 @@ import torch
 
 from . import ops, spec, synthetic
 from .streams import Fork
-from ._lib import BF16, F32, F16X3
+from ._lib import BF16, F32, F16X3, H2
 from .configuration_emage_audio import EmageAudioConfig, EmageVAEConvConfig, EmageVQVAEConvConfig
 
 OUT_KEYS = ("rec_face", "rec_upper", "rec_hands", "rec_lower", "cls_face", "cls_upper", "cls_hands", "cls_lower")
@@ -74,6 +74,9 @@ class _EmageModule(torch.nn.Module):
         self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
         self.health_counter = None             # optional int32 device counter of non-finite logits / latents met by infer_codes (runtime.ClipRunner)
         self.slab_convs = True                 # WavEncoder: LDS-resident-slab convolutions + fused block 0 (A/B switch; same bits)
+        self.h2_residual = False               # EMAGE_H2 mode: the transformer residual stream is read from the H2 images (no float32 twins)
+        self.split_acts = True                 # f16x3 precision: activations that feed a contraction are stored PRE-SPLIT (EMAGE_H2,
+                                               # csrc/h2.h) by their producers; False = float32 activations split inside every GEMM
         self._templates = {}                   # cached default motion / mask of inference() per (batch, length, device)
         self._spec = type(self)._spec_fn(config)
         init = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
@@ -173,13 +176,19 @@ class _EmageModule(torch.nn.Module):
         return model
 
     # ---- engine plumbing -------------------------------------------------------------
-    def _engine(self):
+    _supports_h2 = True      # the class's forward handles EMAGE_H2 activations (the LSTM models keep float32 activations)
+
+    def _engine(self, h2=None):
+        """The packed operand set of the current precision.  h2 (f16x3 only): pre-split EMAGE_H2 operands (default: `split_acts`);
+        the training forward asks for h2=False (float32 activations, weights in the EMAGE_F16X3 packing)."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError(f"{type(self).__name__} runs only on an MI355X device: call .to('cuda') first "
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests only)")
-        if self._packed is None or self._packed.device != dev:
-            self._packed = _Packed(self._flat_params(), dev, self._dt)
+        want_h2 = self._dt == F16X3 and self._supports_h2 and (self.split_acts if h2 is None else h2)
+        dt = H2 if want_h2 else self._dt
+        if self._packed is None or self._packed.device != dev or self._packed.dt != dt:
+            self._packed = _Packed(self._flat_params(), dev, dt)
             self._pack(self._packed)
         return self._packed
 
@@ -197,6 +206,7 @@ class _EmageModule(torch.nn.Module):
 class _Packed:
     def __init__(self, params, device, dt):
         self.p, self.device, self.dt = params, device, dt
+        self.wav_dt = F16X3 if dt == H2 else dt      # the WavEncoder keeps float32 activations (slab kernels split in LDS)
         self.tdt = ops.TORCH_DTYPE[dt]
         self.w = {}
         self.origin = {}     # key -> [(weight name, bias name, row slice of that parameter)] in stacking order (training: gradient unpacking)
@@ -210,11 +220,14 @@ class _Packed:
     def f32(self, name):
         return self.p[name].to(torch.float32).contiguous()
 
-    def _operand(self, w2d):
-        """(N, K) fp32 with K already padded -> the MFMA operand image of this precision and its scale."""
-        if self.dt == F16X3:
+    def _operand(self, w2d, dt=None):
+        """(N, K) fp32 with K already padded -> the MFMA operand image of precision `dt` (default: the model's) and its scale."""
+        dt = self.dt if dt is None else dt
+        if dt == H2:
+            return ops.split_f16_weights_h2(w2d.contiguous())
+        if dt == F16X3:
             return ops.split_f16_weights(w2d.contiguous())
-        return w2d.to(self.tdt).contiguous(), 1.0
+        return w2d.to(ops.TORCH_DTYPE[dt]).contiguous(), 1.0
 
     def _pack_mat(self, w2d):
         n, k = w2d.shape
@@ -235,7 +248,7 @@ class _Packed:
             bs.append(b)
         k_real = ws[0].shape[1]
         w, kp, wsc = self._pack_mat(torch.cat(ws, 0).float())
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc)
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt)
         self.origin[key] = [(nm + ".weight", nm + ".bias", rows[i] if rows is not None else slice(0, self.p[nm + ".weight"].shape[0]))
                             for i, nm in enumerate(names)]
 
@@ -253,7 +266,7 @@ class _Packed:
                 self.origin[key].append((nm + ".in_proj_weight", nm + ".in_proj_bias", sl[part]))
         k_real = ws[0].shape[1]
         w, kp, wsc = self._pack_mat(torch.cat(ws, 0).float())
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc)
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt)
 
     def folded(self, cname, bn=None):
         """Raw Conv1d (weight (Cout,Cin,k), bias) with an eval-mode BatchNorm1d folded in:
@@ -265,9 +278,10 @@ class _Packed:
             b = (b - self.p[bn + ".running_mean"].float()) * s + self.p[bn + ".bias"].float()
         return w, b
 
-    def conv(self, key, name, fold_bn=None, extra=None):
+    def conv(self, key, name, fold_bn=None, extra=None, dt=None):
         """Conv1d weight (Cout,Cin,k) -> (Cout, k*Cp), taps major, channels zero-padded to Cp; `extra`
-        = (conv, bn) stacks a second conv (the downsample shortcut) along Cout."""
+        = (conv, bn) stacks a second conv (the downsample shortcut) along Cout.  dt: operand packing (default: the model's)."""
+        dt = self.dt if dt is None else dt
         w, b = self.folded(name, fold_bn)
         if extra is not None:
             w2, b2 = self.folded(*extra)
@@ -277,8 +291,8 @@ class _Packed:
         w = w.permute(0, 2, 1)                                   # (Cout, k, Cin)
         if cp != cin:
             w = torch.nn.functional.pad(w, (0, cp - cin))
-        wp, wsc = self._operand(w.reshape(cout, k * cp))
-        self.w[key] = dict(w=wp, b=b.contiguous(), n=cout, cp=cp, taps=k, k_real=k * cin, ws=wsc)
+        wp, wsc = self._operand(w.reshape(cout, k * cp), dt)
+        self.w[key] = dict(w=wp, b=b.contiguous(), n=cout, cp=cp, taps=k, k_real=k * cin, ws=wsc, dt=dt)
 
     def conv_pairs(self, key, w, b, slope, stride, pad):
         """A Conv1d over NARROW rows (Cin = 32) as a convolution over PAIRS of positions: the (L, 32) activation rows of a
@@ -311,8 +325,8 @@ class _Packed:
                         wp[:, q, hi, :] = w[:, :, 2 * q + hi]
             wp = wp.reshape(cout, nq * 2 * cin)
             ent = dict(n=cout, taps=nq, pad=0, stride=stride // 2)
-        wpk, wsc = self._operand(wp)
-        self.w[key] = dict(w=wpk, b=b.float().contiguous(), slope=slope.float().contiguous(), cp=2 * cin, k_real=k * cin, ws=wsc, **ent)
+        wpk, wsc = self._operand(wp, self.wav_dt)
+        self.w[key] = dict(w=wpk, b=b.float().contiguous(), slope=slope.float().contiguous(), cp=2 * cin, k_real=k * cin, ws=wsc, dt=self.wav_dt, **ent)
 
     def norm(self, key, name):
         self.w[key] = dict(g=self.f32(name + ".weight"), b=self.f32(name + ".bias"))
@@ -324,11 +338,18 @@ class _Packed:
 class _Ctx:
     """One forward's launch context: packed weights + dtype + allocation helpers."""
 
-    def __init__(self, pk: _Packed):
+    def __init__(self, pk: _Packed, h2_residual=False):
+        # h2_residual (EMAGE_H2 mode): LayerNorm writes ONLY the H2 image and the sub-layer epilogues read the residual from it
+        # ((hi + lo) / 16: 2^-22 relative to the float32 value) instead of from a float32 twin: one 12.6 MB store less per norm
+        self.h2res = bool(h2_residual) and pk.dt == H2
         # dt: storage / elementwise-kernel type of activations; gdt: emage_gemm's operand mode (F16X3 = float32 storage,
         # split-f16 MFMA; equal to dt otherwise)
         self.pk, self.gdt, self.tdt, self.dev = pk, pk.dt, pk.tdt, pk.device
+        self.h2 = pk.dt == H2                   # activations that feed a contraction are EMAGE_H2 images (float32-sized elements)
         self.dt = F32 if pk.dt == F16X3 else pk.dt
+        # WavEncoder: float32 activations in both split-f16 forms (its slab kernels split once per block in LDS)
+        self.wgdt = pk.wav_dt
+        self.wdt = F32 if pk.wav_dt == F16X3 else pk.wav_dt
 
     def lo(self, m, n):
         return torch.empty(m, n, dtype=self.tdt, device=self.dev)
@@ -337,11 +358,13 @@ class _Ctx:
         return torch.empty(m, n, dtype=torch.float32, device=self.dev)
 
     def gemm(self, a, key, *, slope=None, res=None, res_first=False, out=None, out_f32=None, want="lo", n_store=0,
-             out_t=None, t_col0=0, t_rows=0, conv=None, m=None, dt=None, w=None):
+             out_t=None, t_col0=0, t_rows=0, conv=None, m=None, dt=None, w=None, res_h2=False):
         """Run one contraction.  want: "lo", "f32", "both" allocate the outputs when not passed in.
-        conv = (stride, pad, lin, lout) turns it into the implicit-GEMM Conv1d with the entry's tap count."""
+        conv = (stride, pad, lin, lout) turns it into the implicit-GEMM Conv1d with the entry's tap count.
+        The operand mode is the weight entry's packing (EMAGE_H2 entries take an H2 image `a` and write H2 `lo` outputs;
+        res_h2: the residual is an H2 image too, else float32)."""
         e = w if w is not None else self.pk.w[key]
-        dt = self.gdt if dt is None else dt
+        dt = e.get("dt", self.gdt) if dt is None else dt
         m = a.shape[0] if m is None else m
         n = e["n"]
         if out is None and out_t is None and want in ("lo", "both"):
@@ -354,8 +377,21 @@ class _Ctx:
             stride, pad, lin, lout = conv
             kw = dict(taps=e["taps"], stride=stride, pad=pad, lin=lin, lout=lout)
         ops.gemm(dt, a, e["w"], e["b"], sl, res, out, out_f32, out_t, n=n, cp=e["cp"], n_store=n_store,
-                 t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, k_real=e.get("k_real"), w_scale=e.get("ws", 1.0), **kw)
+                 t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, k_real=e.get("k_real"), w_scale=e.get("ws", 1.0),
+                 res_h2=bool(res_h2 and dt == H2), **kw)
         return out, out_f32
+
+    # ---- the two forms of an activation: `.a` feeds contractions (storage type of the mode), `.r` carries the residual stream
+    # (the same tensor, except in EMAGE_H2 mode where it is the float32 twin) ----
+    def gemm_x(self, a, key, **kw):
+        """Contraction whose result is both an operand and a residual: -> _X."""
+        lo, f = self.gemm(a, key, want="both" if self.h2 else "lo", **kw)
+        return _X(lo, f if self.h2 else lo)
+
+    def gemm_r(self, a, key, **kw):
+        """Contraction whose result is only read at residual precision (a pre-norm sum, attention q / k): -> tensor."""
+        lo, f = self.gemm(a, key, want="f32" if self.h2 else "lo", **kw)
+        return f if self.h2 else lo
 
     def conv3(self, a, key, t, **kw):
         return self.gemm(a, key, conv=(1, 1, t, t), **kw)
@@ -366,6 +402,14 @@ class _Ctx:
         return alloc(b, rows, tp, dtype=self.tdt, device=self.dev)
 
 
+class _X:
+    """An activation in its two forms (see _Ctx.gemm_x); h2r: `.r` is an EMAGE_H2 image too (then it IS `.a`)."""
+    __slots__ = ("a", "r", "h2r")
+
+    def __init__(self, a, r, h2r=False):
+        self.a, self.r, self.h2r = a, r, h2r
+
+
 def _conv_encoder(cx: _Ctx, prefix, x_lo, t, n_layer, length, want_f32):
     """VQEncoderV5 / V6 (P:189-235) on a (M, Cp) operand; returns (lo (M,Cp(length)), f32 (M,length)|None)."""
     lp = _rup(length)
@@ -374,7 +418,7 @@ def _conv_encoder(cx: _Ctx, prefix, x_lo, t, n_layer, length, want_f32):
         h, _ = cx.conv3(h, f"{prefix}.main.{3 * i}", t, slope=0.2, n_store=lp)
         r, _ = cx.conv3(h, f"{prefix}.main.{3 * i + 2}.model.0", t, slope=0.2, n_store=lp)
         last = i == n_layer - 1
-        h, hf = cx.conv3(r, f"{prefix}.main.{3 * i + 2}.model.2", t, res=h, n_store=lp,
+        h, hf = cx.conv3(r, f"{prefix}.main.{3 * i + 2}.model.2", t, res=h, res_h2=cx.h2, n_store=lp,
                          want="both" if (last and want_f32) else "lo")
     return h, hf
 
@@ -385,7 +429,7 @@ def _conv_decoder(cx: _Ctx, prefix, z_lo, t, n_layer, length, out_dim):
     h = z_lo
     for i in range(2):
         r, _ = cx.conv3(h, f"{prefix}.main.{i}.model.0", t, slope=0.2, n_store=lp)
-        h, _ = cx.conv3(r, f"{prefix}.main.{i}.model.2", t, res=h, n_store=lp)
+        h, _ = cx.conv3(r, f"{prefix}.main.{i}.model.2", t, res=h, res_h2=cx.h2, n_store=lp)
     for i in range(n_layer):
         h, _ = cx.conv3(h, f"{prefix}.main.{2 + 2 * i}", t, slope=0.2, n_store=dp if i == n_layer - 1 else lp)
     _, out = cx.conv3(h, f"{prefix}.main.{2 + 2 * n_layer}", t, want="f32")
@@ -624,11 +668,11 @@ class _WavEncoderMixin:
                         s0.append(torch.full((cout,), sl, device=pk.device))
                 else:
                     pk.conv(base + ".conv1", base + ".conv1", fold_bn=base + ".bn1",
-                            extra=(base + ".downsample.0", base + ".downsample.1") if ds else None)
+                            extra=(base + ".downsample.0", base + ".downsample.1") if ds else None, dt=pk.wav_dt)
                     n1 = cout * (2 if ds else 1)
                     pk.w[base + ".conv1"]["slope"] = torch.cat([torch.full((cout,), 0.01, device=pk.device),
                                                                 torch.ones(n1 - cout, device=pk.device)]).contiguous()
-                pk.conv(base + ".conv2", base + ".conv2", fold_bn=base + ".bn2")
+                pk.conv(base + ".conv2", base + ".conv2", fold_bn=base + ".bn2", dt=pk.wav_dt)
                 dev = pk.device
                 lrelu, ident = (lambda n: torch.full((n,), 0.01, device=dev)), (lambda n: torch.ones(n, device=dev))
                 if cout == _NARROW:                              # conv2 (stride 1, Cout -> Cout) over position pairs
@@ -665,7 +709,7 @@ class _WavEncoderMixin:
         blocks = self._wav_blocks()
         w_in = cx.pk.w["wav_in"]
         y0 = cx.lo(nwin * audio.shape[0] * lens[0], w_in["w"].shape[0])
-        ops.wav_conv_in(cx.dt, audio, w_in["w"], w_in["b"], w_in["slope"], y0, lens[0], blocks[0][2], blocks[0][3],
+        ops.wav_conv_in(cx.wdt, audio, w_in["w"], w_in["b"], w_in["slope"], y0, lens[0], blocks[0][2], blocks[0][3],
                         nwin=nwin, hop=hop, win_len=win_len)
         return y0
 
@@ -693,7 +737,7 @@ class _WavEncoderMixin:
             if i == 0 and wav is not None:
                 rows = slice(e * 2 * q, e * 2 * q + q), slice(e * 2 * q + q, (e + 1) * 2 * q)
                 x = cx.lo(b * lout, cout)
-                ops.wav_block0(cx.gdt, wav, w_in["w"][rows[0]], w_in["b"][rows[0]], 0.01, w_in["w"][rows[1]], w_in["b"][rows[1]],
+                ops.wav_block0(cx.wgdt, wav, w_in["w"][rows[0]], w_in["b"][rows[0]], 0.01, w_in["w"][rows[1]], w_in["b"][rows[1]],
                                stride, pad, c2["w"], c2["b"], cx.pk.slope(0.01, cout), k, k // 2, x, lout,
                                nwin=nwin, hop=hop, win_len=win_len, w_scale=c2.get("ws", 1.0))
                 lin = lout
@@ -704,7 +748,7 @@ class _WavEncoderMixin:
                 ent = cx.pk.w[base + ".conv1"]
                 if self.slab_convs and not ds and ops.conv_slab_supported(cout, k, stride) and cin == cout:
                     y = cx.lo(b * lout, cout)
-                    ops.conv_slab(cx.gdt, x, ent["w"], ent["b"], ent["slope"], None, y, nseq=b, l=lout, taps=k, pad=pad, w_scale=ent.get("ws", 1.0))
+                    ops.conv_slab(cx.wgdt, x, ent["w"], ent["b"], ent["slope"], None, y, nseq=b, l=lout, taps=k, pad=pad, w_scale=ent.get("ws", 1.0))
                 else:
                     y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout, n_store=_rup(ent["n"]))
                 y1, sc = (y[:, :cout], y[:, cout:2 * cout]) if ds else (y[:, :cout], x)
@@ -712,7 +756,7 @@ class _WavEncoderMixin:
             out = dest if (last and dest is not None and dest.shape[0] == b * lout) else None
             if slab2:
                 x = out if out is not None else cx.lo(b * lout, cout)
-                ops.conv_slab(cx.gdt, y1, c2["w"], c2["b"], cx.pk.slope(0.01, cout), sc, x, nseq=b, l=lout, taps=k, pad=k // 2, w_scale=c2.get("ws", 1.0))
+                ops.conv_slab(cx.wgdt, y1, c2["w"], c2["b"], cx.pk.slope(0.01, cout), sc, x, nseq=b, l=lout, taps=k, pad=k // 2, w_scale=c2.get("ws", 1.0))
             else:
                 x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
                                m=b * lout, out=out, n_store=0 if out is not None else _rup(cout))
@@ -740,7 +784,7 @@ class _WavEncoderMixin:
         outs = []
         for r in (slice(0, q), slice(q, 2 * q)):
             y = cx.lo(audio.shape[0] * lens[0], q)
-            ops.wav_conv_in(cx.dt, audio, w_in["w"][r], w_in["b"][r], w_in["slope"][r], y, lens[0], blocks[0][2], blocks[0][3])
+            ops.wav_conv_in(cx.wdt, audio, w_in["w"][r], w_in["b"][r], w_in["slope"][r], y, lens[0], blocks[0][2], blocks[0][3])
             outs.append(y)
         return outs
 
@@ -755,7 +799,7 @@ class _WavEncoderMixin:
         def slab_pairs(a, key, res, l):
             e = cx.pk.w[key]
             out = cx.lo(a.shape[0], _NARROW)
-            ops.conv_slab(cx.gdt, pairs(a), e["w"], e["b"], e["slope"], None if res is None else pairs(res), pairs(out),
+            ops.conv_slab(cx.wgdt, pairs(a), e["w"], e["b"], e["slope"], None if res is None else pairs(res), pairs(out),
                           nseq=b, l=l // 2, taps=e["taps"], pad=e["pad"], w_scale=e.get("ws", 1.0))
             return out
 
@@ -768,7 +812,7 @@ class _WavEncoderMixin:
                     ent = cx.pk.w[base + ".conv1"]
                     if not ds and ops.conv_slab_supported(cout, k, stride) and cin == cout:
                         y = cx.lo(b * lout, cout)
-                        ops.conv_slab(cx.gdt, x, ent["w"], ent["b"], ent["slope"], None, y, nseq=b, l=lout, taps=k, pad=pad, w_scale=ent.get("ws", 1.0))
+                        ops.conv_slab(cx.wgdt, x, ent["w"], ent["b"], ent["slope"], None, y, nseq=b, l=lout, taps=k, pad=pad, w_scale=ent.get("ws", 1.0))
                     else:
                         y, _ = cx.gemm(x, base + ".conv1", slope=ent["slope"], conv=(stride, pad, lin, lout), m=b * lout, n_store=_rup(ent["n"]))
                     y1, sc = (y[:, :cout], y[:, cout:2 * cout]) if ds else (y[:, :cout], x)
@@ -792,7 +836,7 @@ class _WavEncoderMixin:
                 c2 = cx.pk.w[base + ".conv2"]
                 if ops.conv_slab_supported(cout, k, 1):
                     x = out if out is not None else cx.lo(b * lout, cout)
-                    ops.conv_slab(cx.gdt, y1, c2["w"], c2["b"], cx.pk.slope(0.01, cout), sc, x, nseq=b, l=lout, taps=k, pad=k // 2, w_scale=c2.get("ws", 1.0))
+                    ops.conv_slab(cx.wgdt, y1, c2["w"], c2["b"], cx.pk.slope(0.01, cout), sc, x, nseq=b, l=lout, taps=k, pad=k // 2, w_scale=c2.get("ws", 1.0))
                 else:
                     x, _ = cx.gemm(y1, base + ".conv2", slope=0.01, res=sc, res_first=True, conv=(1, k // 2, lout, lout),
                                    m=b * lout, out=out, n_store=0 if out is not None else _rup(cout))
@@ -862,41 +906,52 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
     # The residual stream x is stored in the compute dtype (fp32 in parity mode, bf16 in bf16 mode): each
     # sub-layer's GEMM epilogue adds the residual and writes the pre-norm sum once, LayerNorm reads it once.
     def _self_attn(self, cx, name, x, b, t):
+        """x: _X.  Returns the pre-norm sum x + out_proj(attention) at residual precision."""
         d, h = self.config.hidden_size, spec.N_HEAD
         m = b * t
-        qk = cx.lo(m, 2 * d)
+        qk = cx.f32(m, 2 * d) if cx.h2 else cx.lo(m, 2 * d)          # the attention kernel reads float32 q / k / v^T in the split modes
         vt = cx.vt_buffer(b, d, t)
-        cx.gemm(x, name + ".sa.qkv", out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
+        if cx.h2:
+            cx.gemm(x.a, name + ".sa.qkv", out_f32=qk, out_t=vt, t_col0=2 * d, t_rows=t, want=None)
+        else:
+            cx.gemm(x.a, name + ".sa.qkv", out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
         att = cx.lo(m, d)
         ops.attention(cx.gdt, qk[:, :d], qk[:, d:], vt, d, att, b, h, t, t, d // h)
-        s, _ = cx.gemm(att, name + ".sa.out", res=x)
-        return s
+        return cx.gemm_r(att, name + ".sa.out", res=x.r, res_h2=x.h2r)
 
-    def _ln(self, cx, key, s, add=None):
+    def _ln(self, cx, key, s, add=None, want_f32=False):
+        """LayerNorm of a pre-norm sum (residual precision) -> _X; `add`: float32 / storage-type tensor folded in behind the norm.
+        want_f32 (EMAGE_H2 mode with H2 residuals): keep a float32 twin anyway (the result is later an `add` operand)."""
         n = cx.pk.w[key]
         y = cx.lo(*s.shape)
+        if cx.h2 and cx.h2res and not want_f32:
+            ops.layernorm(H2, s, n["g"], n["b"], 1e-5, add, None, y)
+            return _X(y, y, True)
+        if cx.h2:
+            yf = cx.f32(*s.shape)
+            ops.layernorm(H2, s, n["g"], n["b"], 1e-5, add, yf, y)
+            return _X(y, yf)
         ops.layernorm(cx.dt, s, n["g"], n["b"], 1e-5, add, None, y)
-        return y
+        return _X(y, y)
 
     def _ffn(self, cx, name, x):
-        f, _ = cx.gemm(x, name + ".ff1", slope=0.0)
-        s, _ = cx.gemm(f, name + ".ff2", res=x)
-        return s
+        f, _ = cx.gemm(x.a, name + ".ff1", slope=0.0)
+        return cx.gemm_r(f, name + ".ff2", res=x.r, res_h2=x.h2r)
 
-    def _encoder_layer(self, cx, name, x, b, t, post_add=None):
+    def _encoder_layer(self, cx, name, x, b, t, post_add=None, want_f32=False):
         """nn.TransformerEncoderLayer, post-norm, ReLU, no masks."""
         x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
-        return self._ln(cx, name + ".norm2", self._ffn(cx, name, x), add=post_add)
+        return self._ln(cx, name + ".norm2", self._ffn(cx, name, x), add=post_add, want_f32=want_f32)
 
     def _decoder_layer(self, cx, name, x, b, t, mem_k, mem_vt, vt_rows, tk, post_add=None):
-        """nn.TransformerDecoderLayer, post-norm, ReLU, no masks.  mem_k: (B*Tk, ld) view of this
+        """nn.TransformerDecoderLayer, post-norm, ReLU, no masks.  x: _X; mem_k: (B*Tk, ld) view of this
         layer's projected memory keys; mem_vt: view at this layer's first row of a (B, vt_rows, Tp) V^T buffer."""
         d, h = self.config.hidden_size, spec.N_HEAD
         x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
-        q, _ = cx.gemm(x, name + ".ca.q")
+        q = cx.gemm_r(x.a, name + ".ca.q")
         att = cx.lo(b * t, d)
         ops.attention(cx.gdt, q, mem_k, mem_vt, vt_rows, att, b, h, t, tk, d // h)
-        s, _ = cx.gemm(att, name + ".ca.out", res=x)
+        s = cx.gemm_r(att, name + ".ca.out", res=x.r, res_h2=x.h2r)
         x = self._ln(cx, name + ".norm2", s)
         return self._ln(cx, name + ".norm3", self._ffn(cx, name, x), add=post_add)
 
@@ -904,9 +959,13 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
         """Project a cross-attention memory for `n_layers` layers at once: K (B*Tk, n_layers*d) and
         V^T (B, n_layers*d, Tp)."""
         d = self.config.hidden_size
-        k = cx.lo(b * tk, n_layers * d)
         vt = cx.vt_buffer(b, n_layers * d, tk)
-        cx.gemm(mem_lo, key, out=k, out_t=vt, t_col0=n_layers * d, t_rows=tk)
+        if cx.h2:                                   # float32 K / V^T for the attention kernel
+            k = cx.f32(b * tk, n_layers * d)
+            cx.gemm(mem_lo, key, out_f32=k, out_t=vt, t_col0=n_layers * d, t_rows=tk, want=None)
+        else:
+            k = cx.lo(b * tk, n_layers * d)
+            cx.gemm(mem_lo, key, out=k, out_t=vt, t_col0=n_layers * d, t_rows=tk)
         return k, vt
 
     # ---- forward -------------------------------------------------------------------------
@@ -935,9 +994,13 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             a_face = self._wav_encoder_chain(cx, "audio_encoder_face", 0, y0, b, lens, dest=feats["memcat"][:, :af], **wkw)
             if ta > t:  # tail windows: face features trimmed to T, body features keep T' = T+1 (M:278-281, sic)
                 feats["memcat"][:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)
+            if cx.h2:   # the WavEncoder writes float32: convert the face-feature columns of the concatenation in place
+                ops.cast_pad(H2, feats["memcat"][:, :af], af, out=feats["memcat"][:, :af])
         with fk.lane(lane_body):
             a_body = self._wav_encoder_chain(cx, "audio_encoder_body", 1, y0, b, lens, **wkw)
             if use_audio:
+                if cx.h2:
+                    a_body = ops.cast_pad(H2, a_body, a_body.shape[1])
                 mem_body, _ = cx.gemm(a_body, "audio_body_motion_proj")                 # M:303
                 feats["bk"], feats["bvt"] = self._memory_kv(cx, "cross.kv_all", mem_body, b, ta, nc)
         feats["_keep"] = (y0, a_face, a_body)       # cross-lane operands stay alive until the caller's join
@@ -952,9 +1015,16 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
         spk_body = ops.gather_rows(pk.w["spk_body"], sid, F32)              # (M,d) fp32
         spk_face = ops.gather_rows(pk.w["spk_face"], sid, F32)
         pe = pk.w["pe"][:t]
-        face0, pos_spk = cx.lo(m, d), cx.lo(m, d)
-        ops.add(cx.dt, spk_face, pe, out=face0, mod_b=t)                    # position_embeddings(speaker_face)
-        ops.add(cx.dt, spk_body, pe, out=pos_spk, mod_b=t)                  # speaker_body + pe, used twice
+        face0, pos_spk = cx.lo(m, d), (cx.f32(m, d) if cx.h2 else cx.lo(m, d))
+        if cx.h2:       # face0 enters the face decoder as operand AND residual; pos_spk is only ever added (residual precision)
+            face0_r = cx.f32(m, d)
+            ops.add(H2, spk_face, pe, out_f32=face0_r, out=face0, mod_b=t)
+            ops.add(F32, spk_body, pe, out=pos_spk, mod_b=t)
+            face0 = _X(face0, face0_r)
+        else:
+            ops.add(cx.dt, spk_face, pe, out=face0, mod_b=t)                # position_embeddings(speaker_face)
+            ops.add(cx.dt, spk_body, pe, out=pos_spk, mod_b=t)              # speaker_body + pe, used twice
+            face0 = _X(face0, face0)
         return dict(spk_body=spk_body, face0=face0, pos_spk=pos_spk, t=t)
 
     def forward(self, audio, speaker_id, masked_motion, mask, use_audio=True, _audio_feats=None, _tables=None, _lean=False,
@@ -967,7 +1037,7 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
         classifier of a latent-routed part, the fp32 copy of a classified part's latent).
         audio / masked_motion / mask may be windows (views) of longer clip tensors: they are read in place."""
         c = self.config
-        cx = _Ctx(self._engine())
+        cx = _Ctx(self._engine(), self.h2_residual)
         pk = cx.pk
         dev = cx.dev
         b, t, cm = masked_motion.shape
@@ -1016,15 +1086,16 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                 for i in range(nf):
                     face = self._decoder_layer(cx, f"face_motion_decoder.layers.{i}", face, b, t,
                                                fkk[:, i * d:(i + 1) * d], fvt[:, i * d:], nf * d, t)
-                rec_lo, out["rec_face"] = cx.gemm(face, "face_out_proj", want="both")
+                rec_lo, out["rec_face"] = cx.gemm(face.a, "face_out_proj", want="both")
                 if not (_lean and c_of["face"] == 0):
                     hc, _ = cx.gemm(rec_lo, "face_cls.fc1", slope=0.1)
                     _, out["cls_face"] = cx.gemm(hc, "face_cls.fc2", want="f32")
 
             with fk.lane(0):
                 # body branch: temporal self-attention (M:297-300)
-                x, _ = cx.gemm(hint_body, "moton_proj", res=pos_spk)
-                x = self._encoder_layer(cx, "motion_self_encoder.layers.0", x, b, t, post_add=pos_spk)   # + speaker + pe (M:304-305)
+                x = cx.gemm_x(hint_body, "moton_proj", res=pos_spk)
+                x = self._encoder_layer(cx, "motion_self_encoder.layers.0", x, b, t, post_add=pos_spk,   # + speaker + pe (M:304-305)
+                                        want_f32=use_audio)          # `base`: added behind the last cross-attention layer's norm
             # audio cross-attention stack (M:303-312) needs lane 2's projected memory
             if use_audio:
                 fk.after(0, 2)
@@ -1033,13 +1104,13 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                     for i in range(nc):
                         x = self._decoder_layer(cx, f"audio_motion_cross_attn.layers.{i}", x, b, t,
                                                 bk[:, i * d:(i + 1) * d], bvt[:, i * d:], nc * d, ta,
-                                                post_add=base if i == nc - 1 else None)             # motion_fea + cross
+                                                post_add=base.r if i == nc - 1 else None)           # motion_fea + cross
             with fk.lane(0):
                 # part latents (M:315-317)
-                hl, _ = cx.gemm(x, "motion2latent.fc1", slope=0.1)               # (M, 3d)
+                hl, _ = cx.gemm(x.a, "motion2latent.fc1", slope=0.1)             # (M, 3d)
                 lat = {}
-                for i, p in enumerate(parts):
-                    lat[p], _ = cx.gemm(hl[:, i * d:(i + 1) * d], f"motion2latent_{p}.fc2")
+                for i, p in enumerate(parts):           # the part latents are only ever added: residual precision
+                    lat[p] = cx.gemm_r(hl[:, i * d:(i + 1) * d], f"motion2latent_{p}.fc2")
             # refinement + heads (M:320-330): three independent chains; "upper" stays on lane 0, "lower" takes
             # lane 2 (idle by now), "hands" queues behind the face decoder on lane 1
             lane_of = {"upper": 0, "hands": 1, "lower": 2}
@@ -1048,13 +1119,19 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             for p in parts:
                 with fk.lane(lane_of[p]):
                     tgt, mem_lo = cx.lo(m, d), cx.lo(m, d)
-                    ops.add(cx.dt, lat[p], spk_body, out=tgt)
+                    if cx.h2:
+                        tgt_r = cx.f32(m, d)
+                        ops.add(H2, lat[p], spk_body, out_f32=tgt_r, out=tgt)
+                        tgt = _X(tgt, tgt_r)
+                    else:
+                        ops.add(cx.dt, lat[p], spk_body, out=tgt)
+                        tgt = _X(tgt, tgt)
                     ops.add(cx.dt, lat[others[p][0]], lat[others[p][1]], out=mem_lo)
                     name = f"body_motion_decoder_{p}.layers.0"
                     k1, vt1 = self._memory_kv(cx, name + ".ca.kv", mem_lo, b, t, 1)
                     ref = self._decoder_layer(cx, name, tgt, b, t, k1, vt1, d, t)
                     sum_lo = cx.lo(m, d)
-                    ops.add(cx.dt, lat[p], ref, out=sum_lo)
+                    ops.add(cx.dt, lat[p], ref.r, out=sum_lo, h2_operands=(1,) if ref.h2r else ())
                     lean_cls = _lean and c_of[p] > 0         # decode takes the arg-max code: rec_* fp32 copy unused
                     rec_lo, out[f"rec_{p}"] = cx.gemm(sum_lo, f"motion_out_proj_{p}", want="lo" if lean_cls else "both")
                     if not (_lean and c_of[p] == 0):

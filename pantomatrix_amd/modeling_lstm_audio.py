@@ -34,6 +34,8 @@ class CamnAudioConfig(_AttrConfig):
 
 
 class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
+    _supports_h2 = False          # float32 activations: the recurrence kernels split h_{t-1} once per step in LDS themselves
+
     def __init__(self, config):
         super().__init__(config)
         self._dt = F16X3

@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, F16X3, check, EmageKernelError
+from ._lib import F32, BF16, F16X3, H2, check, EmageKernelError
 
 _LIBRARY = torch.library.Library("emage", "DEF")
 
@@ -25,7 +25,8 @@ def _op(name, schema):
     return deco
 
 # storage type of activations per precision code; F16X3 is a GEMM-only operand mode over float32 storage
-TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32}
+# H2: the pre-split storage of the split-fp16 mode (csrc/h2.h) — float32-sized elements, 32-byte groups of 8 columns = [8 fp16 hi | 8 fp16 lo]
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32, H2: torch.float32}
 A_SCALE_F16X3 = 16.0    # activations are multiplied by this power of two before the fp16 hi/lo split (|x| < 4094 stays finite)
 
 
@@ -49,6 +50,43 @@ def split_f16_weights(w2d):
     packed = torch.stack([chunked(hi), chunked(lo)], dim=2).reshape(n, 2 * k).contiguous()
     return packed.view(torch.float32), scale
 
+
+
+def _f16_scale(w):
+    import math
+    mx = float(w.abs().max()) if w.numel() else 0.0
+    return 2.0 ** (12 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+
+
+def h2_pack(x, scale=A_SCALE_F16X3):
+    """(..., C) fp32, C % 8 == 0 -> the EMAGE_H2 image (csrc/h2.h) as a float32-typed tensor of the same shape: every group of
+    8 columns becomes [8 fp16 hi | 8 fp16 lo] with x * scale = hi + lo.  Host-side helper (weights, tests, tools); on the hot
+    path the kernels' epilogues write this format themselves."""
+    c = x.shape[-1]
+    assert c % 8 == 0
+    xs = x.to(torch.float32) * scale
+    hi = xs.to(torch.float16)
+    lo = (xs - hi.to(torch.float32)).to(torch.float16)
+    g = torch.stack([hi.reshape(*x.shape[:-1], c // 8, 8), lo.reshape(*x.shape[:-1], c // 8, 8)], dim=-2)
+    return g.reshape(*x.shape[:-1], 2 * c).contiguous().view(torch.float32)
+
+
+def h2_unpack(t, scale=A_SCALE_F16X3):
+    """Inverse of `h2_pack` (up to the 2^-22 relative residual of the split): float32-typed H2 image -> fp32 values."""
+    c = t.shape[-1]
+    assert c % 8 == 0
+    g = t.contiguous().view(torch.float16).reshape(*t.shape[:-1], c // 8, 2, 8).to(torch.float32)
+    return ((g[..., 0, :] + g[..., 1, :]) / scale).reshape(*t.shape[:-1], c)
+
+
+def split_f16_weights_h2(w2d):
+    """Host packing of an (N, K) fp32 weight matrix for EMAGE_H2 (K % 32 == 0): the H2 image of W * w_scale, natural k order
+    (the same layout the activations use).  Returns (packed (N, K) float32-typed, w_scale)."""
+    n, k = w2d.shape
+    assert k % 32 == 0
+    w = w2d.to(torch.float32)
+    scale = _f16_scale(w)
+    return h2_pack(w, scale), scale
 
 
 def _ptr(t):
@@ -144,10 +182,10 @@ def gather_rows(table, idx, dtype, n_store=None):
 
 @_op("gemm", "(int dtype, Tensor a, Tensor w, Tensor? bias, Tensor? slope, Tensor? res, Tensor(a!)? out, Tensor(b!)? out_f32, "
              "Tensor(c!)? out_t, int n, int cp, int n_store, int t_col0, int t_rows, bool res_first, int taps, int stride, int pad, "
-             "int lin, int lout, int m, float w_scale, float a_scale) -> ()")
+             "int lin, int lout, int m, float w_scale, float a_scale, bool res_h2) -> ()")
 def _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, res_first, taps, stride, pad, lin, lout, m,
-          w_scale, a_scale):
-    res_f32 = 1 if (res is not None and res.dtype == torch.float32) else 0
+          w_scale, a_scale, res_h2):
+    res_f32 = 1 if (res is not None and res.dtype == torch.float32 and not res_h2) else 0
     t_ld = out_t.shape[-1] if out_t is not None else 0
     check(_lib.load().emage_gemm(dtype, _ptr(a), _ld(a), _ptr(w), _ptr(bias), _ptr(slope),
                                  _ptr(res), _ld(res) if res is not None else 0, res_f32, 1 if res_first else 0,
@@ -159,16 +197,17 @@ def _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None, w_scale=1.0, a_scale=None):
+         k_real=None, w_scale=1.0, a_scale=None, res_h2=False):
     """See include/emage_hip.h:emage_gemm.  `a` (rows, lda) and `w` (n, taps*cp) are in `dtype`.  `k_real` (the
     unpadded contraction length) is bookkeeping for bench.py's algorithmic-flop count; the kernel ignores it.
-    dtype F16X3: `a` is float32, `w` / `w_scale` come from `split_f16_weights`."""
+    dtype F16X3: `a` is float32, `w` / `w_scale` come from `split_f16_weights`.  dtype H2: `a` / `out` are H2 images
+    (float32-typed), `w` / `w_scale` from `split_f16_weights_h2`, `res` fp32 or (res_h2) an H2 image, `out_f32` / `out_t` fp32."""
     _dev(a)
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin
     lout = m if lout is None else lout
     _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
-          lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale))
+          lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2))
 
 
 @_op("wav_conv_in", "(int dtype, Tensor wav, Tensor w, Tensor? bias, Tensor? slope, Tensor(a!) out, int lout, int stride, int pad, "
@@ -617,15 +656,19 @@ def _add(dtype, a, b, c, out_f32, out, mod_b, mod_c, f32_mask):
                                 f32_mask, _ptr(out_f32), _ptr(out), ldo, m, n, _stream()), "add")
 
 
-def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
-    """out = a + b[m % mod_b] (+ c); each operand may be fp32 or `dtype` (detected from the tensor)."""
+def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0, h2_operands=()):
+    """out = a + b[m % mod_b] (+ c); each operand may be fp32 or `dtype` (detected from the tensor; dtype H2: every operand
+    is float32 unless its position (0 = a, 1 = b, 2 = c) is listed in `h2_operands`; `out` is then an H2 image)."""
     _dev(a)
     m, n = a.shape
     mask = 0
     for bit, t in enumerate((a, b, c)):
         if t is not None:
             assert t.dtype in (torch.float32, TORCH_DTYPE[dtype])
-            mask |= (1 << bit) if t.dtype == torch.float32 else 0
+            if dtype == H2:
+                mask |= 0 if bit in h2_operands else (1 << bit)
+            else:
+                mask |= (1 << bit) if t.dtype == torch.float32 else 0
     if out_f32 is not None and out is not None:
         assert _ld(out) == _ld(out_f32)
     _add(dtype, a, b, c, out_f32, out, mod_b, mod_c, mask)
@@ -666,10 +709,15 @@ def _cast_pad(dtype, src, out):
     check(_lib.load().emage_cast_pad(dtype, _ptr(src), _ld(src), _ptr(out), _ld(out), out.shape[1], m, c, _stream()), "cast_pad")
 
 
-def cast_pad(dtype, src2d, n_store):
+def cast_pad(dtype, src2d, n_store, out=None):
+    """fp32 (M, C) view -> (M, n_store) in `dtype` with a zero tail.  dtype H2 with `out` aliasing `src2d` (same view) converts
+    in place."""
     _dev(src2d)
     m, c = src2d.shape
-    out = torch.empty(m, n_store, dtype=TORCH_DTYPE[dtype], device=src2d.device)
+    if out is None:
+        out = torch.empty(m, n_store, dtype=TORCH_DTYPE[dtype], device=src2d.device)
+    else:
+        assert out.shape == (m, n_store) and out.stride(1) == 1
     _cast_pad(dtype, src2d, out)
     return out
 

@@ -126,6 +126,53 @@ class ClipRunner:
                                      "|x| < 4094 overflows the fp16 planes — run this checkpoint with set_precision('fp32')")
 
 
+class ClipPipeline:
+    """`depth` ClipRunners (own buffers, own captured graph, shared read-only weights) on `depth` streams: batch i is launched on
+    slot i % depth while earlier batches are still in flight.  A batch is a chain of ~300 DEPENDENT launches (the autoregressive
+    windows; the cross-attention stack waits for the waveform features), each with a ramp and a drain during which most of the
+    chip idles; consecutive batches are independent, so the next batch's kernels fill those gaps.  Results are returned in
+    submission order; every batch is complete (poses / expressions / translation in its slot's pinned host buffers, health
+    counter checked) when `collect()` hands it out."""
+
+    def __init__(self, model, vq_model, batch: int, n_samples: int, depth: int = 2, use_graph: bool = True):
+        self.runners = [ClipRunner(model, vq_model, batch, n_samples, use_graph=use_graph) for _ in range(depth)]
+        self.device = self.runners[0].device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        self.done = [torch.cuda.Event() for _ in range(depth)]
+        self.depth, self.frames_out, self.batch = depth, self.runners[0].frames_out, batch
+        self._next, self._inflight = 0, []
+
+    def submit(self, audio=None, speaker_id=None):
+        """Launch one batch (audio (B, L) float32 on the device or in pinned host memory); blocks only when `depth` batches are
+        already in flight (then the oldest is collected first and returned)."""
+        ready = self.collect() if len(self._inflight) == self.depth else None
+        slot = self._next
+        self._next = (slot + 1) % self.depth
+        r, s = self.runners[slot], self.streams[slot]
+        s.wait_stream(torch.cuda.current_stream(self.device))       # the caller's writes to `audio` are ordered before the copy
+        with torch.cuda.stream(s):
+            r.run_device(audio, speaker_id)
+            r._to_host(r.host)
+            r.nonfinite_host.copy_(r.nonfinite, non_blocking=True)
+            self.done[slot].record(s)
+        self._inflight.append(slot)
+        return ready
+
+    def collect(self):
+        """Wait for the OLDEST batch in flight; returns its (poses, expressions, trans) numpy arrays (views of the slot's pinned
+        buffers, valid until that slot is reused `depth` submissions later)."""
+        slot = self._inflight.pop(0)
+        self.done[slot].synchronize()
+        self.runners[slot]._raise_if_nonfinite()
+        return tuple(h.numpy() for h in self.runners[slot].host)
+
+    def drain(self):
+        out = []
+        while self._inflight:
+            out.append(self.collect())
+        return out
+
+
 class LstmClipRunner:
     """One DisCo / CaMN forward (WavEncoder, input projections, one persistent `emage_lstm_layer` launch per LSTM layer — or, in
     the exact-fp32 mode, one `emage_lstm_step_pair` launch per time step —, output MLPs, rot-6D -> axis-angle) captured as ONE

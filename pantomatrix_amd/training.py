@@ -538,7 +538,7 @@ class TrainForward:
         tape=True keeps what `backward()` needs (see there)."""
         model = self.model
         c = model.config
-        cx = _Ctx(model._engine())
+        cx = _Ctx(model._engine(h2=False))       # the training forward keeps float32 activations (split inside the GEMMs in f16x3)
         pk, dev = cx.pk, cx.dev
         self._train_pack(pk)
         self.tape = _Tape(dev) if tape else None

@@ -14,9 +14,9 @@ import torch
 
 from pantomatrix_amd import modeling_emage_audio as M
 from pantomatrix_amd import ops
-from pantomatrix_amd._lib import BF16, F32, F16X3
+from pantomatrix_amd._lib import BF16, F32, F16X3, H2
 
-TD = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32}
+TD = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32, H2: torch.float32}
 CALLS = []
 
 
@@ -31,9 +31,28 @@ def unsplit_f16_weights(packed, n, k):
     return nat[0], nat[1]
 
 
+def h2_planes(img2d, cols, scale=None):
+    """(rows, >= cols) float32-typed EMAGE_H2 image (csrc/h2.h: 32-byte groups [8 hi | 8 lo]) -> (hi, lo) fp32 planes of x * scale."""
+    assert cols % 8 == 0 and img2d.stride(1) == 1 and img2d.stride(0) % 8 == 0 and img2d.storage_offset() % 8 == 0
+    rows = img2d.shape[0]
+    g = torch.as_strided(img2d, (rows, cols), (img2d.stride(0), 1)).contiguous().view(torch.float16).reshape(rows, cols // 8, 2, 8).float()
+    return g[:, :, 0, :].reshape(rows, cols), g[:, :, 1, :].reshape(rows, cols)
+
+
+def h2_values(img2d, cols):
+    hi, lo = h2_planes(img2d, cols)
+    return (hi + lo) / ops.A_SCALE_F16X3
+
+
+def h2_store(dst2d, values):
+    """Write fp32 `values` (rows, cols), cols % 8 == 0, into the first cols logical columns of the H2 image dst2d."""
+    rows, cols = values.shape
+    torch.as_strided(dst2d, (rows, cols), (dst2d.stride(0), 1))[:] = ops.h2_pack(values.float())
+
+
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None, w_scale=1.0, a_scale=None):
+         k_real=None, w_scale=1.0, a_scale=None, res_h2=False):
     CALLS.append("gemm")
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin
@@ -44,7 +63,11 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
     nb = m // lout
     assert a.shape[0] >= nb * lin, (a.shape, nb, lin)
     # read exactly what the kernel reads: cp columns from the row start, even beyond a.shape[1]
-    af = torch.as_strided(a, (nb * lin, cp), (a.stride(0), 1)).float()
+    if dtype == H2:
+        a_hi, a_lo = h2_planes(torch.as_strided(a, (nb * lin, cp), (a.stride(0), 1)), cp)
+        af = torch.cat([a_hi, a_lo], dim=1)          # both planes ride through the row gather below
+    else:
+        af = torch.as_strided(a, (nb * lin, cp), (a.stride(0), 1)).float()
     assert torch.isfinite(af).all(), "padded channels of A must be finite"
     rows = torch.arange(m)
     b_, l_ = rows // lout, rows % lout
@@ -55,7 +78,15 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         r = (b_ * lin + pos.clamp(0, lin - 1))
         cols.append(af[r] * valid[:, None].float())
     x = torch.cat(cols, dim=1)                                   # (M, taps*cp)
-    if dtype == F16X3:
+    if dtype == H2:
+        # both operands arrive pre-split: A planes hold x * 16, W planes w * w_scale (natural k order)
+        sa = ops.A_SCALE_F16X3 if a_scale is None else a_scale
+        xt = x.view(m, taps, 2, cp)
+        xh, xl = xt[:, :, 0].reshape(m, taps * cp).double(), xt[:, :, 1].reshape(m, taps * cp).double()
+        wh, wl = h2_planes(w, taps * cp)
+        wh, wl = wh.double(), wl.double()
+        v = ((xh @ wh.t() + (xh @ wl.t() + xl @ wh.t())) / (sa * w_scale)).float()
+    elif dtype == F16X3:
         # the kernel's arithmetic: fp16 hi/lo planes of A * a_scale against the host-split planes of W * w_scale,
         # hi*hi + hi*lo + lo*hi (the lo*lo term is dropped), accumulated wide, scaled back by exact powers of two
         sa = ops.A_SCALE_F16X3 if a_scale is None else a_scale
@@ -73,7 +104,12 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
     rv = 0.0
     if res is not None:
         assert res.stride(1) == 1
-        rv = torch.as_strided(res, (m, n), (res.stride(0), 1)).float()
+        if res_h2:
+            assert dtype == H2
+            n8 = (n + 7) // 8 * 8
+            rv = h2_values(torch.as_strided(res, (m, n8), (res.stride(0), 1)), n8)[:, :n]
+        else:
+            rv = torch.as_strided(res, (m, n), (res.stride(0), 1)).float()
     if res_first:
         v = v + rv
     if slope is not None:
@@ -82,7 +118,13 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
     if not res_first:
         v = v + rv
     ncol_n = n if out_t is None else t_col0
-    if out is not None:
+    if out is not None and dtype == H2:
+        width = (max(ncol_n, n_store) + 7) // 8 * 8
+        assert out.stride(0) >= width and out.stride(0) % 8 == 0
+        full = torch.zeros(m, width)
+        full[:, :ncol_n] = v[:, :ncol_n]
+        h2_store(out, full)
+    elif out is not None:
         assert out.dtype == TD[dtype]
         o = torch.as_strided(out, (m, max(ncol_n, n_store)), (out.stride(0), 1))
         o[:, :ncol_n] = v[:, :ncol_n].to(TD[dtype])
@@ -100,6 +142,11 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
 
 
 def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
+    if dtype == H2:          # float32 q / k / v^T, the output as an H2 image
+        o = torch.empty(b * tq, h * hd)
+        attention(F16X3, q, k, vt, vt_rows, o, b, h, tq, tk, hd)
+        h2_store(out, o)
+        return
     CALLS.append("attention")
     tp = vt.shape[-1]
     assert tp % 32 == 0 and tp >= tk and tk <= 128 and hd == 192
@@ -331,20 +378,27 @@ def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
     if y_f32 is not None:
         y_f32[:] = v
     if y is not None:
-        y[:] = v.to(TD[dtype])
+        if dtype == H2:      # x / add / y_f32 are float32, y the H2 copy
+            h2_store(y, v)
+        else:
+            y[:] = v.to(TD[dtype])
 
 
-def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0):
+def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0, h2_operands=()):
     CALLS.append("add")
-    m = a.shape[0]
+    m, n = a.shape
     r = torch.arange(m)
-    v = a.float() + b.float()[r % mod_b if mod_b else r]
+    val = lambda t, bit: h2_values(t, n) if (dtype == H2 and bit in h2_operands) else t.float()
+    v = val(a, 0) + val(b, 1)[r % mod_b if mod_b else r]
     if c is not None:
-        v = v + c.float()[r % mod_c if mod_c else r]
+        v = v + val(c, 2)[r % mod_c if mod_c else r]
     if out_f32 is not None:
         out_f32[:] = v
     if out is not None:
-        out[:] = v.to(TD[dtype])
+        if dtype == H2:
+            h2_store(out, v)
+        else:
+            out[:] = v.to(TD[dtype])
 
 
 def pack_motion(dtype, motion, mask, emb, n_store, seed=None):
@@ -361,14 +415,20 @@ def pack_motion(dtype, motion, mask, emb, n_store, seed=None):
         mask[:, :pre] = 0
     out = torch.zeros(b * t, n_store, dtype=TD[dtype])
     out[:, :c] = torch.where(mask == 1, emb.expand_as(motion), motion).reshape(b * t, c).to(TD[dtype])
-    return out
+    return ops.h2_pack(out) if dtype == H2 else out
 
 
-def cast_pad(dtype, src2d, n_store):
+def cast_pad(dtype, src2d, n_store, out=None):
     CALLS.append("cast_pad")
     m, c = src2d.shape
-    out = torch.zeros(m, n_store, dtype=TD[dtype])
-    out[:, :c] = src2d.to(TD[dtype])
+    full = torch.zeros(m, n_store, dtype=TD[dtype])
+    full[:, :c] = src2d.to(TD[dtype])
+    if dtype == H2:
+        full = ops.h2_pack(full)
+    if out is None:
+        return full
+    assert out.shape == (m, n_store)
+    out[:] = full                                  # in place when out aliases src2d (the values were read above)
     return out
 
 
@@ -380,7 +440,7 @@ def gather_rows(table, idx, dtype, n_store=None):
         ops.index_view(idx)                       # the strides the kernel would be handed must be supported
     out = torch.zeros(idx.numel(), n_store, dtype=TD[dtype])
     out[:, :d] = table[idx.reshape(-1)].to(TD[dtype])
-    return out
+    return ops.h2_pack(out) if dtype == H2 else out
 
 
 def _store_idx(res, out):
@@ -580,9 +640,11 @@ def installed():
     saved = {n: getattr(ops, n) for n in _NAMES}
     saved_engine = M._EmageModule._engine
 
-    def _engine(self):
-        if self._packed is None:
-            self._packed = M._Packed(self._flat_params(), self.device, self._dt)
+    def _engine(self, h2=None):
+        want_h2 = self._dt == F16X3 and self._supports_h2 and (self.split_acts if h2 is None else h2)
+        dt = H2 if want_h2 else self._dt
+        if self._packed is None or self._packed.dt != dt:
+            self._packed = M._Packed(self._flat_params(), self.device, dt)
             self._pack(self._packed)
         return self._packed
 

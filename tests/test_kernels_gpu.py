@@ -405,3 +405,145 @@ def test_wav_block0_equals_unfused_bitwise(dtype, nclip, nwin):
                    got, lout, nwin=nwin, hop=hop, win_len=win, w_scale=ws)
     torch.cuda.synchronize()
     assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+
+
+# ---- EMAGE_H2: pre-split activation storage (csrc/h2.h) -------------------------------------------------------------------
+from pantomatrix_amd._lib import H2  # noqa: E402
+
+H2_GEMM_CASES = [c for c in GEMM_CASES if c[0] not in ("conv15_s6", "conv15_s1_resfirst", "conv15_s3")] + [
+    ("h2_kv_all", (4, 64, 64), 768, 3072, 1, 1, 0, dict(bias=True, vt=1536)),
+    ("h2_ragged_tail", (2, 65, 65), 512, 1536, 1, 1, 0, dict(bias=True, vt=768)),
+    ("h2_out106_f32", (2, 29, 29), 106, 106, 3, 1, 1, dict(bias=True, want="f32")),
+    ("h2_res_h2", (3, 64, 64), 256, 256, 3, 1, 1, dict(bias=True, res="h2", n_store=256)),
+    ("h2_small_m", (1, 17, 17), 256, 256, 3, 1, 1, dict(bias=True, slope=0.2)),
+]
+
+
+def _run_h2_gemm(case, mod, dev, cfg=None):
+    name, (nb, lin, lout), cin, n, taps, stride, pad, fl = case
+    g = _g(hash(name) % 1000)
+    cp = ops.round_up(cin, 64)
+    m = nb * lout
+    a = torch.zeros(nb * lin, cp)
+    a[:, :cin] = torch.randn(nb * lin, cin, generator=g)
+    w = torch.zeros(n, taps, cp)
+    w[:, :, :cin] = torch.randn(n, taps, cin, generator=g) / math.sqrt(cin * taps)
+    w_h2, ws = ops.split_f16_weights_h2(w.reshape(n, taps * cp))
+    bias = torch.randn(n, generator=g) * 0.1 if fl.get("bias") else None
+    slope = torch.full((n,), float(fl["slope"])) if "slope" in fl else None
+    n8 = ops.round_up(n, 8)
+    res, res_h2 = None, False
+    if fl.get("res") in ("f32", "lo"):
+        res = torch.randn(m, n8, generator=g)[:, :n]
+    elif fl.get("res") == "h2":
+        res, res_h2 = ops.h2_pack(torch.randn(m, n8, generator=g)), True
+    n_store = fl.get("n_store", 0)
+    want = fl.get("want", "lo")
+    vt0 = fl.get("vt")
+    ncol = vt0 if vt0 else n
+    mv = lambda t: None if t is None else t.to(dev)
+    out = torch.full((m, ops.round_up(max(ncol, n_store), 8)), 7.0, device=dev) if want in ("lo", "both") else None
+    out_f = torch.full((m, ncol), 7.0, device=dev) if want in ("f32", "both") else None
+    out_t = torch.zeros(nb, n - vt0, ops.round_up(lout, 32), device=dev) if vt0 else None
+    mod.gemm(H2, mv(ops.h2_pack(a)), mv(w_h2), mv(bias), mv(slope), mv(res), out, out_f, out_t, n=n, cp=cp, n_store=n_store,
+             t_col0=vt0 or 0, t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m, w_scale=ws, res_h2=res_h2)
+    vals = None if out is None else ops.h2_unpack(out)
+    return vals, out_f, out_t, max(ncol, n_store)
+
+
+@pytest.mark.parametrize("case", H2_GEMM_CASES, ids=[c[0] for c in H2_GEMM_CASES])
+def test_gemm_h2(case):
+    """EMAGE_H2 contraction (pre-split operands, csrc/gemm_h2.hip) against the CPU restatement of the same three-product
+    arithmetic: row-major, zero-filled tail, float32 copy, transposed (V^T) destination, float32 / H2 residuals."""
+    got = _run_h2_gemm(case, ops, DEV)
+    torch.cuda.synchronize()
+    ref = _run_h2_gemm(case, F, "cpu")
+    for nm, gt, rf in zip(("out", "out_f32", "out_t"), got[:3], ref[:3]):
+        if gt is not None:
+            width = got[3] if nm == "out" else gt.shape[-1]
+            _cmp(f"{case[0]}.{nm}", gt[..., :width], rf[..., :width], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", [100, 101, 102, 103, 105, 107, 108, 110, 111, 113, 115, 116, 119, 120, 121, 122, 123, 124, 125, 127, 130, 131, 141, 144, 148, 150])
+def test_gemm_h2_every_tile_configuration(cfg):
+    """Every EMAGE_H2 tile configuration (wave grids, loader waves, register-pipelined / interleaved K-loops, odd fragment
+    counts) on a ragged shape with a transposed tail and on a convolution with a zero-filled channel tail."""
+    from pantomatrix_amd import _lib
+    lib = _lib.load()
+    cases = [("h2cfg_vt", (3, 70, 70), 768, 2304, 1, 1, 0, dict(bias=True, vt=1536)),
+             ("h2cfg_conv", (3, 37, 37), 337, 106, 3, 1, 1, dict(bias=True, slope=0.2, n_store=128, res=None, want="both"))]
+    try:
+        for case in cases:
+            lib.emage_set_tuning(4, cfg)
+            try:
+                got = _run_h2_gemm(case, ops, DEV)
+            except Exception as e:  # noqa: BLE001  (a tile that does not divide t_col0 is refused, not wrong)
+                assert "EINVAL" in str(e) and case[0] == "h2cfg_vt", (cfg, e)
+                continue
+            torch.cuda.synchronize()
+            lib.emage_set_tuning(4, -1)
+            ref = _run_h2_gemm(case, F, "cpu")
+            for nm, gt, rf in zip(("out", "out_f32", "out_t"), got[:3], ref[:3]):
+                if gt is not None:
+                    width = got[3] if nm == "out" else gt.shape[-1]
+                    _cmp(f"cfg{cfg}.{case[0]}.{nm}", gt[..., :width], rf[..., :width], atol=2e-5, rtol=1e-5)
+    finally:
+        lib.emage_set_tuning(4, -1)
+
+
+def test_h2_elementwise_producers():
+    """Every producer of EMAGE_H2 images against the CPU restatement: LayerNorm (float32 twin + H2 copy), add (float32 and H2
+    operands), pack_motion, cast_pad (also in place), gather_rows, attention."""
+    g = _g(11)
+    x = torch.randn(1000, 768, generator=g) * 3 + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
+    addt = torch.randn(1000, 768, generator=g)
+    for add in (None, addt):
+        yf_c, y_c = torch.zeros(1000, 768), torch.zeros(1000, 768)
+        F.layernorm(H2, x, gamma, beta, 1e-5, add, yf_c, y_c)
+        yf, y = torch.zeros(1000, 768, device=DEV), torch.zeros(1000, 768, device=DEV)
+        ops.layernorm(H2, x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, None if add is None else add.to(DEV), yf, y)
+        _cmp("layernorm.f32", yf, yf_c, atol=2e-5)
+        # the H2 copy is the split of the kernel's own float32 result, bit for bit
+        assert torch.equal(y.cpu().view(torch.int32), ops.h2_pack(yf.cpu()).view(torch.int32))
+        # and identical to what the float32 LayerNorm kernel writes
+        y32 = torch.zeros(1000, 768, device=DEV)
+        ops.layernorm(F32, x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, None if add is None else add.to(DEV), None, y32)
+        assert torch.equal(y32, yf)
+    a, b2, c = torch.randn(640, 768, generator=g), torch.randn(64, 768, generator=g), torch.randn(640, 768, generator=g)
+    c_h2 = ops.h2_pack(c)
+    of_c, o_c = torch.zeros(640, 768), torch.zeros(640, 768)
+    F.add(H2, a, b2, c_h2, of_c, o_c, mod_b=64, h2_operands=(2,))
+    of, o = torch.zeros(640, 768, device=DEV), torch.zeros(640, 768, device=DEV)
+    ops.add(H2, a.to(DEV), b2.to(DEV), c_h2.to(DEV), of, o, mod_b=64, h2_operands=(2,))
+    assert torch.equal(of.cpu(), of_c) and torch.equal(o.cpu().view(torch.int32), o_c.view(torch.int32))
+    clip_m, clip_k = torch.randn(5, 70, 337, generator=g), (torch.rand(5, 70, 337, generator=g) > 0.5).float()
+    emb, prev = torch.randn(337, generator=g), torch.randn(5, 17, 337, generator=g)
+    for seed in (False, True):
+        ref = F.pack_motion(H2, clip_m[:, 30:56], clip_k[:, 30:56], emb, 384, seed=prev[:, 13:] if seed else None)
+        got = ops.pack_motion(H2, clip_m.to(DEV)[:, 30:56], clip_k.to(DEV)[:, 30:56], emb.to(DEV), 384, seed=prev.to(DEV)[:, 13:] if seed else None)
+        assert torch.equal(got.cpu().view(torch.int32), ref.view(torch.int32)), seed
+    src = torch.randn(77, 106, generator=g)
+    assert torch.equal(ops.cast_pad(H2, src.to(DEV), 128).cpu().view(torch.int32), F.cast_pad(H2, src, 128).view(torch.int32))
+    wide = torch.randn(90, 512, generator=g)                     # in place on a column block of a wider buffer
+    buf = wide.to(DEV)
+    ops.cast_pad(H2, buf[:, :256], 256, out=buf[:, :256])
+    assert torch.equal(buf[:, :256].cpu().contiguous().view(torch.int32), ops.h2_pack(wide[:, :256]).view(torch.int32)) and torch.equal(buf[:, 256:].cpu(), wide[:, 256:])
+    table, idx = torch.randn(256, 256, generator=g), torch.randint(0, 256, (513,), generator=g)
+    assert torch.equal(ops.gather_rows(table.to(DEV), idx.to(DEV), H2, 320).cpu().view(torch.int32), F.gather_rows(table, idx, H2, 320).view(torch.int32))
+
+
+@pytest.mark.parametrize("b,tq,tk", [(3, 64, 64), (2, 10, 11), (1, 64, 128), (5, 33, 33)])
+def test_attention_h2_output_equals_f16x3(b, tq, tk):
+    """EMAGE_H2 attention = the split-f16 attention with its output stored as an H2 image: same values bit for bit."""
+    g = _g(b * 1000 + tq * 10 + tk)
+    h, hd, d = 4, 192, 768
+    q, k = torch.randn(b * tq, d, generator=g).to(DEV), torch.randn(b * tk, d, generator=g).to(DEV)
+    tp = ops.round_up(tk, 32)
+    vt = torch.zeros(b, d, tp)
+    vt[:, :, :tk] = torch.randn(b, d, tk, generator=g)
+    vt = vt.to(DEV)
+    o32, oh = torch.zeros(b * tq, d, device=DEV), torch.zeros(b * tq, d, device=DEV)
+    ops.attention(F16X3, q, k, vt, d, o32, b, h, tq, tk, hd)
+    ops.attention(H2, q, k, vt, d, oh, b, h, tq, tk, hd)
+    assert torch.equal(oh.cpu().view(torch.int32), ops.h2_pack(o32.cpu()).view(torch.int32))

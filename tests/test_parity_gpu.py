@@ -32,7 +32,20 @@ def x3_models():
 
 @pytest.fixture(scope="module")
 def exact_models(fp32_models, x3_models):
-    return {"fp32": fp32_models, "f16x3": x3_models}
+    """f16x3 (the classes' default) = pre-split EMAGE_H2 activations with float32 residual twins; "f16x3_h2res": the residual stream
+    read from the H2 images; "f16x3_f32acts": float32 activations split inside every GEMM (EMAGE_F16X3, the round-2 form)."""
+    models = {"fp32": fp32_models, "f16x3": x3_models}
+    m, vq = common.product_models(precision="f16x3", device=DEV)
+    m.h2_residual = True
+    models["f16x3_h2res"] = (m, vq)
+    m, vq = common.product_models(precision="f16x3", device=DEV)
+    for part in (m, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
+        part.split_acts = False
+    models["f16x3_f32acts"] = (m, vq)
+    return models
+
+
+X3_FORMS = ["f16x3", "f16x3_h2res", "f16x3_f32acts"]
 
 
 @pytest.fixture(scope="module")
@@ -40,7 +53,7 @@ def bf16_models():
     return common.product_models(precision="bf16", device=DEV)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("precision", ["fp32"] + X3_FORMS)
 def test_forward_window_fp32(exact_models, golden_dir, precision):
     model, _ = exact_models[precision]
     g = np.load(os.path.join(golden_dir, "forward_b1.npz"))
@@ -66,7 +79,7 @@ def test_forward_window_fp32_vs_oracle_batch3(exact_models, precision):
         assert float((out[k].cpu() - ref[k]).abs().max()) < TOL, k
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("precision", ["fp32"] + X3_FORMS)
 @pytest.mark.parametrize("frames,batch", [(128, 2), (70, 1), (129, 1), (310, 1)])
 def test_clip_fp32_matches_reference(exact_models, golden_dir, frames, batch, precision):
     model, vq = exact_models[precision]
@@ -85,7 +98,7 @@ def test_clip_fp32_matches_reference(exact_models, golden_dir, frames, batch, pr
         assert err < TOL, (nm, err)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("precision", X3_FORMS + ["fp32"])
 def test_batch64_matches_reference(exact_models, golden_dir, precision):
     """BASELINE config 2 itself (64 x 128-frame clips) against the REFERENCE's run of the same batch
     (tests/golden/infer_128f_b64.npz): every VQ code index of all 64 clips identical; poses / expressions / trans of

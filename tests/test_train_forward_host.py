@@ -174,7 +174,7 @@ def test_wav_encoder_backward_block_by_block():
 
     fwd._wav_block_backward = spy
     with fake_ops.installed(), torch.no_grad():
-        cx = _Ctx(model._engine())
+        cx = _Ctx(model._engine(h2=False))
         fwd._train_pack(cx.pk)
         fwd.tape, fwd.param_grads = training._Tape(cx.dev), {}
         x, _ = fwd._wav_encoder(cx, enc, 1, audio, 2, {})

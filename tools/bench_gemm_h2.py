@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""Validate and sweep the EMAGE_H2 (pre-split operands) tile configurations of emage_gemm over the shapes of the EMAGE window
+(run on the MI355X).  Every configuration is checked against a float64 reference (tolerance: fp32-grade, the same level the
+EMAGE_F16X3 kernel reaches) and timed as a captured hipGraph of `--iters` launches; the shipped F16X3 heuristic is timed
+beside it.  Usage: python tools/bench_gemm_h2.py [--configs 101,103,...] [--shapes out_proj,ffn1] [--loop N (for rocprofv3)]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pantomatrix_amd import _lib, ops  # noqa: E402
+from pantomatrix_amd._lib import F16X3, H2  # noqa: E402
+
+SHAPES = [
+    # name, (nb, lin, lout), cin, n, taps, stride, pad, extras
+    ("qkv 768->2304 +vt", (64, 64, 64), 768, 2304, 1, 1, 0, dict(vt=1536)),
+    ("qkv 768->2304", (64, 64, 64), 768, 2304, 1, 1, 0, dict()),
+    ("out_proj 768->768 +res", (64, 64, 64), 768, 768, 1, 1, 0, dict(res=True)),
+    ("ffn1 768->1536 relu", (64, 64, 64), 768, 1536, 1, 1, 0, dict(slope=0.0)),
+    ("ffn2 1536->768 +res", (64, 64, 64), 1536, 768, 1, 1, 0, dict(res=True)),
+    ("kv_all 768->12288 +vt", (64, 64, 64), 768, 12288, 1, 1, 0, dict(vt=6144)),
+    ("kv_part 768->1536 +vt", (64, 64, 64), 768, 1536, 1, 1, 0, dict(vt=768)),
+    ("head 768->256", (64, 64, 64), 768, 256, 1, 1, 0, dict()),
+    ("mlp 256->768", (64, 64, 64), 256, 768, 1, 1, 0, dict(slope=0.1)),
+    ("fc 512->768", (64, 64, 64), 512, 768, 1, 1, 0, dict()),
+    ("conv3 256->256", (64, 64, 64), 256, 256, 3, 1, 1, dict(slope=0.2)),
+    ("conv3 337->256", (64, 64, 64), 337, 256, 3, 1, 1, dict(slope=0.2)),
+    ("conv3 256->256 +res", (64, 64, 64), 256, 256, 3, 1, 1, dict(res=True)),
+    ("conv3 T=120 256->256", (64, 120, 120), 256, 256, 3, 1, 1, dict(slope=0.2)),
+    ("conv3 T=17 256->256", (64, 17, 17), 256, 256, 3, 1, 1, dict(slope=0.2)),
+    ("conv3 256->106 pad128", (64, 64, 64), 256, 106, 3, 1, 1, dict(slope=0.2, n_store=128)),
+    ("conv3 128->106 f32out", (64, 64, 64), 106, 106, 3, 1, 1, dict(f32only=True)),
+    ("cls fc 256->256", (64, 64, 64), 256, 256, 1, 1, 0, dict(slope=0.1)),
+    ("ragged M=4100 768->768", (1, 4100, 4100), 768, 768, 1, 1, 0, dict(res=True)),
+]
+CONFIGS = [100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 115, 116, 118, 119, 120, 121, 122, 123, 124, 125, 126, 127, 128,
+           129, 130, 131, 132]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--configs", default="")
+    ap.add_argument("--shapes", default="", help="comma-separated substrings of shape names")
+    ap.add_argument("--loop", type=int, default=0, help="no sweep: run the first selected shape / config this many times eagerly (profiling)")
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = "cuda"
+    configs = [int(c) for c in args.configs.split(",")] if args.configs else CONFIGS
+    want = [s for s in args.shapes.split(",") if s]
+    g = torch.Generator().manual_seed(0)
+    print(f"{'shape':26s} GF  | x3    " + " ".join(f"c{c:<6d}" for c in configs) + " | best")
+    for name, (nb, lin, lout), cin, n, taps, stride, pad, ex in SHAPES:
+        if want and not any(w in name for w in want):
+            continue
+        cp = ops.round_up(cin, 64)
+        m = nb * lout
+        a = torch.zeros(nb * lin, cp)
+        a[:, :cin] = torch.randn(nb * lin, cin, generator=g)
+        w = torch.zeros(n, taps, cp)
+        w[:, :, :cin] = torch.randn(n, taps, cin, generator=g) / (cin * taps) ** 0.5
+        a, w = a.to(dev), w.reshape(n, taps * cp).to(dev)
+        bias = (torch.randn(n, generator=g) * 0.1).to(dev)
+        slope = torch.full((n,), float(ex["slope"]), device=dev) if "slope" in ex else None
+        res = torch.randn(m, n, generator=g).to(dev) if ex.get("res") else None
+        vt0 = ex.get("vt")
+        ncol = vt0 or n
+        n_store = ex.get("n_store", 0)
+        flops = 2.0 * m * n * taps * cin
+        # float64 reference
+        rows = torch.arange(m, device=dev)
+        b_, l_ = rows // lout, rows % lout
+        cols = []
+        for tap in range(taps):
+            pos = l_ * stride + tap - pad
+            valid = ((pos >= 0) & (pos < lin)).double()[:, None]
+            cols.append(a.double()[b_ * lin + pos.clamp(0, lin - 1)] * valid)
+        ref = torch.cat(cols, 1) @ w.double().t() + bias.double()
+        if slope is not None:
+            ref = torch.where(ref > 0, ref, ref * slope.double())
+        if res is not None:
+            ref = ref + res.double()
+        tol = 2e-5 * float(ref.abs().max())
+
+        a_h2 = ops.h2_pack(a)
+        w_h2, ws_h2 = ops.split_f16_weights_h2(w)
+        w_x3, ws_x3 = ops.split_f16_weights(w)
+        ldo = ops.round_up(max(ncol, n_store), 8)
+
+        def run(cfg):
+            h2 = cfg is not None
+            lib.emage_set_tuning(4, cfg if h2 else -1)
+            out = None if ex.get("f32only") else torch.zeros(m, ldo, device=dev)
+            out_f = torch.zeros(m, ncol, device=dev) if (res is not None or ex.get("f32only")) else None
+            out_t = torch.zeros(nb, n - vt0, ops.round_up(lout, 32), device=dev) if vt0 else None
+            if h2:
+                call = lambda: ops.gemm(H2, a_h2, w_h2, bias, slope, res, out, out_f, out_t, n=n, cp=cp, n_store=n_store, t_col0=vt0 or 0,
+                                        t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m, w_scale=ws_h2)
+            else:
+                call = lambda: ops.gemm(F16X3, a, w_x3, bias, slope, res, out, out_f, out_t, n=n, cp=cp, n_store=n_store, t_col0=vt0 or 0,
+                                        t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m, w_scale=ws_x3)
+            call()
+            torch.cuda.synchronize()
+            if args.loop:
+                for _ in range(args.loop):
+                    call()
+                torch.cuda.synchronize()
+                return 0.0, True
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(args.iters):
+                    call()
+            gr.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / args.iters * 1e3
+            ok = True
+            errs = []
+            if out is not None:
+                o = ops.h2_unpack(out) if h2 else out
+                errs.append(float((o[:, :ncol].double() - ref[:, :ncol]).abs().max()))
+                if n_store > ncol:
+                    ok &= bool((o[:, ncol:n_store] == 0).all())
+            if out_f is not None:
+                errs.append(float((out_f.double() - ref[:, :ncol]).abs().max()))
+            if out_t is not None:
+                vt_ref = ref[:, vt0:].reshape(nb, lout, n - vt0).permute(0, 2, 1)
+                errs.append(float((out_t[:, :, :lout].double() - vt_ref).abs().max()))
+            ok &= all(e <= tol for e in errs)
+            return us, ok
+
+        cells, best = [], (1e9, None)
+        try:
+            us0, ok0 = run(None)
+            cells.append(f"{us0:6.1f}{' ' if ok0 else '!'}")
+        except Exception:  # noqa: BLE001
+            cells.append("ERR    ")
+        for cfg in configs:
+            try:
+                us, ok = run(cfg)
+            except Exception:  # noqa: BLE001
+                cells.append("  -    ")
+                continue
+            if args.loop:
+                return
+            cells.append(f"{us:6.1f}{' ' if ok else '!'}")
+            if ok and us < best[0]:
+                best = (us, cfg)
+        lib.emage_set_tuning(4, -1)
+        tf = flops / best[0] / 1e6 if best[1] is not None else 0.0
+        print(f"{name:26s} {flops / 1e9:5.1f}| " + " ".join(cells) + f" | c{best[1]} {tf:6.0f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
