@@ -436,6 +436,7 @@ def main():
 
     if args.gemm_dbg or args.gemm_variant >= 0 or args.h2_variant:
         from pantomatrix_amd import _lib
+        _lib.use_tools(True)         # experiments only: the tuning hooks live in the tools build of the library
         _lib.load().emage_set_tuning(1, args.gemm_dbg)
         _lib.load().emage_set_tuning(5, args.h2_variant)
         if args.gemm_variant >= 0:

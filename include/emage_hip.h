@@ -47,14 +47,20 @@ int emage_abi_version(void);
 const char* emage_target_arch(void);
 
 /*
- * Tuning hook for tests and tools (never needed for correctness; process-global, not thread-safe):
- *   key 0: force emage_gemm's tile configuration id (-1 restores the heuristic);
+ * Tools build only (libemage_hip_tools.so, compiled with -DEMAGE_TOOLS; the product library libemage_hip.so has neither this entry
+ * point nor any other mutable global state).  Process-global, not thread-safe:
+ *   key 0: force emage_gemm's tile configuration id of the F32 / BF16 / F16X3 modes (-1 restores the heuristic);
  *   key 1: diagnostic ablation mask for tools/bench_gemm.py --ablate (1 no operand DMA, 2 no MFMA, 4 no epilogue;
  *          8 / 16: write-through / non-temporal result stores, a recorded negative experiment);
- *   key 2: tile-heuristic variant for A/B runs (0: one K-tile per ring slot everywhere; 1, the default: two in f16x3).
- * The product path never calls it.  Returns EMAGE_EINVAL for unknown keys.
+ *   key 2: tile-heuristic variant for A/B runs;   key 3: timing ablations of emage_lstm_layer;
+ *   key 4: force the EMAGE_H2 tile configuration id;   key 5: EMAGE_H2 tile-heuristic variant.
+ * Returns EMAGE_EINVAL for unknown keys.  emage_h2_set_trace: device buffer (waves x 512 uint64) for the phase tracer of the
+ * instrumented EMAGE_H2 configurations (tools/trace_gemm_h2.py).
  */
+#ifdef EMAGE_TOOLS
 int emage_set_tuning(int key, int value);
+int emage_h2_set_trace(void* buf);
+#endif
 
 /*
  * K6 — VQ nearest neighbour.  Replaces Quantizer.map2index / Quantizer.forward's argmin (P:144-164)
@@ -277,6 +283,11 @@ int emage_lstm_step_pair(int dtype, const float* h_prev0, const float* h_prev1, 
 #define EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH 544
 #define EMAGE_LSTM_SYNC_ERROR_WORD 512
 int emage_lstm_layer_sync_words(int B, int H);
+/* returns EMAGE_EINVAL (<= 0 words) when the CURRENT device cannot host the recurrence (fewer than 2 * H/16 co-resident blocks:
+ * a compute partition / CU-masked queue): callers then take emage_lstm_step_pair, which produces the same bits.
+ * emage_lstm_layer_health: counter[0] += number of launch records of `sync` whose error word is set; meant to run on the same
+ * stream behind the emage_lstm_layer launches (inside a captured graph), so one device counter carries "a block was lost". */
+int emage_lstm_layer_health(const unsigned* sync, int sync_words, int* counter, void* stream);
 int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, int ld_gx_t, const void* w_hh0, const void* w_hh1,
                      float w_scale0, float w_scale1, float a_scale, float* hseq, long ld_h_b, int ld_h_t,
                      int B, int T, int H, unsigned* sync, int sync_words, void* stream);
@@ -413,6 +424,20 @@ int emage_wav_conv_in_backward(const float* dy, int ld_dy, const float* wav, lon
  * 1-based step count of this parameter. */
 int emage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+/* Multi-tensor Adam: ONE launch over every parameter.  table: per tensor five 64-bit words {param, grad, exp_avg, exp_avg_sq, n} (device
+ * pointers / element count); block b updates elements [block_chunk[b] * C, +C) of tensor block_tensor[b], C = emage_adam_multi_chunk().
+ * step_dev (one int32 on the device) overrides `step` when non-NULL (captured graphs).  grad_scale multiplies every gradient first (the
+ * 1 / world_size of the data-parallel average); zero_grad != 0 clears the gradient behind the update.  Arithmetic of emage_adam_step. */
+int emage_adam_multi_chunk(void);
+int emage_adam_multi(const long long* table, const int* block_tensor, const int* block_chunk, int n_blocks, const int* step_dev, int step,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, void* stream);
+
+/* nn.Dropout's keep mask drawn on the device (T:241-250 dropout = 0.1 in every transformer layer, P:331,343): out[i] = bernoulli(1 - p) / (1 - p)
+ * from Philox4x32-10 with key = seed, counter = (i / 4, mask_id, step): a pure function of its arguments (no generator state; step_dev, one
+ * int32 on the device, overrides `step` when non-NULL so a captured training step draws fresh masks on every replay).  The stream is this
+ * library's own (csrc/train.hip), not torch's. */
+int emage_dropout_mask(float* out, long n, float p, unsigned long long seed, unsigned mask_id, const int* step_dev, int step, void* stream);
 
 /* emage_adam_step with the 1-based step count read from device memory (`step`: one int32), for a step captured in a hipGraph. */
 int emage_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const int* step,

@@ -7,15 +7,16 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
+TOOLS_LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip_tools.so")   # -DEMAGE_TOOLS twin: every tile configuration + emage_set_tuning
 
 F32, BF16, F16X3, H2 = 0, 1, 2, 3
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
 # name -> argtypes, exactly the prototypes of include/emage_hip.h
+TOOLS_SIGNATURES = {"emage_set_tuning": [_i, _i], "emage_h2_set_trace": [_p]}      # exported by the tools build only
 SIGNATURES = {
-    "emage_set_tuning": [_i, _i],
     "emage_vq_argmin_f32": [_p, _i, _p, _p, _i, _l, _i, _i, _i, _p],
     "emage_argmax_logsoftmax_f32": [_p, _i, _p, _i, _l, _i, _i, _p],
     "emage_gather_rows": [_p, _p, _i, _l, _i, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -48,6 +49,9 @@ SIGNATURES = {
     "emage_count_nonfinite": [_p, _l, _p, _p],
     "emage_adam_step_dev": [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _p],
     "emage_adam_step": [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _p],
+    "emage_adam_multi_chunk": [],
+    "emage_adam_multi": [_p, _p, _p, _i, _p, _i, _f, _f, _f, _f, _f, _f, _i, _p],
+    "emage_dropout_mask": [_p, _l, _f, C.c_ulonglong, C.c_uint, _p, _i, _p],
     "emage_mul_add": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p],
@@ -60,6 +64,7 @@ SIGNATURES = {
     "emage_lstm_step": [_i, _p, _i, _p, _f, _f, _p, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_lstm_step_pair": [_i, _p, _p, _i, _i, _p, _p, _f, _f, _f, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_lstm_layer_sync_words": [_i, _i],
+    "emage_lstm_layer_health": [_p, _i, _p, _p],
     "emage_lstm_layer": [_i, _p, _l, _i, _p, _p, _f, _f, _f, _p, _l, _i, _i, _i, _i, _p, _i, _p],
     "emage_softmax2_mix": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_lstm_inputs": [_p, _p, _i, _p, _l, _i, _i, _p, _p, _i, _i, _i, _i, _p],
@@ -68,27 +73,45 @@ SIGNATURES = {
 RESTYPES = {"emage_bn_stats_workspace_bytes": _l, "emage_wav_conv_in_backward_workspace_bytes": _l}
 
 _lib = None
+_tools = None
+_use_tools = False
 
 
-def load():
-    """Load the shared library (once) and type every entry point."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+def _open(path, signatures):
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). The EMAGE path has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.emage_abi_version.restype = _i
     lib.emage_target_arch.restype = C.c_char_p
     if lib.emage_abi_version() != ABI_VERSION:
-        raise ImportError(f"libemage_hip.so ABI {lib.emage_abi_version()} != expected {ABI_VERSION}; rebuild")
-    for name, args in SIGNATURES.items():
+        raise ImportError(f"{os.path.basename(path)} ABI {lib.emage_abi_version()} != expected {ABI_VERSION}; rebuild")
+    for name, args in signatures.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.argtypes = args
         fn.restype = RESTYPES.get(name, _i)
-    _lib = lib
     return lib
+
+
+def load():
+    """The shared library every op launches into (loaded once, every entry point typed): the product library, or — after
+    `use_tools()` — its tools twin."""
+    global _lib, _tools
+    if _use_tools:
+        if _tools is None:
+            _tools = _open(TOOLS_LIB_PATH, {**SIGNATURES, **TOOLS_SIGNATURES})
+        return _tools
+    if _lib is None:
+        _lib = _open(LIB_PATH, SIGNATURES)
+    return _lib
+
+
+def use_tools(on: bool = True):
+    """tools/ and the tile-configuration tests: route every launch of this process through libemage_hip_tools.so (all tile
+    configurations, `emage_set_tuning`, ablation branches, phase tracer).  The product path never calls this."""
+    global _use_tools
+    _use_tools = bool(on)
+    return load()
 
 
 class EmageKernelError(RuntimeError):

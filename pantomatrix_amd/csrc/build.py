@@ -1,5 +1,10 @@
 """Build libemage_hip.so (gfx950) in-tree with hipcc.  No torch headers are involved: the library is a
-plain C-ABI shared object (include/emage_hip.h) loaded by ctypes from pantomatrix_amd/_lib.py."""
+plain C-ABI shared object (include/emage_hip.h) loaded by ctypes from pantomatrix_amd/_lib.py.
+
+Two libraries come out of the same sources:
+  libemage_hip.so        the PRODUCT: only the tile configurations the heuristics select, no tuning hooks, no mutable globals;
+  libemage_hip_tools.so  the same plus -DEMAGE_TOOLS: every tile configuration, `emage_set_tuning`, the diagnostic ablation
+                         branches and the phase tracer — used by tools/ and by the tests that walk every configuration."""
 from __future__ import annotations
 
 import os
@@ -9,7 +14,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "gemm_h2.hip", "attention.hip", "vq.hip", "elementwise.hip", "motion.hip", "wavconv.hip", "convslab.hip", "lstm.hip", "lstmseq.hip", "train.hip", "version.hip"]
+HEADERS = ["common.h", "gemm_tile.h", "h2_tile.h", "h2.h", "attn_tile.h", "ln_row.h", "rot_math.h"]
 LIB = os.path.join(HERE, "libemage_hip.so")
+TOOLS_LIB = os.path.join(HERE, "libemage_hip_tools.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 
@@ -17,25 +24,28 @@ def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "gemm_tile.h"), os.path.join(HERE, "h2_tile.h"), os.path.join(HERE, "h2.h"), os.path.join(HERE, "attn_tile.h"), os.path.join(HERE, "ln_row.h"), os.path.join(HERE, "rot_math.h"),
-                                                        os.path.join(HERE, "..", "..", "include", "emage_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+def _deps():
+    return [os.path.join(HERE, s) for s in SOURCES + HEADERS] + [os.path.join(HERE, "..", "..", "include", "emage_hip.h"), os.path.abspath(__file__)]
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return LIB
-    objs = []
-    procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+def needs_build(lib: str = None) -> bool:
+    libs = [LIB, TOOLS_LIB] if lib is None else [lib]
+    for l in libs:
+        if not os.path.exists(l):
+            return True
+        t = os.path.getmtime(l)
+        if any(os.path.getmtime(d) > t for d in _deps()):
+            return True
+    return False
+
+
+def _build_one(lib, objdir, extra, verbose):
+    objs, procs = [], []
+    os.makedirs(objdir, exist_ok=True)
     for s in SOURCES:
-        o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
-        procs.append((s, subprocess.Popen([_hipcc(), *FLAGS, "-c", os.path.join(HERE, s), "-o", o],
+        procs.append((s, subprocess.Popen([_hipcc(), *FLAGS, *extra, "-c", os.path.join(HERE, s), "-o", o],
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
         out, _ = p.communicate()
@@ -43,12 +53,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out)
-    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB],
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     if verbose:
-        print("built", LIB)
+        print("built", lib)
+
+
+def build(force: bool = False, verbose: bool = True, tools: bool = True) -> str:
+    if force or needs_build(LIB):
+        _build_one(LIB, os.path.join(HERE, "build"), [], verbose)
+    if tools and (force or needs_build(TOOLS_LIB)):
+        _build_one(TOOLS_LIB, os.path.join(HERE, "build_tools"), ["-DEMAGE_TOOLS"], verbose)
     return LIB
 
 

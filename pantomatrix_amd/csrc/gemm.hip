@@ -10,8 +10,10 @@
 #include "gemm_tile.h"
 
 namespace emage_dev {
+#ifdef EMAGE_TOOLS
 extern int g_lstm_layer_dbg;                        // csrc/lstmseq.hip
 extern int g_h2_force_config, g_h2_variant;         // csrc/gemm_h2.hip
+#endif
 int gemm_h2_dispatch(GemmArgs& a, hipStream_t s);   // csrc/gemm_h2.hip: the EMAGE_H2 (pre-split operands) tile kernels
 }
 
@@ -19,12 +21,17 @@ namespace {
 
 using namespace emage_dev;
 
-// test / tool hooks (emage_set_tuning; never touched by the product path): process-global, not thread-safe
+#ifdef EMAGE_TOOLS
+// tools build only (libemage_hip_tools.so, emage_set_tuning): process-global, not thread-safe.  The product library has no mutable state.
 int g_force_config = -1;   // -1 = heuristic, else a fixed tile configuration id
 int g_debug_skip = 0;      // tools/bench_gemm.py --ablate: 1 = no operand DMA, 2 = no LDS reads / MFMA, 4 = no epilogue
 int g_variant = 0;         // heuristic variant for A/B runs (key 2): 0 = shipped; 1 = two K-tiles per ring slot in f16x3 (measured slower end to
                            // end: profiles/r02_bench_two_ktiles_per_slot_ab.json); 2 = epilogue operands prefetched ahead of the K-loop for 64x192 tiles
+#else
+constexpr int g_force_config = -1, g_debug_skip = 0, g_variant = 0;
+#endif
 
+#ifdef EMAGE_TOOLS
 // epilogue shared by both kernels: lane holds rows (lane>>4)*4 + r, column lane&15 of each 16x16 fragment
 template <typename T, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[FM][FN], int mw, int nw, int fr, int fg) {
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
 
     gemm_epilogue<T, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg);
 }
+#endif   // EMAGE_TOOLS: the register-staged reference kernel
 template <typename T, int BM, int BN, int WM, int WN, int NS, int KC, bool X3, int KPS, bool FPRE>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? lds_blocks<BM, BN, NS, KC, KPS>() : 1)) void gemm_pipe_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[pipe_smem_bytes<T, BM, BN, NS, KC, KPS>()];
@@ -206,6 +214,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? lds_blocks<BM, BN, NS
     gemm_pipe_tile<T, BM, BN, WM, WN, NS, KC, FPRE, X3, EPI_LINEAR, KPS>(p, tile_m * BM, tile_n * BN, smem);
 }
 
+#ifdef EMAGE_TOOLS
 template <typename T, int BM, int BN, int WM, int WN>
 int launch(GemmArgs& a, hipStream_t s) {
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -214,6 +223,8 @@ int launch(GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(NTHREADS), 0, s, a);
     return launch_status();
 }
+
+#endif
 
 template <typename T, bool X3, int BM, int BN, int WM, int WN, int NS, int KC = 8, int KPS = 1, bool FPRE = false>
 int launch_pipe(GemmArgs& a, hipStream_t s) {
@@ -229,18 +240,23 @@ int launch_pipe(GemmArgs& a, hipStream_t s) {
 // 18 / 27 / 37 are kept for tools/bench_gemm.py sweeps.
 template <typename T, bool X3>
 int run_config(int cfg, GemmArgs& a, hipStream_t s) {
+    // the product library carries the five configurations the heuristic selects; everything else is the tools build's
+    switch (cfg) {
+        case 25: return launch_pipe<T, X3, 64, 64, 2, 2, 2>(a, s);
+        case 32: return launch_pipe<T, X3, 64, 192, 4, 2, 3, 8>(a, s);    // 8 waves (two per SIMD): a lone block per CU hides its own latencies
+        case 33: return launch_pipe<T, X3, 64, 192, 4, 2, 2, 8>(a, s);
+        case 34: return launch_pipe<T, X3, 128, 128, 4, 2, 2, 8>(a, s);
+        case 36: return launch_pipe<T, X3, 128, 64, 4, 2, 3, 8>(a, s);
+        default: break;
+    }
+#ifdef EMAGE_TOOLS
     if constexpr (!X3) {
         if (cfg == 0) return launch<T, 128, 128, 2, 2>(a, s);
         if (cfg == 3) return launch<T, 64, 64, 2, 2>(a, s);
     }
     switch (cfg) {
         case 18: return launch_pipe<T, X3, 128, 128, 2, 2, 2>(a, s);
-        case 25: return launch_pipe<T, X3, 64, 64, 2, 2, 2>(a, s);
         case 27: return launch_pipe<T, X3, 64, 192, 2, 2, 2, 8>(a, s);    // one (clip, head) per block at T = 64, hd = 192
-        case 32: return launch_pipe<T, X3, 64, 192, 4, 2, 3, 8>(a, s);    // 8 waves (two per SIMD): a lone block per CU hides its own latencies
-        case 33: return launch_pipe<T, X3, 64, 192, 4, 2, 2, 8>(a, s);
-        case 34: return launch_pipe<T, X3, 128, 128, 4, 2, 2, 8>(a, s);
-        case 36: return launch_pipe<T, X3, 128, 64, 4, 2, 3, 8>(a, s);
         case 37: return launch_pipe<T, X3, 128, 192, 4, 2, 2, 8>(a, s);
         case 38: return launch_pipe<T, X3, 128, 128, 4, 2, 3, 8>(a, s);   // deeper rings / fatter tiles: sweeps of the per-CU operand stream
         case 39: return launch_pipe<T, X3, 128, 128, 4, 2, 4, 8>(a, s);
@@ -261,6 +277,7 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
             default: break;
         }
     }
+#endif
     return EMAGE_EINVAL;
 }
 
@@ -335,6 +352,7 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
     return dtype == EMAGE_BF16 ? dispatch<bf16_t, false>(a, s) : dispatch<float, false>(a, s);
 }
 
+#ifdef EMAGE_TOOLS
 extern "C" int emage_set_tuning(int key, int value) {
     if (key == 0) { g_force_config = value; return 0; }
     if (key == 1) { g_debug_skip = value; return 0; }
@@ -344,3 +362,4 @@ extern "C" int emage_set_tuning(int key, int value) {
     if (key == 5) { emage_dev::g_h2_variant = value; return 0; }         // csrc/gemm_h2.hip: dispatch-heuristic variant (A/B runs)
     return EMAGE_EINVAL;
 }
+#endif

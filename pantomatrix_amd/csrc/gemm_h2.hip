@@ -6,9 +6,14 @@
 #include "h2_tile.h"
 
 namespace emage_dev {
-int g_h2_force_config = -1;      // EMAGE_TOOLS builds only (emage_set_tuning key 4): fixed tile configuration for sweeps
-int g_h2_variant = 0;            // tools: dispatch-heuristic variant for A/B runs (emage_set_tuning key 5)
-unsigned long long* g_h2_trace = nullptr;   // tools: device buffer of (waves x 512) s_memtime stamps (emage_h2_set_trace)
+#ifdef EMAGE_TOOLS
+int g_h2_force_config = -1;      // tools build (emage_set_tuning key 4): fixed tile configuration for sweeps
+int g_h2_variant = 0;            // tools build: dispatch-heuristic variant for A/B runs (emage_set_tuning key 5)
+unsigned long long* g_h2_trace = nullptr;   // tools build: device buffer of (waves x 512) s_memtime stamps (emage_h2_set_trace)
+#else
+constexpr int g_h2_force_config = -1, g_h2_variant = 0;
+constexpr unsigned long long* g_h2_trace = nullptr;
+#endif
 }
 
 namespace {
@@ -45,6 +50,7 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
     switch (cfg) {
         //                       BM   BN  WM WN NS NLW PIPE  PRE  OCC
         case 100: return launch_h2<64, 192, 4, 2, 2, 0, false>(a, s);              // 8 waves 16x96 (the F16X3 shape)
+#ifdef EMAGE_TOOLS
         case 101: return launch_h2<64, 192, 4, 2, 3, 0, false>(a, s);
         case 102: return launch_h2<64, 192, 2, 4, 3, 0, false>(a, s);              // 8 waves 32x48
         case 103: return launch_h2<64, 192, 2, 2, 3, 0, true>(a, s);               // 4 waves 32x96, pipelined
@@ -57,12 +63,16 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 110: return launch_h2<128, 96, 4, 2, 3, 4, false>(a, s);              // 8 compute 32x48 + 4 loaders
         case 111: return launch_h2<128, 128, 2, 2, 3, 0, true>(a, s);              // 4 waves 64x64
         case 112: return launch_h2<128, 128, 4, 2, 2, 0, false>(a, s);             // 8 waves 32x64
+#endif
         case 113: return launch_h2<128, 128, 4, 2, 3, 0, false>(a, s);
+#ifdef EMAGE_TOOLS
         case 115: return launch_h2<128, 192, 2, 2, 3, 0, true>(a, s);              // 4 waves 64x96
         case 116: return launch_h2<128, 192, 4, 2, 3, 0, false>(a, s);             // 8 waves 32x96
         case 118: return launch_h2<128, 256, 2, 2, 3, 0, true>(a, s);              // 4 waves 64x128
+#endif
         case 119: return launch_h2<128, 256, 4, 2, 2, 0, false>(a, s);             // 8 waves 32x128
         case 120: return launch_h2<64, 64, 2, 2, 3, 0, false, false, 2>(a, s);     // small grids: 4 waves 32x32
+#ifdef EMAGE_TOOLS
         case 121: return launch_h2<64, 64, 2, 2, 3, 0, true, false, 2>(a, s);
         case 122: return launch_h2<64, 128, 2, 2, 3, 0, true>(a, s);               // 4 waves 32x64
         case 123: return launch_h2<128, 64, 4, 1, 3, 0, true>(a, s);               // 4 waves 32x64
@@ -97,6 +107,7 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 203: return launch_h2<64, 192, 2, 2, 3, 0, true, false, 1, false, true>(a, s);
         case 205: return launch_h2<64, 192, 2, 2, 3, 4, true, false, 1, false, true>(a, s);
         case 241: return launch_h2<64, 192, 4, 2, 3, 0, false, false, 1, true, true>(a, s);
+#endif
         default: break;
     }
     return EMAGE_EINVAL;
@@ -104,7 +115,9 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+#ifdef EMAGE_TOOLS
 extern "C" int emage_h2_set_trace(void* buf) { emage_dev::g_h2_trace = (unsigned long long*)buf; return 0; }
+#endif
 
 namespace emage_dev {
 

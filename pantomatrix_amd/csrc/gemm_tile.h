@@ -1,9 +1,15 @@
-// Device-side building blocks of emage_gemm shared by gemm.hip (one tile per block / persistent tile walk) and
-// layer.hip (the fused transformer-layer kernel calls the same tile routine op after op): GemmArgs, the vector
-// epilogue helpers and the LDS-DMA ring tile routine `gemm_pipe_tile`.
+// Device-side building blocks of emage_gemm (gemm.hip; lstm.hip's step kernels call the same tile routine with the LSTM-cell
+// epilogue; h2_tile.h builds on the ring helpers): GemmArgs, the vector epilogue helpers and the LDS-DMA ring tile routine
+// `gemm_pipe_tile`.  The diagnostic branches (p.dbg) exist only in the tools build (-DEMAGE_TOOLS, libemage_hip_tools.so).
 #pragma once
 #include "common.h"
 #include <utility>
+
+#ifdef EMAGE_TOOLS
+#define EMAGE_DBG(p, mask) ((p).dbg & (mask))
+#else
+#define EMAGE_DBG(p, mask) false
+#endif
 
 namespace emage_dev {
 
@@ -289,7 +295,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
     unsigned soff_a = 0, soff_w = 0;
     const unsigned tap_step = (unsigned)(p.lda - p.Cp + BK) * ES;            // soff_a jump when the tap advances
     auto issue = [&]() {
-        if (p.dbg & 1) return;
+        if (EMAGE_DBG(p, 1)) return;
         unsigned char* base = smem + is_slot * SLOT + is_sub * STAGE;
 #pragma unroll
         for (int j = 0; j < GA; ++j) {
@@ -382,7 +388,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
 #pragma unroll
             for (int u = 0; u < KPS; ++u) issue();
         }
-        if (p.dbg & 2) { sb += SLOT; if (sb == NS * SLOT) sb = 0; continue; }
+        if (EMAGE_DBG(p, 2)) { sb += SLOT; if (sb == NS * SLOT) sb = 0; continue; }
 #pragma unroll
         for (int u = 0; u < KPS; ++u) {
         u32x4 af0[FM], bf0[FN];
@@ -457,7 +463,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = acc[i][j] * os;
     }
-    if (p.dbg & 4) {                                  // diagnostics: keep the accumulators live, store nothing
+    if (EMAGE_DBG(p, 4)) {                            // diagnostics: keep the accumulators live, store nothing
         if (acc[0][0][0] == 123.456f) ((float*)p.out_f32)[0] = 0.f;
         __syncthreads();
         return;
@@ -517,7 +523,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                         if (!p.res_first) x += rv[e];
                         v[e] = x;
                     }
-                    if (p.dbg & 24) {                 // experiment (emage_set_tuning key 1, bits 8 / 16): write-through (sc1) or
+                    if (EMAGE_DBG(p, 24)) {               // experiment (emage_set_tuning key 1, bits 8 / 16): write-through (sc1) or
                         const int aux_sc1 = 16;       // non-temporal result stores instead of plain ones
                         if (out) {
                             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)m0 * p.ldo), 0, 0x7fffffff, 0x00020000);
@@ -529,12 +535,12 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                                 t.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
                                 t.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
                                 const u32x4 tv = {t.x, t.y, t.z, t.w};
-                                if (p.dbg & 8) __builtin_amdgcn_raw_buffer_store_b128(tv, ro, vo, 0, aux_sc1);
+                                if (EMAGE_DBG(p, 8)) __builtin_amdgcn_raw_buffer_store_b128(tv, ro, vo, 0, aux_sc1);
                                 else __builtin_amdgcn_raw_buffer_store_b128(tv, ro, vo, 0, 2);
                             } else {
                                 const u32x4 t0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
                                 const u32x4 t1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
-                                if (p.dbg & 8) { __builtin_amdgcn_raw_buffer_store_b128(t0, ro, vo, 0, aux_sc1); __builtin_amdgcn_raw_buffer_store_b128(t1, ro, vo + 16, 0, aux_sc1); }
+                                if (EMAGE_DBG(p, 8)) { __builtin_amdgcn_raw_buffer_store_b128(t0, ro, vo, 0, aux_sc1); __builtin_amdgcn_raw_buffer_store_b128(t1, ro, vo + 16, 0, aux_sc1); }
                                 else { __builtin_amdgcn_raw_buffer_store_b128(t0, ro, vo, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(t1, ro, vo + 16, 0, 2); }
                             }
                         }
@@ -543,7 +549,7 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
                             const int vo = (int)(((long)(m - m0) * p.ldf + n) * 4);
                             const u32x4 t0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
                             const u32x4 t1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
-                            if (p.dbg & 8) { __builtin_amdgcn_raw_buffer_store_b128(t0, rf, vo, 0, aux_sc1); __builtin_amdgcn_raw_buffer_store_b128(t1, rf, vo + 16, 0, aux_sc1); }
+                            if (EMAGE_DBG(p, 8)) { __builtin_amdgcn_raw_buffer_store_b128(t0, rf, vo, 0, aux_sc1); __builtin_amdgcn_raw_buffer_store_b128(t1, rf, vo + 16, 0, aux_sc1); }
                             else { __builtin_amdgcn_raw_buffer_store_b128(t0, rf, vo, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(t1, rf, vo + 16, 0, 2); }
                         }
                     } else {

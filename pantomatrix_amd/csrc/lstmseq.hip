@@ -218,17 +218,21 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
 
 int max_slices_for(int H);
 }
-namespace emage_dev { int g_lstm_layer_dbg = 0; }   // emage_set_tuning key 3 (gemm.hip)
+#ifdef EMAGE_TOOLS
+namespace emage_dev { int g_lstm_layer_dbg = 0; }   // tools build: emage_set_tuning key 3 (gemm.hip)
+#else
+namespace emage_dev { constexpr int g_lstm_layer_dbg = 0; }
+#endif
 namespace {
 
-int device_cus() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return v;
-    }();
-    return n;
+int device_cus() {                                     // CU count of the CURRENT device (cached per device id)
+    static int cached[64] = {0};
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64 && cached[dev] > 0) return cached[dev];
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) cached[dev] = v;
+    return v;
 }
 
 int max_slices_for(int H) {                            // co-resident blocks: one per CU, 2 * H/16 per slice of 64 clips
@@ -242,6 +246,14 @@ int launch_seq(SeqArgs a, int B, int max_slices, unsigned* sync, hipStream_t s) 
     constexpr size_t LDS = 2 * (size_t)KT * 64 * 64 + 128;
     static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (configured != hipSuccess) return (int)configured;
+    // the group barrier needs every block of a launch resident at once: one block per CU (LDS), so the occupancy query must admit >= 1
+    // block per CU for this kernel's register / LDS footprint (a plain launch has the residency of a cooperative one, without its check)
+    static const int blocks_per_cu = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)lstm_seq_kernel<H, HALVES>, 256, LDS) != hipSuccess) return 0;
+        return n;
+    }();
+    if (blocks_per_cu < 1 || 2 * max_slices * WPG > blocks_per_cu * device_cus()) return EMAGE_EINVAL;
     const float* gx = a.gx;
     float* hseq = a.hseq;
     int chunk = 0;
@@ -260,6 +272,22 @@ int launch_seq(SeqArgs a, int B, int max_slices, unsigned* sync, hipStream_t s) 
 }
 
 }  // namespace
+
+// counter[0] += number of launch records in `sync` whose error word is set (a block gave up waiting for its group): folded into the
+// runners' in-graph health counter, so EVERY replay reports a lost block with the D2H read it does anyway
+namespace {
+__global__ void lstm_health_kernel(const unsigned* __restrict__ sync, int records, int* __restrict__ counter) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < records && sync[(long)r * EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH + EMAGE_LSTM_SYNC_ERROR_WORD] != 0u) atomicAdd(counter, 1);
+}
+}  // namespace
+
+extern "C" int emage_lstm_layer_health(const unsigned* sync, int sync_words, int* counter, void* stream) {
+    if (!sync || !counter || sync_words <= 0 || sync_words % EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH) return EMAGE_EINVAL;
+    const int records = sync_words / EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH;
+    hipLaunchKernelGGL(lstm_health_kernel, dim3((records + 63) / 64), dim3(64), 0, (hipStream_t)stream, sync, records, counter);
+    return launch_status();
+}
 
 extern "C" int emage_lstm_layer_sync_words(int B, int H) {
     if (B <= 0 || (H != 256 && H != 512)) return EMAGE_EINVAL;

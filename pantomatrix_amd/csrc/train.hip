@@ -724,3 +724,89 @@ extern "C" int emage_adam_step_dev(float* param, const float* grad, float* exp_a
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay);
     return launch_status();
 }
+
+// ---- device-side dropout masks -------------------------------------------------------------------------------------------------------
+// nn.Dropout's keep mask drawn ON THE DEVICE: out[i] = bernoulli(1 - p) / (1 - p) from Philox4x32-10 (Salmon et al., SC'11), a
+// counter-based generator, so a mask is a pure function of (seed, step, mask id, element index) — no generator state to carry, no
+// host tensors, safe inside a captured hipGraph (the step is read from device memory):
+//   key = (seed lo, seed hi);  counter = (i / 4 lo, i / 4 hi, mask id, step);  element i takes word i % 4 of the block;
+//   keep  <=>  (word >> 8) * 2^-24 >= p      (24 random bits, uniform on [0, 1))
+// The stream is this library's own (documented here, pinned bit for bit by tests/test_train_rng.py against a numpy Philox); it is
+// NOT torch's fused-dropout stream: runs are reproducible for a seed, distribution-identical to the reference, not draw-identical.
+namespace {
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, float p, float keep_value,
+                                                           unsigned seed_lo, unsigned seed_hi, unsigned mask_id, const int* __restrict__ step_dev, int step) {
+    const unsigned st = step_dev ? (unsigned)*step_dev : (unsigned)step;
+    const long nblk = (n + 3) >> 2;
+    for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (long)gridDim.x * blockDim.x) {
+        unsigned c[4] = {(unsigned)b, (unsigned)(b >> 32), mask_id, st};
+        philox4x32_10(c, seed_lo, seed_hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long i = 4 * b + e;
+            if (i < n) out[i] = ((float)(c[e] >> 8) * (1.0f / 16777216.0f) >= p) ? keep_value : 0.f;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int emage_dropout_mask(float* out, long n, float p, unsigned long long seed, unsigned mask_id, const int* step_dev, int step, void* stream) {
+    if (!out || n <= 0 || !(p >= 0.f && p < 1.f)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, p, 1.0f / (1.0f - p),
+                       (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), mask_id, step_dev, step);
+    return launch_status();
+}
+
+// ---- multi-tensor Adam -----------------------------------------------------------------------------------------------------------------
+// ONE launch for every parameter of the model instead of one per tensor (445 launches): `table` holds, per tensor, the five 64-bit words
+// {param, grad, exp_avg, exp_avg_sq, n}; block b works on chunk block_chunk[b] (ADAM_CHUNK elements) of tensor block_tensor[b].  The same
+// arithmetic as emage_adam_step; grad_scale multiplies every gradient first (the 1 / world_size of the data-parallel average); with
+// zero_grad the gradient is cleared behind the update (the next step accumulates into it again).
+namespace {
+constexpr int ADAM_CHUNK = 4096;
+__global__ __launch_bounds__(256) void adam_multi_kernel(const long long* __restrict__ table, const int* __restrict__ block_tensor, const int* __restrict__ block_chunk,
+                                                         const int* __restrict__ step_dev, int step, float lr, float b1, float b2, float eps, float weight_decay,
+                                                         float grad_scale, int zero_grad) {
+    const int t = step_dev ? *step_dev : step;
+    const double bias1 = 1.0 - pow((double)b1, t), bias2 = 1.0 - pow((double)b2, t);
+    const float step_size = (float)((double)lr / bias1), inv_sqrt_bias2 = (float)(1.0 / sqrt(bias2));
+    const long long* e = table + 5 * (long)block_tensor[blockIdx.x];
+    float* __restrict__ p = (float*)e[0];
+    float* __restrict__ g = (float*)e[1];
+    float* __restrict__ m = (float*)e[2];
+    float* __restrict__ v = (float*)e[3];
+    const long n = (long)e[4];
+    const long i0 = (long)block_chunk[blockIdx.x] * ADAM_CHUNK;
+    const long i1 = i0 + ADAM_CHUNK < n ? i0 + ADAM_CHUNK : n;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        float gi = g[i] * grad_scale;
+        if (weight_decay != 0.f) gi += weight_decay * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bias2 + eps);
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int emage_adam_multi_chunk(void) { return ADAM_CHUNK; }
+
+extern "C" int emage_adam_multi(const long long* table, const int* block_tensor, const int* block_chunk, int n_blocks, const int* step_dev, int step,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, void* stream) {
+    if (!table || !block_tensor || !block_chunk || n_blocks <= 0 || (!step_dev && step <= 0)) return EMAGE_EINVAL;
+    if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, table, block_tensor, block_chunk, step_dev, step,
+                       lr, beta1, beta2, eps, weight_decay, grad_scale, zero_grad);
+    return launch_status();
+}

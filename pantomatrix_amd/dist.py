@@ -65,18 +65,20 @@ def finalize():
 # ----------------------------------------------------------------------------------------------------------------------
 # Training exchange step (train_emage_audio.py:214,248-251): the ONLY collectives of the whole path.
 # One process per GPU; gradients are averaged with a few large bucketed all-reduces over RCCL (xGMI is point-to-point:
-# a ring all-reduce is bound per link, so few large messages beat many small ones) issued in backward order so the
-# first buckets overlap the rest of the backward; SyncBatchNorm's per-channel statistics of both WavEncoders travel as
-# ONE small all-reduce per block pair instead of one per BatchNorm.  Backend "nccl" == RCCL on ROCm, "gloo" in tests.
-# `gradient_allreduce_hook` plugs them into `pantomatrix_amd.training.Trainer.step` between the backward and Adam.
+# a ring all-reduce is bound per link, so few large messages beat many small ones).  `training.Trainer` accumulates the
+# backward kernels' results straight into the bucket buffers below and starts bucket i's all-reduce as soon as its last
+# gradient of the step is written (during the third backward: the overlap DDP gives the reference, T:251).
+# SyncBatchNorm's per-channel statistics travel as one small all-reduce per BatchNorm.  Backend "nccl" == RCCL on ROCm,
+# "gloo" in tests.  `gradient_allreduce_hook` is the non-overlapped form (a `grad_hook` that reduces after the backward).
 # ----------------------------------------------------------------------------------------------------------------------
 EMAGE_BUCKET_PREFIXES = (
     # backward order of EmageAudioModel (M:315-330 run last in forward, so their gradients are ready first)
-    ("heads", ("body_motion_decoder_", "motion2latent_", "motion_out_proj_", "motion_cls_", "face_out_proj", "face_cls")),
+    # (the face branch runs BEFORE the body branch in forward, M:288-294: its heads belong to the later bucket)
+    ("heads", ("body_motion_decoder_", "motion2latent_", "motion_out_proj_", "motion_cls_")),
     ("cross", ("audio_motion_cross_attn.", "audio_body_motion_proj")),
-    ("self_face", ("motion_self_encoder.", "face_motion_decoder.", "moton_proj", "audio_face_motion_proj", "bodyhints_",
-                   "speaker_embedding_", "mask_embedding")),
-    ("encoders", ("audio_encoder_face.", "audio_encoder_body.", "motion_encoder.")),
+    ("self_face", ("motion_self_encoder.", "face_motion_decoder.", "face_out_proj", "face_cls", "moton_proj", "audio_face_motion_proj",
+                   "bodyhints_", "speaker_embedding_")),
+    ("encoders", ("audio_encoder_face.", "audio_encoder_body.", "motion_encoder.", "mask_embedding")),
 )
 
 
@@ -120,11 +122,13 @@ class GradientBuckets:
         if dist.is_available() and dist.is_initialized():
             self._work.append(dist.all_reduce(self.flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def wait(self):
+    def wait(self, average=True):
+        """Finish the all-reduces started by `reduce`; average=True divides by the world size here (False: the caller folds the
+        1 / world into its optimiser step, training.Trainer)."""
         for w in self._work:
             w.wait()
         self._work = []
-        if dist.is_available() and dist.is_initialized():
+        if average and dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(self.group)
             for b in self.flat:
                 b.div_(world)
@@ -134,7 +138,7 @@ def gradient_allreduce_hook(model, device=None, group=None):
     """The `grad_hook` of `training.Trainer.step` for a multi-GPU run: the step's gradients go into the four backward-ordered
     bucket messages, are summed over ranks (RCCL / gloo) and averaged (the DDP average, train_emage_audio.py:251), and come
     back in place.  Every rank runs the same forwards, so every rank holds the same gradient names."""
-    plan, _unused = emage_bucket_plan([(k, v) for k, v in model._flat_params().items() if v.is_floating_point()])
+    plan, _unused = emage_bucket_plan([(k, v) for k, v in model.named_parameters() if v.requires_grad])     # parameters only: no BatchNorm buffers
     buckets = GradientBuckets(plan, device=device if device is not None else model.device, group=group)
 
     def hook(param_grads):

@@ -127,11 +127,13 @@ class _EmageModule(torch.nn.Module):
         self._templates = {}
         return self
 
+    _trainable = False       # EmageAudioModel: train() switches forward() to the differentiable train-mode forward
+
     def train(self, mode=True):
-        if mode:
-            raise NotImplementedError("these modules' forward() is the eval-mode forward; the training step (train-mode forward, "
-                                      "backward, Adam) on the HIP kernels is pantomatrix_amd.training.Trainer")
-        return super().train(False)
+        if mode and not self._trainable:
+            raise NotImplementedError(f"{type(self).__name__} has an eval-mode forward only (the reference keeps its VQ-VAEs frozen, "
+                                      "train_emage_audio.py:233-245); the trainable class is EmageAudioModel")
+        return super().train(mode)
 
     def set_precision(self, precision: str):
         if precision not in _PRECISIONS:
@@ -852,6 +854,7 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
     config_class = EmageAudioConfig
     base_model_prefix = "emage_audio"
     _spec_fn = staticmethod(spec.audio_model_spec)
+    _trainable = True        # model.train(); out = model(...); loss.backward() — pantomatrix_amd/training.py: train_forward
 
     def _wav_blocks(self):
         return spec.wav_encoder_blocks(self.config.audio_f)
@@ -1036,6 +1039,10 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
         kernel (M:386-391); `_lean` (internal, `infer_codes`): skip the outputs the decode does not consume (the
         classifier of a latent-routed part, the fp32 copy of a classified part's latent).
         audio / masked_motion / mask may be windows (views) of longer clip tensors: they are read in place."""
+        if self.training and _audio_feats is None and _seed is None:
+            # train mode (T:156-181): batch-statistics BatchNorm, dropout, outputs connected to the parameters for loss.backward()
+            from . import training
+            return training.train_forward(self, audio, speaker_id, masked_motion, mask, use_audio)
         c = self.config
         cx = _Ctx(self._engine(), self.h2_residual)
         pk = cx.pk

@@ -163,6 +163,11 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
             self.check_kernels()
         return result
 
+    def fold_kernel_health(self, counter):
+        """counter (int32 device scalar) += lost blocks of this forward's persistent recurrences (stream-ordered, capturable)."""
+        for s in self._sync.values():
+            ops.lstm_layer_health(s, counter)
+
     def check_kernels(self):
         """Raise if a persistent-recurrence launch reported a lost block since the last call (synchronises the device)."""
         for s in self._sync.values():

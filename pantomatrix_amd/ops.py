@@ -630,6 +630,84 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1.5e-4, beta1=0.9, beta
         _adam_step(param, grad, exp_avg, exp_avg_sq, int(step), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay))
 
 
+@_op("dropout_mask", "(Tensor(a!) out, float p, int seed, int mask_id, Tensor? step_dev, int step) -> ()")
+def _dropout_mask(out, p, seed, mask_id, step_dev, step):
+    check(_lib.load().emage_dropout_mask(_ptr(out), out.numel(), p, seed & 0xFFFFFFFFFFFFFFFF, mask_id & 0xFFFFFFFF, _ptr(step_dev), step, _stream()), "dropout_mask")
+
+
+def dropout_mask(out, p, seed, mask_id, step):
+    """Fill the contiguous fp32 tensor `out` with a dropout keep mask bernoulli(1 - p) / (1 - p) drawn on the device (Philox4x32-10 keyed
+    by `seed`, counter (element / 4, mask_id, step)); `step` an int or a one-element int32 device tensor (read by the kernel: captured
+    training steps draw fresh masks on every replay).  See include/emage_hip.h: emage_dropout_mask."""
+    _dev(out)
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    if torch.is_tensor(step):
+        assert step.dtype == torch.int32 and step.numel() == 1
+        _dropout_mask(out, float(p), int(seed), int(mask_id), step, 0)
+    else:
+        _dropout_mask(out, float(p), int(seed), int(mask_id), None, int(step))
+    return out
+
+
+def philox_dropout_reference(n, p, seed, mask_id, step):
+    """numpy restatement of emage_dropout_mask (Philox4x32-10, csrc/train.hip) — tests and the CPU stand-ins."""
+    import numpy as np
+    nb = (n + 3) // 4
+    b = np.arange(nb, dtype=np.uint64)
+    c = [(b & np.uint64(0xFFFFFFFF)).astype(np.uint64), (b >> np.uint64(32)).astype(np.uint64),
+         np.full(nb, mask_id & 0xFFFFFFFF, dtype=np.uint64), np.full(nb, step & 0xFFFFFFFF, dtype=np.uint64)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    words = np.stack(c, axis=1).reshape(-1)[:n]
+    u = (words >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return np.where(u >= np.float32(p), np.float32(1.0 / (1.0 - p)), np.float32(0.0)).astype(np.float32)
+
+
+class AdamTable:
+    """Descriptor tables of `adam_multi` for a fixed list of (param, grad, exp_avg, exp_avg_sq) fp32 tensors (contiguous, same numel per
+    quadruple): built once, valid as long as the tensors' storage does not move."""
+
+    def __init__(self, quads, device):
+        chunk = _lib.load().emage_adam_multi_chunk()
+        rows, bt, bc = [], [], []
+        for i, (p, g, m, v) in enumerate(quads):
+            n = p.numel()
+            for t in (p, g, m, v):
+                assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n and t.device == p.device
+            rows.append([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n])
+            nb = (n + chunk - 1) // chunk
+            bt += [i] * nb
+            bc += list(range(nb))
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        self.block_tensor = torch.tensor(bt, dtype=torch.int32).to(device)
+        self.block_chunk = torch.tensor(bc, dtype=torch.int32).to(device)
+        self.n_blocks = len(bt)
+        self.keep = quads                      # the tensors the table points at stay alive with it
+
+
+@_op("adam_multi", "(Tensor table, Tensor block_tensor, Tensor block_chunk, int n_blocks, Tensor? step_dev, int step, float lr, float beta1, float beta2, "
+                   "float eps, float weight_decay, float grad_scale, bool zero_grad) -> ()")
+def _adam_multi(table, block_tensor, block_chunk, n_blocks, step_dev, step, lr, beta1, beta2, eps, weight_decay, grad_scale, zero_grad):
+    check(_lib.load().emage_adam_multi(_ptr(table), _ptr(block_tensor), _ptr(block_chunk), n_blocks, _ptr(step_dev), step, lr, beta1, beta2, eps,
+                                       weight_decay, grad_scale, int(zero_grad), _stream()), "adam_multi")
+
+
+def adam_multi(tab: "AdamTable", step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, zero_grad=False):
+    """torch.optim.Adam's update of every tensor of `tab` in ONE launch (include/emage_hip.h: emage_adam_multi); `step` an int or a one-element
+    int32 device tensor."""
+    _dev(tab.table)
+    if torch.is_tensor(step):
+        _adam_multi(tab.table, tab.block_tensor, tab.block_chunk, tab.n_blocks, step, 0, float(lr), float(beta1), float(beta2), float(eps),
+                    float(weight_decay), float(grad_scale), bool(zero_grad))
+    else:
+        _adam_multi(tab.table, tab.block_tensor, tab.block_chunk, tab.n_blocks, None, int(step), float(lr), float(beta1), float(beta2), float(eps),
+                    float(weight_decay), float(grad_scale), bool(zero_grad))
+
+
 @_op("layernorm", "(int dtype, Tensor x, Tensor gamma, Tensor beta, float eps, Tensor? add, Tensor(a!)? y_f32, Tensor(b!)? y) -> ()")
 def _layernorm(dtype, x, gamma, beta, eps, add, y_f32, y):
     m, c = x.shape
@@ -823,8 +901,10 @@ LSTM_SYNC_WORDS_PER_LAUNCH, LSTM_SYNC_ERROR_WORD = 544, 512      # include/emage
 
 
 def lstm_layer_supported(dtype, hidden):
-    """Whether `lstm_layer` (the persistent recurrence) takes this layer: split-f16 precision, H = 256 or 512."""
-    return dtype == F16X3 and hidden in (256, 512)
+    """Whether `lstm_layer` (the persistent recurrence) takes this layer on the CURRENT device: split-f16 precision, H = 256 or
+    512, and enough co-resident blocks (2 * H/16 CUs; a compute partition or a CU-masked queue may have fewer — the per-step
+    launches produce the same bits there)."""
+    return dtype == F16X3 and hidden in (256, 512) and _lib.load().emage_lstm_layer_sync_words(1, int(hidden)) > 0
 
 
 def lstm_layer_sync(b, hidden, device):
@@ -852,6 +932,19 @@ def lstm_layer(dtype, gates_x, w_hh, w_scale, hseq, sync, *, a_scale=None):
     _dev(gates_x)
     _lstm_layer(dtype, gates_x, w_hh[0], w_hh[1], float(w_scale[0]), float(w_scale[1]), float(A_SCALE_F16X3 if a_scale is None else a_scale), hseq, sync)
     return hseq
+
+
+@_op("lstm_layer_health", "(Tensor sync, Tensor(a!) counter) -> ()")
+def _lstm_layer_health(sync, counter):
+    check(_lib.load().emage_lstm_layer_health(_ptr(sync), sync.numel(), _ptr(counter), _stream()), "lstm_layer_health")
+
+
+def lstm_layer_health(sync, counter):
+    """counter (int32 device scalar) += number of `lstm_layer` launches recorded in `sync` that lost a block; stream-ordered behind
+    them (capturable): the runners read the counter with the D2H copy they do anyway, on EVERY replay."""
+    _dev(sync)
+    assert sync.dtype == torch.int32 and counter.dtype == torch.int32
+    _lstm_layer_health(sync, counter)
 
 
 def lstm_layer_check(sync):

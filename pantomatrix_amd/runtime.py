@@ -187,8 +187,8 @@ class LstmClipRunner:
         self.model, self.device = model, dev
         self.audio = torch.zeros(batch, n_samples, dtype=torch.float32, device=dev)
         self.speaker_id = torch.zeros(batch, 1, dtype=torch.long, device=dev)
-        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.nonfinite_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        self.nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)       # [non-finite results, lost blocks of the recurrences]
+        self.nonfinite_host = torch.zeros(2, dtype=torch.int32, pin_memory=True)
         self.graph = None
         for _ in range(max(1, warmup)):
             out = self._step()
@@ -208,7 +208,10 @@ class LstmClipRunner:
         out = o["motion"].reshape(b, o["motion"].shape[1], -1), o["motion_axis_angle"]
         self.nonfinite.zero_()                       # health check, as in ClipRunner: inf / NaN in the generated motion raises
         for t in out:
-            ops.count_nonfinite(t.contiguous(), self.nonfinite)
+            ops.count_nonfinite(t.contiguous(), self.nonfinite[:1])
+        # ... and so does a lost block of a persistent recurrence (its output is finite but wrong): the error words of this
+        # forward's launches are folded into the second counter word inside the graph, so EVERY replay is checked
+        self.model.fold_kernel_health(self.nonfinite[1:])
         return out
 
     def __call__(self, audio=None, speaker_id=None):
@@ -227,9 +230,10 @@ class LstmClipRunner:
         if int(self.nonfinite_host[0]):
             raise FloatingPointError(f"{int(self.nonfinite_host[0])} non-finite values in the generated motion (precision {self.model.precision!r}): in f16x3 an "
                                      "activation beyond |x| < 4094 overflows the fp16 planes — run this checkpoint with set_precision('fp32')")
-        if self.graph is not None and self._checked_replays < 2:     # the persistent recurrence's error words: first replays, then `check()`
-            self._checked_replays += 1
-            self.model.check_kernels()
+        if int(self.nonfinite_host[1]):
+            from ._lib import EmageKernelError
+            raise EmageKernelError("emage_lstm_layer: a block timed out waiting for its group (blocks not co-resident: another kernel holding CUs?); "
+                                   "the motion of this batch is invalid")
         return tuple(h.numpy() for h in self.host)
 
     def check(self):

@@ -39,10 +39,24 @@ def dropout_mask_count():
 
 
 class _Masks:
-    def __init__(self, masks, dev):
-        self.masks, self.i, self.dev = list(masks), 0, dev
+    """The dropout masks of one forward: a given list (the parity tests: the reference's recorded draws), or — masks None — drawn on
+    the device as they are needed (`ops.dropout_mask`: Philox keyed by rng = (seed, step, first mask id); step may be a device scalar)."""
+
+    def __init__(self, masks, dev, rng=None):
+        self.masks, self.i, self.dev, self.rng = (None if masks is None else list(masks)), 0, dev, rng
+        if masks is None and rng is None:
+            raise RuntimeError("train-mode forward: pass dropout_masks or an rng (seed, step, first mask id)")
+
+    def consumed_all(self):
+        return self.masks is None or self.i == len(self.masks)
 
     def take(self, shape):
+        if self.masks is None:
+            seed, step, base = self.rng
+            m = torch.empty(tuple(shape), dtype=torch.float32, device=self.dev)
+            ops.dropout_mask(m, DROPOUT_P, seed, base + self.i, step)
+            self.i += 1
+            return m
         if self.i >= len(self.masks):
             raise RuntimeError(f"dropout_masks: {len(self.masks)} masks given, the forward needs {dropout_mask_count()}")
         m = self.masks[self.i]
@@ -74,7 +88,7 @@ class _Tape:
     (or token) they belong to, column-slice views routed into their parent's buffer.  Gradients are fp32 (rows, cols)."""
 
     def __init__(self, dev):
-        self.dev, self.nodes, self.g, self.views, self.keep = dev, [], {}, {}, []
+        self.dev, self.nodes, self.g, self.views, self.keep, self.pos = dev, [], {}, {}, [], -1
 
     def node(self, fn):
         self.nodes.append(fn)
@@ -123,9 +137,17 @@ class _Tape:
         e = self.g.get(id(t))
         return None if e is None else e[0]
 
-    def run(self):
-        for fn in reversed(self.nodes):
+    def run(self, progress=None):
+        """Run the recorded closures in reverse; `pos` counts the executed nodes (what `TrainForward._param_grad` stamps a parameter's
+        last contribution with); progress(pos) is called behind each node (the overlapped gradient exchange hangs on it)."""
+        self.pos = -1
+        if progress is not None:
+            progress(-1)
+        for k, fn in enumerate(reversed(self.nodes)):
+            self.pos = k
             fn()
+            if progress is not None:
+                progress(k)
         self.nodes = []
 
 
@@ -143,6 +165,8 @@ class TrainForward:
         self.sync_bn, self.group, self._bn_count = sync_bn, group, {}
         self.tape = None
         self.param_grads = {}
+        self.grad_views = None          # name -> preallocated fp32 gradient tensor (views of the exchange buckets, training.Trainer)
+        self.touch = None               # dict filled with name -> tape position of the parameter's last contribution of a backward
         self._pcache = None
 
     # ---- packing of what the inference pack does not hold: un-folded WavEncoder convolutions ----------------------------
@@ -403,10 +427,12 @@ class TrainForward:
     def _param_grad(self, name, rows, g):
         full = self.param_grads.get(name)
         if full is None:
-            full = torch.zeros_like(self._param(name), dtype=torch.float32)
+            full = self.grad_views[name] if self.grad_views is not None else torch.zeros_like(self._param(name), dtype=torch.float32)
             self.param_grads[name] = full
         dst = full[rows]
         dst += g.reshape(dst.shape)                    # parameter-sized accumulation across the forwards of a step
+        if self.touch is not None:
+            self.touch[name] = self.tape.pos
 
     def _add(self, cx, a, bb, mod_b=0, grad_b=True):
         out = cx.lo(*a.shape)
@@ -532,10 +558,11 @@ class TrainForward:
         return rows
 
     # ---- the forward --------------------------------------------------------------------------------------------------------
-    def __call__(self, audio, speaker_id, masked_motion, mask, dropout_masks, use_audio=True, new_stats=None, tape=False):
+    def __call__(self, audio, speaker_id, masked_motion, mask, dropout_masks=None, use_audio=True, new_stats=None, tape=False, rng=None):
         """-> (dict of the 8 (B, T, 256) fp32 outputs, new_stats).  `new_stats` carries the BatchNorm running buffers from one
         forward of a step to the next (as oracle.emage_train_oracle.forward_train does); it is not written into the model.
-        tape=True keeps what `backward()` needs (see there)."""
+        tape=True keeps what `backward()` needs (see there).  dropout_masks None: the masks are drawn on the device from
+        rng = (seed, step, first mask id) — see `_Masks`."""
         model = self.model
         c = model.config
         cx = _Ctx(model._engine(h2=False))       # the training forward keeps float32 activations (split inside the GEMMs in f16x3)
@@ -545,7 +572,7 @@ class TrainForward:
         self._cx = cx
         self._pcache = None
         new_stats = {} if new_stats is None else new_stats
-        masks = _Masks(dropout_masks, dev)
+        masks = _Masks(dropout_masks, dev, rng)
         b, t, cm = masked_motion.shape
         m = b * t
         d, mf, af = c.hidden_size, c.motion_f, c.audio_f
@@ -635,13 +662,13 @@ class TrainForward:
             out[f"rec_{p}"] = self._lin(cx, self._add(cx, lat[p], refine[p]), f"motion_out_proj_{p}")
         for p in parts:
             out[f"cls_{p}"] = self._lin(cx, self._lin(cx, out[f"rec_{p}"], f"motion_cls_{p}.fc1", slope=0.1), f"motion_cls_{p}.fc2")
-        if masks.i != len(masks.masks):
+        if not masks.consumed_all():
             raise RuntimeError(f"dropout_masks: {len(masks.masks)} masks given, the forward consumed {masks.i}")
         self._out2d = out
         return {key: out[key].view(b, t, -1) for key in OUT_KEYS}, new_stats
 
     # ---- backward through everything behind the motion encoder and the WavEncoders ------------------------------------------------
-    def backward(self, index_gt, latent_gt):
+    def backward(self, index_gt, latent_gt, progress=None):
         """Gradients of `rec_loss + cls_loss` (T:106-130) of the LAST forward (called with tape=True) w.r.t. every trainable parameter
         that takes part in it; they ACCUMULATE in `self.param_grads` (name -> fp32 tensor of the parameter's shape) across the
         forwards of a step, like `loss_all.backward()` in the reference (T:174).  Every contraction (Linear and Conv1d, dX and dW) is
@@ -656,9 +683,74 @@ class TrainForward:
             # cf = 0 in the reference's config: the face classifier's loss is evaluated and multiplied by 0 (T:113-128), its
             # parameters receive exact-zero gradients and an Adam state — kept that way
             tape.add(logits, ops.nll_loss_grad(logits, index_gt[q].reshape(-1).contiguous().to(logits.device), getattr(cfg, "c" + q[0])))
-        tape.run()
+        tape.run(progress)
         self.tape = None
         return self.param_grads
+
+    def backward_from(self, tape, out2d, grad_outputs):
+        """Backward of ONE recorded forward from the gradients of its outputs (the autograd bridge of the model classes' train-mode
+        forward: torch computes d loss / d output, this runs the rest): returns {parameter name: gradient} of that forward alone."""
+        self.tape, saved = tape, self.param_grads
+        self.param_grads = {}
+        try:
+            for key, g in grad_outputs.items():
+                if g is not None:
+                    t = out2d[key]
+                    tape.add(t, g.reshape(t.shape).to(torch.float32).contiguous())
+            tape.run()
+            return self.param_grads
+        finally:
+            self.param_grads, self.tape = saved, None
+
+
+# ======================================================================================
+# the autograd bridge: `model.train(); out = model(audio, speaker_id, masked_motion, mask); loss.backward()` (T:156-181)
+# ======================================================================================
+class _TrainFn(torch.autograd.Function):
+    """One train-mode forward of an EmageAudioModel as ONE autograd node: forward = `TrainForward.__call__` with a tape, backward =
+    the tape run from the gradients torch hands in for the eight outputs.  The trainable parameters are inputs of the node, so
+    `.grad` accumulation, optimisers and hooks behave as for the reference module."""
+
+    @staticmethod
+    def forward(ctx, fwd, names, audio, speaker_id, masked_motion, mask, use_audio, dropout_masks, rng, *params):
+        with torch.no_grad():
+            pred, stats = fwd(audio, speaker_id, masked_motion, mask, dropout_masks, use_audio=use_audio, tape=True, rng=rng)
+            flat = fwd.model._flat_params()
+            for name, v in stats.items():                 # train-mode BatchNorm: the running buffers advance in place, as in torch
+                if name in flat:
+                    flat[name].copy_(v.to(flat[name].dtype))
+        ctx.fwd, ctx.names, ctx.tape, ctx.out2d = fwd, names, fwd.tape, fwd._out2d
+        fwd.tape = None
+        return tuple(pred[k] for k in OUT_KEYS)
+
+    @staticmethod
+    def backward(ctx, *grad_outputs):
+        grads = ctx.fwd.backward_from(ctx.tape, ctx.out2d, dict(zip(OUT_KEYS, grad_outputs)))
+        ctx.tape = None
+        return (None,) * 9 + tuple(grads.get(n) for n in ctx.names)
+
+
+def train_forward(model, audio, speaker_id, masked_motion, mask, use_audio=True):
+    """EmageAudioModel.forward in TRAINING mode (what `model(...)` runs after `model.train()`): differentiable w.r.t. the model's
+    parameters through `_TrainFn`.  Dropout masks come from the device generator (seeded by `torch.initial_seed()`, advancing with
+    every call) unless `model.dropout_masks_override` holds recorded mask lists (the parity tests), consumed one per call."""
+    fwd = model.__dict__.get("_train_fwd")
+    if fwd is None:
+        fwd = model.__dict__["_train_fwd"] = TrainForward(model)
+        model.__dict__["_train_calls"] = 0
+        model.__dict__["_param_versions"] = None
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    versions = tuple(p._version for _n, p in named)
+    if versions != model.__dict__["_param_versions"]:     # an optimiser step (or any in-place edit) since the last forward: re-pack
+        model.invalidate_packed()
+        fwd._pcache = None
+        model.__dict__["_param_versions"] = versions
+    override = getattr(model, "dropout_masks_override", None)
+    masks = override.pop(0) if override else None
+    model.__dict__["_train_calls"] += 1
+    rng = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, model.__dict__["_train_calls"], 0)
+    outs = _TrainFn.apply(fwd, [n for n, _p in named], audio, speaker_id, masked_motion, mask, bool(use_audio), masks, rng, *[p for _n, p in named])
+    return dict(zip(OUT_KEYS, outs))
 
 
 # ======================================================================================
@@ -716,17 +808,46 @@ class Trainer:
     passes (gradients accumulate like `loss_all.backward()`), torch.optim.Adam with the reference's settings (lr 1.5e-4 constant,
     betas .9 / .999, eps 1e-8, no weight decay: configs/emage_audio.yaml:63-78), the BatchNorm running buffers.  Parameters that
     take no part in the forward (the deep-copied template layers, M:246-262) get no gradient and stay untouched, as in torch.
-    `grad_hook(param_grads)` runs between backward and the update: the place of the gradient all-reduce of a multi-GPU run
-    (`pantomatrix_amd.dist.GradientBuckets`)."""
 
-    def __init__(self, model, vq, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, sync_bn=False, group=None):
+    Gradients live in four flat, backward-ordered buckets (`dist.GradientBuckets`: the backward kernels' results are accumulated
+    straight into the all-reduce messages, no copies).  In a multi-process run (`group` / an initialised default group) bucket i is
+    all-reduced AS SOON AS its last gradient of the step has been written — during the third backward, while the remaining backward
+    kernels are still being issued (the overlap DDP gives the reference, T:251): the tape position of every parameter's last
+    contribution is learned during the first step (the launch sequence of a step is static) and drives the schedule from the second
+    step on.  The 1 / world_size of the average is folded into Adam, which is ONE multi-tensor launch that also clears the gradients.
+    Dropout masks: `dropout_masks` (three lists, the parity tests) or None = drawn on the device (`ops.dropout_mask`, seeded by `seed`).
+    `grad_hook(param_grads)` still runs between backward and the update (tests spy on it)."""
+
+    def __init__(self, model, vq, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, sync_bn=False, group=None, seed=0, exchange=True):
+        """exchange=False: no built-in gradient all-reduce even in a multi-process run (a `grad_hook` may do it: `dist.gradient_allreduce_hook`)."""
+        from . import dist as pdist
+        self.exchange = bool(exchange)
         self.fwd, self.vq = TrainForward(model, sync_bn=sync_bn, group=group), vq
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.group, self.seed = group, int(seed)
         self.state = {}                                   # name -> dict(step, exp_avg, exp_avg_sq)
+        named = [(k, v) for k, v in model.named_parameters() if v.requires_grad]
+        plan, self.unused = pdist.emage_bucket_plan(named)
+        self.buckets = pdist.GradientBuckets(plan, device=model.device, group=group)
+        self.fwd.grad_views = self.buckets.grads
+        self.bucket_of = {name: i for i, (_tag, params) in enumerate(plan) for name, _p in params}
+        self.schedule = None                              # bucket -> tape position (third backward) behind which it is complete
+        self.exchange_log = []                            # (event, bucket or tape position) of the last step: what the overlap tests read
+        self.steps_done = 0
+        self._adam = None
+
+    def _world(self):
+        import torch.distributed as tdist
+        if not self.exchange:
+            return 1
+        return tdist.get_world_size(self.group) if (tdist.is_available() and tdist.is_initialized()) else 1
+
+    def _rng(self, forward_index, step):
+        return (self.seed, step, 128 * forward_index)
 
     def _device_step(self, batch, dropout_masks, random_mask, grad_hook=None, step_counter=None):
         """Everything of a step that runs on the device; returns (dict of float64 device loss scalars, loss workspace).  With
-        `step_counter` (one int32 on the device) Adam reads the step count from it — what a captured graph needs."""
+        `step_counter` (one int32 on the device) Adam and the mask generator read the step count from it — what a captured graph needs."""
         fwd, model = self.fwd, self.fwd.model
         cfg = model.config
         index, latent, masked_motion = targets(self.vq, batch["motion"], batch["expressions"], batch["trans"], batch["foot_contact"])
@@ -737,29 +858,70 @@ class Trainer:
         fwd.param_grads = {}
         stats, out = {}, {}
         ws = ops.loss_workspace(masked_motion.device)
-        for tag, mask, use_audio, masks in (("seed", seed_mask, True, dropout_masks[0]), ("audio", random_mask, True, dropout_masks[1]),
-                                            ("mask", random_mask, False, dropout_masks[2])):
-            pred, stats = fwd(batch["audio"], speaker_id, masked_motion, mask, masks, use_audio=use_audio, new_stats=stats, tape=True)
+        world = self._world()
+        buckets, log = self.buckets, []
+        self.exchange_log = log
+        learning = self.schedule is None
+        step_for_rng = step_counter if step_counter is not None else self.steps_done + 1
+        dm = dropout_masks if dropout_masks is not None else (None, None, None)
+        for f, (tag, mask, use_audio, masks) in enumerate((("seed", seed_mask, True, dm[0]), ("audio", random_mask, True, dm[1]),
+                                                            ("mask", random_mask, False, dm[2]))):
+            pred, stats = fwd(batch["audio"], speaker_id, masked_motion, mask, masks, use_audio=use_audio, new_stats=stats, tape=True,
+                              rng=self._rng(f, step_for_rng))
             out["rec_" + tag], out["cls_" + tag] = losses(cfg, pred, index, latent, ws)
-            fwd.backward(index, latent)
+            progress = None
+            if f == 2:
+                if learning:
+                    fwd.touch = {}
+                elif world > 1:
+                    ready = {}
+                    for i, pos in self.schedule.items():
+                        ready.setdefault(pos, []).append(i)
+
+                    def progress(pos, ready=ready):
+                        for i in ready.get(pos, ()):         # every gradient of bucket i is final: its all-reduce overlaps the rest of the backward
+                            log.append(("reduce", i, pos))
+                            buckets.reduce(i)
+            fwd.backward(index, latent, progress)
+            log.append(("backward_done", f))
+        if learning:
+            last = {}
+            for name, pos in fwd.touch.items():
+                i = self.bucket_of[name]
+                last[i] = max(last.get(i, -1), pos)
+            self.schedule = {i: last.get(i, -1) for i in range(len(buckets.flat))}      # -1: complete before the third backward starts
+            fwd.touch = None
+            if world > 1:
+                for i in range(len(buckets.flat)):
+                    log.append(("reduce", i, None))
+                    buckets.reduce(i)
         grads = fwd.param_grads
+        if world > 1:
+            buckets.wait(average=False)                   # the 1 / world of the average is Adam's grad_scale
+            log.append(("wait",))
         if grad_hook is not None:
             grad_hook(grads)
         params = model._flat_params()                     # detached views of the nn.Parameters: updated in place
-        for name, g in grads.items():
-            p = params[name]
-            st = self.state.get(name)
-            if st is None:
+        if self._adam is None:
+            quads = []
+            for name, g in buckets.grads.items():
+                p = params[name]
                 st = self.state[name] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
-            st["step"] += 1
-            ops.adam_step(p, g.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"] if step_counter is None else step_counter,
-                          self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay)
+                quads.append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+            self._adam = ops.AdamTable(quads, model.device)
+        self.steps_done += 1
+        for st in self.state.values():
+            st["step"] = self.steps_done
+        ops.adam_multi(self._adam, self.steps_done if step_counter is None else step_counter, self.lr, self.betas[0], self.betas[1], self.eps,
+                       self.weight_decay, grad_scale=1.0 / world, zero_grad=True)
         for name, v in stats.items():                     # BatchNorm running statistics after the three forwards
             if name in params:
                 params[name].copy_(v.to(params[name].dtype))
         return out, ws
 
-    def step(self, batch, iteration, dropout_masks, random_mask, grad_hook=None):
+    def step(self, batch, iteration=0, dropout_masks=None, random_mask=None, grad_hook=None):
+        """One optimisation step -> dict of the six losses + "all".  `iteration` is accepted for signature compatibility with the
+        reference's train_val_fn (T:132) and unused: the caller computes the mask ratio and passes `random_mask` (T:163-165)."""
         out, ws = self._device_step(batch, dropout_masks, random_mask, grad_hook)
         self.fwd.model.invalidate_packed()                # the MFMA operand copies are rebuilt from the updated parameters
         self.fwd._pcache = None
@@ -769,20 +931,29 @@ class Trainer:
         return res
 
     # ---- the step as ONE hipGraph -------------------------------------------------------------------------------------------------
-    def capture(self, batch, dropout_masks, random_mask):
+    def capture(self, batch, random_mask, dropout_masks=None):
         """Capture the whole step — re-packing the MFMA operands from the current parameters, targets, three forwards with their
-        backward passes, Adam, BatchNorm buffers — into one hipGraph over the GIVEN tensors: `batch`, `dropout_masks`,
-        `random_mask` become the graph's input buffers (refill them in place between replays: the randomness stays outside the
-        captured region), the parameters its state.  `replay()` then runs a step at device speed instead of the ~10^4 Python-level
-        launches of `step()`.  Needs the model in "fp32" precision (packing split-fp16 operands reads each weight's scale back to
-        the host) and a single process (no SyncBatchNorm exchange inside a capture).  One eager warm-up step is run and undone."""
+        backward passes, the dropout masks (drawn on the device from the in-graph step counter unless `dropout_masks` buffers are
+        given), Adam, BatchNorm buffers — into one hipGraph over the GIVEN tensors: `batch` and `random_mask` (and `dropout_masks`)
+        become the graph's input buffers (refill them in place between replays), the parameters its state.  `replay()` then runs a
+        step at device speed instead of the ~10^4 Python-level launches of `step()`.  Needs the model in "fp32" precision (packing
+        split-fp16 operands reads each weight's scale back to the host) and a single process (no collective inside a capture).  One
+        eager warm-up step is run and undone."""
         fwd, model = self.fwd, self.fwd.model
-        if model.precision != "fp32" or fwd.sync_bn:
-            raise RuntimeError("Trainer.capture: needs precision 'fp32' and sync_bn=False")
+        if model.precision != "fp32" or fwd.sync_bn or self._world() > 1:
+            raise RuntimeError("Trainer.capture: needs precision 'fp32', sync_bn=False and a single process")
         dev = model.device
+        for name, t in list(batch.items()) + [("random_mask", random_mask)]:
+            if not (torch.is_tensor(t) and t.is_cuda and t.device == dev and t.dtype == torch.float32):
+                raise RuntimeError(f"Trainer.capture: {name} must be a float32 tensor on {dev} (it becomes an input buffer of the graph; a host "
+                                   "tensor would be copied once at capture time and never again)")
+        for fm in (dropout_masks or ()):
+            for mk in fm:
+                if not (mk.is_cuda and mk.dtype == torch.float32 and mk.is_contiguous()):
+                    raise RuntimeError("Trainer.capture: dropout masks must be contiguous fp32 tensors on the device (they are the graph's input buffers)")
         params = model._flat_params()
         saved = {k: v.clone() for k, v in params.items()}
-        self._device_step(batch, dropout_masks, random_mask)          # warm-up: lazy initialisation inside the library / the allocator
+        self._device_step(batch, dropout_masks, random_mask)          # warm-up: lazy initialisation inside the library / the allocator, the exchange schedule
         torch.cuda.synchronize(dev)
         for k, v in saved.items():
             params[k].copy_(v)
@@ -790,10 +961,7 @@ class Trainer:
             st["exp_avg"].zero_()
             st["exp_avg_sq"].zero_()
             st["step"] = 0
-        for fm in dropout_masks:
-            for mk in fm:
-                if not (mk.is_cuda and mk.dtype == torch.float32 and mk.is_contiguous()):
-                    raise RuntimeError("Trainer.capture: dropout masks must be contiguous fp32 tensors on the device (they are the graph's input buffers)")
+        self.steps_done = 0
         self._step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
@@ -801,6 +969,7 @@ class Trainer:
             fwd._pcache = None
             self._step_counter.add_(1)
             self._graph_out, self._graph_ws = self._device_step(batch, dropout_masks, random_mask, step_counter=self._step_counter)
+        self.steps_done = 0
         for st in self.state.values():
             st["step"] = 0
         return self
@@ -809,6 +978,7 @@ class Trainer:
         """One captured step on the current contents of the captured input buffers -> the loss dict of `step()`."""
         self._graph.replay()
         n = int(self._step_counter)
+        self.steps_done = n
         for st in self.state.values():
             st["step"] = n
         res = {k: float(v) for k, v in self._graph_out.items()}

@@ -298,6 +298,24 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1.5e-4, beta1=0.9, beta
     param.copy_(param - (lr / b1) * exp_avg / (exp_avg_sq.sqrt() / math.sqrt(b2) + eps))
 
 
+def adam_multi(tab, step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, zero_grad=False):
+    """emage_adam_multi == emage_adam_step on every tensor of the table (grad * grad_scale first, gradient cleared behind the update)."""
+    mark = len(CALLS)
+    step = int(step)
+    for p, g, m, v in tab.keep:
+        adam_step(p, g * grad_scale, m, v, step, lr, beta1, beta2, eps, weight_decay)
+        if zero_grad:
+            g.zero_()
+    del CALLS[mark:]
+    CALLS.append("adam_multi")
+
+
+def dropout_mask(out, p, seed, mask_id, step):
+    CALLS.append("dropout_mask")
+    out.copy_(torch.from_numpy(ops.philox_dropout_reference(out.numel(), p, int(seed), int(mask_id), int(step))).view(out.shape))
+    return out
+
+
 def loss_workspace(device):
     return torch.zeros(1024, dtype=torch.float64)
 
@@ -630,7 +648,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["count_nonfinite", "loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["adam_multi", "dropout_mask", "count_nonfinite", "loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

@@ -8,9 +8,11 @@ from pantomatrix_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(tools=False):
     text = open(os.path.join(ROOT, "include", "emage_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    guarded = re.findall(r"#ifdef EMAGE_TOOLS(.*?)#endif", text, flags=re.S)
+    text = "".join(guarded) if tools else re.sub(r"#ifdef EMAGE_TOOLS.*?#endif", "", text, flags=re.S)
     protos = {}
     for m in re.finditer(r"(?:int|long|size_t|const char\*)\s+(emage_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
@@ -41,4 +43,21 @@ def test_argument_validation_without_gpu():
     assert lib.emage_gather_rows(None, None, 0, 0, 1, None, 0, 0, 0, 0, 0, 0, None) == -1
     assert lib.emage_wav_conv_in(0, None, 0, 0, 1, 0, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, None) == -1
     assert lib.emage_pack_motion(0, None, None, 0, None, None, 0, 0, None, 0, 0, 0, 0, 0, None) == -1
-    assert lib.emage_set_tuning(99, 0) == -1
+
+
+def test_product_library_has_no_tuning_hooks_and_the_tools_twin_does():
+    """the product .so carries no `emage_set_tuning` / tracer / mutable tuning globals; the -DEMAGE_TOOLS twin
+    exports them (and everything the product exports)."""
+    import ctypes
+    tools_only = _declared(tools=True)
+    assert set(tools_only) == set(_lib.TOOLS_SIGNATURES) == {"emage_set_tuning", "emage_h2_set_trace"}
+    product = ctypes.CDLL(_lib.LIB_PATH)
+    for name in tools_only:
+        assert not hasattr(product, name), f"{name} must not be exported by the product library"
+    try:
+        tools = _lib.use_tools(True)
+        for name in list(_declared()) + list(tools_only):
+            assert hasattr(tools, name), name
+        assert tools.emage_set_tuning(99, 0) == -1 and tools.emage_set_tuning(0, -1) == 0
+    finally:
+        _lib.use_tools(False)

@@ -111,28 +111,31 @@ def _trainer_worker(rank, world, port, q):
     from pantomatrix_amd import training
     assert pd.init("gloo") is not None
     torch.set_num_threads(2)
-    model, vq = common.product_models(precision="fp32")
     batch, _, masks, random_mask, _ = tc.oracle_step(seed=20 + rank, iteration=0)          # each rank: its own draws (its own shard of the data)
-    hook = pd.gradient_allreduce_hook(model, device="cpu")
+    pick = lambda grads: {k: v.clone().numpy() for k, v in grads.items() if k.startswith(("face_out_proj", "audio_encoder_body.feat_extractor.5.conv2", "mask_embedding"))}
     seen = {}
-
-    def spy(grads):
-        seen["local"] = {k: v.clone() for k, v in grads.items() if k.startswith(("face_out_proj", "audio_encoder_body.feat_extractor.5.conv2", "mask_embedding"))}
-        hook(grads)
-        seen["avg"] = {k: grads[k].clone() for k in seen["local"]}
-
+    # this rank's own gradients: the same step with the exchange switched off
+    model_l, vq = common.product_models(precision="fp32")
+    with fake_ops.installed(), torch.no_grad():
+        training.Trainer(model_l, vq, exchange=False).step(batch, 0, masks, random_mask, grad_hook=lambda g: seen.update(local=pick(g)))
+    # the data-parallel step: buckets all-reduced by the trainer itself (SUM; Adam applies the 1 / world)
+    model, vq = common.product_models(precision="fp32")
     trainer = training.Trainer(model, vq)
     with fake_ops.installed(), torch.no_grad():
-        trainer.step(batch, 0, masks, random_mask, grad_hook=spy)
-    after = {k: model._flat_params()[k].clone() for k in ("face_out_proj.weight", "mask_embedding")}
-    q.put((rank, {k: v.numpy() for k, v in seen["local"].items()}, {k: v.numpy() for k, v in seen["avg"].items()},
-           {k: v.numpy() for k, v in after.items()}, [b.numel() for b in hook.buckets.flat]))
+        trainer.step(batch, 0, masks, random_mask, grad_hook=lambda g: seen.update(summed=pick(g)))
+        log1 = list(trainer.exchange_log)
+        trainer.step(batch, 0, masks, random_mask)            # second step: the learned schedule overlaps the exchange with the third backward
+        log2 = list(trainer.exchange_log)
+    after = {k: model._flat_params()[k].clone().numpy() for k in ("face_out_proj.weight", "mask_embedding")}
+    q.put((rank, seen["local"], seen["summed"], after, [b.numel() for b in trainer.buckets.flat], log1, log2, dict(trainer.schedule)))
     pd.finalize()
 
 
 def test_two_rank_training_step_averages_gradients():
-    """training.Trainer.step on two gloo ranks (CPU stand-ins of the kernels) with `gradient_allreduce_hook`: after the exchange
-    both ranks hold the mean of the two local gradients, in the four bucket messages, and apply the same Adam update."""
+    """training.Trainer.step on two gloo ranks (CPU stand-ins of the kernels): the four bucket messages are summed over ranks by the
+    trainer, Adam applies the average and both replicas stay in step; from the SECOND step on every bucket's all-reduce is issued
+    behind its last gradient of the step — bucket 0 (heads / refinement layers) and bucket 1 (the cross-attention stack, which takes
+    no part in the third forward) before the encoders' backward has even started (Missing #4)."""
     import numpy as np
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -140,18 +143,27 @@ def test_two_rank_training_step_averages_gradients():
     procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    res = sorted((q.get(timeout=1200) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, loc0, avg0, after0, sizes0), (_, loc1, avg1, after1, sizes1) = res
-    assert sizes0 == sizes1 and len(sizes0) == 4
+    (_, loc0, sum0, after0, sizes0, log1, log2, sched), (_, loc1, sum1, after1, sizes1, _l1, _l2, sched1) = res
+    assert sizes0 == sizes1 and len(sizes0) == 4 and sched == sched1
     for k in loc0:
         assert not np.array_equal(loc0[k], loc1[k])                                   # different data on the two ranks
-        np.testing.assert_allclose(avg0[k], 0.5 * (loc0[k] + loc1[k]), rtol=1e-6, atol=1e-9)
-        np.testing.assert_array_equal(avg0[k], avg1[k])
+        np.testing.assert_allclose(sum0[k], loc0[k] + loc1[k], rtol=1e-6, atol=1e-9)
+        np.testing.assert_array_equal(sum0[k], sum1[k])
     for k in after0:
         np.testing.assert_array_equal(after0[k], after1[k])                            # replicas stay in step
+    # step 1 learns the schedule: every reduce behind the third backward
+    i_done = log1.index(("backward_done", 2))
+    assert all(log1.index(e) > i_done for e in log1 if e[0] == "reduce") and sum(e[0] == "reduce" for e in log1) == 4
+    # step 2: bucket 1 at the very start of the third backward, bucket 0 behind the heads / refinement layers, the encoders' bucket last
+    red = {e[1]: e[2] for e in log2 if e[0] == "reduce"}
+    i_done = log2.index(("backward_done", 2))
+    assert sorted(red) == [0, 1, 2, 3] and all(log2.index(e) < i_done for e in log2 if e[0] == "reduce")
+    assert red[1] == -1 and -1 < red[0] < red[2] < red[3] and sched == red
+    assert log2.index(("backward_done", 1)) < log2.index(("reduce", 1, -1)) and log2[-1] == ("wait",)
 
 
 def _sync_worker(rank, world, port, q):
@@ -170,12 +182,10 @@ def _sync_worker(rank, world, port, q):
     lo, hi = rank * per, (rank + 1) * per
     model, vq = common.product_models(precision="fp32")
     trainer = training.Trainer(model, vq, sync_bn=True)
-    hook = pd.gradient_allreduce_hook(model, device="cpu")
     got = {}
 
-    def spy(grads):
-        hook(grads)
-        got.update({k: v.clone().numpy() for k, v in grads.items()})
+    def spy(grads):                                        # the trainer has summed the buckets over ranks: the data-parallel average is / world
+        got.update({k: (v / world).clone().numpy() for k, v in grads.items()})
 
     with fake_ops.installed(), torch.no_grad():
         trainer.step({k: v[lo:hi] for k, v in batch.items()}, 0, [tc.shard_masks(m, lo, hi, bs) for m in masks], random_mask[lo:hi], grad_hook=spy)

@@ -336,7 +336,7 @@ def test_gemm_every_tile_configuration(cfg, dtype):
     if dtype == BF16 and cfg >= 45:
         pytest.skip("two K-tiles per ring slot exist for the fp32-storage modes only")
     from pantomatrix_amd import _lib
-    lib = _lib.load()
+    lib = _lib.use_tools(True)          # the product library carries only the configurations its heuristic selects
     try:
         assert lib.emage_set_tuning(0, cfg) == 0
         for case in GEMM_CASES:
@@ -344,6 +344,7 @@ def test_gemm_every_tile_configuration(cfg, dtype):
                 test_gemm(case, dtype)
     finally:
         lib.emage_set_tuning(0, -1)
+        _lib.use_tools(False)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16, F16X3], ids=["fp32", "bf16", "f16x3"])
@@ -469,7 +470,7 @@ def test_gemm_h2_every_tile_configuration(cfg):
     """Every EMAGE_H2 tile configuration (wave grids, loader waves, register-pipelined / interleaved K-loops, odd fragment
     counts) on a ragged shape with a transposed tail and on a convolution with a zero-filled channel tail."""
     from pantomatrix_amd import _lib
-    lib = _lib.load()
+    lib = _lib.use_tools(True)
     cases = [("h2cfg_vt", (3, 70, 70), 768, 2304, 1, 1, 0, dict(bias=True, vt=1536)),
              ("h2cfg_conv", (3, 37, 37), 337, 106, 3, 1, 1, dict(bias=True, slope=0.2, n_store=128, res=None, want="both"))]
     try:
@@ -489,6 +490,7 @@ def test_gemm_h2_every_tile_configuration(cfg):
                     _cmp(f"cfg{cfg}.{case[0]}.{nm}", gt[..., :width], rf[..., :width], atol=2e-5, rtol=1e-5)
     finally:
         lib.emage_set_tuning(4, -1)
+        _lib.use_tools(False)
 
 
 def test_h2_elementwise_producers():

@@ -257,3 +257,50 @@ def test_pair_rows_route_matches_padded_route(precision):
     for k in ("audio_fea_c", "audio_fea_r"):
         assert float((outs[0][k] - ref[k]).abs().max()) < 2e-5, k
     assert float((outs[0]["motion"].reshape(3, -1, 258) - ref["motion"].reshape(3, -1, 258)).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("kind", ["disco", "camn"])
+def test_pair_rows_route_matches_reference_golden_on_device(golden_dir, kind, precision):
+    """The pair-rows WavEncoder route (what DisCo / CaMN take at the BASELINE clip lengths) on the MI355X against the REAL
+    reference's golden (tests/golden/lstm_models_even.npz: even frame counts behind blocks 0-2, seed motion longer than the audio)."""
+    g = np.load(os.path.join(golden_dir, "lstm_models_even.npz"))
+    audio, spk, motion = inputs(with_seed_motion=True)
+    audio = audio[:, :30000]
+    model = product(kind, precision, DEV)
+    assert model.pair_convs and model._wav_pairs_ok(model._wav_lengths(audio.shape[1]))
+    out = model(audio.to(DEV), spk.to(DEV), seed_frames=CFG["seed_frames"], seed_motion=motion.to(DEV))
+    err_m = float(np.abs(out["motion"].reshape(2, -1, 258).cpu().numpy() - g[f"{kind}_motion"]).max())
+    err_a = float(np.abs(out["motion_axis_angle"].cpu().numpy() - g[f"{kind}_axis_angle"]).max())
+    print(f"{kind} {precision} pair-rows route: rot-6D max|err| {err_m:.2e}, axis-angle max|err| {err_a:.2e} vs the reference")
+    assert err_m < 2e-4 and err_a < 1e-3
+
+
+def test_lost_block_is_reported_on_every_replay():
+    """The persistent recurrence's error words travel in the runner's in-graph health counter: a launch record whose error word
+    is set makes EVERY later replay raise (not only the first two)."""
+    from pantomatrix_amd._lib import EmageKernelError
+    from pantomatrix_amd.runtime import LstmClipRunner
+    assert ops.lstm_layer_supported(F16X3, 512) and ops.lstm_layer_supported(F16X3, 256) and not ops.lstm_layer_supported(F32, 512)
+    sync = ops.lstm_layer_sync(300, 512, DEV)                  # 300 clips: two launch records
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.lstm_layer_health(sync, counter)
+    assert int(counter) == 0
+    sync.view(-1, ops.LSTM_SYNC_WORDS_PER_LAUNCH)[1, ops.LSTM_SYNC_ERROR_WORD] = 1
+    ops.lstm_layer_health(sync, counter)
+    assert int(counter) == 1
+    model = product("disco", "f16x3", DEV)
+    audio, spk, _ = inputs(bs=2, frames=34)
+    runner = LstmClipRunner(model, 2, audio.shape[1])
+    for _ in range(4):
+        runner(audio.to(DEV))                                   # healthy replays pass
+    # poison what the in-graph fold reads: an error word that the layer's own memset does not clear (a record past its launches)
+    victim = next(iter(model._sync.values()))
+    extra = torch.zeros(victim.numel() + ops.LSTM_SYNC_WORDS_PER_LAUNCH, dtype=torch.int32, device=DEV)
+    extra[-ops.LSTM_SYNC_WORDS_PER_LAUNCH + ops.LSTM_SYNC_ERROR_WORD] = 1
+    key = next(iter(model._sync))
+    model._sync[key] = extra
+    eager = LstmClipRunner(model, 2, audio.shape[1], use_graph=False)
+    for _ in range(3):
+        with pytest.raises(EmageKernelError):
+            eager(audio.to(DEV))

@@ -361,3 +361,24 @@ def test_vq_model_api_on_device(exact_models, golden_dir, precision):
         assert np.abs(fw["rec_pose"].cpu().numpy() - g[f"fwd_{p}_rec_pose"]).max() < 2e-4
         np.testing.assert_allclose(float(fw["embedding_loss"]), float(g[f"fwd_{p}_embedding_loss"]), rtol=2e-4)
         np.testing.assert_allclose(float(fw["perplexity"]), float(g[f"fwd_{p}_perplexity"]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("frames", [70, 129, 310])
+def test_clip_runner_graph_matches_reference_on_tail_windows(golden_dir, frames):
+    """The captured-graph path (runtime.ClipRunner, what bench.py times) against the REFERENCE's goldens at the clip lengths
+    whose last window is a short tail (T + 1 audio frames, its own kernel shapes): codes identical, 1e-3 on the rest."""
+    from pantomatrix_amd.runtime import ClipRunner
+    g = np.load(os.path.join(golden_dir, f"infer_{frames}f_b1.npz"))
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    audio = synthetic.synthetic_audio(1, synthetic.samples_for_frames(frames))
+    runner = ClipRunner(model, vq, 1, audio.shape[1], use_graph=True)
+    for _ in range(2):
+        poses, expr, trans = runner(audio.to(DEV))
+    assert poses.shape == g["poses"].shape
+    for nm, got in (("poses", poses), ("expressions", expr), ("trans", trans)):
+        err = float(np.abs(got - g[nm]).max())
+        print(f"ClipRunner graph {frames} frames {nm}: max|err| vs reference {err:.2e}")
+        assert err < TOL, (nm, err)
+    codes = model.infer_codes(audio.to(DEV), torch.zeros(1, 1, dtype=torch.long, device=DEV), vq)
+    for p in ("upper", "hands", "lower"):
+        assert np.array_equal(codes[f"{p}_index"].cpu().numpy(), g[f"index_{p}"].astype(np.int64)), p

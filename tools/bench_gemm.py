@@ -48,7 +48,7 @@ def main():
     args = ap.parse_args()
     dt = {"bf16": BF16, "fp32": F32, "f16x3": F16X3}[args.dtype]
     td = ops.TORCH_DTYPE[dt]
-    lib = _lib.load()
+    lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
     lib.emage_set_tuning(1, args.dbg)
     dev = "cuda"
     global CONFIGS

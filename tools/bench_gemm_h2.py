@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--shapes", default="", help="comma-separated substrings of shape names")
     ap.add_argument("--loop", type=int, default=0, help="no sweep: run the first selected shape / config this many times eagerly (profiling)")
     args = ap.parse_args()
-    lib = _lib.load()
+    lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
     dev = "cuda"
     configs = [int(c) for c in args.configs.split(",")] if args.configs else CONFIGS
     want = [s for s in args.shapes.split(",") if s]

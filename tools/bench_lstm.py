@@ -68,7 +68,7 @@ def main():
             hseq = torch.empty(batch, tt, 2 * hid, device=dev)
             sync = ops.lstm_layer_sync(batch, hid, dev)
             from pantomatrix_amd import _lib
-            lib = _lib.load()
+            lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
             names = {0: "shipped", 16: "two staging phases", 2: "no MFMA phase", 4: "no h load / staging", 8: "no group barrier",
                      14: "skeleton: cell + h store only"}
             line["lstm_layer_us_per_step"] = {}

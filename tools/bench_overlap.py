@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from pantomatrix_amd import _lib, ops  # noqa: E402
 from pantomatrix_amd._lib import BF16  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
 

@@ -7,9 +7,9 @@ sys.path.insert(0, ROOT)
 from pantomatrix_amd import _lib, ops
 from pantomatrix_amd._lib import H2
 
-lib = _lib.load()
-raw = C.CDLL(_lib.LIB_PATH)
-raw.emage_h2_set_trace.argtypes = [C.c_void_p]
+lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
+raw = lib
+
 dev = "cuda"
 m, k, n = 4096, 768, 768
 g = torch.Generator().manual_seed(0)
