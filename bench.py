@@ -371,6 +371,135 @@ def cpu_baseline(frames, seconds_budget=15.0):
                       f"(the reference itself cannot travel to this box)"}
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / [4] (DisCo, CaMN inference) and configs[2] (one EMAGE training step), timed beside the headline metric
+# ----------------------------------------------------------------------------------------------------------------------
+def bench_lstm_models(dev, steps=3, cpu=True):
+    """DisCo at batch 128 x 8.5 s clips and CaMN at batch 256 x 28 s clips (BASELINE configs[3], [4]): one step = one hipGraph replay of
+    the whole forward (runtime.LstmClipRunner) + D2H of the motion.  `roofline` is the dominant kernel, the persistent recurrence
+    `emage_lstm_layer` (one launch per LSTM layer), timed live with HIP events on a bare launch of the model's size: its algorithmic
+    flops (2 directions x B x T x 4H x H x 2) against the dense fp16 MFMA peak — every time step ends in a hand-over of h_t between the
+    blocks of a group, which is what bounds it (us_per_time_step)."""
+    from pantomatrix_amd import ops, synthetic
+    from pantomatrix_amd._lib import F16X3
+    from pantomatrix_amd.runtime import LstmClipRunner
+    from test_lstm_host_logic import product
+    from test_lstm_models_oracle import weights, run_oracle
+    out = {}
+    for kind, batch, seconds in (("disco", 128, 8.5), ("camn", 256, 28.0)):
+        n = int(seconds * 16000)
+        model = product(kind, "f16x3", dev)
+        audio = synthetic.synthetic_audio(batch, n, seed=5).to(dev)
+        runner = LstmClipRunner(model, batch, n)
+        runner(audio)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            motion, _aa = runner(audio)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        tt, frames = int(motion.shape[1]), int(motion.shape[0] * motion.shape[1])
+        line = {"workload": f"{kind} inference f16x3, batch={batch} x {seconds} s synthetic clips (BASELINE configs[{3 if kind == 'disco' else 4}])",
+                "ms_per_step": ms, "value": frames / (ms * 1e-3), "unit": "motion-frames/s (15 fps)", "frames_per_clip": tt, "steps": steps,
+                "dtype": "f16x3", "launch": "hipGraph replay"}
+        hid = 512
+        g = torch.Generator().manual_seed(1)
+        wp, ws = [], []
+        for _ in range(2):
+            p_, s_ = ops.split_f16_weights(torch.randn(4 * hid, hid, generator=g) / hid ** 0.5)
+            wp.append(p_.to(dev))
+            ws.append(s_)
+        gx = torch.randn(batch, tt, 8 * hid, generator=g).to(dev)
+        hseq = torch.empty(batch, tt, 2 * hid, device=dev)
+        sync = ops.lstm_layer_sync(batch, hid, dev)
+        ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
+        e1.record()
+        torch.cuda.synchronize()
+        ops.lstm_layer_check(sync)
+        layer_ms = e0.elapsed_time(e1) / 3
+        flops = 2.0 * batch * tt * 4 * hid * hid * 2
+        n_layers = (1 if kind == "disco" else 2) * 4
+        line["roofline"] = {"bound": "mfma", "kernel": "emage_lstm_layer", "achieved": flops / (layer_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                            "frac": flops / (layer_ms * 1e-3) / 1e12 / 2500.0, "traffic": None, "launch_ms": layer_ms, "launches_per_step": n_layers,
+                            "share_of_step": n_layers * layer_ms / ms, "us_per_time_step": 1e3 * layer_ms / tt,
+                            "note": "algorithmic flops of one bidirectional layer (2 x B x T x 4H x H x 2) / its launch time; 3 MFMAs per product; a time "
+                                    "step is bound by the h_t hand-over between the blocks of a group, not by MFMA issue"}
+        del gx, hseq
+        if cpu:
+            torch.set_num_threads(usable_cores())
+            sd = weights(kind)
+            a2 = audio[:2].cpu()
+            spk = torch.zeros(2, 1, dtype=torch.long)
+            run_oracle(kind, sd, a2[:, :n // 4], spk, None)
+            t0 = time.time()
+            ref = run_oracle(kind, sd, a2, spk, None)
+            dt = time.time() - t0
+            line["cpu_baseline"] = {"value": 2 * ref["motion"].shape[1] / dt, "unit": "motion-frames/s (15 fps)", "kind": "port", "cores": torch.get_num_threads(),
+                                    "sample": f"2 clips x {seconds} s, one call ({dt:.1f} s CPU), fp32 torch CPU oracle (oracle/lstm_models_oracle.py)"}
+            line["max_err_vs_oracle_clips_0_1"] = float((torch.from_numpy(motion[:2]) - ref["motion"].reshape(2, -1, 258)).abs().max())
+        out[kind] = line
+        del runner, model, audio
+        torch.cuda.empty_cache()
+    return out
+
+
+def bench_train_step(dev, steps=3, cpu=True, batch=56):
+    """One EMAGE optimisation step at BASELINE configs[2]'s per-GPU batch (56 clips x 64 frames): targets through the frozen VQ-VAEs, three
+    train-mode forwards (batch-statistics BatchNorm, dropout masks drawn on the device), six losses, three backward passes, multi-tensor
+    Adam, BatchNorm buffers — `training.Trainer.capture` / `replay`: the whole step is ONE hipGraph.  `roofline`: the step's algorithmic
+    flops (9 x 20.5 GFLOP per clip-window + 1.16 GFLOP of VQ encoding) against the exact-fp32 MFMA peak its contractions run on."""
+    import common
+    from pantomatrix_amd import training
+    model, vq = common.product_models(precision="fp32", device=dev)
+    t = 64
+    g = torch.Generator().manual_seed(5)
+    data = dict(motion=0.3 * torch.randn(batch, t, 165, generator=g), audio=0.1 * torch.randn(batch, t * 16000 // 30, generator=g),
+                expressions=0.5 * torch.randn(batch, t, 100, generator=g), trans=0.1 * torch.randn(batch, t, 3, generator=g),
+                foot_contact=(torch.rand(batch, t, 4, generator=g) > 0.5).float())
+    data = {k: v.to(dev) for k, v in data.items()}
+    random_mask = (torch.rand(batch, t, 337, generator=g) < 0.5).float().to(dev)
+    torch.cuda.reset_peak_memory_stats()
+    trainer = training.Trainer(model, vq, seed=1).capture(data, random_mask)
+    losses = trainer.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = trainer.replay()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    assert all(np.isfinite(v) for v in losses.values())
+    flops = batch * (9 * 20.5e9 + 1.16e9)
+    line = {"workload": f"EMAGE training step fp32, {batch} x {t}-frame synthetic clips per GPU (BASELINE configs[2] per-GPU batch), one hipGraph replay per step",
+            "ms_per_step": ms, "value": batch / (ms * 1e-3), "unit": "clip-windows/s", "steps": steps, "dtype": "f32",
+            "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "loss_all": losses["all"],
+            "roofline": {"bound": "mfma", "kernel": "emage_gemm (exact-fp32 MFMA: every contraction of the forward and the backward)", "achieved": flops / (ms * 1e-3) / 1e12,
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / 157.3, "traffic": None,
+                         "note": "whole-step algorithmic flops / step time (an upper bound on the GEMM family's share) against the fp32 matrix peak"}}
+    del trainer, model, vq
+    torch.cuda.empty_cache()
+    if cpu:
+        import train_common  # noqa: F401  (tests/)
+        from oracle import emage_train_oracle as tro
+        from pantomatrix_amd import synthetic
+        from pantomatrix_amd.configuration_emage_audio import EmageAudioConfig
+        torch.set_num_threads(usable_cores())
+        cfg = EmageAudioConfig(**common.cfg_dicts()[0])
+        _, ovq = common.oracle_models()
+        sd = synthetic.audio_model_state(cfg, 0)
+        small = {k: v[:2].cpu() for k, v in data.items()}
+        t0 = time.time()
+        tro.train_step(sd, ovq, cfg, small, 0, seed=1)
+        dt = time.time() - t0
+        line["cpu_baseline"] = {"value": 2 / dt, "unit": "clip-windows/s", "kind": "port", "cores": torch.get_num_threads(),
+                                "sample": f"one step on 2 clips ({dt:.1f} s CPU), fp32 torch CPU oracle (oracle/emage_train_oracle.py: a restatement of train_val_fn)"}
+    return line
+
+
 def build(precision, device, args):
     import common
     from pantomatrix_amd import synthetic
@@ -401,6 +530,7 @@ def main():
     ap.add_argument("--also", default="bf16", help="comma list of further precisions timed beside the reported one ('' = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the DisCo / CaMN inference and the EMAGE training-step lines (BASELINE configs[2..4])")
     ap.add_argument("--no-hoist", action="store_true", help="A/B: compute waveform features inside every window")
     ap.add_argument("--no-slab-convs", action="store_true", help="A/B: WavEncoder through emage_wav_conv_in + emage_gemm only (same bits)")
     ap.add_argument("--main-priority", action="store_true", help="experiment: capture the clip graph on a high-priority stream")
@@ -497,6 +627,13 @@ def main():
         result["other_precisions"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.frames)
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        # BASELINE configs[2] / [3] / [4] beside the headline metric (bounded: a few steps each); models of the headline run are released
+        torch.cuda.empty_cache()
+        log("other BASELINE configs: DisCo / CaMN inference")
+        result["lstm_models"] = bench_lstm_models(dev, cpu=not args.no_cpu_baseline)
+        log("other BASELINE configs: one EMAGE training step")
+        result["train_step"] = bench_train_step(dev, cpu=not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(result), flush=True)
     pdist.finalize()

@@ -176,6 +176,27 @@ def sync_batch_stats(sums, sq_sums, count, group=None, return_counts=False):
     return (means, variances, counts) if return_counts else (means, variances)
 
 
+def merge_batch_stats(mean_l, var_l, rows, group=None):
+    """SyncBatchNorm's statistics exchange (train_emage_audio.py:248) as a count-weighted merge of the ranks' (mean, biased variance,
+    row count) in float64 — Chan et al.'s parallel form, what torch.nn.SyncBatchNorm does with mean / invstd: no E[x^2] - mean^2
+    cancellation for channels with |mean| >> std, counts exact beyond 2^24 rows.  ONE all-gather of 2 C + 1 float64 values per rank.
+    Returns (mean, biased variance) as float32 (C,) tensors over the GLOBAL batch and the global row count (Python int)."""
+    c = mean_l.numel()
+    mine = torch.cat([mean_l.reshape(-1).double(), var_l.reshape(-1).double(), torch.tensor([float(rows)], dtype=torch.float64, device=mean_l.device)])
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        flat = torch.empty(world * (2 * c + 1), dtype=torch.float64, device=mean_l.device)
+        dist.all_gather_into_tensor(flat, mine.contiguous(), group=group)
+        allv = flat.view(world, 2 * c + 1)
+    else:
+        allv = mine.view(1, -1)
+    means, variances, n = allv[:, :c], allv[:, c:2 * c], allv[:, 2 * c:2 * c + 1]
+    total = n.sum()
+    mean = (means * n).sum(0) / total
+    m2 = (variances * n).sum(0) + (n * (means - mean) ** 2).sum(0)
+    return mean.float().contiguous(), (m2 / total).float().contiguous(), int(round(float(total)))
+
+
 def sum_over_group(tensors, group=None):
     """Element-wise sum over ranks of a list of small tensors in ONE all-reduce (SyncBatchNorm's backward sums); in place."""
     if not (dist.is_available() and dist.is_initialized()):

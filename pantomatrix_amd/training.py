@@ -200,12 +200,11 @@ class TrainForward:
         if self.sync_bn:                                   # nn.SyncBatchNorm (T:248): statistics over the GLOBAL batch, one small all-reduce
             from . import dist as pdist
             mean_l, var_l = ops.bn_stats(x, None, None, BN_MOMENTUM)
-            rows = float(x.shape[0])
-            (mean,), (var,), (n,) = pdist.sync_batch_stats([mean_l * rows], [(var_l + mean_l * mean_l) * rows], [rows], group=self.group, return_counts=True)
-            stats = (mean.contiguous(), var.clamp_min(0).contiguous())
+            mean, var, n = pdist.merge_batch_stats(mean_l, var_l, x.shape[0], group=self.group)      # float64, count-weighted (Chan) merge
+            stats = (mean, var)
             rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * stats[0])
-            rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * stats[1] * (n / (n - 1)))
-            self._bn_count[name] = int(round(float(n)))
+            rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * stats[1] * (n / max(n - 1, 1)))
+            self._bn_count[name] = n
         else:
             stats = ops.bn_stats(x, rm, rv, BN_MOMENTUM)
         new_stats[name + ".running_mean"], new_stats[name + ".running_var"] = rm, rv

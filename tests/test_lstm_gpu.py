@@ -294,13 +294,19 @@ def test_lost_block_is_reported_on_every_replay():
     runner = LstmClipRunner(model, 2, audio.shape[1])
     for _ in range(4):
         runner(audio.to(DEV))                                   # healthy replays pass
-    # poison what the in-graph fold reads: an error word that the layer's own memset does not clear (a record past its launches)
-    victim = next(iter(model._sync.values()))
+    # the fold is part of `_step` (what the graph captures): poison an error word that the layer's own memset does not clear (a spare
+    # record behind its launches) and every later call raises — not only the first two
+    eager = LstmClipRunner(model, 2, audio.shape[1], use_graph=False)
+    eager(audio.to(DEV))
+    key = next(iter(model._sync))
+    victim = model._sync[key]
     extra = torch.zeros(victim.numel() + ops.LSTM_SYNC_WORDS_PER_LAUNCH, dtype=torch.int32, device=DEV)
     extra[-ops.LSTM_SYNC_WORDS_PER_LAUNCH + ops.LSTM_SYNC_ERROR_WORD] = 1
-    key = next(iter(model._sync))
     model._sync[key] = extra
-    eager = LstmClipRunner(model, 2, audio.shape[1], use_graph=False)
-    for _ in range(3):
-        with pytest.raises(EmageKernelError):
-            eager(audio.to(DEV))
+    try:
+        for _ in range(3):
+            with pytest.raises(EmageKernelError):
+                eager(audio.to(DEV))
+    finally:
+        model._sync[key] = victim
+    eager(audio.to(DEV))
