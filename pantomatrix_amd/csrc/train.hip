@@ -15,7 +15,8 @@
 namespace {
 
 constexpr int STAT_ROWS = 4;          // row lanes per block: 4 x 64 columns = 256 threads
-constexpr int STAT_CHUNK = 2048;      // rows per block
+constexpr int STAT_CHUNK = 256;       // rows per block (2048 left the small-M layers of a training step with ~24 blocks on 256 CUs: 130 us per
+                                      // bias gradient, 17 % of the step — profiles/r03_train_kernel_stats_before.csv)
 
 // partial[(chunk * 2 + {0: sum, 1: sum of squares}) * C + c], deterministic: the finalize kernel adds the chunks in order
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int ldx, int M, int C, double* __restrict__ partial) {
@@ -370,6 +371,119 @@ __global__ __launch_bounds__(256) void attention_backward_kernel(AttnBwdArgs p) 
     }
 }
 
+// ---- the same backward on the matrix cores: Tq = Tk = 64, head_dim = 192 (every attention of a training step) ----------------------------
+// One block (4 waves) per (batch, head); the five contractions run as exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain) on
+// operands staged in LDS: wave w owns rows 16 w .. 16 w + 15 of every product.  LDS plan (floats): X, Y = 64 x 194 / 192 x 66 operand
+// buffers (re-filled per phase), P, dS, dS^T = 64 x 66.  1.44 ms -> tens of microseconds per launch (profiles/r03_train_kernel_stats_*.csv).
+constexpr int AB_LD = 194, AB_LS = 66, AB_BIG = 192 * 66, AB_SMALL = 64 * 66;
+
+// acc (16 x 16 tile at rows row0.., cols n0..) = sum_k A[row][k] * B(k, n); A row-major (k contiguous); B_KN: B stored [k][n], else [n][k]
+template <bool B_KN>
+__device__ __forceinline__ f32x4 ab_tile(const float* __restrict__ A, int lda, int row0, const float* __restrict__ B, int ldb, int n0, int K, int lane) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, kq = lane >> 4;
+    const float* ap = A + (row0 + r) * lda + kq;
+    const float* bp = B_KN ? B + kq * ldb + n0 + r : B + (n0 + r) * ldb + kq;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const float a = ap[k0];
+        const float b = B_KN ? bp[k0 * ldb] : bp[k0];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void attention_backward_mfma_kernel(AttnBwdArgs p) {
+    extern __shared__ float lds[];
+    float* X = lds;
+    float* Y = lds + AB_BIG;
+    float* P = Y + AB_BIG;
+    float* Ds = P + AB_SMALL;
+    float* DsT = Ds + AB_SMALL;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int T = 64, HD = 192;
+    const float* Q = p.q + (long)b * T * p.ldq + h * HD;
+    const float* K = p.k + (long)b * T * p.ldk + h * HD;
+    const float* VT = p.vt + ((long)b * p.vt_rows + h * HD) * p.ldvt;
+    const float* dO = p.d_out + (long)b * T * p.ld_do + h * HD;
+    const float* MK = p.pmask ? p.pmask + ((long)b * p.H + h) * T * T : nullptr;
+    auto load_rows = [&](float* dst, const float* src, int ld_src) {            // 64 rows x 192 floats -> [64][AB_LD]
+        for (int idx = tid; idx < T * (HD / 4); idx += 256) {
+            const int row = idx / (HD / 4), c4 = idx - row * (HD / 4);
+            const float4 v = *(const float4*)(src + (long)row * ld_src + 4 * c4);
+            float* d = dst + row * AB_LD + 4 * c4;
+            *(float2*)d = make_float2(v.x, v.y);
+            *(float2*)(d + 2) = make_float2(v.z, v.w);
+        }
+    };
+    const int row0 = 16 * wave, cr = lane & 15, rq = 4 * (lane >> 4);          // a lane's tile entries: rows row0 + rq + r, column n0 + cr
+    // ---- S = scale * Q K^T -> P ----
+    load_rows(X, Q, p.ldq);
+    load_rows(Y, K, p.ldk);
+    __syncthreads();
+    for (int n0 = 0; n0 < T; n0 += 16) {
+        const f32x4 acc = ab_tile<false>(X, AB_LD, row0, Y, AB_LD, n0, HD, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[(row0 + rq + r) * AB_LS + n0 + cr] = acc[r] * p.scale;
+    }
+    __syncthreads();
+    // ---- dP = dO V -> Ds ----
+    load_rows(X, dO, p.ld_do);
+    for (int idx = tid; idx < HD * (T / 4); idx += 256) {                       // V^T (192 x 64) -> [192][AB_LS]
+        const int d = idx / (T / 4), c4 = idx - d * (T / 4);
+        const float4 v = *(const float4*)(VT + (long)d * p.ldvt + 4 * c4);
+        float* dst = Y + d * AB_LS + 4 * c4;
+        *(float2*)dst = make_float2(v.x, v.y);
+        *(float2*)(dst + 2) = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    for (int n0 = 0; n0 < T; n0 += 16) {
+        const f32x4 acc = ab_tile<true>(X, AB_LD, row0, Y, AB_LS, n0, HD, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ds[(row0 + rq + r) * AB_LS + n0 + cr] = acc[r];
+    }
+    __syncthreads();
+    // ---- softmax rows, dS = P (dP mask - rowsum(dP mask P)) scale; dS, dS^T, (P mask)^T (into Y: V^T is done) ----
+    for (int i = row0; i < row0 + 16; ++i) {                                    // one row per iteration, lane = key j
+        const float sv = P[i * AB_LS + lane];
+        float mx = sv;
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = expf(sv - mx);
+        float sum = e;
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float pr = e * (1.0f / sum);
+        const float mk = MK ? MK[i * T + lane] : 1.0f;
+        const float dpm = Ds[i * AB_LS + lane] * mk;
+        float dsum = dpm * pr;
+        for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
+        const float ds = pr * (dpm - dsum) * p.scale;
+        Ds[i * AB_LS + lane] = ds;
+        DsT[lane * AB_LS + i] = ds;
+        Y[lane * AB_LS + i] = pr * mk;
+    }
+    __syncthreads();
+    // ---- dV = (P mask)^T dO ----
+    for (int n0 = 0; n0 < HD; n0 += 16) {
+        const f32x4 acc = ab_tile<true>(Y, AB_LS, row0, X, AB_LD, n0, T, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.dv[((long)b * T + row0 + rq + r) * p.ld_dv + h * HD + n0 + cr] = acc[r];
+    }
+    __syncthreads();
+    // ---- dQ = dS K, dK = dS^T Q ----
+    load_rows(X, Q, p.ldq);
+    load_rows(Y, K, p.ldk);
+    __syncthreads();
+    for (int n0 = 0; n0 < HD; n0 += 16) {
+        const f32x4 aq = ab_tile<true>(Ds, AB_LS, row0, Y, AB_LD, n0, T, lane);
+        const f32x4 ak = ab_tile<true>(DsT, AB_LS, row0, X, AB_LD, n0, T, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p.dq[((long)b * T + row0 + rq + r) * p.ld_dq + h * HD + n0 + cr] = aq[r];
+            p.dk[((long)b * T + row0 + rq + r) * p.ld_dk + h * HD + n0 + cr] = ak[r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, int ldp, const float* __restrict__ target, int ldt, float scale,
                                                        float* __restrict__ out, int ldo, int M, int C) {
     const long total = (long)M * C;
@@ -440,6 +554,14 @@ extern "C" int emage_attention_backward(const float* q, int ldq, const float* k,
     static const hipError_t configured = hipFuncSetAttribute((const void*)attention_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (configured != hipSuccess) return (int)configured;
     AttnBwdArgs a{q, k, vt, pmask, d_out, dq, dk, dv, ldq, ldk, ldvt, vt_rows, ld_do, ld_dq, ld_dk, ld_dv, B, H, Tq, Tk, hd, 1.0f / sqrtf((float)hd)};
+    const bool aligned = !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)d_out) & 15) && ldq % 4 == 0 && ldk % 4 == 0 && ldvt % 4 == 0 && ld_do % 4 == 0;
+    if (Tq == 64 && Tk == 64 && hd == 192 && aligned) {          // the shape of every attention of a training step: matrix-core form
+        constexpr size_t lds_mfma = (size_t)(2 * AB_BIG + 3 * AB_SMALL) * sizeof(float);
+        static const hipError_t conf2 = hipFuncSetAttribute((const void*)attention_backward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (conf2 != hipSuccess) return (int)conf2;
+        hipLaunchKernelGGL(attention_backward_mfma_kernel, dim3(B * H), dim3(256), lds_mfma, (hipStream_t)stream, a);
+        return launch_status();
+    }
     hipLaunchKernelGGL(attention_backward_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, a);
     return launch_status();
 }

@@ -421,7 +421,7 @@ def col_sum(x, y=None, out=None, accumulate=False):
     _dev(x)
     m, c = x.shape
     out = torch.zeros(c, dtype=torch.float32, device=x.device) if out is None else out
-    ws = torch.empty(((m + 2047) // 2048) * c, dtype=torch.float64, device=x.device)
+    ws = torch.empty(((m + 255) // 256) * c, dtype=torch.float64, device=x.device)       # one partial per 256-row chunk (csrc/train.hip STAT_CHUNK)
     _col_sum(x, y, out, accumulate, ws)
     return out
 

@@ -56,13 +56,9 @@ def main():
 
     trainer = training.Trainer(model, vq) if args.full_step else None
     if args.graph:
-        static_masks = [draw_masks(b, t, c.hidden_size, 2 * c.hidden_size, 4, ta, dev) for _ in range(3)]
-        trainer.capture(batch, static_masks, random_mask)
+        trainer.capture(batch, random_mask)                          # dropout masks are drawn inside the graph (ops.dropout_mask)
 
         def step():
-            for fm in static_masks:                                   # fresh dropout masks, drawn on the device into the graph's input buffers
-                for mk in fm:
-                    mk.copy_((torch.rand(mk.shape, device=dev) >= 0.1).float() / 0.9)
             return trainer.replay(), None
     else:
         step = None
