@@ -452,10 +452,11 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56):
     """One EMAGE optimisation step at BASELINE configs[2]'s per-GPU batch (56 clips x 64 frames): targets through the frozen VQ-VAEs, three
     train-mode forwards (batch-statistics BatchNorm, dropout masks drawn on the device), six losses, three backward passes, multi-tensor
     Adam, BatchNorm buffers — `training.Trainer.capture` / `replay`: the whole step is ONE hipGraph.  `roofline`: the step's algorithmic
-    flops (9 x 20.5 GFLOP per clip-window + 1.16 GFLOP of VQ encoding) against the exact-fp32 MFMA peak its contractions run on."""
+    flops (9 x 20.5 GFLOP per clip-window + 1.16 GFLOP of VQ encoding) against the dense fp16 MFMA peak (every contraction, forward
+    and backward, is split-fp16 MFMA: the backward on EMAGE_H2 operands with power-of-two gradient scaling)."""
     import common
     from pantomatrix_amd import training
-    model, vq = common.product_models(precision="fp32", device=dev)
+    model, vq = common.product_models(precision="f16x3", device=dev)
     t = 64
     g = torch.Generator().manual_seed(5)
     data = dict(motion=0.3 * torch.randn(batch, t, 165, generator=g), audio=0.1 * torch.randn(batch, t * 16000 // 30, generator=g),
@@ -474,12 +475,12 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56):
     ms = 1e3 * (time.perf_counter() - t0) / steps
     assert all(np.isfinite(v) for v in losses.values())
     flops = batch * (9 * 20.5e9 + 1.16e9)
-    line = {"workload": f"EMAGE training step fp32, {batch} x {t}-frame synthetic clips per GPU (BASELINE configs[2] per-GPU batch), one hipGraph replay per step",
-            "ms_per_step": ms, "value": batch / (ms * 1e-3), "unit": "clip-windows/s", "steps": steps, "dtype": "f32",
+    line = {"workload": f"EMAGE training step f16x3, {batch} x {t}-frame synthetic clips per GPU (BASELINE configs[2] per-GPU batch), one hipGraph replay per step",
+            "ms_per_step": ms, "value": batch / (ms * 1e-3), "unit": "clip-windows/s", "steps": steps, "dtype": "f16x3",
             "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "loss_all": losses["all"],
-            "roofline": {"bound": "mfma", "kernel": "emage_gemm (exact-fp32 MFMA: every contraction of the forward and the backward)", "achieved": flops / (ms * 1e-3) / 1e12,
-                         "peak": 157.3, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / 157.3, "traffic": None,
-                         "note": "whole-step algorithmic flops / step time (an upper bound on the GEMM family's share) against the fp32 matrix peak"}}
+            "roofline": {"bound": "mfma", "kernel": "emage_gemm (split-fp16 MFMA, 3 per product: every contraction of the forward and the backward)",
+                         "achieved": flops / (ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
+                         "note": "whole-step algorithmic flops / step time (an upper bound on the GEMM family's share) against the dense fp16 MFMA peak"}}
     del trainer, model, vq
     torch.cuda.empty_cache()
     if cpu:

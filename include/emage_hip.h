@@ -401,6 +401,9 @@ int emage_nll_loss_grad(const float* logits, int ld, const int64_t* index, int M
  */
 int emage_im2col_t(const float* x, int ldx, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq,
                    float* out, long ld_out, void* stream);
+/* emage_im2col_t with the result as an EMAGE_H2 image (taps * C, ld_out): columns [nseq * Lout, rup64(nseq * Lout)) are written as zeros. */
+int emage_im2col_t_h2(const float* x, int ldx, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq,
+                      void* out, long ld_out, void* stream);
 int emage_col2im(const float* dcol, long ld, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq, float* dx, int ldx, void* stream);
 
 /* nn.BatchNorm1d (training) backward on channels-last rows: dgamma = sum dy * xhat, dbeta = sum dy (float64 sums),
@@ -424,6 +427,11 @@ int emage_wav_conv_in_backward(const float* dy, int ld_dy, const float* wav, lon
  * 1-based step count of this parameter. */
 int emage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, int step,
                     float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+/* fp32 (M, C) rows -> EMAGE_H2 image of src * scale (scale a power of two: gradients are pre-scaled so that their fp16 planes stay
+ * normal).  transpose = 0: out (M, n_store), zero tail [C, n_store);  transpose != 0: out (C, n_store) with out[c][m] = src[m][c] * scale
+ * and a zero tail [M, n_store) — the operands of the backward contractions of a training step (dW = dY^T X contracts over the rows). */
+int emage_h2_cast(const float* src, int lds, void* out, int ldo, int n_store, int M, int C, float scale, int transpose, void* stream);
 
 /* Multi-tensor Adam: ONE launch over every parameter.  table: per tensor five 64-bit words {param, grad, exp_avg, exp_avg_sq, n} (device
  * pointers / element count); block b updates elements [block_chunk[b] * C, +C) of tensor block_tensor[b], C = emage_adam_multi_chunk().

@@ -40,6 +40,7 @@ SIGNATURES = {
     "emage_mse_loss_grad": [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p],
     "emage_nll_loss_grad": [_p, _i, _p, _i, _i, _f, _p, _i, _p],
     "emage_im2col_t": [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p],
+    "emage_im2col_t_h2": [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p],
     "emage_col2im": [_p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "emage_bn_backward": [_p, _i, _p, _p, _p, _f, _p, _i, _p, _i, _p, _p, _i, _i, _p, _l, _p],
     "emage_bn_backward_sums": [_p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _p, _l, _p],
@@ -57,6 +58,7 @@ SIGNATURES = {
     "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p],
     "emage_pack_motion": [_i, _p, _p, _l, _p, _p, _l, _i, _p, _i, _i, _i, _i, _i, _p],
     "emage_cast_pad": [_i, _p, _i, _p, _i, _i, _i, _i, _p],
+    "emage_h2_cast": [_p, _i, _p, _i, _i, _i, _i, _f, _i, _p],
     "emage_rot6d_to_axis_angle": [_p, _p, _i, _p],
     "emage_axis_angle_to_rot6d": [_p, _p, _i, _p],
     "emage_merge_parts": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p],

@@ -129,6 +129,38 @@ __global__ __launch_bounds__(256) void cast_pad_h2_kernel(const float* src, int 
     }
 }
 
+// fp32 (M, C) -> EMAGE_H2 with a power-of-two pre-scale, optionally TRANSPOSED: out[c][m] = src[m][c] * scale, (C, m_store) with a zero tail
+// [M, m_store) — the operands of the training step's backward contractions (dW = dY^T X contracts over the rows).  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void h2_cast_t_kernel(const float* __restrict__ src, int lds_, h2_t* __restrict__ out, int ldo, int m_store, int M, int C, float scale) {
+    __shared__ float tile[64][65];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (m0 + r < M && c0 + c < C) ? src[(long)(m0 + r) * lds_ + c0 + c] * scale : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+        const int c = i >> 3, g = i & 7;
+        if (c0 + c < C && m0 + 8 * g < m_store) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[8 * g + e][c];
+            h2_store8(out + (long)(c0 + c) * ldo + m0 + 8 * g, v);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void h2_cast_kernel(const float* src, int lds_, h2_t* out, int ldo, int n_store, int M, int C, float scale) {
+    const int ng = n_store >> 3;
+    const long total = (long)M * ng;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / ng), n0 = 8 * (int)(i - (long)m * ng);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = n0 + e < C ? src[(long)m * lds_ + n0 + e] * scale : 0.f;
+        h2_store8(out + (long)m * ldo + n0, v);
+    }
+}
+
 inline int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -193,6 +225,19 @@ extern "C" int emage_cast_pad(int dtype, const float* src, int lds, void* out, i
         if (n_store % 8 || ldo % 8 || ((uintptr_t)out & 15) || ((const void*)src == out && lds != ldo)) return EMAGE_EINVAL;
         hipLaunchKernelGGL(cast_pad_h2_kernel, dim3(grid_for((long)M * n_store / 8)), block, 0, s, src, lds, (h2_t*)out, ldo, n_store, M, C);
     } else return EMAGE_EINVAL;
+    return launch_status();
+}
+
+extern "C" int emage_h2_cast(const float* src, int lds, void* out, int ldo, int n_store, int M, int C, float scale, int transpose, void* stream) {
+    if (!src || !out || M <= 0 || C <= 0 || lds < C || n_store % 8 || ldo % 8 || ldo < n_store || ((uintptr_t)out & 15) || !(scale > 0.f)) return EMAGE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (transpose) {
+        if (n_store < M) return EMAGE_EINVAL;
+        hipLaunchKernelGGL(h2_cast_t_kernel, dim3((n_store + 63) / 64, (C + 63) / 64), dim3(256), 0, s, src, lds, (h2_t*)out, ldo, n_store, M, C, scale);
+    } else {
+        if (n_store < C) return EMAGE_EINVAL;
+        hipLaunchKernelGGL(h2_cast_kernel, dim3(grid_for((long)M * n_store / 8)), dim3(256), 0, s, src, lds, (h2_t*)out, ldo, n_store, M, C, scale);
+    }
     return launch_status();
 }
 

@@ -10,6 +10,7 @@
 //                      follows it in nn.Transformer*Layer; the mask may be stored (T, B, d) while rows run (B, T)
 // Statistics are accumulated in float64 (one rounding to fp32 at the end): the batch has up to ~4e5 rows per channel.
 #include "common.h"
+#include "h2.h"
 #include <math.h>
 
 namespace {
@@ -633,6 +634,33 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__
     }
 }
 
+// The same matrix as an EMAGE_H2 image (csrc/h2.h; the W operand of the split-fp16 dW contraction): 64 (m) x 32 (c) tiles, every 32-byte
+// group of 8 consecutive m written whole — columns [M, m_store) come out as zeros, no pre-clearing of the (large) buffer.
+__global__ __launch_bounds__(256) void im2col_t_h2_kernel(const float* __restrict__ x, int ldx, int C, int taps, int stride, int pad, int Lin, int Lout, int M,
+                                                          emage_dev::h2_t* __restrict__ out, long ld_out) {
+    __shared__ float tile[64][33];
+    const int ctiles = (C + 31) / 32;
+    const int tap = blockIdx.y / ctiles, c0 = (blockIdx.y % ctiles) * 32, m0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int r = i >> 5, tx = i & 31;
+        const int m = m0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (m < M && c < C) {
+            const int seq = m / Lout, l = m - seq * Lout, pos = l * stride - pad + tap;
+            if (pos >= 0 && pos < Lin) v = x[((long)seq * Lin + pos) * ldx + c];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    const int c = threadIdx.x >> 3, g = threadIdx.x & 7;
+    if (c0 + c < C) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[8 * g + e][c];
+        emage_dev::h2_store8(out + ((long)tap * C + c0 + c) * ld_out + m0 + 8 * g, v);
+    }
+}
+
 // dx[seq * Lin + r][c] = sum over taps with (r + pad - tap) = l * stride, 0 <= l < Lout, of dcol[seq * Lout + l][tap * C + c]
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, long ld, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq,
                                                      float* __restrict__ dx, int ldx) {
@@ -738,6 +766,17 @@ extern "C" int emage_im2col_t(const float* x, int ldx, int C, int taps, int stri
     if (ld_out < M || M >= (1L << 31)) return EMAGE_EINVAL;
     hipLaunchKernelGGL(im2col_t_kernel, dim3((unsigned)((M + 31) / 32), (unsigned)(taps * ((C + 31) / 32))), dim3(256), 0, (hipStream_t)stream,
                        x, ldx, C, taps, stride, pad, Lin, Lout, (int)M, out, ld_out);
+    return launch_status();
+}
+
+extern "C" int emage_im2col_t_h2(const float* x, int ldx, int C, int taps, int stride, int pad, int Lin, int Lout, int nseq,
+                                 void* out, long ld_out, void* stream) {
+    if (!x || !out || C <= 0 || taps <= 0 || stride <= 0 || pad < 0 || Lin <= 0 || Lout <= 0 || nseq <= 0 || ldx < C) return EMAGE_EINVAL;
+    const long M = (long)nseq * Lout;
+    const long mp = (M + 63) / 64 * 64;
+    if (ld_out < mp || ld_out % 8 || M >= (1L << 31) || ((uintptr_t)out & 15)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(im2col_t_h2_kernel, dim3((unsigned)(mp / 64), (unsigned)(taps * ((C + 31) / 32))), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, C, taps, stride, pad, Lin, Lout, (int)M, (emage_dev::h2_t*)out, ld_out);
     return launch_status();
 }
 

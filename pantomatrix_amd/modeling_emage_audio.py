@@ -113,6 +113,7 @@ class _EmageModule(torch.nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self.__dict__["_scale_caches"] = {}      # new weights: the split-fp16 operand scales are chosen afresh
         self.invalidate_packed()
         return out
 
@@ -190,7 +191,7 @@ class _EmageModule(torch.nn.Module):
         want_h2 = self._dt == F16X3 and self._supports_h2 and (self.split_acts if h2 is None else h2)
         dt = H2 if want_h2 else self._dt
         if self._packed is None or self._packed.device != dev or self._packed.dt != dt:
-            self._packed = _Packed(self._flat_params(), dev, dt)
+            self._packed = _Packed(self._flat_params(), dev, dt, self.__dict__.setdefault("_scale_caches", {}).setdefault((str(dev), dt), {}))
             self._pack(self._packed)
         return self._packed
 
@@ -206,8 +207,12 @@ class _EmageModule(torch.nn.Module):
 # packed weights: MFMA-operand dtype, K-contiguous rows, taps flattened, BatchNorm folded
 # ======================================================================================
 class _Packed:
-    def __init__(self, params, device, dt):
+    def __init__(self, params, device, dt, scale_cache=None):
         self.p, self.device, self.dt = params, device, dt
+        # split-fp16 operand scales by packing order: chosen (one read-back of max|w|) at the FIRST packing of a model's weights and kept for
+        # every re-packing (after an optimiser step: a pure sequence of launches, capturable); cleared when a state dict is loaded
+        self.scale_cache = {} if scale_cache is None else scale_cache
+        self._n_operands = 0
         self.wav_dt = F16X3 if dt == H2 else dt      # the WavEncoder keeps float32 activations (slab kernels split in LDS)
         self.tdt = ops.TORCH_DTYPE[dt]
         self.w = {}
@@ -225,10 +230,12 @@ class _Packed:
     def _operand(self, w2d, dt=None):
         """(N, K) fp32 with K already padded -> the MFMA operand image of precision `dt` (default: the model's) and its scale."""
         dt = self.dt if dt is None else dt
-        if dt == H2:
-            return ops.split_f16_weights_h2(w2d.contiguous())
-        if dt == F16X3:
-            return ops.split_f16_weights(w2d.contiguous())
+        if dt in (H2, F16X3):
+            key = (dt, self._n_operands, tuple(w2d.shape))
+            self._n_operands += 1
+            img, scale = (ops.split_f16_weights_h2 if dt == H2 else ops.split_f16_weights)(w2d.contiguous(), self.scale_cache.get(key))
+            self.scale_cache[key] = scale
+            return img, scale
         return w2d.to(ops.TORCH_DTYPE[dt]).contiguous(), 1.0
 
     def _pack_mat(self, w2d):

@@ -30,16 +30,17 @@ TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32, H
 A_SCALE_F16X3 = 16.0    # activations are multiplied by this power of two before the fp16 hi/lo split (|x| < 4094 stays finite)
 
 
-def split_f16_weights(w2d):
+def split_f16_weights(w2d, scale=None):
     """Host packing of an (N, K) fp32 weight matrix for EMAGE_F16X3 (include/emage_hip.h: emage_gemm), K % 32 == 0.
     Returns (packed (N, K) float32-typed buffer holding the fp16 planes, w_scale).  w_scale is the power of two that
-    puts max|w| into [2^12, 2^13): both planes stay normal fp16 numbers for every weight above max|w| * 2^-16."""
-    import math
+    puts max|w| into [2^12, 2^13): both planes stay normal fp16 numbers for every weight above max|w| * 2^-16.
+    scale given (a power of two chosen at an earlier packing of the same weight): no read-back of max|w| — the packing is then a
+    pure sequence of device launches (a training step re-packs after every update, also inside a captured graph)."""
     n, k = w2d.shape
     assert k % 32 == 0
     w = w2d.to(torch.float32)
-    mx = float(w.abs().max())
-    scale = 2.0 ** (12 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+    if scale is None:
+        scale = _f16_scale(w)
     ws = w * scale
     hi = ws.to(torch.float16)
     lo = (ws - hi.to(torch.float32)).to(torch.float16)
@@ -79,13 +80,13 @@ def h2_unpack(t, scale=A_SCALE_F16X3):
     return ((g[..., 0, :] + g[..., 1, :]) / scale).reshape(*t.shape[:-1], c)
 
 
-def split_f16_weights_h2(w2d):
+def split_f16_weights_h2(w2d, scale=None):
     """Host packing of an (N, K) fp32 weight matrix for EMAGE_H2 (K % 32 == 0): the H2 image of W * w_scale, natural k order
-    (the same layout the activations use).  Returns (packed (N, K) float32-typed, w_scale)."""
+    (the same layout the activations use).  Returns (packed (N, K) float32-typed, w_scale); `scale` as for `split_f16_weights`."""
     n, k = w2d.shape
     assert k % 32 == 0
     w = w2d.to(torch.float32)
-    scale = _f16_scale(w)
+    scale = _f16_scale(w) if scale is None else scale
     return h2_pack(w, scale), scale
 
 
@@ -507,6 +508,19 @@ def im2col_t(x, c, taps, stride, pad, lin, lout, nseq, mp):
     return out
 
 
+@_op("im2col_t_h2", "(Tensor x, int c, int taps, int stride, int pad, int lin, int lout, int nseq, Tensor(a!) out) -> ()")
+def _im2col_t_h2(x, c, taps, stride, pad, lin, lout, nseq, out):
+    check(_lib.load().emage_im2col_t_h2(_ptr(x), _ld(x), c, taps, stride, pad, lin, lout, nseq, _ptr(out), out.stride(0), _stream()), "im2col_t_h2")
+
+
+def im2col_t_h2(x, c, taps, stride, pad, lin, lout, nseq, mp):
+    """`im2col_t` as an EMAGE_H2 image (taps*c, mp), mp = rup64(nseq*lout): the W operand of the split-fp16 dW contraction."""
+    _dev(x)
+    out = torch.empty(taps * c, mp, dtype=torch.float32, device=x.device)
+    _im2col_t_h2(x, c, taps, stride, pad, lin, lout, nseq, out)
+    return out
+
+
 @_op("col2im", "(Tensor dcol, int c, int taps, int stride, int pad, int lin, int lout, int nseq, Tensor(a!) dx) -> ()")
 def _col2im(dcol, c, taps, stride, pad, lin, lout, nseq, dx):
     check(_lib.load().emage_col2im(_ptr(dcol), dcol.stride(0), c, taps, stride, pad, lin, lout, nseq, _ptr(dx), _ld(dx), _stream()), "col2im")
@@ -797,6 +811,22 @@ def cast_pad(dtype, src2d, n_store, out=None):
     else:
         assert out.shape == (m, n_store) and out.stride(1) == 1
     _cast_pad(dtype, src2d, out)
+    return out
+
+
+@_op("h2_cast", "(Tensor src, Tensor(a!) out, float scale, bool transpose) -> ()")
+def _h2_cast(src, out, scale, transpose):
+    m, c = src.shape
+    check(_lib.load().emage_h2_cast(_ptr(src), _ld(src), _ptr(out), _ld(out), out.shape[1], m, c, scale, int(transpose), _stream()), "h2_cast")
+
+
+def h2_cast(src2d, n_store, scale=1.0, transpose=False):
+    """fp32 (M, C) view -> the EMAGE_H2 image of src * scale (a power of two): (M, n_store), or transposed (C, n_store) with
+    out[c][m] = src[m][c] * scale; zero tails.  The operands of the training step's backward contractions."""
+    _dev(src2d)
+    m, c = src2d.shape
+    out = torch.empty(c if transpose else m, n_store, dtype=torch.float32, device=src2d.device)
+    _h2_cast(src2d, out, float(scale), bool(transpose))
     return out
 
 

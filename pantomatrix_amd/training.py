@@ -26,7 +26,7 @@ from __future__ import annotations
 import torch
 
 from . import ops, spec
-from ._lib import F32
+from ._lib import F32, H2
 from .modeling_emage_audio import OUT_KEYS, _Ctx, _WAV_TAPS, _rup
 
 BN_MOMENTUM = 0.1          # nn.BatchNorm1d default
@@ -163,6 +163,12 @@ class TrainForward:
             raise ValueError("the training forward runs in the fp32-storage precisions (f16x3 / fp32)")
         self.model = model
         self.sync_bn, self.group, self._bn_count = sync_bn, group, {}
+        # f16x3 precision: the backward contractions run as split-fp16 MFMA on pre-split (EMAGE_H2) operands — gradients pre-scaled by
+        # a power of two so that their fp16 planes stay normal (the loss-scaling of mixed-precision training, undone exactly in the
+        # GEMM epilogue); fp32 precision keeps the exact-fp32 MFMA contractions
+        self.h2_backward = model.precision == "f16x3"
+        self.grad_scale = 1024.0
+        self._w_scale, self._wt_cache = {}, {}
         self.tape = None
         self.param_grads = {}
         self.grad_views = None          # name -> preallocated fp32 gradient tensor (views of the exchange buckets, training.Trainer)
@@ -266,6 +272,8 @@ class TrainForward:
         n = sum(w.shape[0] for w in ws)
         m = dy.shape[0]
         mp = _rup(m)
+        if self.h2_backward:
+            return self._conv_backward_h2(cx, x, cin, origins, ws, dy, n, m, mp, taps, stride, pad, lin, lout, nseq, need_dx)
         dy_t = torch.zeros(n, mp, dtype=torch.float32, device=cx.dev)
         ops.transpose(dy, dy_t)
         col_t = ops.im2col_t(x, cin, taps, stride, pad, lin, lout, nseq, mp)     # (taps*cin, mp)
@@ -286,6 +294,42 @@ class TrainForward:
         wflat = torch.cat([w.permute(0, 2, 1).reshape(w.shape[0], taps * cin) for w in ws], 0).contiguous()        # (N, taps*cin), taps major
         dcol = torch.empty(m, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
         ops.gemm(F32, dy, ops.transpose(wflat), None, None, None, dcol, None, None, n=kc, cp=n)
+        return ops.col2im(dcol, cin, taps, stride, pad, lin, lout, nseq)
+
+    def _conv_backward_h2(self, cx, x, cin, origins, ws, dy, n, m, mp, taps, stride, pad, lin, lout, nseq, need_dx):
+        """`_conv_backward` with both contractions as split-fp16 MFMA on EMAGE_H2 operands: dW = (gs dY)^T im2col(X) with the im2col matrix
+        written directly as an H2 image, dcol = (gs dY) W with the flattened weights converted once per forward."""
+        gs = self.grad_scale
+        kc = taps * cin
+        dy_t = ops.h2_cast(dy, mp, scale=gs, transpose=True)                               # (N, mp)
+        col_t = ops.im2col_t_h2(x, cin, taps, stride, pad, lin, lout, nseq, mp)            # (taps*cin, mp)
+        dw = torch.empty(n, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
+        ops.gemm(H2, dy_t, col_t, None, None, None, None, dw, None, n=kc, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
+        del col_t
+        db = ops.col_sum(dy)
+        r0 = 0
+        for (wn, bn), w in zip(origins, ws):
+            rows = w.shape[0]
+            self._param_grad(wn, slice(None), dw[r0:r0 + rows].reshape(rows, taps, cin).permute(0, 2, 1))
+            self._param_grad(bn, slice(None), db[r0:r0 + rows])
+            r0 += rows
+        if not need_dx:
+            return None
+        key = ("conv",) + tuple(wn for wn, _ in origins)
+        hit = self._wt_cache.get(key)
+        if hit is None:
+            import math
+            wflat = torch.cat([w.permute(0, 2, 1).reshape(w.shape[0], kc) for w in ws], 0).contiguous()          # (N, taps*cin), taps major
+            wsc = self._w_scale.get(key)
+            if wsc is None:
+                mx = float(wflat.abs().max())
+                wsc = self._w_scale[key] = 2.0 ** (11 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+            hit = self._wt_cache[key] = (ops.h2_cast(wflat, _rup(n), scale=wsc / 16.0, transpose=True), wsc)       # (taps*cin, rup64(N))
+        w_t, wsc = hit
+        np_ = _rup(n)
+        dy_h = ops.h2_cast(dy, np_, scale=gs)
+        dcol = torch.empty(m, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
+        ops.gemm(H2, dy_h, w_t, None, None, None, None, dcol, None, n=kc, cp=np_, w_scale=wsc, a_scale=16.0 * gs)
         return ops.col2im(dcol, cin, taps, stride, pad, lin, lout, nseq)
 
     def _bn_backward(self, name, x, stats, dy):
@@ -388,6 +432,9 @@ class TrainForward:
         dpre = dy if slope is None else ops.act_backward(dy, y, slope)
         if dpre.shape[1] != n or dpre.stride(1) != 1:
             raise RuntimeError(f"{key}: gradient of shape {tuple(dpre.shape)} for an output of {n} columns")
+        if self.h2_backward:
+            self._lin_backward_h2(cx, x, key, dpre, n, k, m, need_dx)
+            return
         w32 = torch.cat([self._param(wn)[rs] for wn, _bn, rs in cx.pk.origin[key]], 0).float().contiguous()            # (N, K)
         mp = _rup(m)
         dpre_t = torch.zeros(n, mp, dtype=torch.float32, device=cx.dev)
@@ -411,6 +458,47 @@ class TrainForward:
             dx = torch.empty(m, k, dtype=torch.float32, device=cx.dev)
             ops.gemm(F32, dpre, w_t, None, None, None, dx, None, None, n=k, cp=n)                                        # dX = dpre W
             tape.add(x, dx, cols=k)
+
+    def _weight_t_h2(self, cx, key, n, k):
+        """The transposed weight of a Linear as an EMAGE_H2 operand, (K, rup64(N)) holding w * w_scale: (image, w_scale); built once per
+        forward and key.  The power-of-two scale is fixed at the first use of the key (max |w| into [2^11, 2^12): a weight may grow
+        16x before its fp16 planes overflow, which the trainer's non-finite check would report)."""
+        hit = self._wt_cache.get(key)
+        if hit is not None:
+            return hit
+        w32 = torch.cat([self._param(wn)[rs] for wn, _bn, rs in cx.pk.origin[key]], 0).float().contiguous()            # (N, K)
+        ws = self._w_scale.get(key)
+        if ws is None:
+            import math
+            mx = float(w32.abs().max())
+            ws = self._w_scale[key] = 2.0 ** (11 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+        img = ops.h2_cast(w32, _rup(n), scale=ws / 16.0, transpose=True)              # h2 images carry a fixed x16: the rest of the scale goes in front
+        self._wt_cache[key] = (img, ws)
+        return img, ws
+
+    def _lin_backward_h2(self, cx, x, key, dpre, n, k, m, need_dx):
+        """dW = dpre^T x, db = colsum(dpre), dX = dpre W as split-fp16 MFMA contractions (emage_gemm, EMAGE_H2) on operands converted
+        by `ops.h2_cast`; the gradient operand is pre-scaled by `grad_scale` (undone by the GEMM's output scale)."""
+        gs = self.grad_scale
+        mp = _rup(m)
+        dpre_t = ops.h2_cast(dpre, mp, scale=gs, transpose=True)                      # (N, mp)
+        x_t = ops.h2_cast(x[:, :k], mp, scale=1.0, transpose=True)                    # (K, mp)
+        dw = torch.empty(n, k, dtype=torch.float32, device=cx.dev)
+        ops.gemm(H2, dpre_t, x_t, None, None, None, None, dw, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
+        db = ops.col_sum(dpre)
+        r0 = 0
+        for wn, bn, rs in cx.pk.origin[key]:
+            rows = rs.stop - rs.start
+            self._param_grad(wn, rs, dw[r0:r0 + rows])
+            self._param_grad(bn, rs, db[r0:r0 + rows])
+            r0 += rows
+        if need_dx:
+            w_t, ws = self._weight_t_h2(cx, key, n, k)
+            np_ = _rup(n)
+            dpre_h = ops.h2_cast(dpre, np_, scale=gs)                                 # (M, rup64(N))
+            dx = torch.empty(m, k, dtype=torch.float32, device=cx.dev)
+            ops.gemm(H2, dpre_h, w_t, None, None, None, None, dx, None, n=k, cp=np_, w_scale=ws, a_scale=16.0 * gs)
+            self.tape.add(x, dx, cols=k)
 
     def _params(self):
         """name -> detached parameter / buffer view, built once per forward (walking the module tree per lookup costs more than
@@ -570,6 +658,7 @@ class TrainForward:
         self.tape = _Tape(dev) if tape else None
         self._cx = cx
         self._pcache = None
+        self._wt_cache = {}
         new_stats = {} if new_stats is None else new_stats
         masks = _Masks(dropout_masks, dev, rng)
         b, t, cm = masked_motion.shape
@@ -935,12 +1024,12 @@ class Trainer:
         backward passes, the dropout masks (drawn on the device from the in-graph step counter unless `dropout_masks` buffers are
         given), Adam, BatchNorm buffers — into one hipGraph over the GIVEN tensors: `batch` and `random_mask` (and `dropout_masks`)
         become the graph's input buffers (refill them in place between replays), the parameters its state.  `replay()` then runs a
-        step at device speed instead of the ~10^4 Python-level launches of `step()`.  Needs the model in "fp32" precision (packing
-        split-fp16 operands reads each weight's scale back to the host) and a single process (no collective inside a capture).  One
-        eager warm-up step is run and undone."""
+        step at device speed instead of the ~10^4 Python-level launches of `step()`.  Both fp32-storage precisions: in f16x3 the
+        split-fp16 operand scales are the ones chosen by the warm-up step's packing (a re-packing with known scales is a pure sequence
+        of launches).  Needs a single process (no collective inside a capture).  One eager warm-up step is run and undone."""
         fwd, model = self.fwd, self.fwd.model
-        if model.precision != "fp32" or fwd.sync_bn or self._world() > 1:
-            raise RuntimeError("Trainer.capture: needs precision 'fp32', sync_bn=False and a single process")
+        if fwd.sync_bn or self._world() > 1:
+            raise RuntimeError("Trainer.capture: needs sync_bn=False and a single process (no collective inside a captured graph)")
         dev = model.device
         for name, t in list(batch.items()) + [("random_mask", random_mask)]:
             if not (torch.is_tensor(t) and t.is_cuda and t.device == dev and t.dtype == torch.float32):

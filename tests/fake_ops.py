@@ -244,6 +244,14 @@ def im2col_t(x, c, taps, stride, pad, lin, lout, nseq, mp):
     return out
 
 
+def im2col_t_h2(x, c, taps, stride, pad, lin, lout, nseq, mp):
+    mark = len(CALLS)
+    r = ops.h2_pack(im2col_t(x, c, taps, stride, pad, lin, lout, nseq, mp))
+    del CALLS[mark:]
+    CALLS.append("im2col_t_h2")
+    return r
+
+
 def col2im(dcol, c, taps, stride, pad, lin, lout, nseq):
     CALLS.append("col2im")
     d = dcol.reshape(nseq, lout, taps, c)
@@ -450,6 +458,15 @@ def cast_pad(dtype, src2d, n_store, out=None):
     return out
 
 
+def h2_cast(src2d, n_store, scale=1.0, transpose=False):
+    CALLS.append("h2_cast")
+    v = (src2d.float() * scale)
+    v = v.t() if transpose else v
+    full = torch.zeros(v.shape[0], n_store)
+    full[:, :v.shape[1]] = v
+    return ops.h2_pack(full)
+
+
 def gather_rows(table, idx, dtype, n_store=None):
     CALLS.append("gather_rows")
     k, d = table.shape
@@ -648,7 +665,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["adam_multi", "dropout_mask", "count_nonfinite", "loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["im2col_t_h2", "h2_cast", "adam_multi", "dropout_mask", "count_nonfinite", "loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 
@@ -662,7 +679,7 @@ def installed():
         want_h2 = self._dt == F16X3 and self._supports_h2 and (self.split_acts if h2 is None else h2)
         dt = H2 if want_h2 else self._dt
         if self._packed is None or self._packed.dt != dt:
-            self._packed = M._Packed(self._flat_params(), self.device, dt)
+            self._packed = M._Packed(self._flat_params(), self.device, dt, self.__dict__.setdefault("_scale_caches", {}).setdefault((str(self.device), dt), {}))
             self._pack(self._packed)
         return self._packed
 

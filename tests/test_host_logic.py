@@ -207,5 +207,8 @@ def test_models_are_nn_modules_with_reference_parameter_tree():
     bad.pop("face_out_proj.bias")
     with pytest.raises(RuntimeError, match="Missing key"):
         model.load_state_dict(bad)
-    with pytest.raises(NotImplementedError):
-        model.train()
+    model.train()                                                                    # EmageAudioModel trains through its class API (training.train_forward)
+    assert model.training
+    model.eval()
+    with pytest.raises(NotImplementedError):                                         # the VQ-VAEs are frozen in the reference (T:233-245)
+        vq.vq_model_face.train()
