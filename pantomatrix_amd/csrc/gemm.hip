@@ -341,7 +341,7 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.ldf = ldf; a.res_is_f32 = res_is_f32; a.res_first = res_first; a.n_store = out ? n_store : 0;
     a.t_col0 = out_t ? t_col0 : N; a.t_rows = t_rows > 0 ? t_rows : 1; a.t_ld = t_ld;
     a.dbg = g_debug_skip;
-    a.trace = nullptr; a.cstate = nullptr; a.ldc = 0;
+    a.trace = nullptr; a.cstate = nullptr; a.ldc = 0; a.ksplit = 1; a.nk_split = 0;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
     const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2;
     a.a_scale = split ? a_scale : 1.f;

@@ -23,15 +23,16 @@ using namespace emage_dev;
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV, bool TRACE>
 __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) void gemm_h2_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[h2_smem_bytes<BM, BN, NS>()];
-    // XCD-aware tile order (gemm.hip): each XCD walks a contiguous run of tiles
+    // XCD-aware tile order (gemm.hip): each XCD walks a contiguous run of tiles; split-K: slice s = blockIdx / tiles
     const int nblk = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
+    const int split = p.ksplit > 1 ? (int)blockIdx.x / nblk : 0;
+    int bid = (int)blockIdx.x - split * nblk;
     {
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE>(p, tile_m * BM, tile_n * BN, smem);
+    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE>(p, tile_m * BM, tile_n * BN, smem, split);
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false, bool TRACE = false>
@@ -41,7 +42,26 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     a.tiles_n = (ncols + BN - 1) / BN;
     a.trace = TRACE ? g_h2_trace : nullptr;
-    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE>), dim3(a.tiles_m * a.tiles_n), dim3((WM * WN + NLW) * 64), 0, s, a);
+    // split-K: a bare contraction (only out_f32, no bias / activation / residual — the weight gradients of a training step: few output
+    // tiles, a very long K) with too few tiles to fill the chip is cut into K-slices whose partial tiles are atomically added in memory
+    a.ksplit = 1;
+    const long tiles = (long)a.tiles_m * a.tiles_n;
+    const int nk_all = a.K / 32;
+    if (a.taps == 1 && !a.out && !a.out_t && !a.res && !a.bias && !a.slope && a.out_f32 && tiles < 192 && nk_all >= 64) {
+        int want = (int)((512 + tiles - 1) / tiles);
+        const int most = nk_all / 16;                  // >= 16 K-tiles (512 k) per slice
+        if (want > most) want = most;
+        if (want > 64) want = 64;
+        if (want > 1) {
+            int per = (nk_all + want - 1) / want;
+            per = (per + 1) & ~1;                      // the register-pipelined loops take K-tiles in pairs
+            a.nk_split = per;
+            a.ksplit = (nk_all + per - 1) / per;
+            const hipError_t e = hipMemset2DAsync(a.out_f32, (size_t)a.ldf * sizeof(float), 0, (size_t)a.N * sizeof(float), (size_t)a.M, s);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
     return launch_status();
 }
 

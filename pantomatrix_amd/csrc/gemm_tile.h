@@ -23,6 +23,7 @@ struct GemmArgs {
     int dbg;
     float a_scale, o_scale;   // split-f16 mode: A is multiplied by a_scale before the hi/lo split, accumulators by o_scale after the K-loop
     float* cstate; int ldc;   // EPI_LSTM: the (M, N/4) cell state, updated in place
+    int ksplit, nk_split;        // EMAGE_H2 split-K (gemm_h2.hip): > 1 K-slices of nk_split K-tiles each, partial tiles atomically added into out_f32
     unsigned long long* trace;   // tools builds: per-wave s_memtime stamps of one block (h2_tile.h TRACE), else NULL
 };
 

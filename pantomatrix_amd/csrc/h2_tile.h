@@ -27,7 +27,7 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 template <int BM, int BN, int NS> constexpr int h2_smem_bytes() { return NS * (BM + BN) * 128; }
 
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, bool DILV = false, bool TRACE = false>
-__device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem) {
+__device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem, const int split = 0) {
     constexpr int ES = 4, BK = 32, RB = 128, RPI = 8;
     constexpr int NCW = WM * WN, NL = NLW ? NLW : NCW;
     constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16, FP = FN / 2;
@@ -95,8 +95,11 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
         const int lc = lslot ^ swzW<8>(row);
         b_voff[j] = n < p.N ? (unsigned)n * (unsigned)(p.K * ES) + (unsigned)((2 * (lc & 3) + (lc >> 2)) * 16) : OOB;
     }
-    int is_tap = 0, is_c0 = 0, is_slot = 0;
-    unsigned soff_a = 0, soff_w = 0;
+    // split-K (p.ksplit > 1, Linear only): this block contracts K-tiles [kt0, kt0 + nk) and adds its partial tile into out_f32
+    const int nk_all = p.K / BK;
+    const int kt0 = p.ksplit > 1 ? split * p.nk_split : 0;
+    int is_tap = 0, is_c0 = kt0 * BK, is_slot = 0;
+    unsigned soff_a = (unsigned)(kt0 * BK * ES), soff_w = (unsigned)(kt0 * BK * ES);
     const unsigned tap_step = (unsigned)(p.lda - p.Cp + BK) * ES;
     // DMA instruction J of a stage (J < GA: A rows, else W rows) and the bookkeeping that follows the last one
     auto issue_piece = [&](auto jc) {
@@ -153,7 +156,7 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = p.ksplit > 1 ? (nk_all - kt0 < p.nk_split ? nk_all - kt0 : p.nk_split) : nk_all;
     if (is_loader) {
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)
@@ -440,7 +443,11 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
         }
         if (p.out_f32 && n < ncol_n) {
             float* dst = p.out_f32 + (long)m * p.ldf + n;
-            if (full && f32_vec) {
+            if (p.ksplit > 1) {                       // partial sums of the K-slices meet in memory (the destination was cleared by the host call)
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (n + e < ncol_n) __hip_atomic_fetch_add(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (full && f32_vec) {
                 if constexpr (W == 8) store8<float>(dst, v);
                 else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
             } else {

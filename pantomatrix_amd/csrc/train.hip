@@ -20,12 +20,12 @@ constexpr int STAT_CHUNK = 256;       // rows per block (2048 left the small-M l
                                       // bias gradient, 17 % of the step — profiles/r03_train_kernel_stats_before.csv)
 
 // partial[(chunk * 2 + {0: sum, 1: sum of squares}) * C + c], deterministic: the finalize kernel adds the chunks in order
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int ldx, int M, int C, double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int ldx, int M, int C, double* __restrict__ partial, int chunk_rows) {
     __shared__ double red[2][STAT_ROWS][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
-    const long r0 = (long)blockIdx.x * STAT_CHUNK;
-    const long r1 = r0 + STAT_CHUNK < M ? r0 + STAT_CHUNK : M;
+    const long r0 = (long)blockIdx.x * chunk_rows;
+    const long r1 = r0 + chunk_rows < M ? r0 + chunk_rows : M;
     double s = 0.0, ss = 0.0;
     if (c < C)
         for (long r = r0 + rl; r < r1; r += STAT_ROWS) {
@@ -158,6 +158,12 @@ inline int grid_for(long total) {
 
 }  // namespace
 
+// rows per partial block: 256 at least, at most ~512 chunks (the finalize kernels add the chunks of a column serially, in order: deterministic)
+static inline int stat_rows(int M) {
+    int r = ((M + 511) / 512 + 3) & ~3;
+    return r < STAT_CHUNK ? STAT_CHUNK : r;
+}
+
 extern "C" long emage_bn_stats_workspace_bytes(int M, int C) {
     if (M <= 0 || C <= 0) return EMAGE_EINVAL;
     return (long)((M + STAT_CHUNK - 1) / STAT_CHUNK) * 2 * C * (long)sizeof(double);
@@ -167,9 +173,9 @@ extern "C" int emage_bn_stats(const float* x, int ldx, int M, int C, void* works
                               float* mean, float* var, float* running_mean, float* running_var, float momentum, void* stream) {
     if (!x || !workspace || !mean || !var || M <= 0 || C <= 0 || ldx < C || !(momentum >= 0.f && momentum <= 1.f)) return EMAGE_EINVAL;
     if (workspace_bytes < emage_bn_stats_workspace_bytes(M, C) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
-    const int chunks = (M + STAT_CHUNK - 1) / STAT_CHUNK;
+    const int chunk_rows = stat_rows(M), chunks = (M + chunk_rows - 1) / chunk_rows;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, M, C, (double*)workspace);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, M, C, (double*)workspace, chunk_rows);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, M, C, mean, var, running_mean, running_var, momentum);
@@ -241,12 +247,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y, int ldy, int M, int C,
-                                                              double* __restrict__ partial) {
+                                                              double* __restrict__ partial, int chunk_rows) {
     __shared__ double red[STAT_ROWS][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
-    const long r0 = (long)blockIdx.x * STAT_CHUNK;
-    const long r1 = r0 + STAT_CHUNK < M ? r0 + STAT_CHUNK : M;
+    const long r0 = (long)blockIdx.x * chunk_rows;
+    const long r1 = r0 + chunk_rows < M ? r0 + chunk_rows : M;
     double s = 0.0;
     if (c < C)
         for (long r = r0 + rl; r < r1; r += STAT_ROWS) s += y ? (double)(x[r * ldx + c] * y[r * ldy + c]) : (double)x[r * ldx + c];
@@ -523,10 +529,10 @@ extern "C" int emage_transpose_f32(const float* in, int ld_in, float* out, int l
 extern "C" int emage_col_sum(const float* x, int ldx, const float* y, int ldy, int M, int C, float* out, int accumulate,
                              void* workspace, long workspace_bytes, void* stream) {
     if (!x || !out || !workspace || M <= 0 || C <= 0 || ldx < C || (y && ldy < C) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
-    const int chunks = (M + STAT_CHUNK - 1) / STAT_CHUNK;
+    const int chunk_rows = stat_rows(M), chunks = (M + chunk_rows - 1) / chunk_rows;
     if (workspace_bytes < (long)chunks * C * (long)sizeof(double)) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(col_sum_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, y, ldy, M, C, (double*)workspace);
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, y, ldy, M, C, (double*)workspace, chunk_rows);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C, out, accumulate);
@@ -683,12 +689,12 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
 // BatchNorm (training) backward: sums of dy and dy * xhat per channel (float64 partials), then
 // dx = gamma * rstd * (dy - sum_dy / M - xhat * sum_dyxhat / M); dgamma = sum_dyxhat, dbeta = sum_dy
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                                             const float* __restrict__ dy, int ldd, int M, int C, double* __restrict__ partial) {
+                                                             const float* __restrict__ dy, int ldd, int M, int C, double* __restrict__ partial, int chunk_rows) {
     __shared__ double red[2][STAT_ROWS][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
-    const long r0 = (long)blockIdx.x * STAT_CHUNK;
-    const long r1 = r0 + STAT_CHUNK < M ? r0 + STAT_CHUNK : M;
+    const long r0 = (long)blockIdx.x * chunk_rows;
+    const long r1 = r0 + chunk_rows < M ? r0 + chunk_rows : M;
     double s = 0.0, sx = 0.0;
     if (c < C) {
         const float mu = mean[c], rstd = 1.0f / sqrtf(var[c] + eps);
@@ -790,9 +796,9 @@ extern "C" int emage_bn_backward(const float* x, int ldx, const float* mean, con
                                  float* dx, int ld_dx, float* dgamma, float* dbeta, int M, int C, void* workspace, long workspace_bytes, void* stream) {
     if (!x || !mean || !var || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || ldx < C || ld_dy < C || ld_dx < C) return EMAGE_EINVAL;
     if (workspace_bytes < emage_bn_stats_workspace_bytes(M, C) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
-    const int chunks = (M + STAT_CHUNK - 1) / STAT_CHUNK;
+    const int chunk_rows = stat_rows(M), chunks = (M + chunk_rows - 1) / chunk_rows;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, mean, var, eps, dy, ld_dy, M, C, (double*)workspace);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, mean, var, eps, dy, ld_dy, M, C, (double*)workspace, chunk_rows);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C, dgamma, dbeta);
@@ -827,9 +833,9 @@ extern "C" int emage_bn_backward_sums(const float* x, int ldx, const float* mean
                                       float* sum_dy_xhat, float* sum_dy, int M, int C, void* workspace, long workspace_bytes, void* stream) {
     if (!x || !mean || !var || !dy || !sum_dy_xhat || !sum_dy || !workspace || M <= 0 || C <= 0 || ldx < C || ld_dy < C) return EMAGE_EINVAL;
     if (workspace_bytes < emage_bn_stats_workspace_bytes(M, C) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
-    const int chunks = (M + STAT_CHUNK - 1) / STAT_CHUNK;
+    const int chunk_rows = stat_rows(M), chunks = (M + chunk_rows - 1) / chunk_rows;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, mean, var, eps, dy, ld_dy, M, C, (double*)workspace);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, mean, var, eps, dy, ld_dy, M, C, (double*)workspace, chunk_rows);
     const int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C, sum_dy_xhat, sum_dy);

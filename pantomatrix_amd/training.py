@@ -367,7 +367,16 @@ class TrainForward:
             origins.append((base + ".downsample.0.weight", base + ".downsample.0.bias"))
             dys = torch.cat([dc1, dcds], 1)
         if sv["i"] == 0:
-            dw = ops.wav_conv_in_backward(dys, sv["audio"], lout, k, stride, pad)          # (2*cout, k): conv1 rows, then the shortcut conv's
+            if self.h2_backward:       # the first layer's weight gradient (Cin = 1) as ONE split-fp16 contraction over all positions (split-K)
+                audio = sv["audio"]
+                m = dys.shape[0]
+                mp = _rup(m)
+                dys_t = ops.h2_cast(dys, mp, scale=self.grad_scale, transpose=True)                         # (2*cout, mp)
+                col = ops.im2col_t_h2(audio.reshape(-1, 1), 1, k, stride, pad, audio.shape[1], lout, b, mp)  # (k, mp)
+                dw = torch.empty(dys.shape[1], _rup(k, 4), dtype=torch.float32, device=cx.dev)[:, :k]
+                ops.gemm(H2, dys_t, col, None, None, None, None, dw, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * self.grad_scale)
+            else:
+                dw = ops.wav_conv_in_backward(dys, sv["audio"], lout, k, stride, pad)      # (2*cout, k): conv1 rows, then the shortcut conv's
             db = ops.col_sum(dys)
             for j, (wn, bn) in enumerate(origins):
                 self._param_grad(wn, slice(None), dw[j * cout:(j + 1) * cout].view(cout, 1, k))
