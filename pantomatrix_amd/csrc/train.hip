@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int STAT_ROWS = 4;          // row lanes per block: 4 x 64 columns = 256 threads
-constexpr int STAT_CHUNK = 256;       // rows per block (2048 left the small-M layers of a training step with ~24 blocks on 256 CUs: 130 us per
+constexpr int STAT_CHUNK = 64;        // least rows per block (2048 left the small-M layers of a training step with ~24 blocks on 256 CUs: 130 us per
                                       // bias gradient, 17 % of the step — profiles/r03_train_kernel_stats_before.csv)
 
 // partial[(chunk * 2 + {0: sum, 1: sum of squares}) * C + c], deterministic: the finalize kernel adds the chunks in order

@@ -422,7 +422,7 @@ def col_sum(x, y=None, out=None, accumulate=False):
     _dev(x)
     m, c = x.shape
     out = torch.zeros(c, dtype=torch.float32, device=x.device) if out is None else out
-    ws = torch.empty(((m + 255) // 256) * c, dtype=torch.float64, device=x.device)       # one partial per 256-row chunk (csrc/train.hip STAT_CHUNK)
+    ws = torch.empty(((m + 63) // 64) * c, dtype=torch.float64, device=x.device)         # one partial per chunk of >= 64 rows (csrc/train.hip STAT_CHUNK)
     _col_sum(x, y, out, accumulate, ws)
     return out
 

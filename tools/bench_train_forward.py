@@ -78,8 +78,8 @@ def main():
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / args.steps
     what = ("one whole EMAGE optimisation step (targets, 3 x (train-mode forward, losses, backward), Adam), "
-            + ("ONE hipGraph replay (+ drawing the dropout masks)" if args.graph else "eager, one stream") + "; backward "
-            "contractions in exact-fp32 MFMA" if args.full_step else
+            + ("ONE hipGraph replay (+ drawing the dropout masks)" if args.graph else "eager, one stream") + "; f16x3: split-fp16 MFMA "
+            "contractions forward and backward, fp32: exact-fp32 MFMA" if args.full_step else
             "forward side of one EMAGE training step (targets + 3 train-mode forwards + 6 losses), eager, one stream")
     print(json.dumps({"what": what, "config": {"workload": "BASELINE config 3", "clips_per_gpu": b, "frames_per_clip": t}, "dtype": args.precision,
                       "ms_per_step": ms, "clip_windows_per_s": b / (ms * 1e-3), "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
