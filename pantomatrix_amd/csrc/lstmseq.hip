@@ -11,15 +11,19 @@
 //     swizzled rows: conflict-free writes and reads), 3 MFMAs per product as in emage_gemm's X3 form — same operand
 //     roles, same order of the three terms, K ascending: BIT-IDENTICAL to the emage_lstm_step sequence — then the LSTM
 //     cell in registers, h_t written into the (B, T, 2H) layer output, which is also the exchange buffer of the next step;
-//   * group barrier = one arrival counter per (direction, 64-clip slice) (the blocks of a group can sit on any XCD; with
-//     8 groups the launch order puts each group on one XCD).  The exchange uses agent-scope ACCESSES, not fences: h_t is
-//     stored write-through (`sc1`), the stores are drained (`s_waitcnt vmcnt(0)`) ahead of the block's relaxed agent-scope
-//     atomic add; readers poll with agent-scope loads and read h_{t-1} with `sc1` buffer loads.  (Release / acquire FENCES at
-//     agent scope cost a whole-L2 write-back / invalidate per wave and step — `buffer_wbl2` / `buffer_inv` — and made the
-//     first version slower than one launch per step: 30-34 us per step against 10, profiles/r02_lstm_layer_breakdown.json.)
+//   * hand-over of h_t inside a group (same direction, same clips; its H/16 blocks can sit on any XCD), round 3: THE DATA IS THE
+//     FLAG.  The entry point fills the layer output with a sentinel word (0xFFFFFFFF, a NaN no LSTM cell produces); producers
+//     store h_t write-through (`sc1`, relaxed agent-scope 4-byte stores) and move on; consumers read h_{t-1} with `sc1` buffer
+//     loads and simply re-read while any word of their share still holds the sentinel (one v_max_u32 chain + a wave vote per
+//     attempt).  No store drain, no arrival counter, no second poll: the serial path of a step is store -> L2 -> load.
+//     Round 2's protocol — drain the stores (`s_waitcnt vmcnt(0)`), block barrier, relaxed agent-scope atomic add on a per-group
+//     counter, poll it, then load — is kept as the LL = false instantiation for A/B in the tools build (emage_set_tuning key 3,
+//     bit 32).  (Release / acquire FENCES at agent scope cost a whole-L2 write-back / invalidate per wave and step —
+//     `buffer_wbl2` / `buffer_inv` — and made the very first version slower than one launch per step: 30-34 us per step against
+//     10, profiles/r02_lstm_layer_breakdown.json.)
 //     Blocks must be co-resident (one per CU: 128 KB of LDS), so
 //     a launch covers at most n_CU / (2 * H/16) slices of 64 clips; larger batches are walked in sequential launches.
-//     The polling loop is bounded: a block that waits longer than ~1 s raises the error word and every block leaves
+//     The waiting loop is bounded: a wave that waits longer than ~1 s raises the error word and every block leaves
 //     (the host checks the word) — a lost block can never hang the device.
 #include "common.h"
 #include <math.h>
@@ -40,6 +44,7 @@ struct SeqArgs {
 };
 
 constexpr unsigned SPIN_LIMIT = 1u << 20;
+constexpr unsigned H_SENTINEL = 0xFFFFFFFFu;           // "not written yet": what emage_lstm_layer fills the layer output with (memset 0xFF)
 constexpr int MAX_GROUPS = 16;                         // 2 directions x at most 8 slices of 64 clips per launch
 static_assert(EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH == 32 * (MAX_GROUPS + 1), "sync record layout");
 
@@ -53,7 +58,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int H, int HALVES>
+template <int H, int HALVES, bool LL>
 __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
     constexpr int KT = H / 32, WPG = H / 16;           // K-tiles; blocks per group
     constexpr unsigned PLANE = KT * 64 * 64;           // one fp16 plane of the 64 x H slice: [kt][row][4 chunks of 16 B]
@@ -97,6 +102,10 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
     };
     float4 rv[4];
     load_gx(0, rv);
+    if constexpr (LL) {
+        if (tid == 0) *s_flag = 0;
+        __syncthreads();
+    }
 
     for (int s = 0; s < p.T; ++s) {
         const int t = dir ? p.T - 1 - s : s;
@@ -109,6 +118,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
         for (int fb = 0; fb < 4; ++fb) acc[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         if (s > 0) {
+            if constexpr (!LL) {
             if (p.dbg & 8) {
                 __syncthreads();
             } else {
@@ -127,6 +137,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
             __syncthreads();
             if (*s_flag) return;
             }
+            }
 
             // stage h_{t-1}[b_base .. +64][dir * H .. +H] as split fp16 planes
             const int tp = dir ? t + 1 : t - 1;
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
             constexpr int KH = KT / HALVES;                 // K-tiles per staging phase
             auto kt_of = [&](int it) { return (it / KH) * KH + wave * (KH / 4) + ((it % KH) >> 2); };
             u32x4 c0[KT], c1[KT];
-            if (!(p.dbg & 4)) {
+            auto load_h = [&]() {
 #pragma unroll
                 for (int it = 0; it < KT; ++it) {
                     const int row = 16 * (it & 3) + st_row, kt = kt_of(it);
@@ -148,6 +159,38 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
                     c0[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 16));      // aux 16 = sc1: agent-coherent reads
                     c1[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 64, 0, 16));
                 }
+            };
+            if constexpr (LL) {
+                // the data is the flag: re-read this wave's share until no word of it holds the sentinel any more
+                unsigned spins = 0;
+                int bad = 0;
+                if (!(p.dbg & 4)) {
+                    for (;;) {
+                        load_h();
+                        unsigned mx = 0u;
+#pragma unroll
+                        for (int it = 0; it < KT; ++it) {
+                            const unsigned a = max(max(c0[it].x, c0[it].y), max(c0[it].z, c0[it].w));
+                            const unsigned b2 = max(max(c1[it].x, c1[it].y), max(c1[it].z, c1[it].w));
+                            mx = max(mx, max(a, b2));
+                        }
+                        if (__builtin_amdgcn_ballot_w64(mx == H_SENTINEL) == 0ull || (p.dbg & 8)) break;
+                        ++spins;
+                        if (spins > SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { bad = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (bad) {                                  // wave-uniform
+                    if (lane == 0) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *s_flag = 1;
+                    }
+                }
+                // every wave is past its LDS reads of the previous step (staging below overwrites them) and has voted
+                lds_barrier();
+                if (*s_flag) return;
+            } else {
+                if (!(p.dbg & 4)) load_h();
             }
             if (s + 1 < p.T) load_gx(s + 1, rvn);          // behind the h loads in the queue, lands during this step
 #pragma unroll
@@ -208,10 +251,12 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) rv[fb] = rvn[fb];
 
+        if constexpr (!LL) {
         if (s + 1 < p.T) {                              // publish h_t to the group
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's h stores have reached the agent coherence point
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         }
     }
 }
@@ -240,17 +285,17 @@ int max_slices_for(int H) {                            // co-resident blocks: on
     return m > MAX_GROUPS / 2 ? MAX_GROUPS / 2 : m;
 }
 
-template <int H, int HALVES>
+template <int H, int HALVES, bool LL>
 int launch_seq(SeqArgs a, int B, int max_slices, unsigned* sync, hipStream_t s) {
     constexpr int KT = H / 32, WPG = H / 16;
     constexpr size_t LDS = 2 * (size_t)KT * 64 * 64 + 128;
-    static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (configured != hipSuccess) return (int)configured;
     // the group barrier needs every block of a launch resident at once: one block per CU (LDS), so the occupancy query must admit >= 1
     // block per CU for this kernel's register / LDS footprint (a plain launch has the residency of a cooperative one, without its check)
     static const int blocks_per_cu = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)lstm_seq_kernel<H, HALVES>, 256, LDS) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)lstm_seq_kernel<H, HALVES, LL>, 256, LDS) != hipSuccess) return 0;
         return n;
     }();
     if (blocks_per_cu < 1 || 2 * max_slices * WPG > blocks_per_cu * device_cus()) return EMAGE_EINVAL;
@@ -264,7 +309,7 @@ int launch_seq(SeqArgs a, int B, int max_slices, unsigned* sync, hipStream_t s) 
         a.B = nb;
         a.slices = (nb + 63) / 64;
         a.sync = sync + chunk * EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH;
-        hipLaunchKernelGGL((lstm_seq_kernel<H, HALVES>), dim3(2 * a.slices * WPG), dim3(256), LDS, s, a);
+        hipLaunchKernelGGL((lstm_seq_kernel<H, HALVES, LL>), dim3(2 * a.slices * WPG), dim3(256), LDS, s, a);
         const int rc = launch_status();
         if (rc) return rc;
     }
@@ -312,6 +357,16 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(sync, 0, (size_t)need * sizeof(unsigned), s);
     if (e != hipSuccess) return (int)e;
+    const bool ll = !(emage_dev::g_lstm_layer_dbg & 32);
+    if (ll) {
+        // the hand-over protocol: every word of the layer output starts as the sentinel (0xFFFFFFFF), "not written yet"
+        if (ld_h_t == 2 * H && ld_h_b == (long)T * ld_h_t) e = hipMemsetAsync(hseq, 0xFF, (size_t)B * T * 2 * H * sizeof(float), s);
+        else if (ld_h_b == (long)T * ld_h_t) e = hipMemset2DAsync(hseq, (size_t)ld_h_t * sizeof(float), 0xFF, (size_t)2 * H * sizeof(float), (size_t)B * T, s);
+        else
+            for (int b = 0; b < B && e == hipSuccess; ++b)
+                e = hipMemset2DAsync(hseq + (long)b * ld_h_b, (size_t)ld_h_t * sizeof(float), 0xFF, (size_t)2 * H * sizeof(float), (size_t)T, s);
+        if (e != hipSuccess) return (int)e;
+    }
     SeqArgs a{};
     a.gx = gates_x; a.ld_gx_b = ld_gx_b; a.ld_gx_t = ld_gx_t;
     a.hseq = hseq; a.ld_h_b = ld_h_b; a.ld_h_t = ld_h_t;
@@ -320,6 +375,11 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
     a.a_scale = a_scale;
     a.T = T;
     a.dbg = emage_dev::g_lstm_layer_dbg;
-    if (a.dbg & 16) return H == 512 ? launch_seq<512, 2>(a, B, max_slices, sync, s) : launch_seq<256, 2>(a, B, max_slices, sync, s);   // A/B: two staging phases (measured equal)
-    return H == 512 ? launch_seq<512, 1>(a, B, max_slices, sync, s) : launch_seq<256, 1>(a, B, max_slices, sync, s);
+#ifdef EMAGE_TOOLS
+    if (!ll) {                                          // tools A/B: round 2's counter protocol (bit 16: two staging phases, measured equal)
+        if (a.dbg & 16) return H == 512 ? launch_seq<512, 2, false>(a, B, max_slices, sync, s) : launch_seq<256, 2, false>(a, B, max_slices, sync, s);
+        return H == 512 ? launch_seq<512, 1, false>(a, B, max_slices, sync, s) : launch_seq<256, 1, false>(a, B, max_slices, sync, s);
+    }
+#endif
+    return H == 512 ? launch_seq<512, 1, true>(a, B, max_slices, sync, s) : launch_seq<256, 1, true>(a, B, max_slices, sync, s);
 }

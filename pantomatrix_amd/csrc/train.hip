@@ -19,7 +19,42 @@ constexpr int STAT_ROWS = 4;          // row lanes per block: 4 x 64 columns = 2
 constexpr int STAT_CHUNK = 64;        // least rows per block (2048 left the small-M layers of a training step with ~24 blocks on 256 CUs: 130 us per
                                       // bias gradient, 17 % of the step — profiles/r03_train_kernel_stats_before.csv)
 
-// partial[(chunk * 2 + {0: sum, 1: sum of squares}) * C + c], deterministic: the finalize kernel adds the chunks in order
+// The finalize step of every chunked column reduction below: 16 columns x 16 lanes per block; lane l adds its contiguous range of
+// chunks in order, lane 0 then adds the 16 lane sums in order — deterministic for a given chunk count, and 16x shorter than one thread
+// walking all (up to 512) chunks of its column (which cost 20-80 us per call: 14 % of a training step,
+// profiles/r03_train_kernel_stats_final.csv).  partial[(chunk * NV + v) * C + c]; true for the thread that holds column c's totals.
+constexpr int FIN_COLS = 16, FIN_LANES = 16;
+template <int NV>
+__device__ __forceinline__ bool finalize_sums(const double* __restrict__ partial, int chunks, int C, double (&tot)[NV], int& c_out) {
+    __shared__ double red[NV][FIN_LANES][FIN_COLS];
+    const int cl = threadIdx.x % FIN_COLS, rl = threadIdx.x / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + cl;
+    const int per = (chunks + FIN_LANES - 1) / FIN_LANES;
+    const int i0 = rl * per, i1 = i0 + per < chunks ? i0 + per : chunks;
+    double s[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s[v] = 0.0;
+    if (c < C)
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s[v] += partial[((long)i * NV + v) * C + c];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[v][rl][cl] = s[v];
+    __syncthreads();
+    c_out = c;
+    if (rl != 0 || c >= C) return false;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double a = 0.0;
+        for (int l = 0; l < FIN_LANES; ++l) a += red[v][l][cl];
+        tot[v] = a;
+    }
+    return true;
+}
+static inline dim3 fin_grid(int C) { return dim3((C + FIN_COLS - 1) / FIN_COLS); }
+constexpr int FIN_THREADS = FIN_COLS * FIN_LANES;
+
+// partial[(chunk * 2 + {0: sum, 1: sum of squares}) * C + c], deterministic: the finalize kernel adds the chunks in a fixed order
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int ldx, int M, int C, double* __restrict__ partial, int chunk_rows) {
     __shared__ double red[2][STAT_ROWS][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -47,10 +82,10 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partial, int chunks, int M, int C,
                                                           float* __restrict__ mean, float* __restrict__ var,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int i = 0; i < chunks; ++i) { s += partial[((long)i * 2 + 0) * C + c]; ss += partial[((long)i * 2 + 1) * C + c]; }
+    double tot[2];
+    int c;
+    if (!finalize_sums<2>(partial, chunks, C, tot, c)) return;
+    const double s = tot[0], ss = tot[1];
     const double mu = s / M;
     double vb = ss / M - mu * mu;
     if (vb < 0.0) vb = 0.0;
@@ -178,7 +213,7 @@ extern "C" int emage_bn_stats(const float* x, int ldx, int M, int C, void* works
     hipLaunchKernelGGL(bn_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, M, C, (double*)workspace, chunk_rows);
     int rc = launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, M, C, mean, var, running_mean, running_var, momentum);
+    hipLaunchKernelGGL(bn_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, M, C, mean, var, running_mean, running_var, momentum);
     return launch_status();
 }
 
@@ -266,10 +301,10 @@ __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void col_sum_finalize_kernel(const double* __restrict__ partial, int chunks, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int i = 0; i < chunks; ++i) s += partial[(long)i * C + c];
+    double tot[1];
+    int c;
+    if (!finalize_sums<1>(partial, chunks, C, tot, c)) return;
+    const double s = tot[0];
     out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
@@ -535,7 +570,7 @@ extern "C" int emage_col_sum(const float* x, int ldx, const float* y, int ldy, i
     hipLaunchKernelGGL(col_sum_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, y, ldy, M, C, (double*)workspace, chunk_rows);
     int rc = launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C, out, accumulate);
+    hipLaunchKernelGGL(col_sum_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, C, out, accumulate);
     return launch_status();
 }
 
@@ -716,12 +751,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int chunks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int i = 0; i < chunks; ++i) { s += partial[((long)i * 2 + 0) * C + c]; sx += partial[((long)i * 2 + 1) * C + c]; }
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)sx;
+    double tot[2];
+    int c;
+    if (!finalize_sums<2>(partial, chunks, C, tot, c)) return;
+    dbeta[c] = (float)tot[0];
+    dgamma[c] = (float)tot[1];
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mean, const float* __restrict__ var, float eps,
@@ -801,7 +835,7 @@ extern "C" int emage_bn_backward(const float* x, int ldx, const float* mean, con
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, mean, var, eps, dy, ld_dy, M, C, (double*)workspace, chunk_rows);
     int rc = launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, C, dgamma, dbeta);
     rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long)M * C)), dim3(256), 0, s, x, ldx, mean, var, eps, gamma, dy, ld_dy, dgamma, dbeta, dx, ld_dx, M, C);
@@ -838,7 +872,7 @@ extern "C" int emage_bn_backward_sums(const float* x, int ldx, const float* mean
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, mean, var, eps, dy, ld_dy, M, C, (double*)workspace, chunk_rows);
     const int rc = launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)workspace, chunks, C, sum_dy_xhat, sum_dy);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, C, sum_dy_xhat, sum_dy);
     return launch_status();
 }
 

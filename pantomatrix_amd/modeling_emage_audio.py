@@ -573,6 +573,10 @@ class EmageVQModel(torch.nn.Module):
             m.set_precision(precision)
         return self
 
+    @property
+    def precision(self):
+        return self.vq_model_face.precision
+
     def spilt_inputs(self, smplx_body_rot6d, expression, tar_contact=None, tar_trans=None):     # (sic) M:97-108
         bs, t, j6 = smplx_body_rot6d.shape
         r = smplx_body_rot6d.reshape(bs, t, j6 // 6, 6)

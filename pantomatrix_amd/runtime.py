@@ -21,11 +21,18 @@ from . import ops
 
 class ClipRunner:
     def __init__(self, model, vq_model, batch: int, n_samples: int, use_graph: bool = True, warmup: int = 2,
-                 sub_batches: int = 1, main_priority: bool = False):
+                 sub_batches: int = 1, main_priority: bool = False, on_overflow: str = "raise"):
         """main_priority (experiment): capture on a HIGH-priority stream, so the launch chain issued on lane 0 (the critical
         path: motion encoder -> body stack -> decode) outranks the side lanes (face decoder, WavEncoders) when both have
-        ready kernels — if the runtime's graph kernel nodes inherit the capturing stream's priority."""
+        ready kernels — if the runtime's graph kernel nodes inherit the capturing stream's priority.
+        on_overflow: what `__call__` does with a batch whose health counter is non-zero (in f16x3: an activation beyond the split-fp16
+        range) — "raise" (FloatingPointError) or "fp32": run THAT batch again through an exact-fp32 twin of this runner (built on
+        first use: +26 ms per affected batch instead of an error; `fallbacks` counts them); a batch that is non-finite in fp32 too raises."""
+        if on_overflow not in ("raise", "fp32"):
+            raise ValueError("on_overflow must be 'raise' or 'fp32'")
         self.model, self.vq = model, vq_model
+        self.on_overflow, self.fallbacks, self._fp32_twin = on_overflow, 0, None
+        self._args = dict(batch=batch, n_samples=n_samples, use_graph=use_graph, warmup=warmup)
         dev = model.device
         if dev.type != "cuda":
             raise RuntimeError("ClipRunner needs the models on an MI355X device")
@@ -56,6 +63,9 @@ class ClipRunner:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local", **kw):   # other threads (an RCCL watchdog) may touch the runtime meanwhile
                 out = self._step()
         self.out = out
+        # the captured launches read the packed operand sets built by the warm-up: keep them alive for the life of the graph even if
+        # the models are re-packed later (set_precision / load_state_dict / a training step)
+        self._operands = (model._packed, [m._packed for m in vq_model._models()])
         self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)
         self.frames_out = int(out[0].shape[1])
         self._checked_replays = 0
@@ -100,6 +110,8 @@ class ClipRunner:
             self._to_host(self.host)
             self.nonfinite_host.copy_(self.nonfinite, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
+            if int(self.nonfinite_host[0]) and self.on_overflow == "fp32" and self.model.precision != "fp32":
+                return self._run_in_fp32()
             self._raise_if_nonfinite()
             return tuple(h.numpy() for h in self.host)
         main = torch.cuda.current_stream(self.device)
@@ -118,6 +130,21 @@ class ClipRunner:
         for child in self.children:
             child._raise_if_nonfinite()
         return tuple(h.numpy() for h in self.host)
+
+    def _run_in_fp32(self):
+        """The batch in `self.audio` / `self.speaker_id` again through an exact-fp32 twin runner (same weights; its own packed operands and
+        graph, built at the first overflow); the models' precision setting is restored afterwards."""
+        self.fallbacks += 1
+        if self._fp32_twin is None:
+            was = (self.model.precision, self.vq.precision)
+            self.model.set_precision("fp32")
+            self.vq.set_precision("fp32")
+            try:
+                self._fp32_twin = ClipRunner(self.model, self.vq, on_overflow="raise", **self._args)
+            finally:
+                self.model.set_precision(was[0])
+                self.vq.set_precision(was[1])
+        return self._fp32_twin(self.audio, self.speaker_id)
 
     def _raise_if_nonfinite(self):
         n = int(self.nonfinite_host[0])
@@ -198,6 +225,7 @@ class LstmClipRunner:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 out = self._step()
         self.out = out
+        self._operands = model._packed               # what the captured launches read: alive as long as the graph is
         self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)
         self.frames_out = int(out[0].shape[1])
         self._checked_replays = 0

@@ -219,9 +219,18 @@ def test_clip_runner_raises_on_overflow_of_the_split_fp16_range():
     model.load_state_dict(sd)
     with pytest.raises(FloatingPointError, match="non-finite"):
         ClipRunner(model, vq, 2, n, use_graph=True)(a)
+    # on_overflow="fp32": the affected batch is re-run through an exact-fp32 twin of the runner instead of raising, the models stay f16x3
+    auto = ClipRunner(model, vq, 2, n, use_graph=True, on_overflow="fp32")
+    got = [x.copy() for x in auto(a)]
+    assert auto.fallbacks == 1 and model.precision == "f16x3" and vq.precision == "f16x3"
     model.set_precision("fp32")
-    poses, _, _ = ClipRunner(model, vq, 2, n, use_graph=False)(a)
-    assert np.isfinite(poses).all()
+    vq.set_precision("fp32")
+    want = ClipRunner(model, vq, 2, n, use_graph=False)(a)
+    assert np.isfinite(want[0]).all()
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    got2 = auto(a)                                                          # the captured f16x3 graph survived the re-packing of the models
+    assert auto.fallbacks == 2 and np.array_equal(got2[0], want[0])
 
 
 def test_clip_runner_sub_batches_match():

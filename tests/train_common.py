@@ -93,3 +93,79 @@ def shard_masks(masks, lo, hi, batch):
         else:
             out.append(m[:, lo:hi].contiguous())
     return out
+
+
+def wav_encoder_backward_check(model, dev, enc="audio_encoder_body", batch=2):
+    """The train-mode WavEncoder of `model` (fp32 precision) forward + backward on `dev` against float64 autograd of the oracle's
+    encoder (P:263-314 with batch-statistics BatchNorm).  A LeakyReLU pre-activation within fp32 rounding of 0 takes the other
+    slope in two fp32 implementations that round differently, which changes every gradient upstream of it by a visible amount; so the
+    comparison walks back from the output: as long as NO activation of the blocks seen so far changed sign against the float64 run,
+    the gradient arriving at the block output AND the block's parameter gradients must agree to fp32 accuracy; behind the first flip
+    only the norms are compared.  Returns counts for the caller's assertions."""
+    import torch.nn.functional as Fn
+    from oracle import emage_oracle as orc
+    from pantomatrix_amd import training
+    from pantomatrix_amd.modeling_emage_audio import _Ctx
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in synthetic.audio_model_state(EmageAudioConfig(**common.cfg_dicts()[0]), 0).items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if k.startswith(enc + ".") and v.is_floating_point() and "running_" not in k}
+    audio = common.window_inputs(batch)[0]
+    h, outs, ns = audio.double().unsqueeze(1), [], {}
+    for i, (stride, pad, has_ds) in enumerate(orc.WAV_BLOCKS):
+        b = f"{enc}.feat_extractor.{i}"
+        y = Fn.conv1d(h, sd[b + ".conv1.weight"], sd[b + ".conv1.bias"], stride=stride, padding=pad)
+        y = Fn.leaky_relu(tro._bn_train(sd, b + ".bn1", y, ns), 0.01)
+        y = tro._bn_train(sd, b + ".bn2", Fn.conv1d(y, sd[b + ".conv2.weight"], sd[b + ".conv2.bias"], stride=1, padding=7), ns)
+        if has_ds:
+            h = tro._bn_train(sd, b + ".downsample.1", Fn.conv1d(h, sd[b + ".downsample.0.weight"], sd[b + ".downsample.0.bias"], stride=stride, padding=pad), ns)
+        h = Fn.leaky_relu(y + h, 0.01)
+        h.retain_grad()
+        outs.append(h)
+    up = torch.randn(h.transpose(1, 2).shape, generator=torch.Generator().manual_seed(1))
+    (h.transpose(1, 2) * up.double()).sum().backward()
+
+    fwd = training.TrainForward(model)
+    seen, flips = {}, {}
+    orig = fwd._wav_block_backward
+
+    def spy(cx, sv):
+        seen[sv["i"]] = fwd.tape.get(sv["out"]).clone()
+        ref_out = outs[sv["i"]].detach().permute(0, 2, 1).reshape(sv["out"].shape).to(sv["out"].device)
+        flips[sv["i"]] = int(((sv["out"] > 0) != (ref_out > 0)).sum())
+        return orig(cx, sv)
+
+    fwd._wav_block_backward = spy
+    with torch.no_grad():
+        cx = _Ctx(model._engine(h2=False))
+        fwd._train_pack(cx.pk)
+        fwd.tape, fwd.param_grads = training._Tape(cx.dev), {}
+        x, _ = fwd._wav_encoder(cx, enc, 1, audio.to(dev), batch, {})
+        fwd.tape.add(x, up.reshape(x.shape).to(dev))
+        fwd.tape.run()
+    grads = {k: v.detach().cpu() for k, v in fwd.param_grads.items()}
+    n_blocks = len(orc.WAV_BLOCKS)
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values())
+    clean, clean_blocks, params_checked, worst = True, 0, 0, 0.0
+    for i in reversed(range(n_blocks)):               # walking back from the output
+        ref = outs[i].grad.permute(0, 2, 1).reshape(seen[i].shape)
+        got = seen[i].double().cpu()
+        rel = float((got - ref).abs().max() / ref.abs().max())
+        if clean:
+            assert rel < 2e-5, (i, rel)
+        else:
+            assert float((got - ref).norm() / ref.norm()) < 5e-2, i
+        clean = clean and flips[i] == 0
+        if clean:                                     # no flip in this block or behind it: its parameter gradients are pinned, too
+            clean_blocks += 1
+            for k, leaf in leaves.items():
+                if not k.startswith(f"{enc}.feat_extractor.{i}."):
+                    continue
+                g = grads[k].double().reshape(leaf.grad.shape)
+                # a conv bias in front of a train-mode BatchNorm has an exactly-zero gradient: fp32 noise there is judged against the
+                # largest gradient of the encoder
+                err = float((g - leaf.grad).abs().max())
+                scale = float(leaf.grad.abs().max())
+                assert err <= 2e-4 * scale + 2e-6 * gmax, (k, err, scale, gmax)
+                worst = max(worst, err / (scale + 1e-2 * gmax))
+                params_checked += 1
+    assert sum(flips.values()) <= 8, flips
+    return dict(flips=dict(flips), clean_blocks=clean_blocks, params_checked=params_checked, worst_param_rel=worst)
