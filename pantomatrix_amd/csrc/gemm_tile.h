@@ -32,7 +32,19 @@ struct GemmArgs {
 // projection x_t W_ih^T + b_ih + b_hh in the same layout, and the epilogue applies the LSTM cell (torch.nn.LSTM:
 // c' = sigmoid(f) c + sigmoid(i) tanh(g), h' = sigmoid(o) tanh(c')) — c' to cstate[m][u], h' to out_f32[m][u].
 constexpr int EPI_LINEAR = 0, EPI_LSTM = 1;
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The cell's non-linearities.  FAST = false (exact-fp32 mode): libm-grade expf / tanhf and IEEE divisions.  FAST = true (split-f16
+// mode): hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32, 1 ulp each; saturate correctly at +-inf).  The cell sits on the SERIAL
+// path of the persistent recurrence (lstmseq.hip): libm's tanhf + three IEEE divisions per (clip, unit) were ~2.8 us of a 9 us
+// time step (the "cell + h store only" ablation, profiles/r03_lstm_layer_breakdown.json).  Absolute error ~1e-7 per gate; the step
+// kernels and the persistent kernel share these functions, so they stay bit-identical to each other.
+template <bool FAST> __device__ __forceinline__ float lstm_sigmoid(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    else return 1.0f / (1.0f + expf(-x));
+}
+template <bool FAST> __device__ __forceinline__ float lstm_tanh(float x) {
+    if constexpr (FAST) return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+    else return tanhf(x);
+}
 
 constexpr int NTHREADS = 256;
 constexpr int KCH = 8;   // 16-byte chunks per K-tile row
@@ -506,11 +518,11 @@ __device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& p, const int m0, 
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const f32x4 a4 = acc[i][2 * jp + u];
-                            const float gi = sigmoid_f(a4[0] + rv[4 * u + 0]), gf = sigmoid_f(a4[1] + rv[4 * u + 1]);
-                            const float gg = tanhf(a4[2] + rv[4 * u + 2]), go = sigmoid_f(a4[3] + rv[4 * u + 3]);
+                            const float gi = lstm_sigmoid<X3>(a4[0] + rv[4 * u + 0]), gf = lstm_sigmoid<X3>(a4[1] + rv[4 * u + 1]);
+                            const float gg = lstm_tanh<X3>(a4[2] + rv[4 * u + 2]), go = lstm_sigmoid<X3>(a4[3] + rv[4 * u + 3]);
                             const float cn = gf * (u == 0 ? cs.x : cs.y) + gi * gg;
                             (u == 0 ? cs.x : cs.y) = cn;
-                            hv[u] = go * tanhf(cn);
+                            hv[u] = go * lstm_tanh<X3>(cn);
                         }
                         *(float2*)(p.cstate + (long)m * p.ldc + (n >> 2)) = cs;
                         *(float2*)(p.out_f32 + (long)m * p.ldf + (n >> 2)) = make_float2(hv[0], hv[1]);

@@ -40,7 +40,7 @@ struct SeqArgs {
     unsigned* sync;                                    // this launch's record: arrival counter of group g at word 32 g (one 128-B line each), error word at 32 * 16
     int B, T, slices;
     int dbg;                                           // emage_set_tuning key 3 (tools): timing-only
-                                                       // ablations (wrong results): 2 = no MFMA phase, 4 = no h load / staging, 8 = no group barrier; 16 = two staging phases instead of one (same bits)
+                                                       // ablations (wrong results): 2 = no MFMA phase, 4 = no h load / staging, 8 = no waiting for the group; same bits: 16 = two staging phases (counter protocol only), 32 = round 2's counter protocol, 64 = s_sleep 1 between re-reads
 };
 
 constexpr unsigned SPIN_LIMIT = 1u << 20;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
                         if (__builtin_amdgcn_ballot_w64(mx == H_SENTINEL) == 0ull || (p.dbg & 8)) break;
                         ++spins;
                         if (spins > SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { bad = 1; break; }
-                        __builtin_amdgcn_s_sleep(1);
+                        if (p.dbg & 64) __builtin_amdgcn_s_sleep(1);          // re-read immediately (measured: 8.5 vs 8.9 us per step); tools A/B, bit 64: sleep 64 clocks first
                     }
                 }
                 if (bad) {                                  // wave-uniform
@@ -238,13 +238,13 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
             const int b = b_base + fb * 16 + fr;
-            const float gi = sigmoid_f(acc[fb][0] + rv[fb].x), gf = sigmoid_f(acc[fb][1] + rv[fb].y);
-            const float gg = tanhf(acc[fb][2] + rv[fb].z), go = sigmoid_f(acc[fb][3] + rv[fb].w);
+            const float gi = lstm_sigmoid<true>(acc[fb][0] + rv[fb].x), gf = lstm_sigmoid<true>(acc[fb][1] + rv[fb].y);
+            const float gg = lstm_tanh<true>(acc[fb][2] + rv[fb].z), go = lstm_sigmoid<true>(acc[fb][3] + rv[fb].w);
             const float cn = gf * c[fb] + gi * gg;
             c[fb] = cn;
             if (b < p.B) {
                 float* dst = p.hseq + (long)b * p.ld_h_b + (long)t * p.ld_h_t + dir * H + unit;
-                __hip_atomic_store(dst, go * tanhf(cn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
+                __hip_atomic_store(dst, go * lstm_tanh<true>(cn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
             }
         }
 

@@ -32,6 +32,7 @@ class ClipRunner:
             raise ValueError("on_overflow must be 'raise' or 'fp32'")
         self.model, self.vq = model, vq_model
         self.on_overflow, self.fallbacks, self._fp32_twin = on_overflow, 0, None
+        self.precision = model.precision             # what THIS runner's launches compute in (the models may be re-packed later)
         self._args = dict(batch=batch, n_samples=n_samples, use_graph=use_graph, warmup=warmup)
         dev = model.device
         if dev.type != "cuda":
@@ -65,7 +66,7 @@ class ClipRunner:
         self.out = out
         # the captured launches read the packed operand sets built by the warm-up: keep them alive for the life of the graph even if
         # the models are re-packed later (set_precision / load_state_dict / a training step)
-        self._operands = (model._packed, [m._packed for m in vq_model._models()])
+        self._operands = (model._packed, [m._packed for m in vq_model._models()], dict(model._templates), dict(vq_model._templates))
         self.host = tuple(torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in out)
         self.frames_out = int(out[0].shape[1])
         self._checked_replays = 0
@@ -110,7 +111,7 @@ class ClipRunner:
             self._to_host(self.host)
             self.nonfinite_host.copy_(self.nonfinite, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
-            if int(self.nonfinite_host[0]) and self.on_overflow == "fp32" and self.model.precision != "fp32":
+            if int(self.nonfinite_host[0]) and self.on_overflow == "fp32" and self.precision != "fp32":
                 return self._run_in_fp32()
             self._raise_if_nonfinite()
             return tuple(h.numpy() for h in self.host)
@@ -149,7 +150,7 @@ class ClipRunner:
     def _raise_if_nonfinite(self):
         n = int(self.nonfinite_host[0])
         if n:
-            raise FloatingPointError(f"{n} non-finite values among the network outputs / the generated motion (precision {self.model.precision!r}): in f16x3 an activation beyond "
+            raise FloatingPointError(f"{n} non-finite values among the network outputs / the generated motion (precision {self.precision!r}): in f16x3 an activation beyond "
                                      "|x| < 4094 overflows the fp16 planes — run this checkpoint with set_precision('fp32')")
 
 

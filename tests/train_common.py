@@ -144,7 +144,7 @@ def wav_encoder_backward_check(model, dev, enc="audio_encoder_body", batch=2):
     grads = {k: v.detach().cpu() for k, v in fwd.param_grads.items()}
     n_blocks = len(orc.WAV_BLOCKS)
     gmax = max(float(v.grad.abs().max()) for v in leaves.values())
-    clean, clean_blocks, params_checked, worst = True, 0, 0, 0.0
+    clean, clean_blocks, params_checked, worst, bad = True, 0, 0, 0.0, []
     for i in reversed(range(n_blocks)):               # walking back from the output
         ref = outs[i].grad.permute(0, 2, 1).reshape(seen[i].shape)
         got = seen[i].double().cpu()
@@ -164,8 +164,11 @@ def wav_encoder_backward_check(model, dev, enc="audio_encoder_body", batch=2):
                 # largest gradient of the encoder
                 err = float((g - leaf.grad).abs().max())
                 scale = float(leaf.grad.abs().max())
-                assert err <= 2e-4 * scale + 2e-6 * gmax, (k, err, scale, gmax)
+                shadowed = scale < 1e-5 * gmax        # true gradient zero: what is left is the rounding noise of a sum over all positions
+                if err > 2e-4 * scale + (2e-5 if shadowed else 5e-6) * gmax:
+                    bad.append((k, err, scale))
                 worst = max(worst, err / (scale + 1e-2 * gmax))
                 params_checked += 1
+    assert not bad, (bad, gmax)
     assert sum(flips.values()) <= 8, flips
     return dict(flips=dict(flips), clean_blocks=clean_blocks, params_checked=params_checked, worst_param_rel=worst)

@@ -70,9 +70,9 @@ def main():
             from pantomatrix_amd import _lib
             lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
             names = {0: "shipped (data-as-flag hand-over)", 32: "round 2's arrival-counter protocol", 2: "no MFMA phase", 4: "no h load / staging",
-                     8: "no wait for the group (one read)", 14: "skeleton: cell + h store only"}
+                     8: "no wait for the group (one read)", 14: "skeleton: cell + h store only", 64: "shipped + s_sleep 1 between re-reads"}
             line["lstm_layer_us_per_step"] = {}
-            for dbg in (0, 32, 2, 4, 8, 14):
+            for dbg in (0, 32, 64, 2, 4, 8, 14):
                 lib.emage_set_tuning(3, dbg)
                 ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
                 torch.cuda.synchronize()
