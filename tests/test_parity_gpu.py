@@ -152,7 +152,7 @@ def test_clip_bf16_agreement(bf16_models, golden_dir):
     assert poses.shape == g["poses"].shape and np.isfinite(poses).all() and np.isfinite(trans).all()
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["f16x3"])
 def test_full_size_batch_properties(precision, golden_dir):
     """BASELINE config 2 size (B=64 x 128-frame clips): each clip's result must not depend on its batch-mates
     (clips 0,1 equal the B=2 run bit-for-bit: same kernels, same per-row arithmetic) and must be deterministic."""
