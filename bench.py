@@ -540,6 +540,7 @@ def main():
     ap.add_argument("--no-split-acts", action="store_true", help="A/B: float32 activations split inside every GEMM (EMAGE_F16X3) instead of pre-split EMAGE_H2 storage")
     ap.add_argument("--pipeline", type=int, default=1, help="also time the step with this many batches in flight (runtime.ClipPipeline)")
     ap.add_argument("--h2-residual", action="store_true", help="A/B: EMAGE_H2 residual stream read from the H2 images (no float32 twins)")
+    ap.add_argument("--attn-variant", type=int, default=0, help="experiments: emage_set_tuning key 6 (1 = split-f16 attention without the LDS-staged K / V^T)")
     ap.add_argument("--h2-variant", type=int, default=0, help="experiments: emage_set_tuning key 5 (EMAGE_H2 tile-heuristic variant)")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
@@ -565,11 +566,12 @@ def main():
     from pantomatrix_amd import dist as pdist
     from pantomatrix_amd import synthetic
 
-    if args.gemm_dbg or args.gemm_variant >= 0 or args.h2_variant:
+    if args.gemm_dbg or args.gemm_variant >= 0 or args.h2_variant or args.attn_variant:
         from pantomatrix_amd import _lib
         _lib.use_tools(True)         # experiments only: the tuning hooks live in the tools build of the library
         _lib.load().emage_set_tuning(1, args.gemm_dbg)
         _lib.load().emage_set_tuning(5, args.h2_variant)
+        _lib.load().emage_set_tuning(6, args.attn_variant)
         if args.gemm_variant >= 0:
             _lib.load().emage_set_tuning(2, args.gemm_variant)
     log(f"rank {rank}/{world}: building the {args.precision} models on {dev} and capturing the clip graph")

@@ -12,6 +12,14 @@
 #include <math.h>
 #include "attn_tile.h"
 
+namespace emage_dev {
+#ifdef EMAGE_TOOLS
+int g_attn_variant = 0;            // tools build: emage_set_tuning key 6; 1 = the register path (every wave fetches K / V^T itself) for A/B
+#else
+constexpr int g_attn_variant = 0;
+#endif
+}
+
 namespace {
 
 using namespace emage_dev;
@@ -29,11 +37,38 @@ __global__ __launch_bounds__(64 * QW * DS, 1) void attn_kernel(AttnArgs p) {
     attn_tile<T, HD, NT, DS, X3, H2OUT>(p, b, h, qt, wave % DS);
 }
 
+// Split-f16 form, Tk <= 64: K and V^T of the workgroup's (batch, head) are staged once in LDS as split fp16 planes (attn_tile.h,
+// attn_stage_kv); the four query-tile waves then run attn_tile on LDS fragments.  Bit-identical to attn_kernel<float, ..., true, ...>.
+template <int HD, int NT, bool H2OUT>
+__global__ __launch_bounds__(64 * QW, 1) void attn_x3_lds_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int qtiles = (p.Tq + 15) >> 4;
+    const int qgroups = (qtiles + QW - 1) / QW;
+    int bid = blockIdx.x;
+    const int wave = (int)(threadIdx.x >> 6);
+    const int qt = (bid % qgroups) * QW + wave; bid /= qgroups;
+    const int h = bid % p.H;
+    const int b = bid / p.H;
+    attn_tile<float, HD, NT, 1, true, H2OUT, true>(p, b, h, qt, 0, smem);     // stages K / V^T with all four waves, then leaves if qt >= qtiles
+}
+
+template <int NT, bool H2OUT>
+int launch_x3_lds(AttnArgs& a, int grid, hipStream_t s) {
+    constexpr int LDS = AttnLds<192, NT>::BYTES;
+    static const hipError_t configured = hipFuncSetAttribute((const void*)attn_x3_lds_kernel<192, NT, H2OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (configured != hipSuccess) return (int)configured;
+    hipLaunchKernelGGL((attn_x3_lds_kernel<192, NT, H2OUT>), dim3(grid), dim3(64 * QW), LDS, s, a);
+    return launch_status();
+}
+
 template <typename T, bool X3, bool H2OUT = false>
 int dispatch(AttnArgs& a, int hd, hipStream_t s) {
     if (hd != 192) return EMAGE_EINVAL;
     const int qtiles = (a.Tq + 15) / 16;
     const int grid = a.B * a.H * ((qtiles + QW - 1) / QW);
+    if constexpr (X3 && DS == 1) {
+        if (a.Tk <= 64 && !(emage_dev::g_attn_variant & 1)) return a.Tk <= 32 ? launch_x3_lds<2, H2OUT>(a, grid, s) : launch_x3_lds<4, H2OUT>(a, grid, s);
+    }
     if (a.Tk <= 32) hipLaunchKernelGGL((attn_kernel<T, 192, 2, X3, H2OUT>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
     else if (a.Tk <= 64) hipLaunchKernelGGL((attn_kernel<T, 192, 4, X3, H2OUT>), dim3(grid), dim3(64 * QW * DS), 0, s, a);
     else hipLaunchKernelGGL((attn_kernel<T, 192, 8, X3, H2OUT>), dim3(grid), dim3(64 * QW * DS), 0, s, a);

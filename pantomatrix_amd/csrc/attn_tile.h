@@ -66,8 +66,88 @@ constexpr int DS = 1;    // waves per query tile: with DS = 2 each wave recomput
 // softmax(Q K^T * scale) V for query tile qt (16 queries) of (batch b, head h); one wave64 (wave `dpart` of the DSP that share that tile: each recomputes the scores and owns NDT / DSP of the output d tiles).
 // H2OUT (split-f16 form only): the output is written as an EMAGE_H2 image (csrc/h2.h) — V^T rows are fetched in a permuted order
 // so that a lane ends with 8 consecutive d of its query from each PAIR of d tiles (one 32-byte group).
-template <typename T, int HD, int NT, int DSP = DS, bool X3 = false, bool H2OUT = false>
-__device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const int h, const int qt, const int dpart) {
+// ---- K / V^T of one (batch, head) staged ONCE per workgroup in LDS as split fp16 planes (split-f16 form, Tk <= 64) ---------------
+// Without it each of the 4 query-tile waves of a (batch, head) fetched all of K and V^T itself (4 x 96 KB through the CU's
+// texture path) and split every chunk on its own VALU.  Staged layout = the MFMA operand order: one 32-byte cell [8 fp16 hi | 8 fp16
+// lo] per (row, 32-wide contraction step, lane group fg) holding the 8 values lane (row, fg) feeds one MFMA with — columns
+// {32 s + 4 fg + r} U {32 s + 16 + 4 fg + r} — so a fragment is two ds_read_b128 and the arithmetic (operands, order of the three
+// MFMAs, order over the contraction) is EXACTLY that of the register path: results are bit-identical.  Rows are padded by 16 bytes:
+// the 16 rows a quarter-wave reads land in 16 different 16-byte bank groups.
+template <int HD, int NT> struct AttnLds {
+    static constexpr int KS = HD / 32;                    // contraction steps of Q K^T
+    static constexpr int KROW = KS * 4 * 32 + 16;         // bytes per staged key row
+    static constexpr int NKEY = NT * 16;
+    static constexpr int VS = NT / 2;                     // contraction steps of P V (32 keys each)
+    static constexpr int VROW = VS * 4 * 32 + 16;         // bytes per staged V^T row (one d)
+    static constexpr int K_BYTES = NKEY * KROW, V_BYTES = HD * VROW, BYTES = K_BYTES + V_BYTES;
+};
+
+// all 256 threads of the workgroup; H2OUT selects the permuted d order of attn_tile's V^T rows.  Every global load of the thread is
+// issued before the first split (compile-time trip counts, fully unrolled): one memory latency per workgroup, not one per cell.
+template <int HD, int NT, bool H2OUT>
+__device__ __forceinline__ void attn_stage_kv(const AttnArgs& p, const int b, const int h, unsigned char* smem) {
+    using L = AttnLds<HD, NT>;
+    constexpr int NTHR = 64 * QW;
+    constexpr int KU = L::NKEY * L::KS * 4 / NTHR, VU = HD * L::VS * 4 / NTHR;      // cells per thread
+    static_assert(L::NKEY * L::KS * 4 % NTHR == 0 && HD * L::VS * 4 % NTHR == 0, "cells divide evenly over the workgroup");
+    const float* __restrict__ K = (const float*)p.k;
+    const float* __restrict__ V = (const float*)p.vt;
+    const int tid = threadIdx.x;
+    uint4 k0[KU], k1[KU], v0[VU], v1[VU];
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+        const int u = i * NTHR + tid;
+        const int key = u / (L::KS * 4), cell = u - key * (L::KS * 4), s = cell >> 2, fg = cell & 3;
+        const int krow = min(key, p.Tk - 1);
+        const float* src = K + ((long)b * p.Tk + krow) * p.ldk + h * HD + 32 * s + 4 * fg;
+        k0[i] = *(const uint4*)src;
+        k1[i] = *(const uint4*)(src + 16);
+    }
+#pragma unroll
+    for (int i = 0; i < VU; ++i) {
+        const int u = i * NTHR + tid;
+        const int j = u / (L::VS * 4), cell = u - j * (L::VS * 4), c = cell >> 2, fg = cell & 3;
+        const int dt = j >> 4, fr = j & 15;               // staged row j = operand row fr of d tile dt
+        const int drow = H2OUT ? 32 * (dt >> 1) + 4 * (dt & 1) + 8 * (fr >> 2) + (fr & 3) : j;
+        const float* src = V + ((long)b * p.vt_rows + h * HD + drow) * p.ldvt + 32 * c + 4 * fg;
+        v0[i] = *(const uint4*)src;
+        v1[i] = *(const uint4*)(src + 16);
+    }
+    // keep EVERY load above the first split: the splits are pure arithmetic the instruction selector would otherwise hoist between the
+    // loads (each with its s_waitcnt: ~6 loads in flight instead of all of them); the empty asm statements pin the loaded registers
+    // behind the scheduling barrier
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+        asm volatile("" : "+v"(k0[i].x), "+v"(k0[i].y), "+v"(k0[i].z), "+v"(k0[i].w), "+v"(k1[i].x), "+v"(k1[i].y), "+v"(k1[i].z), "+v"(k1[i].w));
+    }
+#pragma unroll
+    for (int i = 0; i < VU; ++i) {
+        asm volatile("" : "+v"(v0[i].x), "+v"(v0[i].y), "+v"(v0[i].z), "+v"(v0[i].w), "+v"(v1[i].x), "+v"(v1[i].y), "+v"(v1[i].z), "+v"(v1[i].w));
+    }
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+        const int u = i * NTHR + tid;
+        const int key = u / (L::KS * 4), cell = u - key * (L::KS * 4);
+        const SplitF16 f = split_chunks(k0[i], k1[i], ATT_QKV_SCALE);
+        unsigned char* dst = smem + key * L::KROW + cell * 32;
+        *(h16x8*)dst = f.hi;
+        *(h16x8*)(dst + 16) = f.lo;
+    }
+#pragma unroll
+    for (int i = 0; i < VU; ++i) {
+        const int u = i * NTHR + tid;
+        const int j = u / (L::VS * 4), cell = u - j * (L::VS * 4);
+        const SplitF16 f = split_chunks(v0[i], v1[i], ATT_QKV_SCALE);
+        unsigned char* dst = smem + L::K_BYTES + j * L::VROW + cell * 32;
+        *(h16x8*)dst = f.hi;
+        *(h16x8*)(dst + 16) = f.lo;
+    }
+}
+
+template <typename T, int HD, int NT, int DSP = DS, bool X3 = false, bool H2OUT = false, bool LDSKV = false>
+__device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const int h, const int qt, const int dpart, unsigned char* smem = nullptr) {
+    static_assert(!LDSKV || (X3 && DSP == 1 && NT <= 4 && NT % 2 == 0), "staged K / V^T: split-f16 form, Tk <= 64");
     constexpr int EPC = Elem<T>::EPC;
     static_assert(!X3 || (EPC == 4 && NT % 2 == 0), "split-f16 attention: fp32 operands, key tiles pair up");
     constexpr int ES = 16 / EPC;
@@ -91,12 +171,27 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
     uint4 qf[NSTEP];
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) qf[s] = bload128(rq, qoff, s * 64);
+    if constexpr (LDSKV) {
+        // the workgroup's K / V^T go to LDS behind this wave's Q loads (already in flight); EVERY wave of the workgroup takes part,
+        // also one whose query tile lies past Tq (it leaves behind the barrier)
+        attn_stage_kv<HD, NT, H2OUT>(p, b, h, smem);
+        __syncthreads();
+        if (q0 >= p.Tq) return;
+    }
 
     // Tk <= 64 (every inference window): everything in flight at once — when it fits the 256 registers a wave gets with
     // two waves per SIMD (fp32 operands are twice as wide: only up to Tk <= 32)
-    constexpr bool PRE = NT <= 4 && (DSP == 1 || EPC == 8 || NT <= 2);
+    constexpr bool PRE = !LDSKV && NT <= 4 && (DSP == 1 || EPC == 8 || NT <= 2);
     constexpr int KT = PRE ? NT : 1;
     uint4 kf[KT][NSTEP];
+    // staged fragments (LDSKV): the cell of (row, step, fg) in the layout of attn_stage_kv
+    auto lds_frag = [&](const unsigned char* base, int row_bytes, int row, int step) {
+        const unsigned char* c = base + row * row_bytes + (step * 4 + fg) * 32;
+        SplitF16 f;
+        f.hi = *(const h16x8*)c;
+        f.lo = *(const h16x8*)(c + 16);
+        return f;
+    };
     auto load_k = [&](int nt, uint4 (&dst)[NSTEP]) {
         const int krow = min(nt * 16 + fr, p.Tk - 1);
         const int koff = ((b * p.Tk + krow) * p.ldk + h * HD + fg * EPC) * ES;
@@ -146,10 +241,15 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (!PRE) load_k(nt, kf[0]);
+            if constexpr (LDSKV) {
 #pragma unroll
-            for (int s = 0; s < NSTEP / 2; ++s)
-                acc = mma_split(split_chunks(kf[PRE ? nt : 0][2 * s], kf[PRE ? nt : 0][2 * s + 1], ATT_QKV_SCALE), qs[s], acc);
+                for (int s = 0; s < NSTEP / 2; ++s) acc = mma_split(lds_frag(smem, AttnLds<HD, NT>::KROW, nt * 16 + fr, s), qs[s], acc);
+            } else {
+                if constexpr (!PRE) load_k(nt, kf[0]);
+#pragma unroll
+                for (int s = 0; s < NSTEP / 2; ++s)
+                    acc = mma_split(split_chunks(kf[PRE ? nt : 0][2 * s], kf[PRE ? nt : 0][2 * s + 1], ATT_QKV_SCALE), qs[s], acc);
+            }
             sc[nt] = acc * (1.0f / (ATT_QKV_SCALE * ATT_QKV_SCALE));
         }
     } else {
@@ -235,8 +335,13 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
     for (int dw = 0; dw < NDW; ++dw) {
         const int dt = dt0 + dw;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (!PRE) load_v(dt, vf[0]);
-        if constexpr (X3) {
+        if constexpr (!PRE && !LDSKV) load_v(dt, vf[0]);
+        if constexpr (LDSKV) {
+#pragma unroll
+            for (int c = 0; c < NPC / 2; ++c)
+                acc = mma_split(lds_frag(smem + AttnLds<HD, NT>::K_BYTES, AttnLds<HD, NT>::VROW, dt * 16 + fr, c), ps[c], acc);
+            acc = acc * (1.0f / (ATT_QKV_SCALE * ATT_P_SCALE));
+        } else if constexpr (X3) {
 #pragma unroll
             for (int c = 0; c < NPC / 2; ++c)
                 acc = mma_split(split_chunks(vf[PRE ? dw : 0][2 * c], vf[PRE ? dw : 0][2 * c + 1], ATT_QKV_SCALE), ps[c], acc);

@@ -549,3 +549,38 @@ def test_attention_h2_output_equals_f16x3(b, tq, tk):
     ops.attention(F16X3, q, k, vt, d, o32, b, h, tq, tk, hd)
     ops.attention(H2, q, k, vt, d, oh, b, h, tq, tk, hd)
     assert torch.equal(oh.cpu().view(torch.int32), ops.h2_pack(o32.cpu()).view(torch.int32))
+
+
+@pytest.mark.parametrize("b,tq,tk", [(3, 64, 64), (2, 10, 11), (2, 24, 25), (2, 60, 60), (5, 33, 33), (2, 100, 64), (1, 37, 48)])
+def test_attention_lds_staged_kv_is_bit_identical_to_the_register_path(b, tq, tk):
+    """Split-f16 attention with K / V^T staged once per workgroup in LDS (the product path for Tk <= 64) against the round-2 form in
+    which every query-tile wave fetches and splits K / V^T itself (tools library, emage_set_tuning key 6): the same operands in the
+    same MFMA order, so the same bits — float32 output, EMAGE_H2 output and the dropout variant of the training forward; ragged
+    query tiles (surplus waves stage and leave), ragged key counts, several query groups per (batch, head)."""
+    from pantomatrix_amd import _lib
+    g = _g(b * 1000 + tq * 10 + tk)
+    h, hd, d = 4, 192, 768
+    q = torch.randn(b * tq, 2 * d, generator=g).to(DEV)[:, :d]
+    k = torch.randn(b * tk, 2 * d, generator=g).to(DEV)[:, d:]
+    tp = ops.round_up(tk, 32)
+    vt = torch.zeros(b, 2 * d, tp)
+    vt[:, :, :tk] = torch.randn(b, 2 * d, tk, generator=g)
+    vt = vt.to(DEV)
+    pmask = ((torch.rand(b, h, tq, tk, generator=g) >= 0.1).float() / 0.9).to(DEV)
+    lib = _lib.use_tools(True)
+    try:
+        outs = []
+        for variant in (0, 1):
+            lib.emage_set_tuning(6, variant)
+            o32, oh, od = (torch.zeros(b * tq, d, device=DEV) for _ in range(3))
+            ops.attention(F16X3, q, k, vt[:, d:], 2 * d, o32, b, h, tq, tk, hd)
+            ops.attention(H2, q, k, vt[:, d:], 2 * d, oh, b, h, tq, tk, hd)
+            ops.attention_dropout(F16X3, q, k, vt[:, d:], 2 * d, od, b, h, tq, tk, hd, pmask)
+            torch.cuda.synchronize()
+            outs.append((o32, oh, od))
+    finally:
+        lib.emage_set_tuning(6, 0)
+        _lib.use_tools(False)
+    for new, old, name in zip(outs[0], outs[1], ("float32 out", "h2 out", "dropout")):
+        assert torch.equal(new.view(torch.int32), old.view(torch.int32)), name
+    assert bool(torch.isfinite(outs[0][0]).all()) and float(outs[0][0].abs().max()) > 0
