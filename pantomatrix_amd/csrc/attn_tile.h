@@ -1,5 +1,5 @@
-// Device-side body of emage_attention, shared by attention.hip (one launch per attention) and layer.hip (the fused
-// transformer-layer kernel runs it for its (clip, head) between two projection tiles).
+// Device-side body of emage_attention (attention.hip): one query tile of one (batch, head) per wave64, and the staging of a
+// workgroup's K / V^T in LDS for the split-f16 form.
 #pragma once
 #include "common.h"
 #include "h2.h"

@@ -1,4 +1,4 @@
-// One-row LayerNorm shared by elementwise.hip (one launch per LayerNorm) and layer.hip (fused transformer layer).
+// One-row LayerNorm of emage_layernorm (elementwise.hip): one wave per row, float32 statistics, optional H2 image of the result.
 #pragma once
 #include "common.h"
 #include "h2.h"
