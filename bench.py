@@ -484,7 +484,6 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56):
     del trainer, model, vq
     torch.cuda.empty_cache()
     if cpu:
-        import train_common  # noqa: F401  (tests/)
         from oracle import emage_train_oracle as tro
         from pantomatrix_amd import synthetic
         from pantomatrix_amd.configuration_emage_audio import EmageAudioConfig

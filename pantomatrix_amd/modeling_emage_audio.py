@@ -21,7 +21,6 @@ from __future__ import annotations
 
 import json
 import os
-from collections import OrderedDict
 
 import torch
 

@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 
 from . import ops, spec
-from ._lib import F32, F16X3
+from ._lib import F16X3
 from .configuration_emage_audio import _AttrConfig
 from .modeling_emage_audio import _EmageModule, _WavEncoderMixin, _Ctx, _rup
 

@@ -87,6 +87,19 @@ def golden_vq_api(acfg, vqc, gc):
     np.savez_compressed(os.path.join(HERE, "vq_api.npz"), **rec)
 
 
+def golden_clips(model, vq, which):
+    """End-to-end clips: 128 frames (2 windows, no tail), 70 frames (tail of 10 frames -> T+1 audio memory), 129 frames (tail of 9);
+    round 3: 40 frames (shorter than a window: only the remainder pass runs, 40 frames out) and 64 frames (exactly one window and no
+    remainder pass: 60 frames out)."""
+    for frames, batch in which:
+        a = synthetic.synthetic_audio(batch, synthetic.samples_for_frames(frames))
+        lat, pred, idx = ref_infer_clip(model, vq, a)
+        np.savez(os.path.join(HERE, f"infer_{frames}f_b{batch}.npz"),
+                 poses=pred["motion_axis_angle"].numpy(), expressions=pred["expression"].numpy(),
+                 trans=pred["trans"].numpy(), rec_face=lat["rec_face"].numpy(),
+                 **{f"index_{p}": idx[p].numpy() for p in common.PARTS})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -95,6 +108,10 @@ def main():
     if "--only-long" in sys.argv:
         golden_long(model, vq)
         print("wrote infer_310f_b1.npz")
+        return
+    if "--only-short" in sys.argv:           # round-3 additions only
+        golden_clips(model, vq, ((40, 1), (64, 1)))
+        print("wrote infer_40f_b1.npz, infer_64f_b1.npz")
         return
     if "--only-new" in sys.argv:             # round-2 additions only (the round-1 fixtures are unchanged)
         golden_long(model, vq)
@@ -114,15 +131,8 @@ def main():
     np.savez(os.path.join(HERE, "forward_b1.npz"), **{k: v.numpy() for k, v in out.items()},
              **{"noaudio_" + k: v.numpy() for k, v in out_na.items() if k.startswith("rec")})
 
-    # 2. end-to-end clips: 128 frames (2 windows, no tail), 70 frames (tail of 10 frames -> T+1
-    #    audio memory), 129 frames (tail of 9)
-    for frames, batch in ((128, 2), (70, 1), (129, 1)):
-        a = synthetic.synthetic_audio(batch, synthetic.samples_for_frames(frames))
-        lat, pred, idx = ref_infer_clip(model, vq, a)
-        np.savez(os.path.join(HERE, f"infer_{frames}f_b{batch}.npz"),
-                 poses=pred["motion_axis_angle"].numpy(), expressions=pred["expression"].numpy(),
-                 trans=pred["trans"].numpy(), rec_face=lat["rec_face"].numpy(),
-                 **{f"index_{p}": idx[p].numpy() for p in common.PARTS})
+    # 2. end-to-end clips
+    golden_clips(model, vq, ((128, 2), (70, 1), (129, 1), (40, 1), (64, 1)))
 
     # 3. VQ-VAE / AE stacks at two depths (vae_layer is a checkpoint parameter, SURVEY §8a note)
     for layer in (2, 3):

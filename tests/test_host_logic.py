@@ -78,7 +78,7 @@ def test_forward_window_f16x3_host_logic(golden_dir):
     assert float(((hi + lo) / scale - w).abs().max()) <= 2.0 ** -22 * float(w.abs().max())
 
 
-@pytest.mark.parametrize("frames,batch,precision", [(128, 2, "fp32"), (70, 1, "fp32"), (129, 1, "fp32"), (129, 1, "f16x3"), (310, 1, "f16x3")])
+@pytest.mark.parametrize("frames,batch,precision", [(128, 2, "fp32"), (70, 1, "fp32"), (129, 1, "fp32"), (129, 1, "f16x3"), (310, 1, "f16x3"), (40, 1, "f16x3"), (64, 1, "fp32")])
 def test_inference_and_decode_host_logic(golden_dir, frames, batch, precision):
     """Whole clip: window schedule, seed carry-over through the VQ decode, tail windows with T+1 audio
     frames, final decode with global translation — against the REFERENCE's golden outputs."""

@@ -31,7 +31,7 @@ def test_forward_window(golden_dir):
     assert np.abs(g["rec_upper"] - g["noaudio_rec_upper"]).max() > 1e-2  # use_audio matters
 
 
-@pytest.mark.parametrize("frames,batch,expect", [(128, 2, 120), (70, 1, 70), (129, 1, 129), (310, 1, 310)])
+@pytest.mark.parametrize("frames,batch,expect", [(128, 2, 120), (70, 1, 70), (129, 1, 129), (310, 1, 310), (40, 1, 40), (64, 1, 60)])
 def test_end_to_end_clip(golden_dir, frames, batch, expect):
     g = _load(golden_dir, f"infer_{frames}f_b{batch}.npz")
     model, vq = common.oracle_models()

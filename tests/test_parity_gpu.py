@@ -80,7 +80,7 @@ def test_forward_window_fp32_vs_oracle_batch3(exact_models, precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32"] + X3_FORMS)
-@pytest.mark.parametrize("frames,batch", [(128, 2), (70, 1), (129, 1), (310, 1)])
+@pytest.mark.parametrize("frames,batch", [(128, 2), (70, 1), (129, 1), (310, 1), (40, 1), (64, 1)])      # 40: shorter than a window; 64: one window, no remainder pass
 def test_clip_fp32_matches_reference(exact_models, golden_dir, frames, batch, precision):
     model, vq = exact_models[precision]
     g = np.load(os.path.join(golden_dir, f"infer_{frames}f_b{batch}.npz"))
