@@ -38,7 +38,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 METRIC = "motion-frames/sec (30fps SMPL-X) EMAGE infer, 128-frame clips"
 PRECISION_NOTE = {
-    "f16x3": "float32 storage, each product as 3 split-fp16 MFMAs (hi*hi + hi*lo + lo*hi), fp32 accumulate: parity-green "
+    "f16x3": "4-byte storage (float32; contraction operands pre-split by their producers into fp16 hi | lo images), each product as 3 split-fp16 MFMAs (hi*hi + hi*lo + lo*hi), fp32 accumulate: parity-green "
              "(bit-exact VQ indices, 1e-3 rotations vs the reference)",
     "bf16": "bf16 operands, fp32 accumulate: NOT index-exact (about 97.5 % of frames keep all body codes)",
     "fp32": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): parity-green, slow",
