@@ -1060,6 +1060,7 @@ class Trainer:
             st["step"] = 0
         self.steps_done = 0
         self._step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._graph_inputs = (batch, random_mask, dropout_masks)       # the graph reads these buffers at every replay: keep them alive
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             model.invalidate_packed()                                  # so that the packing of the current parameters is part of the graph

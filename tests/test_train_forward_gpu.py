@@ -278,6 +278,37 @@ def test_captured_training_step_equals_the_eager_step(golden_dir):
     assert abs(eager.state["face_out_proj.weight"]["step"] - 2) == 0 and graphed.state["face_out_proj.weight"]["step"] == 2
 
 
+def test_captured_f16x3_step_matches_the_reference(golden_dir):
+    """VERDICT round 2, "do this" 4: the step as ONE hipGraph in the split-fp16 mode (forward and backward contractions as f16x3 MFMA,
+    operand re-packing with cached scales, multi-tensor Adam with the step count on the device) against the REAL reference step's
+    golden: the seven losses and every live parameter's sum after the update."""
+    g = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    batch, _, masks, random_mask, _ = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    masks = [[m.to(DEV).contiguous() for m in fm] for fm in masks]
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    before = {k: v.clone() for k, v in model._flat_params().items()}
+    trainer = training.Trainer(model, vq)
+    random_mask = random_mask.to(DEV)                            # an input buffer of the graph
+    trainer.capture(batch, random_mask, masks)
+    for k, v in before.items():                                  # capture() ran and undid a warm-up step
+        assert torch.equal(model._flat_params()[k], v), k
+    losses = trainer.replay()
+    for k in ("rec_seed", "cls_seed", "rec_audio", "cls_audio", "rec_mask", "cls_mask", "all"):
+        want = float(g["loss_" + k])
+        assert abs(losses[k] - want) < 2e-4 * max(1.0, abs(want)), (k, losses[k], want)
+    params, lr, checked = model._flat_params(), 1.5e-4, 0
+    for n, shadowed, s in zip([str(x) for x in g["grad_names"]], g["shadowed"], g["param_sum_after"]):
+        if shadowed:
+            continue
+        wav = n.startswith(("audio_encoder_face.", "audio_encoder_body."))
+        p = params[n]
+        assert abs(float(p.double().sum()) - float(s)) <= 3e-5 * p.numel() ** 0.5 + 2e-3 + (0.3 * lr * p.numel() if wav else 0), n
+        assert not torch.equal(p, before[n]), n
+        checked += 1
+    assert checked > 400 and trainer.steps_done == 1
+
+
 def test_device_dropout_mask_and_multi_tensor_adam_kernels():
     """`emage_dropout_mask` is the documented Philox4x32-10 stream bit for bit (numpy restatement, itself pinned to Random123's known
     answers in tests/test_train_forward_host.py), also with the step read from device memory; `emage_adam_multi` equals
