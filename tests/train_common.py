@@ -31,7 +31,23 @@ def recorded_masks(store):
         tro._drop = saved
 
 
+_FORWARD_CACHE = {}
+
+
 def oracle_forward(seed, use_audio=True, new_stats=None, batch=2):
+    """One train-mode forward of the oracle with its dropout masks recorded.  Calls that start from fresh BatchNorm buffers are cached
+    per (seed, use_audio, batch) — the two precisions of a parametrised test replay the same forward; callers get fresh containers and
+    must not modify the tensors in place."""
+    if new_stats is None:
+        key = (seed, bool(use_audio), batch)
+        if key not in _FORWARD_CACHE:
+            _FORWARD_CACHE[key] = _oracle_forward(seed, use_audio, None, batch)
+        inputs, out, masks, ns = _FORWARD_CACHE[key]
+        return inputs, dict(out), list(masks), dict(ns)
+    return _oracle_forward(seed, use_audio, new_stats, batch)
+
+
+def _oracle_forward(seed, use_audio, new_stats, batch):
     cfg = EmageAudioConfig(**common.cfg_dicts()[0])
     sd = synthetic.audio_model_state(cfg, 0)
     audio, spk, motion, mask = common.window_inputs(batch)
