@@ -610,37 +610,46 @@ def main():
         result["pipelined"] = {"depth": args.pipeline, "value": frames_per_step * world * args.steps / el_p, "ms_per_step": 1e3 * el_p / args.steps}
         del pipe
 
+    def guarded(key, fn):
+        """The headline measurement above is done: a failure in one of the additional objects is reported in its place, not raised."""
+        try:
+            result[key] = fn()
+        except Exception as e:  # noqa: BLE001
+            log(f"{key} failed: {type(e).__name__}: {e}")
+            result[key] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            torch.cuda.empty_cache()
+
     if rank == 0 and not args.no_roofline:
-        records, _marker_ms = profile_kernels(runner, model, vq)
-        serial_ms = None if args.no_graph else serialized_graph_ms(model, vq, args, n_samples, audio, args.steps)
-        result["roofline"] = roofline_report(records, args.precision, result["ms_per_step"], serial_ms)
-        if world == 1:
-            result["roofline"].setdefault("vq_argmin", {})["n_1m"] = vq_argmin_large(dev)
+        def roofline():
+            records, _marker_ms = profile_kernels(runner, model, vq)
+            serial_ms = None if args.no_graph else serialized_graph_ms(model, vq, args, n_samples, audio, args.steps)
+            rep = roofline_report(records, args.precision, result["ms_per_step"], serial_ms)
+            if world == 1:
+                rep.setdefault("vq_argmin", {})["n_1m"] = vq_argmin_large(dev)
+            return rep
+        guarded("roofline", roofline)
     if world == 1 and args.also:
-        others = {}
         del runner, model, vq
         torch.cuda.empty_cache()
-        for p in [x for x in args.also.split(",") if x and x != args.precision]:
-            m2, v2, r2, _ = build(p, dev, args)
-            el2, _ = timed_steps(lambda: r2(audio), args.steps, args.warmup, barrier, reduce_max)
-            others[p] = {"value": frames_per_step * args.steps / el2, "ms_per_step": 1e3 * el2 / args.steps, "precision": PRECISION_NOTE[p]}
-            del m2, v2, r2
-            torch.cuda.empty_cache()
-        result["other_precisions"] = others
+
+        def other_precisions():
+            others = {}
+            for p in [x for x in args.also.split(",") if x and x != args.precision]:
+                m2, v2, r2, _ = build(p, dev, args)
+                el2, _ = timed_steps(lambda: r2(audio), args.steps, args.warmup, barrier, reduce_max)
+                others[p] = {"value": frames_per_step * args.steps / el2, "ms_per_step": 1e3 * el2 / args.steps, "precision": PRECISION_NOTE[p]}
+                del m2, v2, r2
+                torch.cuda.empty_cache()
+            return others
+        guarded("other_precisions", other_precisions)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.frames)
+        guarded("cpu_baseline", lambda: cpu_baseline(args.frames))
     if rank == 0 and world == 1 and not args.no_other_configs:
         # BASELINE configs[2] / [3] / [4] beside the headline metric (bounded: a few steps each); models of the headline run are released
         torch.cuda.empty_cache()
-        # a failure here must not cost the headline line: it is reported in place of the object
         for key, what, fn in (("lstm_models", "DisCo / CaMN inference", bench_lstm_models), ("train_step", "one EMAGE training step", bench_train_step)):
             log(f"other BASELINE configs: {what}")
-            try:
-                result[key] = fn(dev, cpu=not args.no_cpu_baseline)
-            except Exception as e:  # noqa: BLE001
-                log(f"{key} failed: {type(e).__name__}: {e}")
-                result[key] = {"error": f"{type(e).__name__}: {e}"[:500]}
-                torch.cuda.empty_cache()
+            guarded(key, lambda fn=fn: fn(dev, cpu=not args.no_cpu_baseline))
     if rank == 0:
         print(json.dumps(result), flush=True)
     pdist.finalize()

@@ -69,3 +69,61 @@ def test_timed_region_on_two_gloo_ranks():
     assert l0["n_gpus"] == 2 and l0["scaling"] == "weak" and l0["steps"] == 5 and l0["warmup"] == 2
     assert abs(l0["value"] - 2 * 64 * 120 * 5 / e0) < 1e-6  # whole-job frames / max-over-ranks time
     assert l0["config"]["frames_out_per_clip"] == 120 and "replicas x2" in l0["config"]["parallelism"]
+
+
+def test_main_prints_one_json_line_and_reports_a_failing_extra(monkeypatch, capsys):
+    """bench.main() end to end with the device work stubbed out (a stand-in runner, stand-in profiling): ONE JSON line with the
+    contract's keys and every additional object; an exception inside an additional object (here: the training-step line) is reported
+    in that object's place and does not cost the headline line."""
+    import json
+    import numpy as np
+    import torch
+    import bench
+    from pantomatrix_amd import dist as pd
+    from pantomatrix_amd import synthetic
+
+    class _Audio:                                                      # what main() does with the synthetic audio batch
+        def pin_memory(self):
+            return self
+
+        def to(self, dev):
+            return self
+
+        def numel(self):
+            return 64 * 68267
+
+    poses = np.zeros((64, 120, 165), np.float32)
+    runner = lambda a=None: (poses, np.zeros((64, 120, 100), np.float32), np.zeros((64, 120, 3), np.float32))
+
+    def failing_train_step(dev, cpu=True):
+        raise RuntimeError("out of memory (stand-in)")
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1"])
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    monkeypatch.setattr(synthetic, "synthetic_audio", lambda *a, **k: _Audio())
+    monkeypatch.setattr(pd, "init", lambda backend, dev=None: None)
+    monkeypatch.setattr(bench, "build", lambda precision, dev, args: (object(), object(), runner, 68267))
+    monkeypatch.setattr(bench, "profile_kernels", lambda r, m, v: ([], 0.0))
+    monkeypatch.setattr(bench, "serialized_graph_ms", lambda *a, **k: 15.0)
+    monkeypatch.setattr(bench, "roofline_report", lambda records, precision, ms, serial_ms: {"bound": "mfma", "achieved": 1.0, "peak": 2500.0, "unit": "TFLOP/s",
+                                                                                             "frac": 4e-4, "traffic": None, "serialized_kernel_ms": serial_ms})
+    monkeypatch.setattr(bench, "vq_argmin_large", lambda dev: {"n": 1 << 20})
+    monkeypatch.setattr(bench, "cpu_baseline", lambda frames: {"value": 2000.0, "unit": "motion-frames/s", "cores": 16, "kind": "port", "sample": "stand-in"})
+    monkeypatch.setattr(bench, "bench_lstm_models", lambda dev, cpu=True: {"disco": {"ms_per_step": 9.0}, "camn": {"ms_per_step": 72.0}})
+    monkeypatch.setattr(bench, "bench_train_step", failing_train_step)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "pcie_inclusive", "other_precisions", "lstm_models", "train_step"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f16x3" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert d["roofline"]["vq_argmin"]["n_1m"] == {"n": 1 << 20} and set(d["other_precisions"]) == {"bf16"}
+    assert d["lstm_models"]["camn"]["ms_per_step"] == 72.0
+    assert d["train_step"] == {"error": "RuntimeError: out of memory (stand-in)"}
