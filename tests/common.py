@@ -54,20 +54,32 @@ def vq_api_inputs(batch=3, frames=24, seed=41):
     return rot6d, expr, contact, trans
 
 
+_STATE_CACHE = {}
+
+
+def _synthetic_state(make, *key):
+    """The seeded synthetic weights of a model, generated once per process (`load_state_dict` copies them into the parameters, so the
+    cached tensors are never aliased by a model; the suites build ~100 model sets from the same seeds)."""
+    if key not in _STATE_CACHE:
+        _STATE_CACHE[key] = make()
+    return _STATE_CACHE[key]
+
+
 def product_models(seed=0, vae_layer=2, precision="fp32", device="cpu"):
     """pantomatrix_amd model objects loaded with the same synthetic weights as `oracle_models`."""
+    import json
     import pantomatrix_amd as pa
     acfg, vqc, gc = cfg_dicts(vae_layer)
     cfg = pa.EmageAudioConfig(**acfg)
     model = pa.EmageAudioModel(cfg)
-    model.load_state_dict(synthetic.audio_model_state(cfg, seed))
+    model.load_state_dict(_synthetic_state(lambda: synthetic.audio_model_state(cfg, seed), "audio", json.dumps(acfg, sort_keys=True), seed))
     parts = {}
     for p in PARTS:
         c = pa.EmageVQVAEConvConfig(**vqc[p])
         parts[p] = pa.EmageVQVAEConv(c)
-        parts[p].load_state_dict(synthetic.vqvae_state(c, p, seed))
+        parts[p].load_state_dict(_synthetic_state(lambda: synthetic.vqvae_state(c, p, seed), "vq", p, json.dumps(vqc[p], sort_keys=True), seed))
     g = pa.EmageVAEConv(pa.EmageVAEConvConfig(**gc))
-    g.load_state_dict(synthetic.vae_state(pa.EmageVAEConvConfig(**gc), seed))
+    g.load_state_dict(_synthetic_state(lambda: synthetic.vae_state(pa.EmageVAEConvConfig(**gc), seed), "global", json.dumps(gc, sort_keys=True), seed))
     vq = pa.EmageVQModel(face_model=parts["face"], upper_model=parts["upper"], hands_model=parts["hands"],
                          lower_model=parts["lower"], global_model=g)
     model.set_precision(precision)
