@@ -28,7 +28,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -283,13 +282,18 @@ def roofline_report(records, precision, ms_per_step, serial_ms=None):
     else:
         ach = byts / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-    traffic = None
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         with open(tfile) as f:
-            traffic = json.load(f).get(f"{name}:{precision}")
+            tj = json.load(f)
+        traffic = tj.get(f"{name}:{precision}")
+        if traffic is not None:
+            traffic_source = ("STATIC — not measured in this run: bytes per launch read from profiles/hbm_traffic.json ("
+                              + str(tj.get("_source", "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over bench.py, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per the microarch guide"))
+                              + "); PMC counters cannot be collected from inside the timed process")
     roof.update({
-        "traffic": traffic, "kernel": name, "launches_per_step": cnt, "avg_launch_us": 1e3 * ms / cnt,
+        "traffic": traffic, "traffic_source": traffic_source, "kernel": name, "launches_per_step": cnt, "avg_launch_us": 1e3 * ms / cnt,
         "algorithmic_gflop_per_launch": flops / cnt / 1e9,
         "note": "algorithmic flops (2*M*N*K, unpadded K) / serialized kernel time; in f16x3 every product issues 3 MFMAs, so the "
                 "MFMA pipes are busy for about 3x this fraction",
@@ -343,7 +347,7 @@ def vq_argmin_large(device, n=1 << 20, iters=5):
 def cpu_baseline(frames, seconds_budget=15.0):
     """The CPU oracle (a port of the reference path, oracle/emage_oracle.py) on a bounded sample of the same
     workload: `bs` 128-frame clips per call, repeated until ~seconds_budget of CPU work."""
-    import common
+    from tools import workloads as common
     from oracle import emage_oracle as orc
     from pantomatrix_amd import synthetic
     # use the cores this container may actually run on (affinity AND cgroup CPU quota): forcing os.cpu_count()
@@ -383,8 +387,7 @@ def bench_lstm_models(dev, steps=3, cpu=True):
     from pantomatrix_amd import ops, synthetic
     from pantomatrix_amd._lib import F16X3
     from pantomatrix_amd.runtime import LstmClipRunner
-    from test_lstm_host_logic import product
-    from test_lstm_models_oracle import weights, run_oracle
+    from tools.workloads import lstm_product as product, lstm_weights as weights, lstm_oracle as run_oracle
     out = {}
     for kind, batch, seconds in (("disco", 128, 8.5), ("camn", 256, 28.0)):
         n = int(seconds * 16000)
@@ -454,16 +457,12 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56):
     Adam, BatchNorm buffers — `training.Trainer.capture` / `replay`: the whole step is ONE hipGraph.  `roofline`: the step's algorithmic
     flops (9 x 20.5 GFLOP per clip-window + 1.16 GFLOP of VQ encoding) against the dense fp16 MFMA peak (every contraction, forward
     and backward, is split-fp16 MFMA: the backward on EMAGE_H2 operands with power-of-two gradient scaling)."""
-    import common
+    from tools import workloads as common
     from pantomatrix_amd import training
     model, vq = common.product_models(precision="f16x3", device=dev)
     t = 64
-    g = torch.Generator().manual_seed(5)
-    data = dict(motion=0.3 * torch.randn(batch, t, 165, generator=g), audio=0.1 * torch.randn(batch, t * 16000 // 30, generator=g),
-                expressions=0.5 * torch.randn(batch, t, 100, generator=g), trans=0.1 * torch.randn(batch, t, 3, generator=g),
-                foot_contact=(torch.rand(batch, t, 4, generator=g) > 0.5).float())
-    data = {k: v.to(dev) for k, v in data.items()}
-    random_mask = (torch.rand(batch, t, 337, generator=g) < 0.5).float().to(dev)
+    data = {k: v.to(dev) for k, v in common.train_batch(bs=batch, t=t).items()}
+    random_mask = (torch.rand(batch, t, 337, generator=torch.Generator().manual_seed(6)) < 0.5).float().to(dev)
     torch.cuda.reset_peak_memory_stats()
     trainer = training.Trainer(model, vq, seed=1).capture(data, random_mask)
     losses = trainer.replay()
@@ -477,31 +476,54 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56):
     flops = batch * (9 * 20.5e9 + 1.16e9)
     line = {"workload": f"EMAGE training step f16x3, {batch} x {t}-frame synthetic clips per GPU (BASELINE configs[2] per-GPU batch), one hipGraph replay per step",
             "ms_per_step": ms, "value": batch / (ms * 1e-3), "unit": "clip-windows/s", "steps": steps, "dtype": "f16x3",
-            "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "loss_all": losses["all"],
+            "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "loss_all_after_replays": losses["all"], "replays": steps + 1,
+            "skipped_steps": trainer.skipped_steps, "operand_rescales": trainer.rescaled,
             "roofline": {"bound": "mfma", "kernel": "emage_gemm (split-fp16 MFMA, 3 per product: every contraction of the forward and the backward)",
                          "achieved": flops / (ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
                          "note": "whole-step algorithmic flops / step time (an upper bound on the GEMM family's share) against the dense fp16 MFMA peak"}}
-    del trainer, model, vq
+    del trainer
+    torch.cuda.empty_cache()
+    # the EAGER step — the path a multi-process run takes (a collective cannot sit inside the captured graph): same model, same inputs
+    try:
+        eager = training.Trainer(model, vq, seed=1)
+        eager.step(data, random_mask=random_mask)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            eager.step(data, random_mask=random_mask)
+        torch.cuda.synchronize()
+        ems = 1e3 * (time.perf_counter() - t0) / 2
+        line["eager"] = {"ms_per_step": ems, "ratio_to_captured": ems / ms,
+                         "note": "Trainer.step: the same launches issued from Python, one host read of losses + health word per step (the form world > 1 uses)"}
+        del eager
+    except Exception as exc:                      # noqa: BLE001 — an extra never costs the line
+        line["eager"] = {"error": f"{type(exc).__name__}: {exc}"}
+    del model, vq
     torch.cuda.empty_cache()
     if cpu:
-        from oracle import emage_train_oracle as tro
-        from pantomatrix_amd import synthetic
-        from pantomatrix_amd.configuration_emage_audio import EmageAudioConfig
         torch.set_num_threads(usable_cores())
-        cfg = EmageAudioConfig(**common.cfg_dicts()[0])
-        _, ovq = common.oracle_models()
-        sd = synthetic.audio_model_state(cfg, 0)
-        small = {k: v[:2].cpu() for k, v in data.items()}
         t0 = time.time()
-        tro.train_step(sd, ovq, cfg, small, 0, seed=1)
+        ref = common.oracle_train_step_recorded(seed=1, iteration=0, bs=2, backward=True)
         dt = time.time() - t0
         line["cpu_baseline"] = {"value": 2 / dt, "unit": "clip-windows/s", "kind": "port", "cores": torch.get_num_threads(),
                                 "sample": f"one step on 2 clips ({dt:.1f} s CPU), fp32 torch CPU oracle (oracle/emage_train_oracle.py: a restatement of train_val_fn)"}
+        # the same step on the device (eager f16x3, the oracle's recorded dropout draws): losses and gradient norms against the oracle's
+        model, vq = common.product_models(precision="f16x3", device=dev)
+        got = {}
+        dl = training.Trainer(model, vq).step({k: v.to(dev) for k, v in ref["batch"].items()}, 0, [[m.to(dev).contiguous() for m in fm] for fm in ref["masks"]],
+                                              ref["random_mask"].to(dev), grad_hook=lambda gr: got.update({k: float(v.norm()) for k, v in gr.items()}))
+        gmax = max(float(g.abs().max()) for g in ref["grads"].values())
+        live = [k for k, g in ref["grads"].items() if float(g.abs().max()) >= 1e-5 * gmax and not k.startswith(("audio_encoder_face.", "audio_encoder_body."))]
+        line["max_rel_loss_err_vs_oracle_2_clips"] = max(abs(dl[k] - v) / max(1.0, abs(v)) for k, v in ref["losses"].items())
+        line["max_rel_grad_norm_err_vs_oracle_2_clips"] = max(abs(got[k] - float(ref["grads"][k].norm())) / float(ref["grads"][k].norm()) for k in live)
+        line["grad_tensors_compared"] = len(live)
+        del model, vq
+        torch.cuda.empty_cache()
     return line
 
 
 def build(precision, device, args):
-    import common
+    from tools import workloads as common
     from pantomatrix_amd import synthetic
     from pantomatrix_amd.runtime import ClipRunner
     model, vq = common.product_models(precision=precision, device=device)
@@ -600,7 +622,10 @@ def main():
     el_pcie, _ = timed_steps(lambda: runner(audio_host), args.steps, 1, barrier, reduce_max)
     result["pcie_inclusive"] = {"value": frames_per_step * world * args.steps / el_pcie, "ms_per_step": 1e3 * el_pcie / args.steps,
                                 "h2d_bytes_per_step": audio_host.numel() * 4,
-                                "note": "audio batch copied pinned-host -> HBM inside every timed step; `value` above is HBM-resident"}
+                                "note": "SURVEY 8(d)'s definition of the metric (H2D of the audio inside the timed step: pinned host -> HBM in every step, "
+                                        "D2H of the three result arrays in both figures).  The bench contract fixes `value` above as the HBM-resident rate "
+                                        "('inputs already resident in HBM when the timed region starts ... the PCIe-inclusive rate is never `value`'), "
+                                        "so the conforming 8(d) figure is THIS object"}
 
     if args.pipeline > 1:
         from pantomatrix_amd.runtime import ClipPipeline

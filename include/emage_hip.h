@@ -436,10 +436,14 @@ int emage_h2_cast(const float* src, int lds, void* out, int ldo, int n_store, in
 /* Multi-tensor Adam: ONE launch over every parameter.  table: per tensor five 64-bit words {param, grad, exp_avg, exp_avg_sq, n} (device
  * pointers / element count); block b updates elements [block_chunk[b] * C, +C) of tensor block_tensor[b], C = emage_adam_multi_chunk().
  * step_dev (one int32 on the device) overrides `step` when non-NULL (captured graphs).  grad_scale multiplies every gradient first (the
- * 1 / world_size of the data-parallel average); zero_grad != 0 clears the gradient behind the update.  Arithmetic of emage_adam_step. */
+ * 1 / world_size of the data-parallel average); zero_grad != 0 clears the gradient behind the update.  Arithmetic of emage_adam_step.
+ * skip (one int32 on the device, may be NULL): when non-zero at launch time — the trainer's count of non-finite gradient words
+ * (emage_count_nonfinite over the gradient buckets, inside the same captured step) — parameters and moments are left untouched (the
+ * gradients are still cleared): an overflow of the split-fp16 backward never reaches the weights (the step-skip of loss-scaled training). */
 int emage_adam_multi_chunk(void);
 int emage_adam_multi(const long long* table, const int* block_tensor, const int* block_chunk, int n_blocks, const int* step_dev, int step,
-                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, void* stream);
+                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, const int* skip,
+                     void* stream);
 
 /* nn.Dropout's keep mask drawn on the device (T:241-250 dropout = 0.1 in every transformer layer, P:331,343): out[i] = bernoulli(1 - p) / (1 - p)
  * from Philox4x32-10 with key = seed, counter = (i / 4, mask_id, step): a pure function of its arguments (no generator state; step_dev, one

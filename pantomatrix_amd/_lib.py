@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 TOOLS_LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip_tools.so")   # -DEMAGE_TOOLS twin: every tile configuration + emage_set_tuning
 
 F32, BF16, F16X3, H2 = 0, 1, 2, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -51,7 +51,7 @@ SIGNATURES = {
     "emage_adam_step_dev": [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _p],
     "emage_adam_step": [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _p],
     "emage_adam_multi_chunk": [],
-    "emage_adam_multi": [_p, _p, _p, _i, _p, _i, _f, _f, _f, _f, _f, _f, _i, _p],
+    "emage_adam_multi": [_p, _p, _p, _i, _p, _i, _f, _f, _f, _f, _f, _f, _i, _p, _p],
     "emage_dropout_mask": [_p, _l, _f, C.c_ulonglong, C.c_uint, _p, _i, _p],
     "emage_mul_add": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],

@@ -976,7 +976,8 @@ namespace {
 constexpr int ADAM_CHUNK = 4096;
 __global__ __launch_bounds__(256) void adam_multi_kernel(const long long* __restrict__ table, const int* __restrict__ block_tensor, const int* __restrict__ block_chunk,
                                                          const int* __restrict__ step_dev, int step, float lr, float b1, float b2, float eps, float weight_decay,
-                                                         float grad_scale, int zero_grad) {
+                                                         float grad_scale, int zero_grad, const int* __restrict__ skip) {
+    const bool skipped = skip && *skip != 0;             // a non-finite gradient was counted: parameters and moments stay as they are
     const int t = step_dev ? *step_dev : step;
     const double bias1 = 1.0 - pow((double)b1, t), bias2 = 1.0 - pow((double)b2, t);
     const float step_size = (float)((double)lr / bias1), inv_sqrt_bias2 = (float)(1.0 / sqrt(bias2));
@@ -988,6 +989,11 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const long long* __rest
     const long n = (long)e[4];
     const long i0 = (long)block_chunk[blockIdx.x] * ADAM_CHUNK;
     const long i1 = i0 + ADAM_CHUNK < n ? i0 + ADAM_CHUNK : n;
+    if (skipped) {
+        if (zero_grad)
+            for (long i = i0 + threadIdx.x; i < i1; i += 256) g[i] = 0.f;
+        return;
+    }
     for (long i = i0 + threadIdx.x; i < i1; i += 256) {
         float gi = g[i] * grad_scale;
         if (weight_decay != 0.f) gi += weight_decay * p[i];
@@ -1004,10 +1010,11 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const long long* __rest
 extern "C" int emage_adam_multi_chunk(void) { return ADAM_CHUNK; }
 
 extern "C" int emage_adam_multi(const long long* table, const int* block_tensor, const int* block_chunk, int n_blocks, const int* step_dev, int step,
-                                float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, void* stream) {
+                                float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, const int* skip,
+                                void* stream) {
     if (!table || !block_tensor || !block_chunk || n_blocks <= 0 || (!step_dev && step <= 0)) return EMAGE_EINVAL;
     if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return EMAGE_EINVAL;
     hipLaunchKernelGGL(adam_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, table, block_tensor, block_chunk, step_dev, step,
-                       lr, beta1, beta2, eps, weight_decay, grad_scale, zero_grad);
+                       lr, beta1, beta2, eps, weight_decay, grad_scale, zero_grad, skip);
     return launch_status();
 }

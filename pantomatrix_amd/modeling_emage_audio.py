@@ -121,11 +121,25 @@ class _EmageModule(torch.nn.Module):
         self.invalidate_packed()
         return out
 
-    def invalidate_packed(self):
-        """Drop the packed operand copies; the next forward re-packs from the current parameters."""
+    def invalidate_packed(self, reset_scales=False):
+        """Drop the packed operand copies; the next forward re-packs from the current parameters.  reset_scales: also forget the
+        power-of-two operand scales of the split-fp16 modes (chosen at the first packing and kept across re-packings so that a training
+        step re-packs without a host read-back) — for weights REPLACED other than through this module's `load_state_dict`."""
         self._packed = None
         self._templates = {}
+        self.__dict__["_version_tensors"] = None
+        if reset_scales:
+            self.__dict__["_scale_caches"] = {}
         return self
+
+    def _version_stamp(self):
+        """In-place version counters of every parameter and buffer: what `_engine()` compares with the stamp taken at packing time, so an
+        optimiser step, a BatchNorm-buffer update of a train-mode forward, `p.data.copy_()`, a parent module's `load_state_dict` ... are
+        all followed by a re-pack — in eval mode too (train, `optimizer.step()`, `model.eval(); model(...)`)."""
+        ts = self.__dict__.get("_version_tensors")
+        if ts is None:
+            ts = self.__dict__["_version_tensors"] = list(super().state_dict(keep_vars=True).values())
+        return tuple(t._version for t in ts)
 
     _trainable = False       # EmageAudioModel: train() switches forward() to the differentiable train-mode forward
 
@@ -180,18 +194,35 @@ class _EmageModule(torch.nn.Module):
     # ---- engine plumbing -------------------------------------------------------------
     _supports_h2 = True      # the class's forward handles EMAGE_H2 activations (the LSTM models keep float32 activations)
 
+    @staticmethod
+    def _require_device(dev):
+        if dev.type != "cuda":
+            raise RuntimeError("the EMAGE model classes run only on an MI355X device: call .to('cuda') first "
+                               "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests only)")
+
     def _engine(self, h2=None):
         """The packed operand set of the current precision.  h2 (f16x3 only): pre-split EMAGE_H2 operands (default: `split_acts`);
         the training forward asks for h2=False (float32 activations, weights in the EMAGE_F16X3 packing)."""
         dev = self.device
-        if dev.type != "cuda":
-            raise RuntimeError(f"{type(self).__name__} runs only on an MI355X device: call .to('cuda') first "
-                               "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests only)")
+        self._require_device(dev)
         want_h2 = self._dt == F16X3 and self._supports_h2 and (self.split_acts if h2 is None else h2)
         dt = H2 if want_h2 else self._dt
-        if self._packed is None or self._packed.device != dev or self._packed.dt != dt:
-            self._packed = _Packed(self._flat_params(), dev, dt, self.__dict__.setdefault("_scale_caches", {}).setdefault((str(dev), dt), {}))
-            self._pack(self._packed)
+        stamp = self._version_stamp()
+        if self._packed is None or self._packed.device != dev or self._packed.dt != dt or self._packed.stamp != stamp:
+            capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+            for attempt in (0, 1):
+                cache = self.__dict__.setdefault("_scale_caches", {}).setdefault((str(dev), dt), {})
+                pk = _Packed(self._flat_params(), dev, dt, cache)
+                pk.stamp = stamp
+                self._pack(pk)
+                # a weight that left the range its cached power-of-two scale was chosen for (it grew / shrank 4x since the first packing, or
+                # was replaced): choose the scales afresh.  Outside a stream capture only (the flag is read on the host); a training step
+                # (`training.Trainer`, eager or captured) leaves the flag unread here and reads it with its losses
+                if attempt == 0 and not capturing and not self.__dict__.get("_defer_range_check") and pk.range_flag is not None and int(pk.range_flag) != 0:
+                    self.__dict__["_scale_caches"].pop((str(dev), dt), None)
+                    continue
+                break
+            self._packed = pk
         return self._packed
 
     def _flat_params(self):
@@ -212,6 +243,10 @@ class _Packed:
         # every re-packing (after an optimiser step: a pure sequence of launches, capturable); cleared when a state dict is loaded
         self.scale_cache = {} if scale_cache is None else scale_cache
         self._n_operands = 0
+        self.stamp = None            # `_EmageModule._version_stamp()` of the parameters this set was packed from
+        # int32 device counter of operands packed with a CACHED scale whose max |w * scale| has left [2^10, 2^14) (chosen into
+        # [2^12, 2^13): the fp16 hi plane overflows at 2^16); None until such a packing happens
+        self.range_flag = None
         self.wav_dt = F16X3 if dt == H2 else dt      # the WavEncoder keeps float32 activations (slab kernels split in LDS)
         self.tdt = ops.TORCH_DTYPE[dt]
         self.w = {}
@@ -232,8 +267,13 @@ class _Packed:
         if dt in (H2, F16X3):
             key = (dt, self._n_operands, tuple(w2d.shape))
             self._n_operands += 1
-            img, scale = (ops.split_f16_weights_h2 if dt == H2 else ops.split_f16_weights)(w2d.contiguous(), self.scale_cache.get(key))
+            cached = self.scale_cache.get(key)
+            img, scale = (ops.split_f16_weights_h2 if dt == H2 else ops.split_f16_weights)(w2d.contiguous(), cached)
             self.scale_cache[key] = scale
+            if cached is not None and w2d.numel():
+                if self.range_flag is None:
+                    self.range_flag = torch.zeros((), dtype=torch.int32, device=w2d.device)
+                self.range_flag += ops.f16_scale_out_of_range(w2d, scale)
             return img, scale
         return w2d.to(ops.TORCH_DTYPE[dt]).contiguous(), 1.0
 

@@ -59,6 +59,18 @@ def _f16_scale(w):
     return 2.0 ** (12 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
 
 
+F16_SCALE_LO, F16_SCALE_HI = 2.0 ** 10, 2.0 ** 14     # `_f16_scale` puts max |w * scale| into [2^12, 2^13); outside this band the scale is re-derived
+
+
+def f16_scale_out_of_range(w, scale):
+    """int32 device scalar: 1 when max |w| * scale has left [2^10, 2^14) — a weight packed with a power-of-two scale chosen at an EARLIER
+    packing has since grown towards the fp16 range (the hi plane overflows at 2^16: two doublings of margin are left when this fires)
+    or shrunk so far that its planes lose bits; NaN / inf count as out of range.  No host read-back (a training step re-packs inside a
+    captured graph); the caller accumulates the flags and reads them where it reads its results."""
+    mx = w.detach().abs().amax().to(torch.float32) * float(scale)
+    return (~(((mx >= F16_SCALE_LO) & (mx < F16_SCALE_HI)) | (mx == 0))).to(torch.int32)       # an all-zero weight has no range to leave
+
+
 def h2_pack(x, scale=A_SCALE_F16X3):
     """(..., C) fp32, C % 8 == 0 -> the EMAGE_H2 image (csrc/h2.h) as a float32-typed tensor of the same shape: every group of
     8 columns becomes [8 fp16 hi | 8 fp16 lo] with x * scale = hi + lo.  Host-side helper (weights, tests, tools); on the hot
@@ -655,11 +667,14 @@ def dropout_mask(out, p, seed, mask_id, step):
     training steps draw fresh masks on every replay).  See include/emage_hip.h: emage_dropout_mask."""
     _dev(out)
     assert out.dtype == torch.float32 and out.is_contiguous()
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    if seed >= 1 << 63:           # the op schema's `int` is a signed 64-bit word: pass the same 64 bits in two's complement
+        seed -= 1 << 64
     if torch.is_tensor(step):
         assert step.dtype == torch.int32 and step.numel() == 1
-        _dropout_mask(out, float(p), int(seed), int(mask_id), step, 0)
+        _dropout_mask(out, float(p), seed, int(mask_id), step, 0)
     else:
-        _dropout_mask(out, float(p), int(seed), int(mask_id), None, int(step))
+        _dropout_mask(out, float(p), seed, int(mask_id), None, int(step))
     return out
 
 
@@ -704,22 +719,25 @@ class AdamTable:
 
 
 @_op("adam_multi", "(Tensor table, Tensor block_tensor, Tensor block_chunk, int n_blocks, Tensor? step_dev, int step, float lr, float beta1, float beta2, "
-                   "float eps, float weight_decay, float grad_scale, bool zero_grad) -> ()")
-def _adam_multi(table, block_tensor, block_chunk, n_blocks, step_dev, step, lr, beta1, beta2, eps, weight_decay, grad_scale, zero_grad):
+                   "float eps, float weight_decay, float grad_scale, bool zero_grad, Tensor? skip) -> ()")
+def _adam_multi(table, block_tensor, block_chunk, n_blocks, step_dev, step, lr, beta1, beta2, eps, weight_decay, grad_scale, zero_grad, skip):
     check(_lib.load().emage_adam_multi(_ptr(table), _ptr(block_tensor), _ptr(block_chunk), n_blocks, _ptr(step_dev), step, lr, beta1, beta2, eps,
-                                       weight_decay, grad_scale, int(zero_grad), _stream()), "adam_multi")
+                                       weight_decay, grad_scale, int(zero_grad), _ptr(skip), _stream()), "adam_multi")
 
 
-def adam_multi(tab: "AdamTable", step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, zero_grad=False):
+def adam_multi(tab: "AdamTable", step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, zero_grad=False, skip=None):
     """torch.optim.Adam's update of every tensor of `tab` in ONE launch (include/emage_hip.h: emage_adam_multi); `step` an int or a one-element
-    int32 device tensor."""
+    int32 device tensor.  skip: one int32 on the device — non-zero (a count of non-finite gradient words) leaves parameters and moments
+    untouched (the gradients are still cleared when zero_grad)."""
     _dev(tab.table)
+    if skip is not None:
+        assert skip.dtype == torch.int32 and skip.numel() == 1 and skip.is_cuda
     if torch.is_tensor(step):
         _adam_multi(tab.table, tab.block_tensor, tab.block_chunk, tab.n_blocks, step, 0, float(lr), float(beta1), float(beta2), float(eps),
-                    float(weight_decay), float(grad_scale), bool(zero_grad))
+                    float(weight_decay), float(grad_scale), bool(zero_grad), skip)
     else:
         _adam_multi(tab.table, tab.block_tensor, tab.block_chunk, tab.n_blocks, None, int(step), float(lr), float(beta1), float(beta2), float(eps),
-                    float(weight_decay), float(grad_scale), bool(zero_grad))
+                    float(weight_decay), float(grad_scale), bool(zero_grad), skip)
 
 
 @_op("layernorm", "(int dtype, Tensor x, Tensor gamma, Tensor beta, float eps, Tensor? add, Tensor(a!)? y_f32, Tensor(b!)? y) -> ()")

@@ -39,6 +39,8 @@ class ClipRunner:
             raise RuntimeError("ClipRunner needs the models on an MI355X device")
         if batch % sub_batches:
             raise ValueError("batch must be divisible by sub_batches")
+        if sub_batches > 1 and on_overflow != "raise":
+            raise ValueError("on_overflow='fp32' needs sub_batches=1 (the exact-fp32 re-run is built per single-graph runner)")
         self.device, self.batch, self.sub = dev, batch, sub_batches
         self.children, self.streams = [], []
         if sub_batches > 1:
@@ -159,8 +161,12 @@ class ClipPipeline:
     slot i % depth while earlier batches are still in flight.  A batch is a chain of ~300 DEPENDENT launches (the autoregressive
     windows; the cross-attention stack waits for the waveform features), each with a ramp and a drain during which most of the
     chip idles; consecutive batches are independent, so the next batch's kernels fill those gaps.  Results are returned in
-    submission order; every batch is complete (poses / expressions / translation in its slot's pinned host buffers, health
-    counter checked) when `collect()` hands it out."""
+    submission order; every batch is complete (poses / expressions / translation in pinned host buffers, health counter checked)
+    when `collect()` hands it out.
+
+    Host buffers: `depth + 1` sets in rotation, submission i writes set i % (depth + 1) — never the set of a batch that is still in
+    flight or that the same `submit()` call is handing out (the slot's own buffers were overwritten by the batch launched
+    right behind the one returned).  Arrays handed out stay valid until the NEXT `submit()` call."""
 
     def __init__(self, model, vq_model, batch: int, n_samples: int, depth: int = 2, use_graph: bool = True):
         self.runners = [ClipRunner(model, vq_model, batch, n_samples, use_graph=use_graph) for _ in range(depth)]
@@ -168,7 +174,10 @@ class ClipPipeline:
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
         self.done = [torch.cuda.Event() for _ in range(depth)]
         self.depth, self.frames_out, self.batch = depth, self.runners[0].frames_out, batch
-        self._next, self._inflight = 0, []
+        r0 = self.runners[0]
+        self.host_sets = [(tuple(torch.empty(h.shape, dtype=h.dtype, pin_memory=True) for h in r0.host),
+                           torch.zeros(1, dtype=torch.int32, pin_memory=True)) for _ in range(depth + 1)]
+        self._next, self._inflight, self._submitted = 0, [], 0
 
     def submit(self, audio=None, speaker_id=None):
         """Launch one batch (audio (B, L) float32 on the device or in pinned host memory); blocks only when `depth` batches are
@@ -176,25 +185,33 @@ class ClipPipeline:
         ready = self.collect() if len(self._inflight) == self.depth else None
         slot = self._next
         self._next = (slot + 1) % self.depth
+        hset = self._submitted % (self.depth + 1)
+        self._submitted += 1
         r, s = self.runners[slot], self.streams[slot]
+        host, flag = self.host_sets[hset]
         s.wait_stream(torch.cuda.current_stream(self.device))       # the caller's writes to `audio` are ordered before the copy
         with torch.cuda.stream(s):
             r.run_device(audio, speaker_id)
-            r._to_host(r.host)
-            r.nonfinite_host.copy_(r.nonfinite, non_blocking=True)
+            r._to_host(host)
+            flag.copy_(r.nonfinite, non_blocking=True)
             self.done[slot].record(s)
-        self._inflight.append(slot)
+        self._inflight.append((slot, hset))
         return ready
 
     def collect(self):
-        """Wait for the OLDEST batch in flight; returns its (poses, expressions, trans) numpy arrays (views of the slot's pinned
-        buffers, valid until that slot is reused `depth` submissions later)."""
-        slot = self._inflight.pop(0)
+        """Wait for the OLDEST batch in flight; returns its (poses, expressions, trans) numpy arrays (views of pinned buffers, valid
+        until the next `submit()` call)."""
+        slot, hset = self._inflight.pop(0)
         self.done[slot].synchronize()
-        self.runners[slot]._raise_if_nonfinite()
-        return tuple(h.numpy() for h in self.runners[slot].host)
+        host, flag = self.host_sets[hset]
+        r = self.runners[slot]
+        r.nonfinite_host.copy_(flag)
+        r._raise_if_nonfinite()
+        return tuple(h.numpy() for h in host)
 
     def drain(self):
+        """Collect everything in flight -> list of result tuples in submission order (the batches in flight use distinct host sets: all of
+        them stay valid until the next `submit()`)."""
         out = []
         while self._inflight:
             out.append(self.collect())

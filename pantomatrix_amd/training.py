@@ -169,6 +169,7 @@ class TrainForward:
         self.h2_backward = model.precision == "f16x3"
         self.grad_scale = 1024.0
         self._w_scale, self._wt_cache = {}, {}
+        self.range_flag = None          # int32 device counter: transposed-weight operands (backward dX) whose cached scale no longer fits
         self.tape = None
         self.param_grads = {}
         self.grad_views = None          # name -> preallocated fp32 gradient tensor (views of the exchange buckets, training.Trainer)
@@ -318,12 +319,8 @@ class TrainForward:
         key = ("conv",) + tuple(wn for wn, _ in origins)
         hit = self._wt_cache.get(key)
         if hit is None:
-            import math
             wflat = torch.cat([w.permute(0, 2, 1).reshape(w.shape[0], kc) for w in ws], 0).contiguous()          # (N, taps*cin), taps major
-            wsc = self._w_scale.get(key)
-            if wsc is None:
-                mx = float(wflat.abs().max())
-                wsc = self._w_scale[key] = 2.0 ** (11 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+            wsc = self._backward_scale(key, wflat)
             hit = self._wt_cache[key] = (ops.h2_cast(wflat, _rup(n), scale=wsc / 16.0, transpose=True), wsc)       # (taps*cin, rup64(N))
         w_t, wsc = hit
         np_ = _rup(n)
@@ -468,19 +465,37 @@ class TrainForward:
             ops.gemm(F32, dpre, w_t, None, None, None, dx, None, None, n=k, cp=n)                                        # dX = dpre W
             tape.add(x, dx, cols=k)
 
+    def _backward_scale(self, key, w):
+        """Power-of-two scale of a backward weight operand: chosen at the first use of `key` (one read-back: max |w| into [2^11, 2^12)) and
+        kept, so that later steps — and a captured step — convert without a host round trip.  Every later use checks ON THE DEVICE that
+        max |w| * scale is still inside [2^10, 2^14) (`ops.f16_scale_out_of_range`; the fp16 hi plane overflows at 2^16) and counts a
+        miss in `range_flag`, which `Trainer` reads with the losses and answers by re-deriving the scales (`reset_scales`)."""
+        ws = self._w_scale.get(key)
+        if ws is None:
+            import math
+            mx = float(w.abs().max())
+            ws = self._w_scale[key] = 2.0 ** (11 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+        elif w.numel():
+            if self.range_flag is None:
+                self.range_flag = torch.zeros((), dtype=torch.int32, device=w.device)
+            self.range_flag += ops.f16_scale_out_of_range(w, ws)
+        return ws
+
+    def reset_scales(self):
+        """Forget the cached operand scales (backward weight operands here, the forward's packed operands in the model): the next
+        forward chooses them afresh from the current weights."""
+        self._w_scale, self._wt_cache, self.range_flag = {}, {}, None
+        self.model.invalidate_packed(reset_scales=True)
+        self._pcache = None
+
     def _weight_t_h2(self, cx, key, n, k):
         """The transposed weight of a Linear as an EMAGE_H2 operand, (K, rup64(N)) holding w * w_scale: (image, w_scale); built once per
-        forward and key.  The power-of-two scale is fixed at the first use of the key (max |w| into [2^11, 2^12): a weight may grow
-        16x before its fp16 planes overflow, which the trainer's non-finite check would report)."""
+        forward and key, scale from `_backward_scale`."""
         hit = self._wt_cache.get(key)
         if hit is not None:
             return hit
         w32 = torch.cat([self._param(wn)[rs] for wn, _bn, rs in cx.pk.origin[key]], 0).float().contiguous()            # (N, K)
-        ws = self._w_scale.get(key)
-        if ws is None:
-            import math
-            mx = float(w32.abs().max())
-            ws = self._w_scale[key] = 2.0 ** (11 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
+        ws = self._backward_scale(key, w32)
         img = ops.h2_cast(w32, _rup(n), scale=ws / 16.0, transpose=True)              # h2 images carry a fixed x16: the rest of the scale goes in front
         self._wt_cache[key] = (img, ws)
         return img, ws
@@ -835,13 +850,9 @@ def train_forward(model, audio, speaker_id, masked_motion, mask, use_audio=True)
     if fwd is None:
         fwd = model.__dict__["_train_fwd"] = TrainForward(model)
         model.__dict__["_train_calls"] = 0
-        model.__dict__["_param_versions"] = None
+    # an optimiser step (or any in-place edit of a parameter / BatchNorm buffer) since the last forward is seen by `model._engine()`
+    # itself (`_version_stamp`), in train and in eval mode: the packed operands are rebuilt from the current parameters
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-    versions = tuple(p._version for _n, p in named)
-    if versions != model.__dict__["_param_versions"]:     # an optimiser step (or any in-place edit) since the last forward: re-pack
-        model.invalidate_packed()
-        fwd._pcache = None
-        model.__dict__["_param_versions"] = versions
     override = getattr(model, "dropout_masks_override", None)
     masks = override.pop(0) if override else None
     model.__dict__["_train_calls"] += 1
@@ -915,9 +926,22 @@ class Trainer:
     Dropout masks: `dropout_masks` (three lists, the parity tests) or None = drawn on the device (`ops.dropout_mask`, seeded by `seed`).
     `grad_hook(param_grads)` still runs between backward and the update (tests spy on it)."""
 
-    def __init__(self, model, vq, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, sync_bn=False, group=None, seed=0, exchange=True):
-        """exchange=False: no built-in gradient all-reduce even in a multi-process run (a `grad_hook` may do it: `dist.gradient_allreduce_hook`)."""
+    def __init__(self, model, vq, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, sync_bn=False, group=None, seed=0, exchange=True,
+                 on_nonfinite="raise"):
+        """exchange=False: no built-in gradient all-reduce even in a multi-process run (a `grad_hook` may do it: `dist.gradient_allreduce_hook`).
+
+        Health of a step (the f16x3 backward runs on fp16 planes of `grad_scale` x dY and of scaled weights: an overflow turns into
+        inf / NaN): `emage_count_nonfinite` over the four gradient buckets runs INSIDE the step (eager and captured), in front of Adam, and
+        Adam takes the count as its skip word — a poisoned step never reaches the parameters, the moments or the BatchNorm buffers.  The
+        count travels to the host with the losses; on_nonfinite = "raise": FloatingPointError (the state is that of the previous step);
+        "skip": the step is dropped (`skipped_steps`), `grad_scale` is halved and training goes on (a captured step is re-captured with
+        the new scale: it is a launch argument) — the step-skip of loss-scaled mixed-precision training.  Weight operand scales are
+        power-of-two constants chosen once; every re-packing checks on the device that max |w| x scale is still in [2^10, 2^14) and the
+        trainer re-derives the scales behind the step that reports a miss (two doublings before an fp16 plane could overflow)."""
         from . import dist as pdist
+        if on_nonfinite not in ("raise", "skip"):
+            raise ValueError("on_nonfinite must be 'raise' or 'skip'")
+        self.on_nonfinite, self.skipped_steps, self.rescaled = on_nonfinite, 0, 0
         self.exchange = bool(exchange)
         self.fwd, self.vq = TrainForward(model, sync_bn=sync_bn, group=group), vq
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -932,6 +956,8 @@ class Trainer:
         self.exchange_log = []                            # (event, bucket or tape position) of the last step: what the overlap tests read
         self.steps_done = 0
         self._adam = None
+        self._graph, self._recapture_pending = None, False
+        self.health = torch.zeros(1, dtype=torch.int32, device=model.device)       # non-finite gradient words of the last step (Adam's skip word)
 
     def _world(self):
         import torch.distributed as tdist
@@ -998,6 +1024,10 @@ class Trainer:
             log.append(("wait",))
         if grad_hook is not None:
             grad_hook(grads)
+        # health: inf / NaN among the (exchanged) gradients -> Adam's skip word.  After the exchange, so every rank sees the same count
+        self.health.zero_()
+        for flat in buckets.flat:
+            ops.count_nonfinite(flat, self.health)
         params = model._flat_params()                     # detached views of the nn.Parameters: updated in place
         if self._adam is None:
             quads = []
@@ -1010,21 +1040,71 @@ class Trainer:
         for st in self.state.values():
             st["step"] = self.steps_done
         ops.adam_multi(self._adam, self.steps_done if step_counter is None else step_counter, self.lr, self.betas[0], self.betas[1], self.eps,
-                       self.weight_decay, grad_scale=1.0 / world, zero_grad=True)
+                       self.weight_decay, grad_scale=1.0 / world, zero_grad=True, skip=self.health)
+        skipped = self.health[0] > 0                      # device scalar: the buffers below keep their values in a skipped step
         for name, v in stats.items():                     # BatchNorm running statistics after the three forwards
             if name in params:
-                params[name].copy_(v.to(params[name].dtype))
+                params[name].copy_(torch.where(skipped, params[name], v.to(params[name].dtype)))
+        if step_counter is not None:                      # a skipped step does not count (Adam's bias correction, the mask generator's step)
+            step_counter.sub_(skipped.to(step_counter.dtype))
         return out, ws
+
+    def _deferred_range_check(self):
+        """Context: `model._engine()` leaves the operand-scale flags of a re-packing unread (no host synchronisation in front of a step);
+        `_finish` reads them with the losses."""
+        import contextlib
+        model = self.fwd.model
+
+        @contextlib.contextmanager
+        def cm():
+            model.__dict__["_defer_range_check"] = True
+            try:
+                yield
+            finally:
+                model.__dict__["_defer_range_check"] = False
+        return cm()
+
+    def _range_flags(self):
+        """The device counters of weight operands whose cached power-of-two scale no longer fits (forward packing, backward operands)."""
+        pk = self.fwd.model._packed
+        return [f for f in (self.fwd.range_flag, pk.range_flag if pk is not None else None) if f is not None]
+
+    def _finish(self, out, ws):
+        """Host side of a step: losses, the health word, the range flags (one synchronisation) -> loss dict; raises / skips / re-derives
+        scales as `__init__` describes.  Returns (losses, recapture needed)."""
+        res = {k: float(v) for k, v in out.items()}
+        bad = int(self.health[0])
+        stale = any(int(f) != 0 for f in self._range_flags())
+        ops.loss_check(ws)
+        res["all"] = sum(res.values())
+        recapture = False
+        if stale:                                         # results of this step are fine (margin of 4x); the NEXT packing takes fresh scales
+            self.rescaled += 1
+            self.fwd.reset_scales()
+            recapture = self._recapture_pending = True
+        if bad or not all(v == v and abs(v) != float("inf") for v in res.values()):
+            self.steps_done -= 1
+            for st in self.state.values():
+                st["step"] = self.steps_done
+            msg = (f"training step {self.steps_done + 1}: {bad} non-finite gradient words (losses {res}) — the update was skipped on the device, "
+                   f"parameters / Adam moments / BatchNorm buffers are those of the previous step (precision {self.fwd.model.precision!r}, "
+                   f"grad_scale {self.fwd.grad_scale:g}: an fp16 plane of the split-fp16 backward overflowed, or the forward met an activation beyond "
+                   "|x| < 4094); lower the loss scale (on_nonfinite='skip' halves it) or train with set_precision('fp32')")
+            if self.on_nonfinite == "raise":
+                raise FloatingPointError(msg)
+            self.skipped_steps += 1
+            self.fwd.grad_scale *= 0.5
+            recapture = self._recapture_pending = True
+        return res, recapture
 
     def step(self, batch, iteration=0, dropout_masks=None, random_mask=None, grad_hook=None):
         """One optimisation step -> dict of the six losses + "all".  `iteration` is accepted for signature compatibility with the
         reference's train_val_fn (T:132) and unused: the caller computes the mask ratio and passes `random_mask` (T:163-165)."""
-        out, ws = self._device_step(batch, dropout_masks, random_mask, grad_hook)
+        with self._deferred_range_check():                # the operand-scale flags are read HERE with the losses, not at packing time
+            out, ws = self._device_step(batch, dropout_masks, random_mask, grad_hook)
+        res, _ = self._finish(out, ws)
         self.fwd.model.invalidate_packed()                # the MFMA operand copies are rebuilt from the updated parameters
         self.fwd._pcache = None
-        res = {k: float(v) for k, v in out.items()}
-        ops.loss_check(ws)
-        res["all"] = sum(res.values())
         return res
 
     # ---- the step as ONE hipGraph -------------------------------------------------------------------------------------------------
@@ -1050,36 +1130,56 @@ class Trainer:
                     raise RuntimeError("Trainer.capture: dropout masks must be contiguous fp32 tensors on the device (they are the graph's input buffers)")
         params = model._flat_params()
         saved = {k: v.clone() for k, v in params.items()}
-        self._device_step(batch, dropout_masks, random_mask)          # warm-up: lazy initialisation inside the library / the allocator, the exchange schedule
+        done = self.steps_done                                         # a RE-capture (new loss scale / operand scales) keeps the optimiser state
+        moments = {k: (st["exp_avg"].clone(), st["exp_avg_sq"].clone()) for k, st in self.state.items()}
+        self._graph = None
+        with self._deferred_range_check():
+            self._device_step(batch, dropout_masks, random_mask)      # warm-up: lazy initialisation inside the library / the allocator, the exchange schedule
         torch.cuda.synchronize(dev)
         for k, v in saved.items():
             params[k].copy_(v)
-        for st in self.state.values():                                 # the moments live OUTSIDE the graph's memory (created by the warm-up step)
-            st["exp_avg"].zero_()
-            st["exp_avg_sq"].zero_()
-            st["step"] = 0
-        self.steps_done = 0
-        self._step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        for k, st in self.state.items():                               # the moments live OUTSIDE the graph's memory (created by the first warm-up step)
+            if k in moments:
+                st["exp_avg"].copy_(moments[k][0])
+                st["exp_avg_sq"].copy_(moments[k][1])
+            else:
+                st["exp_avg"].zero_()
+                st["exp_avg_sq"].zero_()
+            st["step"] = done
+        self.steps_done = done
+        self._step_counter = torch.full((1,), done, dtype=torch.int32, device=dev)
         self._graph_inputs = (batch, random_mask, dropout_masks)       # the graph reads these buffers at every replay: keep them alive
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             model.invalidate_packed()                                  # so that the packing of the current parameters is part of the graph
             fwd._pcache = None
             self._step_counter.add_(1)
             self._graph_out, self._graph_ws = self._device_step(batch, dropout_masks, random_mask, step_counter=self._step_counter)
-        self.steps_done = 0
+        self._graph, self._recapture_pending = graph, False
+        self._graph_operands = model._packed                           # what the captured launches read (and re-write at every replay)
+        model.invalidate_packed()                                      # ... and nobody else: they hold the weights BEFORE the replay's update
+        self.steps_done = done
         for st in self.state.values():
-            st["step"] = 0
+            st["step"] = done
         return self
 
     def replay(self):
-        """One captured step on the current contents of the captured input buffers -> the loss dict of `step()`."""
+        """One captured step on the current contents of the captured input buffers -> the loss dict of `step()`.  A step whose health word
+        or operand-scale flags call for it (see `__init__`) is followed by a re-capture over the same input buffers."""
+        if self._graph is None:
+            raise RuntimeError("Trainer.replay: capture() first")
+        if self._recapture_pending:                       # a step that raised behind a scale reset: the graph still carries the old scales
+            self.capture(*self._graph_inputs)
         self._graph.replay()
-        n = int(self._step_counter)
-        self.steps_done = n
+        self.steps_done = int(self._step_counter) + (1 if int(self.health[0]) else 0)      # _finish() takes a skipped step back off
         for st in self.state.values():
-            st["step"] = n
-        res = {k: float(v) for k, v in self._graph_out.items()}
-        ops.loss_check(self._graph_ws)
-        res["all"] = sum(res.values())
+            st["step"] = self.steps_done
+        model = self.fwd.model
+        model._packed = self._graph_operands              # the flags of the graph's own packing
+        try:
+            res, recapture = self._finish(self._graph_out, self._graph_ws)
+        finally:
+            model.invalidate_packed()                     # a replay moves the parameters without touching their version counters: an eval
+        if recapture:                                     # forward behind it must re-pack (and never reads the graph's operand set)
+            self.capture(*self._graph_inputs)
         return res

@@ -306,12 +306,15 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1.5e-4, beta1=0.9, beta
     param.copy_(param - (lr / b1) * exp_avg / (exp_avg_sq.sqrt() / math.sqrt(b2) + eps))
 
 
-def adam_multi(tab, step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, zero_grad=False):
-    """emage_adam_multi == emage_adam_step on every tensor of the table (grad * grad_scale first, gradient cleared behind the update)."""
+def adam_multi(tab, step, lr=1.5e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, zero_grad=False, skip=None):
+    """emage_adam_multi == emage_adam_step on every tensor of the table (grad * grad_scale first, gradient cleared behind the update);
+    a non-zero `skip` word leaves parameters and moments untouched."""
     mark = len(CALLS)
     step = int(step)
+    skipped = skip is not None and int(skip) != 0
     for p, g, m, v in tab.keep:
-        adam_step(p, g * grad_scale, m, v, step, lr, beta1, beta2, eps, weight_decay)
+        if not skipped:
+            adam_step(p, g * grad_scale, m, v, step, lr, beta1, beta2, eps, weight_decay)
         if zero_grad:
             g.zero_()
     del CALLS[mark:]
@@ -673,23 +676,14 @@ _NAMES = ["im2col_t_h2", "h2_cast", "adam_multi", "dropout_mask", "count_nonfini
 def installed():
     """Patch pantomatrix_amd.ops with the CPU restatements and lift the device check, for the duration of a test."""
     saved = {n: getattr(ops, n) for n in _NAMES}
-    saved_engine = M._EmageModule._engine
-
-    def _engine(self, h2=None):
-        want_h2 = self._dt == F16X3 and self._supports_h2 and (self.split_acts if h2 is None else h2)
-        dt = H2 if want_h2 else self._dt
-        if self._packed is None or self._packed.dt != dt:
-            self._packed = M._Packed(self._flat_params(), self.device, dt, self.__dict__.setdefault("_scale_caches", {}).setdefault((str(self.device), dt), {}))
-            self._pack(self._packed)
-        return self._packed
-
+    saved_require = M._EmageModule._require_device      # the one thing lifted: `_engine()` itself (version stamp, operand-scale flags) is the product's
     try:
         for n in _NAMES:
             setattr(ops, n, globals()[n])
-        M._EmageModule._engine = _engine
+        M._EmageModule._require_device = staticmethod(lambda dev: None)
         CALLS.clear()
         yield
     finally:
         for n, f in saved.items():
             setattr(ops, n, f)
-        M._EmageModule._engine = saved_engine
+        M._EmageModule._require_device = saved_require

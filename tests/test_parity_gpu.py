@@ -391,3 +391,31 @@ def test_clip_runner_graph_matches_reference_on_tail_windows(golden_dir, frames)
     codes = model.infer_codes(audio.to(DEV), torch.zeros(1, 1, dtype=torch.long, device=DEV), vq)
     for p in ("upper", "hands", "lower"):
         assert np.array_equal(codes[f"{p}_index"].cpu().numpy(), g[f"index_{p}"].astype(np.int64)), p
+
+
+def test_clip_pipeline_results_survive_the_next_submission(x3_models):
+    """ADVICE round 3 (medium #3): with `depth` batches in flight `submit()` handed out views of the very host buffers the batch it
+    launched next was about to overwrite.  Different audio per batch (the bench's identical batches could not see it): every result
+    handed out — by `submit()` and by `drain()` — equals the single runner's result for ITS audio, checked after the following
+    submission has completed."""
+    from pantomatrix_amd.runtime import ClipPipeline, ClipRunner
+    model, vq = x3_models
+    n = synthetic.samples_for_frames(70)
+    audios = [synthetic.synthetic_audio(2, n, seed=100 + i).to(DEV) for i in range(5)]
+    single = ClipRunner(model, vq, 2, n)
+    want = [tuple(a.copy() for a in single(a)) for a in audios]
+    pipe = ClipPipeline(model, vq, 2, n, depth=2)
+    got = []
+    for a in audios:
+        r = pipe.submit(a)
+        if r is not None:
+            torch.cuda.synchronize()                    # the batch launched by this submit() has finished writing ITS host set
+            got.append(tuple(x.copy() for x in r))
+    got += [tuple(x.copy() for x in r) for r in pipe.drain()]
+    assert len(got) == len(want)
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        for a, b in zip(g_, w_):
+            assert np.array_equal(a, b), i
+    assert not np.array_equal(want[0][0], want[1][0])
+    with pytest.raises(ValueError, match="sub_batches"):
+        ClipRunner(model, vq, 2, n, sub_batches=2, on_overflow="fp32")

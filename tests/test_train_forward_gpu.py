@@ -433,3 +433,138 @@ def test_sync_batchnorm_on_one_device_equals_plain_batchnorm(golden_dir):
         assert float((g0[k] - g1[k]).norm()) <= tol * float(g0[k].norm()) + 1e-7, k
     for k in b0:
         assert float((b0[k] - b1[k]).abs().max()) <= 1e-5 * max(1.0, float(b0[k].abs().max())), k
+
+
+def _check_step_against(g, losses, params, before, grads=None, what=""):
+    """Losses, (optionally) gradient norms, and post-Adam parameter sums of a device step against a reference-step golden; returns
+    the worst ratios to the allowances (printed by the callers: how close to the bound the step sits)."""
+    worst = dict(loss=0.0, norm=0.0, psum=0.0)
+    for k in ("rec_seed", "cls_seed", "rec_audio", "cls_audio", "rec_mask", "cls_mask", "all"):
+        want = float(g["loss_" + k])
+        r = abs(losses[k] - want) / (2e-4 * max(1.0, abs(want)))
+        worst["loss"] = max(worst["loss"], r)
+        assert r < 1, (what, k, losses[k], want)
+    gmax, lr, checked = float(np.max(g["grad_norms"])), 1.5e-4, 0
+    for n, norm, shadowed, s in zip([str(x) for x in g["grad_names"]], g["grad_norms"], g["shadowed"], g["param_sum_after"]):
+        if shadowed:
+            continue
+        wav = n.startswith(("audio_encoder_face.", "audio_encoder_body."))
+        if grads is not None:
+            r = abs(grads[n] - float(norm)) / ((3e-2 if wav else 5e-3) * float(norm) + 1e-6 * gmax)
+            worst["norm"] = max(worst["norm"], r)
+            assert r <= 1, (what, n, grads[n], float(norm))
+        p = params[n]
+        r = abs(float(p.double().sum()) - float(s)) / (3e-5 * p.numel() ** 0.5 + 2e-3 + (0.3 * lr * p.numel() if wav else 0))
+        worst["psum"] = max(worst["psum"], r)
+        assert r <= 1, (what, n, float(p.double().sum()), float(s))
+        assert not torch.equal(p, before[n]), (what, n)
+        checked += 1
+    assert checked > 440
+    return worst
+
+
+def test_baseline_batch_step_matches_the_reference(golden_dir):
+    """VERDICT round 3, next #1a: BASELINE configs[2] at its PER-GPU BATCH — 56 clips x 64 frames (BatchNorm couples the clips; the f16x3
+    weight gradients meet in split-K fp32 atomics) — against the REAL reference's step (tests/golden/train_step_b56.npz, generated by
+    tests/golden/make_golden_train.py 56): the eager f16x3 step (seven losses, every gradient norm, post-Adam parameter sums) and the
+    step as ONE hipGraph replay, captured twice on fresh models to bound the run-to-run jitter of the atomic accumulation order."""
+    g = np.load(os.path.join(golden_dir, "train_step_b56.npz"))
+    bs = int(g["bs"])
+    batch, oracle_losses, masks, random_mask, _ = tc.oracle_step(int(g["seed"]), int(g["iteration"]), bs=bs)      # CPU oracle: replays the reference's draws
+    for k, v in oracle_losses.items():                           # the restatement itself at this batch size
+        assert abs(v - float(g["loss_" + k])) <= 2e-4 * max(1.0, abs(float(g["loss_" + k]))), k
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    masks = [[m.to(DEV).contiguous() for m in fm] for fm in masks]
+    random_mask = random_mask.to(DEV)
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    before = {k: v.clone() for k, v in model._flat_params().items()}
+    norms = {}
+    losses = training.Trainer(model, vq).step(batch, int(g["iteration"]), masks, random_mask,
+                                              grad_hook=lambda gr: norms.update({k: float(v.norm()) for k, v in gr.items()}))
+    worst = _check_step_against(g, losses, model._flat_params(), before, norms, "eager")
+    print(f"eager f16x3 step at {bs} clips vs the reference: worst fraction of the allowance: {worst}")
+    del model
+    runs = []
+    for rep in range(2):
+        model, _ = common.product_models(precision="f16x3", device=DEV)
+        trainer = training.Trainer(model, vq).capture(batch, random_mask, masks)
+        lg = trainer.replay()
+        worst = _check_step_against(g, lg, model._flat_params(), before, None, f"captured #{rep}")
+        assert trainer.steps_done == 1 and trainer.skipped_steps == 0 and trainer.rescaled == 0 and int(trainer.health) == 0
+        runs.append((lg, {k: float(v.double().sum()) for k, v in model._flat_params().items() if v.is_floating_point()}))
+        print(f"captured f16x3 step #{rep} at {bs} clips vs the reference: {worst}")
+        del trainer, model
+        torch.cuda.empty_cache()
+    (l0, s0), (l1, s1) = runs
+    jitter = max(abs(l0[k] - l1[k]) / max(1.0, abs(l0[k])) for k in l0)
+    assert jitter < 1e-6, jitter                                   # forward: no atomics; the losses of step 1 do not depend on dW order at all
+    drift = max(abs(s0[k] - s1[k]) for k in s0)
+    print(f"two captures of the same step: loss jitter {jitter:.2e}, largest parameter-sum difference {drift:.3e}")
+    assert drift < 2e-3          # Adam's first step is lr * sign-like: an entry whose gradient is atomic-order noise may move the other way
+
+
+def test_captured_step_health_and_operand_rescaling(golden_dir):
+    """VERDICT round 3, next #1b: (i) a weight pushed out of the range its cached power-of-two operand scale was chosen for is reported by
+    the device-side flag of the graph's own re-packing; `replay()` re-derives the scales and re-captures, keeping the optimiser state;
+    (ii) a weight large enough to overflow the fp16 planes of the backward poisons the gradients: the in-graph count of non-finite
+    gradient words makes Adam skip, nothing is written, and the step raises."""
+    g = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    batch, _, masks, random_mask, _ = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    masks = [[m.to(DEV).contiguous() for m in fm] for fm in masks]
+    random_mask = random_mask.to(DEV)
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    trainer = training.Trainer(model, vq).capture(batch, random_mask, masks)
+    l1 = trainer.replay()
+    assert trainer.steps_done == 1 and trainer.rescaled == 0
+    m1 = trainer.state["face_out_proj.weight"]["exp_avg"].clone()
+    name = "audio_motion_cross_attn.layers.3.linear1.weight"
+    with torch.no_grad():
+        model._flat_params()[name].mul_(4.0)                        # 4x: max |w| x cached scale in [2^14, 2^15) — finite in fp16, flagged
+    l2 = trainer.replay()                                            # this step is still computed correctly; behind it the scales are re-derived
+    assert trainer.rescaled == 1 and trainer.steps_done == 2 and all(np.isfinite(v) for v in l2.values())
+    assert not torch.equal(trainer.state["face_out_proj.weight"]["exp_avg"], m1)
+    m2 = trainer.state["face_out_proj.weight"]["exp_avg"].clone()
+    l3 = trainer.replay()                                            # the re-captured graph: same state, fresh scales
+    assert trainer.rescaled == 1 and trainer.steps_done == 3 and all(np.isfinite(v) for v in l3.values())
+    assert not torch.equal(trainer.state["face_out_proj.weight"]["exp_avg"], m2)
+    # (ii) overflow: 2^12 x on top pushes the hi plane past 65504 -> inf - inf = NaN in the products
+    snap = {k: v.clone() for k, v in model._flat_params().items()}
+    with torch.no_grad():
+        model._flat_params()[name].mul_(4096.0)
+    snap[name] = model._flat_params()[name].clone()
+    moments = {k: st["exp_avg"].clone() for k, st in trainer.state.items()}
+    with pytest.raises(FloatingPointError, match="non-finite gradient words"):
+        trainer.replay()
+    assert trainer.steps_done == 3
+    after = model._flat_params()
+    assert all(torch.equal(after[k], snap[k]) for k in snap)        # parameters and BatchNorm buffers untouched
+    assert all(torch.equal(trainer.state[k]["exp_avg"], moments[k]) for k in moments)
+    assert all(float(b.abs().max()) == 0.0 for b in trainer.buckets.flat)
+
+
+def test_train_then_eval_uses_the_updated_weights(golden_dir):
+    """ADVICE round 3 (medium #1): the reference's train / val loop — train-mode forward, backward, `optimizer.step()`, then
+    `model.eval(); model(...)` — on the device in the configuration where nothing else forced a re-pack (fp32 precision): the eval
+    forward after the update equals a fresh model loaded with the updated state dict."""
+    g = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    batch, _, masks, random_mask, _ = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
+    model, vq = common.product_models(precision="fp32", device=DEV)
+    audio, spk, motion, mask = (x.to(DEV) for x in common.window_inputs(2))
+    with torch.no_grad():
+        ev0 = model(audio, spk, motion, mask)                      # packs the eval operands (BatchNorm folded)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    model.dropout_masks_override = [[m.to(DEV) for m in masks[0]]]
+    out = model(batch["audio"].to(DEV), spk, motion, mask)
+    sum(v.square().mean() for v in out.values()).backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        ev1 = model(audio, spk, motion, mask)
+        fresh, _ = common.product_models(precision="fp32", device=DEV)
+        fresh.load_state_dict(model.state_dict())
+        ev2 = fresh(audio, spk, motion, mask)
+    for k in ev1:
+        assert torch.equal(ev1[k], ev2[k]), k
+        assert float((ev1[k] - ev0[k]).abs().max()) > 1e-4, k      # lr 1e-2 moved every head; the BatchNorm buffers moved too

@@ -15,11 +15,7 @@ from pantomatrix_amd import synthetic
 from pantomatrix_amd.configuration_emage_audio import EmageAudioConfig
 
 
-def train_batch(bs=2, t=64, seed=5):
-    g = torch.Generator().manual_seed(seed)
-    return dict(motion=0.3 * torch.randn(bs, t, 165, generator=g), audio=0.1 * torch.randn(bs, t * 16000 // 30, generator=g),
-                expressions=0.5 * torch.randn(bs, t, 100, generator=g), trans=0.1 * torch.randn(bs, t, 3, generator=g),
-                foot_contact=(torch.rand(bs, t, 4, generator=g) > 0.5).float())
+from tools.workloads import train_batch  # noqa: E402  (shared with bench.py and tests/golden/make_golden_train.py)
 
 
 def _oracle_step(iteration, seed):

@@ -73,31 +73,11 @@ def oracle_step(seed, iteration, bs=2):
 
 
 def _oracle_step(seed, iteration, bs=2):
-    """tro.train_step_losses with every forward's dropout masks and the random motion mask recorded:
-    -> (batch, loss dict of floats, [masks of forward 1, 2, 3], random_mask, BatchNorm buffers)."""
-    from test_train_oracle import train_batch
-    cfg = EmageAudioConfig(**common.cfg_dicts()[0])
-    _, vq = common.oracle_models()
-    sd = synthetic.audio_model_state(cfg, 0)
-    per_forward, motion_masks = [], []
-    orig = tro.forward_train
-
-    def spy(sd_, audio, spk, motion, mask, use_audio=True, p=tro.DROPOUT_P, new_stats=None):
-        masks = []
-        with recorded_masks(masks):
-            out = orig(sd_, audio, spk, motion, mask, use_audio=use_audio, p=p, new_stats=new_stats)
-        per_forward.append(masks)
-        motion_masks.append(mask.clone())
-        return out
-
-    tro.forward_train = spy
-    try:
-        torch.manual_seed(seed)
-        with torch.no_grad():
-            losses, stats = tro.train_step_losses(sd, vq, cfg, train_batch(bs=bs), iteration)
-    finally:
-        tro.forward_train = orig
-    return train_batch(bs=bs), {k: float(v) for k, v in losses.items()}, per_forward, motion_masks[1], stats
+    """The oracle's `train_step_losses` with every forward's dropout masks and the random motion mask recorded (tools/workloads.py,
+    shared with bench.py's training leg): -> (batch, loss dict of floats, [masks of forward 1, 2, 3], random_mask, BatchNorm buffers)."""
+    from tools import workloads
+    r = workloads.oracle_train_step_recorded(seed, iteration, bs=bs)
+    return r["batch"], r["losses"], r["masks"], r["random_mask"], r["stats"]
 
 
 def shard_masks(masks, lo, hi, batch):
