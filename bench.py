@@ -131,58 +131,44 @@ def result_line(precision, elapsed, steps, warmup, world, frames_per_step, batch
 def profile_kernels(runner, model, vq):
     """One extra, untimed pass of the SAME launch sequence the timed graph replays (`ClipRunner._step`: the lean code
     path), issued eagerly on ONE stream (no fork / join lanes) with a HIP-event pair around every kernel launch on that
-    stream.  A backlog of filler GEMMs is enqueued first so that the host runs ahead of the device: each event pair then
+    stream — through the op layer's measurement hook (`ops._TRACE`), which brackets every ACTUAL launch: single ops and the
+    grouped contractions of the lock-step chains (`emage_gemm_grouped`: one record per library launch, flops = the sum over its problems).
+    A backlog of filler GEMMs is enqueued first so that the host runs ahead of the device: each event pair then
     brackets exactly one kernel's device time (plus the event markers), not host launch latency.
-    Returns (records, families): records = [(tag, scope, ms, flops, bytes)]."""
+    Returns (records, marker_ms): records = [(tag, scope, ms, flops, bytes)]."""
     from pantomatrix_amd import ops, modeling_emage_audio as M
     from pantomatrix_amd._lib import BF16
-    records, saved, scope = [], {}, {"name": None}
+    records, scope = [], {"name": None}
 
-    def wrap(name, fn, cost):
-        def inner(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(*a, **k)
-            e1.record()
-            records.append((e0, e1, scope["name"]) + cost(a, k, r))
-            return r
-        return inner
-
-    def gemm_cost(a, k, r):
-        dtype, A = a[0], a[1]
-        n, cp, taps = k["n"], k["cp"], k.get("taps", 1)
-        m = k.get("m") or A.shape[0]
+    def gemm_cost(a, meta):
+        dtype, A, n, cp, taps, m = a[0], a[1], a[9], a[10], a[15], a[20]
         es = 2 if dtype == BF16 else 4
-        kk = k.get("k_real") or taps * cp                    # unpadded contraction length
+        kk = meta.get("k_real") or taps * cp                 # unpadded contraction length
         return ("emage_gemm", 2.0 * m * n * kk, float(m * cp * es + n * taps * cp * es + m * n * es))
 
-    def attn_cost(a, k, r):
+    def attn_cost(a, meta):
         dtype, b, h, tq, tk, hd = a[0], a[6], a[7], a[8], a[9], a[10]
         es = 2 if dtype == BF16 else 4
         return ("emage_attention", 4.0 * b * h * tq * tk * hd, float((2 * b * tq + 2 * b * tk) * h * hd * es))
 
-    def vq_cost(a, k, r):
+    def vq_cost(a, meta):
         z, cb = a[0], a[1]
         n, d = z.shape
         return ("emage_vq_argmin", 2.0 * n * cb.shape[0] * d, float(n * d * 4 + cb.shape[0] * d * 4 + n * 8))
 
     def generic_cost(tag):
-        def c(a, k, r):
-            byts = 0
-            for t in list(a) + list(k.values()) + (list(r) if isinstance(r, tuple) else [r]):
-                if torch.is_tensor(t):
-                    byts += t.numel() * t.element_size()
-            return ("emage_" + tag, 0.0, float(byts))
+        def c(a, meta):
+            return ("emage_" + tag, 0.0, float(sum(t.numel() * t.element_size() for t in a if torch.is_tensor(t))))
         return c
 
-    def slab_cost(a, k, r):
-        dtype, A, W = a[0], a[1], a[2]
+    def slab_cost(a, meta):
+        dtype, W, nseq, l, taps = a[0], a[2], a[7], a[8], a[9]
         c = W.shape[0]
-        rows = k["nseq"] * k["l"]
+        rows = nseq * l
         es = 2 if dtype == BF16 else 4
-        return ("emage_conv_slab", 2.0 * rows * c * k["taps"] * c, float(2 * rows * c * es + c * k["taps"] * c * es))
+        return ("emage_conv_slab", 2.0 * rows * c * taps * c, float(2 * rows * c * es + c * taps * c * es))
 
-    def block0_cost(a, k, r):
+    def block0_cost(a, meta):
         dtype, wav, w1, taps2, out = a[0], a[1], a[2], a[12], a[14]
         c, t1 = w1.shape
         rows = out.shape[0]
@@ -190,9 +176,29 @@ def profile_kernels(runner, model, vq):
         return ("emage_conv_slab", 2.0 * rows * c * taps2 * c + 2.0 * rows * 2 * c * t1, float(wav.numel() * 4 + rows * c * es))
 
     table = {"gemm": gemm_cost, "attention": attn_cost, "vq_argmin": vq_cost, "conv_slab": slab_cost, "wav_block0": block0_cost}
-    for nm in ("layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "argmax_logsoftmax", "wav_conv_in", "merge_parts",
-               "velocity_to_position"):
-        table[nm] = generic_cost(nm)
+
+    def cost_of(entry):
+        name, _op, a, meta = entry
+        return table.get(name, generic_cost(name))(a, meta)
+
+    class Tracer:
+        def tag(self):
+            return scope["name"]
+
+        def fire(self, kind, entries, launch):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = launch()
+            e1.record()
+            costs = [cost_of(e) for e in entries]
+            tags = {e[3].get("tag") for e in entries}
+            sc = tags.pop() if len(tags) == 1 else None
+            launches = ops.grouped_launch_count(entries) if kind == "gemm_grouped" else 1
+            # a grouped call that the library splits into several launches is booked as that many equal records
+            for _ in range(launches):
+                records.append((e0 if _ == 0 else None, e1 if _ == 0 else None, sc, costs[0][0], sum(c[1] for c in costs) / launches,
+                                sum(c[2] for c in costs) / launches, launches))
+            return r
 
     def scoped(fn, name):
         def inner(*a, **k):
@@ -207,9 +213,7 @@ def profile_kernels(runner, model, vq):
     concurrent = [p.concurrent for p in parts]
     layer_fns = {nm: getattr(M.EmageAudioModel, nm) for nm in ("_decoder_layer", "_encoder_layer", "_memory_kv")}
     try:
-        for nm, cost in table.items():
-            saved[nm] = getattr(ops, nm)
-            setattr(ops, nm, wrap(nm, saved[nm], cost))
+        ops._TRACE[0] = Tracer()
         for nm, fn in layer_fns.items():                    # the 16 transformer layers incl. their memory K/V projections
             setattr(M.EmageAudioModel, nm, scoped(fn, "transformer_blocks"))
         for p in parts:
@@ -228,13 +232,17 @@ def profile_kernels(runner, model, vq):
         torch.cuda.synchronize()
         marker_ms = float(np.median([a.elapsed_time(b) for a, b in empties]))
     finally:
-        for nm, fn in saved.items():
-            setattr(ops, nm, fn)
+        ops._TRACE[0] = None
         for nm, fn in layer_fns.items():
             setattr(M.EmageAudioModel, nm, fn)
         for p, c in zip(parts, concurrent):
             p.concurrent = c
-    return [(tag, sc, e0.elapsed_time(e1), flops, byts) for (e0, e1, sc, tag, flops, byts) in records], marker_ms
+    out, last_ms = [], 0.0
+    for e0, e1, sc, tag, flops, byts, launches in records:
+        if e0 is not None:
+            last_ms = e0.elapsed_time(e1) / launches
+        out.append((tag, sc, last_ms, flops, byts))
+    return out, marker_ms
 
 
 def serialized_graph_ms(model, vq, args, n_samples, audio, steps):
@@ -531,9 +539,10 @@ def build(precision, device, args):
     model.slab_convs = not args.no_slab_convs
     for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.split_acts = not args.no_split_acts
-    model.h2_residual = args.h2_residual
+    model.h2_residual = not args.f32_residual
     for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.concurrent = not args.no_concurrent
+        part.group_gemms = not args.no_group_gemms
     n_samples = synthetic.samples_for_frames(args.frames)
     runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph, main_priority=args.main_priority)
     return model, vq, runner, n_samples
@@ -560,7 +569,8 @@ def main():
     ap.add_argument("--gemm-dbg", type=int, default=0, help="experiments: emage_set_tuning key 1 mask (8: sc1 result stores, 16: nt)")
     ap.add_argument("--no-split-acts", action="store_true", help="A/B: float32 activations split inside every GEMM (EMAGE_F16X3) instead of pre-split EMAGE_H2 storage")
     ap.add_argument("--pipeline", type=int, default=1, help="also time the step with this many batches in flight (runtime.ClipPipeline)")
-    ap.add_argument("--h2-residual", action="store_true", help="A/B: EMAGE_H2 residual stream read from the H2 images (no float32 twins)")
+    ap.add_argument("--f32-residual", action="store_true", help="A/B: float32 residual twins beside the EMAGE_H2 images (round 3's default) instead of residuals read from the images")
+    ap.add_argument("--no-group-gemms", action="store_true", help="A/B: one stream lane per part-wise chain and one launch per contraction instead of lock-step chains with grouped launches")
     ap.add_argument("--attn-variant", type=int, default=0, help="experiments: emage_set_tuning key 6 (1 = split-f16 attention without the LDS-staged K / V^T)")
     ap.add_argument("--h2-variant", type=int, default=0, help="experiments: emage_set_tuning key 5 (EMAGE_H2 tile-heuristic variant)")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")

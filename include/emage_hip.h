@@ -126,6 +126,27 @@ int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bi
                float a_scale, float w_scale, void* stream);
 
 /*
+ * Several INDEPENDENT emage_gemm problems in as few launches as possible — the part-wise stacks of the model run the same shapes on
+ * different weights side by side: the four VQ-VAE part decoders (M:126-193 -> P:237-261), the three refinement decoder layers and
+ * their heads (M:248-263, 320-330), `motion2latent_{upper,hands,lower}.fc2` (M:315-317), the two `bodyhints_*` MLPs (M:232-233).
+ * Each problem is one emage_gemm call (same fields, same meaning, same validation); the result is bit for bit that of issuing the
+ * calls one by one.  No problem may read what another problem of the same call writes.  EMAGE_H2: problems that select the same tile
+ * configuration share a launch (up to 8 per launch; a block finds its problem by a prefix sum over the problems' tile counts, then
+ * runs the unchanged tile routine) — a stack of N = 256 problems that leaves most CUs with one 4-wave block each becomes one launch
+ * with several resident blocks per CU.  Other dtypes: one launch per problem.
+ */
+typedef struct emage_gemm_problem {
+    const void* A; const void* W; const float* bias; const float* slope; const void* res;
+    void* out; float* out_f32; void* out_t;
+    int lda, ldr, res_is_f32, res_first, ldo, n_store, ldf, t_col0, t_rows, t_ld;
+    int M, N, Cp, taps, stride, pad, Lin, Lout;
+    float a_scale, w_scale;
+} emage_gemm_problem;
+int emage_gemm_grouped(int dtype, const emage_gemm_problem* problems, int n_problems, void* stream);
+/* Launches nothing: the number of kernel launches emage_gemm_grouped would make of these problems (> 0), or a negative EMAGE_E* code. */
+int emage_gemm_grouped_launches(int dtype, const emage_gemm_problem* problems, int n_problems);
+
+/*
  * K1 first layer — WavEncoder block 0 on the raw waveform (Cin = 1), P:301 + P:283-290:
  *   out[b][l][c] = leaky( sum_k wav[b][l*stride + k - pad] * w[c][k] + bias[c], slope[c] )
  * wav: fp32, clip b at wav + b*ldw; the launch covers `nwin` windows of L samples per clip, window i starting at

@@ -10,9 +10,17 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 TOOLS_LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip_tools.so")   # -DEMAGE_TOOLS twin: every tile configuration + emage_set_tuning
 
 F32, BF16, F16X3, H2 = 0, 1, 2, 3
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+class GemmProblem(C.Structure):
+    """`emage_gemm_problem` of include/emage_hip.h: one emage_gemm call's arguments (emage_gemm_grouped takes an array of them)."""
+    _fields_ = ([(n, _p) for n in ("A", "W", "bias", "slope", "res", "out", "out_f32", "out_t")]
+                + [(n, _i) for n in ("lda", "ldr", "res_is_f32", "res_first", "ldo", "n_store", "ldf", "t_col0", "t_rows", "t_ld",
+                                     "M", "N", "Cp", "taps", "stride", "pad", "Lin", "Lout")]
+                + [("a_scale", _f), ("w_scale", _f)])
+
 
 # name -> argtypes, exactly the prototypes of include/emage_hip.h
 TOOLS_SIGNATURES = {"emage_set_tuning": [_i, _i], "emage_h2_set_trace": [_p]}      # exported by the tools build only
@@ -22,6 +30,8 @@ SIGNATURES = {
     "emage_gather_rows": [_p, _p, _i, _l, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_gemm": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i,
                    _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p],
+    "emage_gemm_grouped": [_i, C.POINTER(GemmProblem), _i, _p],
+    "emage_gemm_grouped_launches": [_i, C.POINTER(GemmProblem), _i],
     "emage_wav_conv_in": [_i, _p, _l, _i, _i, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "emage_conv_slab": [_i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p],
     "emage_wav_block0": [_i, _p, _l, _i, _i, _l, _i, _p, _p, _f, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _i, _i, _f, _f, _p],

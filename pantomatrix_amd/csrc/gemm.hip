@@ -16,6 +16,7 @@ extern int g_h2_force_config, g_h2_variant;         // csrc/gemm_h2.hip
 extern int g_attn_variant;                          // csrc/attention.hip
 #endif
 int gemm_h2_dispatch(GemmArgs& a, hipStream_t s);   // csrc/gemm_h2.hip: the EMAGE_H2 (pre-split operands) tile kernels
+int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only);   // several independent problems, same-configuration ones in shared launches
 }
 
 namespace {
@@ -312,12 +313,13 @@ int dispatch(GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
-                          const void* res, int ldr, int res_is_f32, int res_first,
-                          void* out, int ldo, int n_store, float* out_f32, int ldf,
-                          void* out_t, int t_col0, int t_rows, int t_ld,
-                          int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
-                          float a_scale, float w_scale, void* stream) {
+namespace {
+// argument checks of emage_gemm / emage_gemm_grouped -> the kernels' argument block
+int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
+              const void* res, int ldr, int res_is_f32, int res_first,
+              void* out, int ldo, int n_store, float* out_f32, int ldf,
+              void* out_t, int t_col0, int t_rows, int t_ld,
+              int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout, float a_scale, float w_scale) {
     const int epc = dtype == EMAGE_BF16 ? 8 : 4;
     if (!A || !W || M <= 0 || N <= 0 || taps <= 0 || Cp <= 0 || Cp % 64 != 0) return EMAGE_EINVAL;
     if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3 && dtype != EMAGE_H2) return EMAGE_EINVAL;
@@ -337,20 +339,67 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
         const long a_span = ((((long)(M / Lout)) * Lin - 1) * lda + Cp + (long)pad * lda) * es;
         if (a_span >= (1L << 31) || (long)N * taps * Cp * es >= (1L << 31)) return EMAGE_EINVAL;
     }
-    GemmArgs a;
     a.A = A; a.W = W; a.bias = bias; a.slope = slope; a.res = res; a.out = out; a.out_f32 = out_f32; a.out_t = out_t;
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.ldf = ldf; a.res_is_f32 = res_is_f32; a.res_first = res_first; a.n_store = out ? n_store : 0;
     a.t_col0 = out_t ? t_col0 : N; a.t_rows = t_rows > 0 ? t_rows : 1; a.t_ld = t_ld;
+    a.tiles_m = a.tiles_n = 0;
     a.dbg = g_debug_skip;
     a.trace = nullptr; a.cstate = nullptr; a.ldc = 0; a.ksplit = 1; a.nk_split = 0;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
     const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2;
     a.a_scale = split ? a_scale : 1.f;
     a.o_scale = split ? 1.f / (a_scale * w_scale) : 1.f;
-    hipStream_t s = (hipStream_t)stream;
+    return 0;
+}
+
+int dispatch_one(int dtype, GemmArgs& a, hipStream_t s) {
     if (dtype == EMAGE_H2) return gemm_h2_dispatch(a, s);
     if (dtype == EMAGE_F16X3) return dispatch<float, true>(a, s);
     return dtype == EMAGE_BF16 ? dispatch<bf16_t, false>(a, s) : dispatch<float, false>(a, s);
+}
+}  // namespace
+
+extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
+                          const void* res, int ldr, int res_is_f32, int res_first,
+                          void* out, int ldo, int n_store, float* out_f32, int ldf,
+                          void* out_t, int t_col0, int t_rows, int t_ld,
+                          int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
+                          float a_scale, float w_scale, void* stream) {
+    GemmArgs a;
+    const int rc = make_args(a, dtype, A, lda, W, bias, slope, res, ldr, res_is_f32, res_first, out, ldo, n_store, out_f32, ldf, out_t, t_col0, t_rows, t_ld,
+                             M, N, Cp, taps, stride, pad, Lin, Lout, a_scale, w_scale);
+    if (rc) return rc;
+    return dispatch_one(dtype, a, (hipStream_t)stream);
+}
+
+namespace {
+int grouped(int dtype, const emage_gemm_problem* problems, int n_problems, hipStream_t s, bool count_only) {
+    constexpr int MAX_PROBLEMS = 64;
+    if (!problems || n_problems <= 0 || n_problems > MAX_PROBLEMS) return EMAGE_EINVAL;
+    GemmArgs args[MAX_PROBLEMS];
+    for (int i = 0; i < n_problems; ++i) {         // every problem is checked before the first launch
+        const emage_gemm_problem& q = problems[i];
+        const int rc = make_args(args[i], dtype, q.A, q.lda, q.W, q.bias, q.slope, q.res, q.ldr, q.res_is_f32, q.res_first, q.out, q.ldo, q.n_store,
+                                 q.out_f32, q.ldf, q.out_t, q.t_col0, q.t_rows, q.t_ld, q.M, q.N, q.Cp, q.taps, q.stride, q.pad, q.Lin, q.Lout,
+                                 q.a_scale, q.w_scale);
+        if (rc) return rc;
+    }
+    if (dtype == EMAGE_H2) return gemm_h2_dispatch_group(args, n_problems, s, count_only);
+    if (count_only) return n_problems;
+    for (int i = 0; i < n_problems; ++i) {
+        const int rc = dispatch_one(dtype, args[i], s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int emage_gemm_grouped(int dtype, const emage_gemm_problem* problems, int n_problems, void* stream) {
+    return grouped(dtype, problems, n_problems, (hipStream_t)stream, false);
+}
+
+extern "C" int emage_gemm_grouped_launches(int dtype, const emage_gemm_problem* problems, int n_problems) {
+    return grouped(dtype, problems, n_problems, nullptr, true);
 }
 
 #ifdef EMAGE_TOOLS

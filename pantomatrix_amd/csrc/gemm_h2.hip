@@ -65,6 +65,73 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
     return launch_status();
 }
 
+// ---- grouped launch: several independent problems of ONE tile configuration in one grid (emage_gemm_grouped) ----
+// The argument block carries the problems by value (kernarg segment: no device table to allocate); a block finds its problem by
+// comparing its (XCD-remapped) id with the running tile counts — scalar work — and then runs the unchanged tile routine on that
+// problem's arguments: the result is bit for bit that of the single-problem launch.
+constexpr int MAXG = 8;
+struct GroupArgs {
+    GemmArgs p[MAXG];
+    int tile_end[MAXG];          // running sum of tiles_m * tiles_n
+    int n, total;
+};
+
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV>
+__global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) void gemm_h2_group_kernel(GroupArgs g) {
+    __shared__ __attribute__((aligned(128))) unsigned char smem[h2_smem_bytes<BM, BN, NS>()];
+    // XCD-aware order over the WHOLE grid: each XCD walks a contiguous run of the concatenated tile list, i.e. mostly one problem
+    // (its W panel stays in that XCD's L2)
+    int bid = (int)blockIdx.x;
+    {
+        const int nblk = g.total;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int pi = 0;
+#pragma unroll
+    for (int i = 0; i < MAXG - 1; ++i) pi += (i + 1 < g.n && bid >= g.tile_end[i]) ? 1 : 0;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    const int t = bid - (pi ? g.tile_end[pi - 1] : 0);
+    const GemmArgs& p = g.p[pi];
+    const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
+    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, false>(p, tile_m * BM, tile_n * BN, smem, 0);
+}
+
+template <int BM, int BN>
+void h2_tiles(GemmArgs& a) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    const int ncols = a.n_store > a.N ? a.n_store : a.N;
+    a.tiles_n = (ncols + BN - 1) / BN;
+}
+
+// the split-K condition of launch_h2 (bare contractions with few tiles and a long K: the weight gradients of a training step)
+template <int BM, int BN>
+bool h2_wants_split_k(const GemmArgs& a) {
+    const long tiles = (long)((a.M + BM - 1) / BM) * (((a.n_store > a.N ? a.n_store : a.N) + BN - 1) / BN);
+    return a.taps == 1 && !a.out && !a.out_t && !a.res && !a.bias && !a.slope && a.out_f32 && tiles < 192 && a.K / 32 >= 64;
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false>
+int launch_h2_group(GemmArgs** a, int n, hipStream_t s) {
+    GroupArgs g;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs& q = *a[i];
+        if (q.out_t && q.t_col0 % BN != 0) return EMAGE_EINVAL;
+        h2_tiles<BM, BN>(q);
+        q.trace = nullptr;
+        q.ksplit = 1;
+        total += q.tiles_m * q.tiles_n;
+        g.p[i] = q;
+        g.tile_end[i] = total;
+    }
+    for (int i = n; i < MAXG; ++i) { g.p[i] = *a[0]; g.tile_end[i] = total; }
+    g.n = n;
+    g.total = total;
+    hipLaunchKernelGGL((gemm_h2_group_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV>), dim3(total), dim3((WM * WN + NLW) * 64), 0, s, g);
+    return launch_status();
+}
+
 // Tile configurations (id: block tile, compute-wave grid [wave tile], ring depth, loader waves, register-pipelined K-loop)
 int run_config(int cfg, GemmArgs& a, hipStream_t s) {
     switch (cfg) {
@@ -141,24 +208,79 @@ extern "C" int emage_h2_set_trace(void* buf) { emage_dev::g_h2_trace = (unsigned
 
 namespace emage_dev {
 
-// called by emage_gemm (gemm.hip) for dtype EMAGE_H2 after the common argument checks
-int gemm_h2_dispatch(GemmArgs& a, hipStream_t s) {
-    if (g_h2_force_config >= 0) return run_config(g_h2_force_config, a, s);
-    // measured on MI355X (tools/bench_gemm_h2.py, profiles/r03_h2_sweep*.txt).  Wide outputs: 8-wave 64x192 / 128x256 tiles; everything
-    // else: 64x64 tiles, three resident blocks per CU (their barriers de-synchronise, which hides each block's DMA / LDS phases
-    // behind the others' MFMAs better than one fat block per CU does at M = 4096)
+// the tile configuration of one problem.  Measured on MI355X (tools/bench_gemm_h2.py, profiles/r03_h2_sweep*.txt).  Wide outputs: 8-wave
+// 64x192 / 128x256 tiles; everything else: 64x64 tiles, three resident blocks per CU (their barriers de-synchronise, which hides each
+// block's DMA / LDS phases behind the others' MFMAs better than one fat block per CU does at M = 4096).  < 0: unsupported argument
+static int h2_config_for(const GemmArgs& a) {
+    if (g_h2_force_config >= 0) return g_h2_force_config;
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     const int v = g_h2_variant;
-    if ((v & 1) && ncols < 1024 && ncols % 192 == 0 && a.M >= 2048 && !a.out_t) return run_config(101, a, s);       // one 8-wave block per CU
-    if ((v & 4) && ncols < 1024 && ncols % 192 == 0 && a.M >= 2048 && !a.out_t) return run_config(124, a, s);       // 64x96, two 4-wave blocks per CU
+    if ((v & 1) && ncols < 1024 && ncols % 192 == 0 && a.M >= 2048 && !a.out_t) return 101;       // one 8-wave block per CU
+    if ((v & 4) && ncols < 1024 && ncols % 192 == 0 && a.M >= 2048 && !a.out_t) return 124;       // 64x96, two 4-wave blocks per CU
     if (ncols >= 1024 && a.M >= 1024) {
         const long t128x256 = (long)((a.M + 127) / 128) * ((ncols + 255) / 256);
-        if (!(v & 2) && t128x256 >= 512 && ncols % 256 == 0 && (!a.out_t || a.t_col0 % 256 == 0)) return run_config(119, a, s);
-        if (ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return run_config(100, a, s);
-        if (!a.out_t || a.t_col0 % 128 == 0) return run_config(113, a, s);
+        if (!(v & 2) && t128x256 >= 512 && ncols % 256 == 0 && (!a.out_t || a.t_col0 % 256 == 0)) return 119;
+        if (ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return 100;
+        if (!a.out_t || a.t_col0 % 128 == 0) return 113;
     }
     if (a.out_t && a.t_col0 % 64 != 0) return EMAGE_EINVAL;
-    return run_config((v & 8) ? 130 : 120, a, s);
+    return (v & 8) ? 130 : 120;
+}
+
+// called by emage_gemm (gemm.hip) for dtype EMAGE_H2 after the common argument checks
+int gemm_h2_dispatch(GemmArgs& a, hipStream_t s) {
+    const int cfg = h2_config_for(a);
+    return cfg < 0 ? cfg : run_config(cfg, a, s);
+}
+
+// called by emage_gemm_grouped: problems that take the same (groupable) configuration share launches of up to MAXG problems; the rest —
+// other configurations, split-K contractions — are launched one by one.  Launch order follows the first problem of each launch.
+// count_only: no launch, returns the number of launches the call would make (bench.py's per-launch accounting)
+int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only) {
+    int launches = 0;
+    int cfg[64];
+    bool done[64];
+    for (int i = 0; i < n; ++i) {
+        cfg[i] = h2_config_for(a[i]);
+        if (cfg[i] < 0) return cfg[i];
+        done[i] = false;
+    }
+    auto groupable = [&](int i) {
+        switch (cfg[i]) {
+            case 100: return !h2_wants_split_k<64, 192>(a[i]);
+            case 113: return !h2_wants_split_k<128, 128>(a[i]);
+            case 119: return !h2_wants_split_k<128, 256>(a[i]);
+            case 120: return !h2_wants_split_k<64, 64>(a[i]);
+            default: return false;
+        }
+    };
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        GemmArgs* grp[MAXG];
+        int m = 0;
+        if (groupable(i))
+            for (int j = i; j < n && m < MAXG; ++j)
+                if (!done[j] && cfg[j] == cfg[i] && groupable(j)) { grp[m++] = &a[j]; done[j] = true; }
+        int rc;
+        ++launches;
+        if (count_only) {
+            done[i] = true;
+            continue;
+        }
+        if (m >= 2) {
+            switch (cfg[i]) {
+                case 100: rc = launch_h2_group<64, 192, 4, 2, 2, 0, false>(grp, m, s); break;
+                case 113: rc = launch_h2_group<128, 128, 4, 2, 3, 0, false>(grp, m, s); break;
+                case 119: rc = launch_h2_group<128, 256, 4, 2, 2, 0, false>(grp, m, s); break;
+                default: rc = launch_h2_group<64, 64, 2, 2, 3, 0, false, false, 2>(grp, m, s); break;
+            }
+        } else {
+            done[i] = true;
+            rc = run_config(cfg[i], a[i], s);
+        }
+        if (rc) return rc;
+    }
+    return count_only ? launches : 0;
 }
 
 }  // namespace emage_dev

@@ -73,9 +73,14 @@ class _EmageModule(torch.nn.Module):
         self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
         self.health_counter = None             # optional int32 device counter of non-finite logits / latents met by infer_codes (runtime.ClipRunner)
         self.slab_convs = True                 # WavEncoder: LDS-resident-slab convolutions + fused block 0 (A/B switch; same bits)
-        self.h2_residual = False               # EMAGE_H2 mode: the transformer residual stream is read from the H2 images (no float32 twins)
+        self.h2_residual = True                # EMAGE_H2 mode: LayerNorm writes ONE output, the H2 image, and the sub-layers read their residual from
+                                               # it ((hi + lo) / 16: 2^-22 relative); False = a float32 twin beside every H2 image (round 3's default:
+                                               # 25 instead of 12.6 MB per LayerNorm at 64 clips).  Parity-green on every golden in both forms
         self.split_acts = True                 # f16x3 precision: activations that feed a contraction are stored PRE-SPLIT (EMAGE_H2,
                                                # csrc/h2.h) by their producers; False = float32 activations split inside every GEMM
+        self.group_gemms = True                # part-wise stacks (VQ part decoders, refinement layers + heads, ...) walk in lock step and
+                                               # their contractions share launches (ops.lockstep / emage_gemm_grouped); False = one stream
+                                               # lane per chain, one launch per contraction (the round-3 form; same bits)
         self._templates = {}                   # cached default motion / mask of inference() per (batch, length, device)
         self._spec = type(self)._spec_fn(config)
         init = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
@@ -654,27 +659,39 @@ class EmageVQModel(torch.nn.Module):
         dev = self.vq_model_face.device
         todo = (("lower", lower_index, lower_latent), ("hands", hands_index, hands_latent),
                 ("upper", upper_index, upper_latent), ("face", face_index, face_latent))
-        trans = None
-        # the four part decoders are independent chains: one stream lane each; the global-translation AE only
-        # needs the lower stream, so it follows it on lane 0
-        with Fork(dev, 4, getattr(self.vq_model_face, "concurrent", True)) as fk:
-            for lane, (name, index, latent) in enumerate(todo):
-                model = getattr(self, f"vq_model_{name}")
-                with fk.lane(lane):
-                    if index is not None:
-                        cx = _Ctx(model._engine())
-                        parts[name] = model._decode_idx(cx, index, bs, t)
-                    elif latent is not None:
-                        cx = _Ctx(model._engine())
-                        idx = model._nearest(cx, latent.reshape(m, -1).float().contiguous())
-                        parts[name] = model._decode_idx(cx, idx, bs, t)
-                    else:
-                        parts[name] = None
-                    if name == "lower" and get_global_motion:
-                        lower_mix = parts["lower"]
-                        if lower_mix is None:   # zeros pose: identity rot6d + zero trans/contact (M:174-177)
-                            lower_mix = torch.tensor([1.0, 0, 0, 0, 1, 0] * 9 + [0.0] * 7, device=dev).repeat(m, 1)
-                        trans = self.get_global_motion(lower_mix.view(bs, t, -1), ref_trans)
+        trans = [None]
+
+        def part_chain(name, index, latent):
+            model = getattr(self, f"vq_model_{name}")
+            if index is not None:
+                cx = _Ctx(model._engine())
+                parts[name] = model._decode_idx(cx, index, bs, t)
+            elif latent is not None:
+                cx = _Ctx(model._engine())
+                idx = model._nearest(cx, latent.reshape(m, -1).float().contiguous())
+                parts[name] = model._decode_idx(cx, idx, bs, t)
+            else:
+                parts[name] = None
+            if name == "lower" and get_global_motion:
+                lower_mix = parts["lower"]
+                if lower_mix is None:   # zeros pose: identity rot6d + zero trans/contact (M:174-177)
+                    lower_mix = torch.tensor([1.0, 0, 0, 0, 1, 0] * 9 + [0.0] * 7, device=dev).repeat(m, 1)
+                trans[0] = self.get_global_motion(lower_mix.view(bs, t, -1), ref_trans)
+
+        # the four part decoders are independent chains of the same shapes on different weights (the global-translation AE follows the
+        # lower stream): walked in lock step, their contractions share launches (4 x 8 launches with one block per CU -> 8 with four);
+        # group_gemms = False: one stream lane per chain, one launch per contraction
+        if getattr(self.vq_model_face, "group_gemms", True) and dev.type == "cuda":
+            with ops.lockstep() as ls:
+                for name, index, latent in todo:
+                    with ls.chain():
+                        part_chain(name, index, latent)
+        else:
+            with Fork(dev, 4, getattr(self.vq_model_face, "concurrent", True)) as fk:
+                for lane, (name, index, latent) in enumerate(todo):
+                    with fk.lane(lane):
+                        part_chain(name, index, latent)
+        trans = trans[0]
         aa, motion, expr = ops.merge_parts(parts["face"], parts["upper"], parts["hands"], parts["lower"], m, dev)
         return dict(expression=expr.view(bs, t, 100), all_motion4inference=motion.view(bs, t, 337),
                     motion_axis_angle=aa.view(bs, t, 165), trans=trans)
@@ -1131,8 +1148,11 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                 x0 = ops.pack_motion(cx.dt, motion3, mask3, pk.w["mask_emb"], _rup(cm), seed=_seed)
                 hint, _ = _conv_encoder(cx, "motion_encoder", x0, t, spec.MOTION_ENC_LAYERS, mf, False)
                 hh, _ = cx.gemm(hint, "bodyhints.fc1", slope=0.1)               # [face | body] hidden, (M, 2d)
-                cx.gemm(hh[:, :d], "bodyhints_face.fc2", out=memcat[:, af:])
-                hint_body, _ = cx.gemm(hh[:, d:], "bodyhints_body.fc2")
+                with ops.lockstep(self.group_gemms) as ls:                      # the two second layers: one launch
+                    with ls.chain():
+                        cx.gemm(hh[:, :d], "bodyhints_face.fc2", out=memcat[:, af:])
+                    with ls.chain():
+                        hint_body, _ = cx.gemm(hh[:, d:], "bodyhints_body.fc2")
 
             # face branch (M:288-294) on lane 1, once the hints (lane 0) are there
             fk.after(1, 0)
@@ -1166,34 +1186,46 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                 # part latents (M:315-317)
                 hl, _ = cx.gemm(x.a, "motion2latent.fc1", slope=0.1)             # (M, 3d)
                 lat = {}
-                for i, p in enumerate(parts):           # the part latents are only ever added: residual precision
-                    lat[p] = cx.gemm_r(hl[:, i * d:(i + 1) * d], f"motion2latent_{p}.fc2")
-            # refinement + heads (M:320-330): three independent chains; "upper" stays on lane 0, "lower" takes
-            # lane 2 (idle by now), "hands" queues behind the face decoder on lane 1
-            lane_of = {"upper": 0, "hands": 1, "lower": 2}
-            fk.after(1, 0)
-            fk.after(2, 0)
-            for p in parts:
-                with fk.lane(lane_of[p]):
-                    tgt, mem_lo = cx.lo(m, d), cx.lo(m, d)
-                    if cx.h2:
-                        tgt_r = cx.f32(m, d)
-                        ops.add(H2, lat[p], spk_body, out_f32=tgt_r, out=tgt)
-                        tgt = _X(tgt, tgt_r)
-                    else:
-                        ops.add(cx.dt, lat[p], spk_body, out=tgt)
-                        tgt = _X(tgt, tgt)
-                    ops.add(cx.dt, lat[others[p][0]], lat[others[p][1]], out=mem_lo)
-                    name = f"body_motion_decoder_{p}.layers.0"
-                    k1, vt1 = self._memory_kv(cx, name + ".ca.kv", mem_lo, b, t, 1)
-                    ref = self._decoder_layer(cx, name, tgt, b, t, k1, vt1, d, t)
-                    sum_lo = cx.lo(m, d)
-                    ops.add(cx.dt, lat[p], ref.r, out=sum_lo, h2_operands=(1,) if ref.h2r else ())
-                    lean_cls = _lean and c_of[p] > 0         # decode takes the arg-max code: rec_* fp32 copy unused
-                    rec_lo, out[f"rec_{p}"] = cx.gemm(sum_lo, f"motion_out_proj_{p}", want="lo" if lean_cls else "both")
-                    if not (_lean and c_of[p] == 0):
-                        hc, _ = cx.gemm(rec_lo, f"motion_cls_{p}.fc1", slope=0.1)
-                        _, out[f"cls_{p}"] = cx.gemm(hc, f"motion_cls_{p}.fc2", want="f32")
+                with ops.lockstep(self.group_gemms) as ls:
+                    for i, p in enumerate(parts):       # the part latents are only ever added: residual precision
+                        with ls.chain():
+                            lat[p] = cx.gemm_r(hl[:, i * d:(i + 1) * d], f"motion2latent_{p}.fc2")
+            # refinement + heads (M:320-330): three independent chains of the same shapes on different weights.  group_gemms: walked in
+            # lock step on lane 0 — every contraction of the three decoder layers and of the heads is one grouped launch (3 x 11 launches
+            # -> 11).  Otherwise: "upper" stays on lane 0, "lower" takes lane 2 (idle by now), "hands" queues behind the face decoder on lane 1
+            def refine_chain(p):
+                tgt, mem_lo = cx.lo(m, d), cx.lo(m, d)
+                if cx.h2:
+                    tgt_r = cx.f32(m, d)
+                    ops.add(H2, lat[p], spk_body, out_f32=tgt_r, out=tgt)
+                    tgt = _X(tgt, tgt_r)
+                else:
+                    ops.add(cx.dt, lat[p], spk_body, out=tgt)
+                    tgt = _X(tgt, tgt)
+                ops.add(cx.dt, lat[others[p][0]], lat[others[p][1]], out=mem_lo)
+                name = f"body_motion_decoder_{p}.layers.0"
+                k1, vt1 = self._memory_kv(cx, name + ".ca.kv", mem_lo, b, t, 1)
+                ref = self._decoder_layer(cx, name, tgt, b, t, k1, vt1, d, t)
+                sum_lo = cx.lo(m, d)
+                ops.add(cx.dt, lat[p], ref.r, out=sum_lo, h2_operands=(1,) if ref.h2r else ())
+                lean_cls = _lean and c_of[p] > 0         # decode takes the arg-max code: rec_* fp32 copy unused
+                rec_lo, out[f"rec_{p}"] = cx.gemm(sum_lo, f"motion_out_proj_{p}", want="lo" if lean_cls else "both")
+                if not (_lean and c_of[p] == 0):
+                    hc, _ = cx.gemm(rec_lo, f"motion_cls_{p}.fc1", slope=0.1)
+                    _, out[f"cls_{p}"] = cx.gemm(hc, f"motion_cls_{p}.fc2", want="f32")
+
+            if self.group_gemms and dev.type == "cuda":
+                with fk.lane(0), ops.lockstep() as ls:
+                    for p in parts:
+                        with ls.chain():
+                            refine_chain(p)
+            else:
+                lane_of = {"upper": 0, "hands": 1, "lower": 2}
+                fk.after(1, 0)
+                fk.after(2, 0)
+                for p in parts:
+                    with fk.lane(lane_of[p]):
+                        refine_chain(p)
         return {k: (out[k].view(b, t, -1) if out.get(k) is not None else None) for k in OUT_KEYS}
 
 

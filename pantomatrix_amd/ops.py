@@ -16,13 +16,145 @@ from ._lib import F32, BF16, F16X3, H2, check, EmageKernelError
 _LIBRARY = torch.library.Library("emage", "DEF")
 
 
+_RECORDER = [None]        # the active `Lockstep` (ops issued inside one of its chains are recorded, not launched), else None
+_TRACE = [None]           # measurement hook (bench.py / tools): an object with tag() -> label of the calling scope, evaluated when an op is
+                          # CALLED, and fire(kind, entries, launch) which must call launch() — it brackets every actual launch
+_META = {}                # bookkeeping the next op call carries to the hook (gemm: k_real, the unpadded contraction length)
+
+
+def _entry(name, op, args):
+    meta = dict(_META)
+    _META.clear()
+    tr = _TRACE[0]
+    if tr is not None:
+        meta["tag"] = tr.tag()
+    return (name, op, args, meta)
+
+
+def _fire(kind, entries, launch):
+    tr = _TRACE[0]
+    return tr.fire(kind, entries, launch) if tr is not None else launch()
+
+
 def _op(name, schema):
-    """Register `emage::name` with `schema`; the decorated function is its CUDA implementation."""
+    """Register `emage::name` with `schema`; the decorated function is its CUDA implementation.  Returns the callable the public
+    functions below use: the operator itself, or — inside a `lockstep()` chain — a recording of the call."""
     def deco(fn):
         _LIBRARY.define(name + schema)
         _LIBRARY.impl(name, fn, "CUDA")
-        return getattr(torch.ops.emage, name)
+        op = getattr(torch.ops.emage, name)
+
+        def call(*args):
+            e = _entry(name, op, args)
+            rec = _RECORDER[0]
+            if rec is not None:
+                return rec.record(e)
+            return _fire(name, [e], lambda: op(*args))
+
+        call.op = op
+        return call
     return deco
+
+
+class Lockstep:
+    """Several INDEPENDENT launch chains issued in lock step, so that their contractions meet in grouped launches
+    (`emage_gemm_grouped`): the four VQ part decoders, the three refinement layers with their heads, ... run the same sequence of
+    shapes on different weights.  Inside `with ops.lockstep() as ls:` every chain is written as before, under `with ls.chain():` —
+    its emage ops are RECORDED instead of launched (their outputs are allocated as usual: a later op of the chain needs the tensor,
+    not its values).  On exit the chains are walked together: each chain's ops up to its next EMAGE_H2 contraction are launched in
+    order, then the contractions waiting at the head of the chains go out as ONE `emage_gemm_grouped` call (the library puts those
+    that select the same tile configuration into one launch), and so on.  Per chain the launch order is unchanged; across chains there
+    is no dependency by contract.  Only emage ops (and allocations / fills that PRECEDE their consumers) may appear inside a chain: a
+    torch op that reads a chain's result would run at record time, before the producer.  Everything goes to the current stream."""
+
+    def __init__(self, enabled=True):
+        self.enabled, self.chains, self.cur = bool(enabled), [], None
+        self.launches = []                # (kind, count) log of the last run: ("group", n) / ("gemm", 1) / (op name, 1)
+        self.groups = []                  # the recorded contractions of every grouped call of the last run (tests: `grouped_launch_count`)
+
+    def chain(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            if self.cur is not None:
+                raise RuntimeError("ops.lockstep: chains do not nest")
+            self.cur = []
+            self.chains.append(self.cur)
+            try:
+                yield
+            finally:
+                self.cur = None
+        return cm()
+
+    def record(self, entry):
+        if self.cur is None:
+            raise RuntimeError(f"ops.lockstep: emage::{entry[0]} issued outside a chain (it would overtake the recorded launches)")
+        self.cur.append(entry)
+
+    @staticmethod
+    def _groupable(entry):
+        return entry[0] == "gemm" and entry[2][0] == H2
+
+    def _issue(self, entry):
+        _fire(entry[0], [entry], lambda: entry[1](*entry[2]))
+        self.launches.append((entry[0], 1))
+
+    def _issue_group(self, entries):
+        _fire("gemm_grouped", entries, lambda: _gemm_grouped_entries(entries))
+        self.launches.append(("group", len(entries)))
+        self.groups.append(entries)
+
+    def run(self):
+        self.launches, self.groups = [], []
+        ptr = [0] * len(self.chains)
+        while True:
+            heads = []
+            for ci, ch in enumerate(self.chains):
+                while ptr[ci] < len(ch) and not self._groupable(ch[ptr[ci]]):
+                    self._issue(ch[ptr[ci]])
+                    ptr[ci] += 1
+                if ptr[ci] < len(ch):
+                    heads.append(ch[ptr[ci]])
+                    ptr[ci] += 1
+            if not heads:
+                break
+            if len(heads) == 1 or not self.enabled:
+                for e in heads:
+                    self._issue(e)
+            else:
+                self._issue_group(heads)
+        self.chains = []
+
+
+def lockstep(enabled=True):
+    """Context manager -> `Lockstep` (see there).  enabled=False: the chains are still recorded and walked in lock step, but every
+    contraction is its own launch (the A/B form: same launch order, no grouping).  Nested use joins the outer lockstep's CURRENT chain."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        outer = _RECORDER[0]
+        if outer is not None:             # already recording: the inner chains are simply part of the outer chain
+            class _Join:
+                enabled, launches = outer.enabled, outer.launches
+
+                @staticmethod
+                def chain():
+                    return contextlib.nullcontext()
+            yield _Join()
+            return
+        ls = Lockstep(enabled)
+        _RECORDER[0] = ls
+        ok = False
+        try:
+            yield ls
+            ok = True
+        finally:
+            _RECORDER[0] = None
+            if ok:
+                ls.run()
+    return cm()
 
 # storage type of activations per precision code; F16X3 is a GEMM-only operand mode over float32 storage
 # H2: the pre-split storage of the split-fp16 mode (csrc/h2.h) — float32-sized elements, 32-byte groups of 8 columns = [8 fp16 hi | 8 fp16 lo]
@@ -193,19 +325,89 @@ def gather_rows(table, idx, dtype, n_store=None):
     return out
 
 
+def _gemm_fields(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, res_first, taps, stride, pad, lin, lout, m,
+                 w_scale, a_scale, res_h2):
+    """The arguments of the `emage::gemm` operator -> the fields of one emage_gemm call (the order of `emage_gemm_problem`)."""
+    res_f32 = 1 if (res is not None and res.dtype == torch.float32 and not res_h2) else 0
+    t_ld = out_t.shape[-1] if out_t is not None else 0
+    return dict(A=_ptr(a), W=_ptr(w), bias=_ptr(bias), slope=_ptr(slope), res=_ptr(res), out=_ptr(out), out_f32=_ptr(out_f32), out_t=_ptr(out_t),
+                lda=_ld(a), ldr=_ld(res) if res is not None else 0, res_is_f32=res_f32, res_first=1 if res_first else 0,
+                ldo=_ld(out) if out is not None else 0, n_store=n_store, ldf=_ld(out_f32) if out_f32 is not None else 0,
+                t_col0=t_col0, t_rows=t_rows, t_ld=t_ld, M=m, N=n, Cp=cp, taps=taps, stride=stride, pad=pad, Lin=lin, Lout=lout,
+                a_scale=a_scale, w_scale=w_scale)
+
+
 @_op("gemm", "(int dtype, Tensor a, Tensor w, Tensor? bias, Tensor? slope, Tensor? res, Tensor(a!)? out, Tensor(b!)? out_f32, "
              "Tensor(c!)? out_t, int n, int cp, int n_store, int t_col0, int t_rows, bool res_first, int taps, int stride, int pad, "
              "int lin, int lout, int m, float w_scale, float a_scale, bool res_h2) -> ()")
-def _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, res_first, taps, stride, pad, lin, lout, m,
-          w_scale, a_scale, res_h2):
-    res_f32 = 1 if (res is not None and res.dtype == torch.float32 and not res_h2) else 0
-    t_ld = out_t.shape[-1] if out_t is not None else 0
-    check(_lib.load().emage_gemm(dtype, _ptr(a), _ld(a), _ptr(w), _ptr(bias), _ptr(slope),
-                                 _ptr(res), _ld(res) if res is not None else 0, res_f32, 1 if res_first else 0,
-                                 _ptr(out), _ld(out) if out is not None else 0, n_store,
-                                 _ptr(out_f32), _ld(out_f32) if out_f32 is not None else 0,
-                                 _ptr(out_t), t_col0, t_rows, t_ld,
-                                 m, n, cp, taps, stride, pad, lin, lout, a_scale, w_scale, _stream()), "gemm")
+def _gemm(dtype, *args):
+    f = _gemm_fields(dtype, *args)
+    check(_lib.load().emage_gemm(dtype, f["A"], f["lda"], f["W"], f["bias"], f["slope"], f["res"], f["ldr"], f["res_is_f32"], f["res_first"],
+                                 f["out"], f["ldo"], f["n_store"], f["out_f32"], f["ldf"], f["out_t"], f["t_col0"], f["t_rows"], f["t_ld"],
+                                 f["M"], f["N"], f["Cp"], f["taps"], f["stride"], f["pad"], f["Lin"], f["Lout"], f["a_scale"], f["w_scale"], _stream()), "gemm")
+
+
+# Descriptor-table operator: `tensors` lists every tensor the problems touch (dispatch key, aliasing: they may be written), `desc` holds
+# per problem the 26 integer words of `emage_gemm_problem` in field order (device addresses first), `scales` its (a_scale, w_scale).
+_GEMM_PROBLEM_INTS = ("A", "W", "bias", "slope", "res", "out", "out_f32", "out_t", "lda", "ldr", "res_is_f32", "res_first", "ldo", "n_store", "ldf",
+                      "t_col0", "t_rows", "t_ld", "M", "N", "Cp", "taps", "stride", "pad", "Lin", "Lout")
+
+
+def _problem_array(desc, scales):
+    k = len(_GEMM_PROBLEM_INTS)
+    n = len(desc) // k
+    arr = (_lib.GemmProblem * n)()
+    for i in range(n):
+        for j, name in enumerate(_GEMM_PROBLEM_INTS):
+            v = desc[i * k + j]
+            setattr(arr[i], name, (v or None) if j < 8 else v)
+        arr[i].a_scale, arr[i].w_scale = scales[2 * i], scales[2 * i + 1]
+    return arr, n
+
+
+@_op("gemm_grouped", "(int dtype, Tensor(a!)[] tensors, int[] desc, float[] scales) -> ()")
+def _gemm_grouped(dtype, tensors, desc, scales):
+    arr, n = _problem_array(desc, scales)
+    check(_lib.load().emage_gemm_grouped(dtype, arr, n, _stream()), "gemm_grouped")
+
+
+def grouped_launch_count(entries):
+    """Kernel launches `emage_gemm_grouped` makes of these recorded `emage::gemm` calls (measurement bookkeeping; launches nothing)."""
+    dtype, desc, scales = entries[0][2][0], [], []
+    for e in entries:
+        f = _gemm_fields(*e[2])
+        desc += [int(f[k] or 0) for k in _GEMM_PROBLEM_INTS]
+        scales += [float(f["a_scale"]), float(f["w_scale"])]
+    arr, n = _problem_array(desc, scales)
+    rc = _lib.load().emage_gemm_grouped_launches(dtype, arr, n)
+    if rc <= 0:
+        check(rc or -1, "gemm_grouped_launches")
+    return rc
+
+
+def _gemm_grouped_entries(entries):
+    """Recorded `emage::gemm` calls (Lockstep) of ONE dtype -> one `emage::gemm_grouped` call."""
+    dtype = entries[0][2][0]
+    tensors, desc, scales = [], [], []
+    for _name, _op_, args, _meta in entries:
+        assert args[0] == dtype
+        f = _gemm_fields(*args)
+        desc += [int(f[k] or 0) for k in _GEMM_PROBLEM_INTS]
+        scales += [float(f["a_scale"]), float(f["w_scale"])]
+        tensors += [t for t in args[1:9] if t is not None]
+    _gemm_grouped.op(dtype, tensors, desc, scales)
+
+
+def gemm_grouped(dtype, problems):
+    """Several independent `gemm` problems (a list of dicts of `gemm`'s arguments: a, w, bias, slope, res, out, out_f32, out_t + its
+    keywords) in as few launches as the library can make of them (include/emage_hip.h: emage_gemm_grouped); bit-identical to issuing
+    them one by one."""
+    with lockstep() as ls:
+        for pr in problems:
+            with ls.chain():
+                pr = dict(pr)
+                gemm(dtype, pr.pop("a"), pr.pop("w"), pr.pop("bias", None), pr.pop("slope", None), pr.pop("res", None), pr.pop("out", None),
+                     pr.pop("out_f32", None), pr.pop("out_t", None), **pr)
 
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
@@ -219,6 +421,8 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin
     lout = m if lout is None else lout
+    if k_real is not None:
+        _META["k_real"] = k_real
     _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
           lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2))
 

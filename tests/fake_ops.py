@@ -676,7 +676,7 @@ _NAMES = ["im2col_t_h2", "h2_cast", "adam_multi", "dropout_mask", "count_nonfini
 def installed():
     """Patch pantomatrix_amd.ops with the CPU restatements and lift the device check, for the duration of a test."""
     saved = {n: getattr(ops, n) for n in _NAMES}
-    saved_require = M._EmageModule._require_device      # the one thing lifted: `_engine()` itself (version stamp, operand-scale flags) is the product's
+    saved_require = M._EmageModule.__dict__["_require_device"]      # the one thing lifted: `_engine()` itself (version stamp, operand-scale flags) is the product's
     try:
         for n in _NAMES:
             setattr(ops, n, globals()[n])

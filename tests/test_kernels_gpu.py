@@ -584,3 +584,96 @@ def test_attention_lds_staged_kv_is_bit_identical_to_the_register_path(b, tq, tk
     for new, old, name in zip(outs[0], outs[1], ("float32 out", "h2 out", "dropout")):
         assert torch.equal(new.view(torch.int32), old.view(torch.int32)), name
     assert bool(torch.isfinite(outs[0][0]).all()) and float(outs[0][0].abs().max()) > 0
+
+
+# ---- emage_gemm_grouped: independent problems of one tile configuration in one launch (csrc/gemm_h2.hip: gemm_h2_group_kernel) -----------
+GROUP_CASES = H2_GEMM_CASES + [
+    ("g_out_proj", (64, 64, 64), 768, 768, 1, 1, 0, dict(bias=True, res="f32", want="both")),
+    ("g_out_proj_h2res", (64, 64, 64), 768, 768, 1, 1, 0, dict(bias=True, res="h2", want="f32")),
+    ("g_ffn1", (64, 64, 64), 768, 1536, 1, 1, 0, dict(bias=True, slope=0.0)),
+    ("g_ffn1_b", (64, 64, 64), 768, 1536, 1, 1, 0, dict(bias=True, slope=0.0)),
+    ("g_kv", (64, 64, 64), 768, 1536, 1, 1, 0, dict(bias=True, vt=768, want="f32")),
+    ("g_kv_b", (64, 64, 64), 768, 1536, 1, 1, 0, dict(bias=True, vt=768, want="f32")),
+    ("g_dec_a", (64, 120, 120), 256, 256, 3, 1, 1, dict(bias=True, slope=0.2, n_store=256)),
+    ("g_dec_b", (64, 120, 120), 256, 256, 3, 1, 1, dict(bias=True, slope=0.2, n_store=256)),
+    ("g_dec_c", (64, 12, 12), 256, 256, 3, 1, 1, dict(bias=True, res="h2", n_store=256)),
+    ("g_dec_out", (64, 120, 120), 256, 180, 3, 1, 1, dict(bias=True, want="f32")),
+]
+
+
+def _h2_problem(case):
+    """Device operands + keyword arguments of one EMAGE_H2 `ops.gemm` call and a maker of fresh (poisoned) output buffers."""
+    name, (nb, lin, lout), cin, n, taps, stride, pad, fl = case
+    g = _g(hash(name) % 1000)
+    cp = ops.round_up(cin, 64)
+    m = nb * lout
+    a = torch.zeros(nb * lin, cp)
+    a[:, :cin] = torch.randn(nb * lin, cin, generator=g)
+    w = torch.zeros(n, taps, cp)
+    w[:, :, :cin] = torch.randn(n, taps, cin, generator=g) / math.sqrt(cin * taps)
+    w_h2, ws = ops.split_f16_weights_h2(w.reshape(n, taps * cp))
+    bias = torch.randn(n, generator=g) * 0.1 if fl.get("bias") else None
+    slope = torch.full((n,), float(fl["slope"])) if "slope" in fl else None
+    n8 = ops.round_up(n, 8)
+    res, res_h2 = None, False
+    if fl.get("res") in ("f32", "lo"):
+        res = torch.randn(m, n8, generator=g)[:, :n]
+    elif fl.get("res") == "h2":
+        res, res_h2 = ops.h2_pack(torch.randn(m, n8, generator=g)), True
+    n_store, want, vt0 = fl.get("n_store", 0), fl.get("want", "lo"), fl.get("vt")
+    ncol = vt0 if vt0 else n
+    mv = lambda t: None if t is None else t.to(DEV)
+    operands = (mv(ops.h2_pack(a)), mv(w_h2), mv(bias), mv(slope), mv(res))
+    kw = dict(n=n, cp=cp, n_store=n_store, t_col0=vt0 or 0, t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m,
+              w_scale=ws, res_h2=res_h2)
+
+    def outputs():
+        out = torch.full((m, ops.round_up(max(ncol, n_store), 8)), 7.0, device=DEV) if want in ("lo", "both") else None
+        out_f = torch.full((m, ncol), 7.0, device=DEV) if want in ("f32", "both") else None
+        out_t = torch.full((nb, n - vt0, ops.round_up(lout, 32)), 7.0, device=DEV) if vt0 else None
+        return out, out_f, out_t
+    return operands, kw, outputs
+
+
+def test_gemm_grouped_is_bit_identical_to_single_launches():
+    """`emage_gemm_grouped` (through `ops.lockstep`: recorded contractions issued as one grouped call) on a mix
+    of every EMAGE_H2 test case and model-sized problems — four tile configurations, more problems of one configuration than fit one
+    launch (8), convolutions, V^T destinations, H2 / float32 residuals, ragged M and N — writes exactly the bytes the single launches
+    write; `ops.gemm_grouped` (the direct form) likewise; and the library reports fewer launches than problems."""
+    probs = [_h2_problem(c) for c in GROUP_CASES]
+    single = []
+    for operands, kw, outputs in probs:
+        o = outputs()
+        ops.gemm(H2, *operands, *o, **kw)
+        single.append(o)
+    grouped = [outputs() for _operands, _kw, outputs in probs]
+    with ops.lockstep() as ls:
+        for (operands, kw, _), o in zip(probs, grouped):
+            with ls.chain():
+                ops.gemm(H2, *operands, *o, **kw)
+    torch.cuda.synchronize()
+    assert ls.launches == [("group", len(probs))]
+    n_launch = ops.grouped_launch_count(ls.groups[0])
+    assert 4 <= n_launch < len(probs) // 2, n_launch
+    for case, so, go in zip(GROUP_CASES, single, grouped):
+        for nm, a, b in zip(("out", "out_f32", "out_t"), so, go):
+            if a is not None:
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (case[0], nm)
+    direct = [outputs() for _operands, _kw, outputs in probs[-6:]]
+    ops.gemm_grouped(H2, [dict(a=op[0], w=op[1], bias=op[2], slope=op[3], res=op[4], out=o[0], out_f32=o[1], out_t=o[2], **kw)
+                          for (op, kw, _), o in zip(probs[-6:], direct)])
+    for so, go in zip(single[-6:], direct):
+        for a, b in zip(so, go):
+            if a is not None:
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # lock step with grouping disabled: the same walk, every contraction its own launch
+    with ops.lockstep(False) as ls:
+        for (operands, kw, outputs) in probs[:3]:
+            with ls.chain():
+                ops.gemm(H2, *operands, *outputs(), **kw)
+    assert ls.launches == [("gemm", 1)] * 3
+    # an invalid problem is refused before anything is launched
+    from pantomatrix_amd._lib import EmageKernelError
+    operands, kw, outputs = probs[0]
+    with pytest.raises(EmageKernelError):
+        ops.gemm_grouped(H2, [dict(a=operands[0], w=operands[1], out=outputs()[0], **{**kw, "cp": kw["cp"] + 8})] * 2)

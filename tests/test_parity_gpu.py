@@ -32,12 +32,13 @@ def x3_models():
 
 @pytest.fixture(scope="module")
 def exact_models(fp32_models, x3_models):
-    """f16x3 (the classes' default) = pre-split EMAGE_H2 activations with float32 residual twins; "f16x3_h2res": the residual stream
-    read from the H2 images; "f16x3_f32acts": float32 activations split inside every GEMM (EMAGE_F16X3, the round-2 form)."""
+    """f16x3 (the classes' default) = pre-split EMAGE_H2 activations, the residual stream read from the H2 images (LayerNorm writes one
+    output); "f16x3_f32res": float32 residual twins beside the H2 images (round 3's default); "f16x3_f32acts": float32 activations split
+    inside every GEMM (EMAGE_F16X3, the round-2 form)."""
     models = {"fp32": fp32_models, "f16x3": x3_models}
     m, vq = common.product_models(precision="f16x3", device=DEV)
-    m.h2_residual = True
-    models["f16x3_h2res"] = (m, vq)
+    m.h2_residual = False
+    models["f16x3_f32res"] = (m, vq)
     m, vq = common.product_models(precision="f16x3", device=DEV)
     for part in (m, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.split_acts = False
@@ -45,7 +46,7 @@ def exact_models(fp32_models, x3_models):
     return models
 
 
-X3_FORMS = ["f16x3", "f16x3_h2res", "f16x3_f32acts"]
+X3_FORMS = ["f16x3", "f16x3_f32res", "f16x3_f32acts"]
 
 
 @pytest.fixture(scope="module")
@@ -419,3 +420,51 @@ def test_clip_pipeline_results_survive_the_next_submission(x3_models):
     assert not np.array_equal(want[0][0], want[1][0])
     with pytest.raises(ValueError, match="sub_batches"):
         ClipRunner(model, vq, 2, n, sub_batches=2, on_overflow="fp32")
+
+
+def test_grouped_launches_change_no_bit(golden_dir):
+    """VERDICT round 3, next #2 ("bit-identical to the ungrouped path"): the lock-step chains with grouped contractions (the classes'
+    default: VQ part decoders, refinement layers + heads, `motion2latent_*.fc2`, `bodyhints_*.fc2`) against the round-3 form (one
+    stream lane per chain, one launch per contraction): the eight outputs of a forward window, every code index and every result of a
+    2-window + tail clip, bit for bit — and far fewer contraction launches."""
+    from pantomatrix_amd import ops
+    a_model, a_vq = common.product_models(precision="f16x3", device=DEV)
+    b_model, b_vq = common.product_models(precision="f16x3", device=DEV)
+    for part in (b_model, b_vq.vq_model_face, b_vq.vq_model_upper, b_vq.vq_model_hands, b_vq.vq_model_lower, b_vq.global_motion):
+        part.group_gemms = False
+    audio, spk, motion, mask = (x.to(DEV) for x in common.window_inputs(3))
+    counts = {}
+
+    class Count:
+        def __init__(self):
+            self.n = {}
+
+        def tag(self):
+            return None
+
+        def fire(self, kind, entries, launch):
+            k = "gemm" if kind in ("gemm", "gemm_grouped") else kind
+            self.n[k] = self.n.get(k, 0) + (ops.grouped_launch_count(entries) if kind == "gemm_grouped" else 1)
+            return launch()
+
+    with torch.no_grad():
+        for tag, model in (("grouped", a_model), ("single", b_model)):
+            ops._TRACE[0] = counts[tag] = Count()
+            try:
+                out = model.forward(audio, spk, motion, mask)
+            finally:
+                ops._TRACE[0] = None
+            counts[tag].out = out
+    for k in orc.OUT_KEYS:
+        assert torch.equal(counts["grouped"].out[k], counts["single"].out[k]), k
+    ng, ns = counts["grouped"].n["gemm"], counts["single"].n["gemm"]
+    assert ns - ng >= 24, (ng, ns)                       # 3 x 11 refinement / head launches -> 11, 3 + 2 second layers -> 2
+    assert {k: v for k, v in counts["grouped"].n.items() if k != "gemm"} == {k: v for k, v in counts["single"].n.items() if k != "gemm"}
+    clip = synthetic.synthetic_audio(2, synthetic.samples_for_frames(150)).to(DEV)
+    (pa, ea, ta), la = common.product_infer_clip(a_model, a_vq, clip)
+    (pb, eb, tb), lb = common.product_infer_clip(b_model, b_vq, clip)
+    assert np.array_equal(pa, pb) and np.array_equal(ea, eb) and np.array_equal(ta, tb)
+    ca, cb = a_model.infer_codes(clip, torch.zeros(2, 1, dtype=torch.long, device=DEV), a_vq), b_model.infer_codes(clip, torch.zeros(2, 1, dtype=torch.long, device=DEV), b_vq)
+    for k in ca:
+        if ca[k] is not None:
+            assert torch.equal(ca[k], cb[k]), k
