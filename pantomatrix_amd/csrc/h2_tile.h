@@ -26,6 +26,170 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 
 template <int BM, int BN, int NS> constexpr int h2_smem_bytes() { return NS * (BM + BN) * 128; }
 
+// ---- the epilogue of an EMAGE_H2 tile, shared by gemm_h2_tile and gemm_h2w_tile (h2w_tile.h) ----
+// acc: the wave's FM x FN accumulator fragments; (mw, nw): first row / column of the wave tile.  NAT = false: W rows were fed to the MFMAs in
+// the pair-permuted order (a lane ends with 8 consecutive columns per fragment pair; an odd last fragment in natural order); NAT = true:
+// every fragment in natural row order (a lane holds 4 consecutive columns per fragment).  Swapped MFMA operands (row-major tiles): lane
+// (fr, fg) holds row mw + 16 i + fr; V^T tiles (un-swapped): lane holds rows mw + 16 i + 4 fg + r of one column.
+template <int FM, int FN, bool NAT, bool PRE, int PM, int PP>
+__device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)[FM][FN], const int mw, const int nw, const int fr, const int fg,
+                                                 const bool vt_tile, const float (&pre_r)[PM][PP][8]) {
+    constexpr int FP = NAT ? 0 : FN / 2;
+    constexpr bool LONE = !NAT && (FN & 1) != 0;
+    constexpr int NLONE = NAT ? FN : (LONE ? 1 : 0);          // trailing fragments handled 4 columns at a time
+    const int ncol_n = p.out_t ? p.t_col0 : p.N;     // columns below this go to out / out_f32
+    h2_t* __restrict__ out = (h2_t*)p.out;
+    const float os = p.o_scale;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = acc[i][j] * os;
+
+    if (vt_tile) {
+        // un-swapped MFMAs: lane (fr, fg) holds rows m0 + wm*WTM + 16 i + 4 fg + r (r = 0..3) of column n(j, fr)
+        float* __restrict__ out_t = (float*)p.out_t;
+        const int t_ncols = p.N - p.t_col0;
+        const bool tvec = (p.t_rows % 4 == 0) && (p.t_ld % 4 == 0) && (((uintptr_t)out_t & 15) == 0);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int wrow = (NAT || (LONE && j == FN - 1)) ? j * 16 + fr : (j >> 1) * 32 + (j & 1) * 4 + 8 * (fr >> 2) + (fr & 3);
+            const int n = nw + wrow;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f, sv = p.slope ? p.slope[n] : 1.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = mw + i * 16 + fg * 4;
+                if (m >= p.M) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = leaky(acc[i][j][r] + bv, sv);
+                if (tvec && m + 3 < p.M) {
+                    const int b = m / p.t_rows, l = m - b * p.t_rows;
+                    *(float4*)(out_t + ((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int mm = m + r;
+                        if (mm < p.M) {
+                            const int b = mm / p.t_rows, l = mm - b * p.t_rows;
+                            out_t[((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l] = v[r];
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- row-major epilogue.  Lane (fr, fg): row m0 + wm*WTM + 16 i + fr; fragment pair jp -> 8 consecutive columns
+    // n0 + wn*WTN + jp*32 + fg*8 + e (e < 4 from acc[i][2jp], e >= 4 from acc[i][2jp+1]); lone fragment -> 4 columns ----
+    const int n_lim = ncol_n > p.n_store ? ncol_n : p.n_store;   // columns any store may touch (`out` zero-fills [N, n_store))
+    const bool f32_vec = p.out_f32 && (p.ldf % 4 == 0) && (((uintptr_t)p.out_f32 & 15) == 0);
+    auto finish = [&](auto wc, const int m, const int n, float (&x)[decltype(wc)::value], const float (&rpre)[decltype(wc)::value], const bool have_pre) {
+        // x: accumulators (already scaled) of W consecutive columns n.. of row m -> bias, residual, activation, stores
+        constexpr int W = decltype(wc)::value;
+        const bool full = n + W <= ncol_n;
+        float bv[W], sv[W], rv[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) { bv[e] = 0.f; sv[e] = 1.f; rv[e] = 0.f; }
+        if (full) {
+            if (p.bias) { if constexpr (W == 8) load8<float>(p.bias + n, bv); else { const float4 t = *(const float4*)(p.bias + n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; } }
+            if (p.slope) { if constexpr (W == 8) load8<float>(p.slope + n, sv); else { const float4 t = *(const float4*)(p.slope + n); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; } }
+            if (have_pre) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) rv[e] = rpre[e];
+            } else if (p.res) {
+                if (p.res_is_f32) {
+                    if constexpr (W == 8) load8<float>((const float*)p.res + (long)m * p.ldr + n, rv);
+                    else { const float4 t = *(const float4*)((const float*)p.res + (long)m * p.ldr + n); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
+                } else {
+                    if constexpr (W == 8) h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, rv);
+                    else h2_load4((const h2_t*)p.res + (long)m * p.ldr + n, n, rv);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                if (n + e < ncol_n) {
+                    if (p.bias) bv[e] = p.bias[n + e];
+                    if (p.slope) sv[e] = p.slope[n + e];
+                }
+            }
+            if (p.res && n < ncol_n) {               // the group exists in the residual's padded row
+                float t[W];
+                if (p.res_is_f32) {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) t[e] = n + e < ncol_n ? ((const float*)p.res)[(long)m * p.ldr + n + e] : 0.f;
+                } else {
+                    if constexpr (W == 8) h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, t);
+                    else h2_load4((const h2_t*)p.res + (long)m * p.ldr + n, n, t);
+                }
+#pragma unroll
+                for (int e = 0; e < W; ++e) rv[e] = n + e < ncol_n ? t[e] : 0.f;
+            }
+        }
+        float v[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float y = x[e] + bv[e];
+            if (p.res_first) y += rv[e];
+            y = leaky(y, sv[e]);
+            if (!p.res_first) y += rv[e];
+            v[e] = (n + e < ncol_n) ? y : 0.f;
+        }
+        if (out && n < n_lim) {
+            // out rows are padded to a multiple of 8 columns (host contract): the whole group is always addressable
+            if constexpr (W == 8) h2_store8(out + (long)m * p.ldo + n, v);
+            else h2_store4(out + (long)m * p.ldo + n, n, v);
+        }
+        if (p.out_f32 && n < ncol_n) {
+            float* dst = p.out_f32 + (long)m * p.ldf + n;
+            if (p.ksplit > 1) {                       // partial sums of the K-slices meet in memory (the destination was cleared by the host call)
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (n + e < ncol_n) __hip_atomic_fetch_add(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (full && f32_vec) {
+                if constexpr (W == 8) store8<float>(dst, v);
+                else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e)
+                    if (n + e < ncol_n) dst[e] = v[e];
+            }
+        }
+    };
+#pragma unroll
+    for (int jp = 0; jp < FP; ++jp) {
+        const int n = nw + jp * 32 + fg * 8;
+        if (n >= n_lim) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = mw + i * 16 + fr;
+            if (m >= p.M) continue;
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4];
+            finish(IC<8>{}, m, n, x, pre_r[i % PM][jp % PP], PRE && p.res && n + 8 <= ncol_n);
+        }
+    }
+#pragma unroll
+    for (int jl = FN - NLONE; jl < FN; ++jl) {
+        const int n = nw + jl * 16 + fg * 4;
+        if (n < n_lim) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = mw + i * 16 + fr;
+                if (m >= p.M) continue;
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = acc[i][jl][e];
+                const float none[4] = {0.f, 0.f, 0.f, 0.f};
+                finish(IC<4>{}, m, n, x, none, false);
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, bool DILV = false, bool TRACE = false>
 __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem, const int split = 0) {
     constexpr int ES = 4, BK = 32, RB = 128, RPI = 8;
@@ -337,155 +501,8 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     if (!is_compute) { if constexpr (TRACE) { if (p.trace && blockIdx.x == 0 && lane == 0) p.trace[wave * 512] = (unsigned long long)tr_n; } __syncthreads(); return; }
     if constexpr (PRE && NLW > 0) wait_vmcnt<0>();
 
-    const float os = p.o_scale;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = acc[i][j] * os;
-
-    if (vt_tile) {
-        // un-swapped MFMAs: lane (fr, fg) holds rows m0 + wm*WTM + 16 i + 4 fg + r (r = 0..3) of column n(j, fr)
-        float* __restrict__ out_t = (float*)p.out_t;
-        const int t_ncols = p.N - p.t_col0;
-        const bool tvec = (p.t_rows % 4 == 0) && (p.t_ld % 4 == 0) && (((uintptr_t)out_t & 15) == 0);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int wrow = (LONE && j == FN - 1) ? (FN - 1) * 16 + fr : (j >> 1) * 32 + (j & 1) * 4 + 8 * (fr >> 2) + (fr & 3);
-            const int n = n0 + wn * WTN + wrow;
-            if (n >= p.N) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f, sv = p.slope ? p.slope[n] : 1.f;
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * WTM + i * 16 + fg * 4;
-                if (m >= p.M) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = leaky(acc[i][j][r] + bv, sv);
-                if (tvec && m + 3 < p.M) {
-                    const int b = m / p.t_rows, l = m - b * p.t_rows;
-                    *(float4*)(out_t + ((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int mm = m + r;
-                        if (mm < p.M) {
-                            const int b = mm / p.t_rows, l = mm - b * p.t_rows;
-                            out_t[((long)b * t_ncols + (n - p.t_col0)) * p.t_ld + l] = v[r];
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        return;
-    }
-
-    // ---- row-major epilogue.  Lane (fr, fg): row m0 + wm*WTM + 16 i + fr; fragment pair jp -> 8 consecutive columns
-    // n0 + wn*WTN + jp*32 + fg*8 + e (e < 4 from acc[i][2jp], e >= 4 from acc[i][2jp+1]); lone fragment -> 4 columns ----
-    const int n_lim = ncol_n > p.n_store ? ncol_n : p.n_store;   // columns any store may touch (`out` zero-fills [N, n_store))
-    const bool f32_vec = p.out_f32 && (p.ldf % 4 == 0) && (((uintptr_t)p.out_f32 & 15) == 0);
-    auto finish = [&](auto wc, const int m, const int n, float (&x)[decltype(wc)::value], const float (&rpre)[decltype(wc)::value], const bool have_pre) {
-        // x: accumulators (already scaled) of W consecutive columns n.. of row m -> bias, residual, activation, stores
-        constexpr int W = decltype(wc)::value;
-        const bool full = n + W <= ncol_n;
-        float bv[W], sv[W], rv[W];
-#pragma unroll
-        for (int e = 0; e < W; ++e) { bv[e] = 0.f; sv[e] = 1.f; rv[e] = 0.f; }
-        if (full) {
-            if (p.bias) { if constexpr (W == 8) load8<float>(p.bias + n, bv); else { const float4 t = *(const float4*)(p.bias + n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; } }
-            if (p.slope) { if constexpr (W == 8) load8<float>(p.slope + n, sv); else { const float4 t = *(const float4*)(p.slope + n); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; } }
-            if (have_pre) {
-#pragma unroll
-                for (int e = 0; e < W; ++e) rv[e] = rpre[e];
-            } else if (p.res) {
-                if (p.res_is_f32) {
-                    if constexpr (W == 8) load8<float>((const float*)p.res + (long)m * p.ldr + n, rv);
-                    else { const float4 t = *(const float4*)((const float*)p.res + (long)m * p.ldr + n); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
-                } else {
-                    if constexpr (W == 8) h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, rv);
-                    else h2_load4((const h2_t*)p.res + (long)m * p.ldr + n, n, rv);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < W; ++e) {
-                if (n + e < ncol_n) {
-                    if (p.bias) bv[e] = p.bias[n + e];
-                    if (p.slope) sv[e] = p.slope[n + e];
-                }
-            }
-            if (p.res && n < ncol_n) {               // the group exists in the residual's padded row
-                float t[W];
-                if (p.res_is_f32) {
-#pragma unroll
-                    for (int e = 0; e < W; ++e) t[e] = n + e < ncol_n ? ((const float*)p.res)[(long)m * p.ldr + n + e] : 0.f;
-                } else {
-                    if constexpr (W == 8) h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, t);
-                    else h2_load4((const h2_t*)p.res + (long)m * p.ldr + n, n, t);
-                }
-#pragma unroll
-                for (int e = 0; e < W; ++e) rv[e] = n + e < ncol_n ? t[e] : 0.f;
-            }
-        }
-        float v[W];
-#pragma unroll
-        for (int e = 0; e < W; ++e) {
-            float y = x[e] + bv[e];
-            if (p.res_first) y += rv[e];
-            y = leaky(y, sv[e]);
-            if (!p.res_first) y += rv[e];
-            v[e] = (n + e < ncol_n) ? y : 0.f;
-        }
-        if (out && n < n_lim) {
-            // out rows are padded to a multiple of 8 columns (host contract): the whole group is always addressable
-            if constexpr (W == 8) h2_store8(out + (long)m * p.ldo + n, v);
-            else h2_store4(out + (long)m * p.ldo + n, n, v);
-        }
-        if (p.out_f32 && n < ncol_n) {
-            float* dst = p.out_f32 + (long)m * p.ldf + n;
-            if (p.ksplit > 1) {                       // partial sums of the K-slices meet in memory (the destination was cleared by the host call)
-#pragma unroll
-                for (int e = 0; e < W; ++e)
-                    if (n + e < ncol_n) __hip_atomic_fetch_add(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (full && f32_vec) {
-                if constexpr (W == 8) store8<float>(dst, v);
-                else *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < W; ++e)
-                    if (n + e < ncol_n) dst[e] = v[e];
-            }
-        }
-    };
-#pragma unroll
-    for (int jp = 0; jp < FP; ++jp) {
-        const int n = n0 + wn * WTN + jp * 32 + fg * 8;
-        if (n >= n_lim) continue;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + fr;
-            if (m >= p.M) continue;
-            float x[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4];
-            finish(IC<8>{}, m, n, x, pre_r[i % PM][jp % PP], PRE && p.res && n + 8 <= ncol_n);
-        }
-    }
-    if constexpr (LONE) {
-        const int n = n0 + wn * WTN + (FN - 1) * 16 + fg * 4;
-        if (n < n_lim) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = m0 + wm * WTM + i * 16 + fr;
-                if (m >= p.M) continue;
-                float x[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = acc[i][FN - 1][e];
-                const float none[4] = {0.f, 0.f, 0.f, 0.f};
-                finish(IC<4>{}, m, n, x, none, false);
-            }
-        }
-    }
+    h2_tile_epilogue<FM, FN, false, PRE, PM, PP>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r);
+    if (vt_tile) { __syncthreads(); return; }
     tr();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tr();

@@ -170,6 +170,7 @@ class TrainForward:
         self.grad_scale = 1024.0
         self._w_scale, self._wt_cache = {}, {}
         self.range_flag = None          # int32 device counter: transposed-weight operands (backward dX) whose cached scale no longer fits
+        self._range_pending, self._range_seen = [], set()
         self.tape = None
         self.param_grads = {}
         self.grad_views = None          # name -> preallocated fp32 gradient tensor (views of the exchange buckets, training.Trainer)
@@ -197,6 +198,7 @@ class TrainForward:
                     pk.w[f"{base}.{bn}.affine"] = (pk.f32(f"{base}.{bn}.weight"), pk.f32(f"{base}.{bn}.bias"))
         pk.w["train.wav_in"] = dict(w=torch.cat(w0, 0).float().contiguous(), b=torch.cat(b0).float().contiguous())
         pk.w["train.ones"] = torch.ones(pk.w["train.wav_in"]["w"].shape[0], dtype=torch.float32, device=pk.device)
+        pk.finish_range_check()
 
     # ---- BatchNorm bookkeeping ----------------------------------------------------------------------------------------------
     def _bn(self, cx, name, x, new_stats):
@@ -475,16 +477,26 @@ class TrainForward:
             import math
             mx = float(w.abs().max())
             ws = self._w_scale[key] = 2.0 ** (11 - math.floor(math.log2(mx))) if mx > 0 and math.isfinite(mx) else 1.0
-        elif w.numel():
-            if self.range_flag is None:
-                self.range_flag = torch.zeros((), dtype=torch.int32, device=w.device)
-            self.range_flag += ops.f16_scale_out_of_range(w, ws)
+        elif w.numel() and key not in self._range_seen:     # once per key and step, all keys in a few launches (`flush_range_checks`)
+            self._range_seen.add(key)
+            self._range_pending.append((w, ws))
         return ws
+
+    def flush_range_checks(self, new_step=False):
+        """Fold the backward operands queued by `_backward_scale` into `range_flag`; new_step: forget which keys this step has seen."""
+        if self._range_pending:
+            ws, scales = zip(*self._range_pending)
+            self._range_pending = []
+            bad = ops.f16_scales_out_of_range(list(ws), list(scales))
+            self.range_flag = bad if self.range_flag is None else self.range_flag + bad
+        if new_step:
+            self._range_seen = set()
 
     def reset_scales(self):
         """Forget the cached operand scales (backward weight operands here, the forward's packed operands in the model): the next
         forward chooses them afresh from the current weights."""
         self._w_scale, self._wt_cache, self.range_flag = {}, {}, None
+        self._range_pending, self._range_seen = [], set()
         self.model.invalidate_packed(reset_scales=True)
         self._pcache = None
 
@@ -1024,6 +1036,7 @@ class Trainer:
             log.append(("wait",))
         if grad_hook is not None:
             grad_hook(grads)
+        fwd.flush_range_checks(new_step=True)
         # health: inf / NaN among the (exchanged) gradients -> Adam's skip word.  After the exchange, so every rank sees the same count
         self.health.zero_()
         for flat in buckets.flat:
