@@ -36,7 +36,8 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
                                                  const bool vt_tile, const float (&pre_r)[PM][PP][8]) {
     constexpr int FP = NAT ? 0 : FN / 2;
     constexpr bool LONE = !NAT && (FN & 1) != 0;
-    constexpr int NLONE = NAT ? FN : (LONE ? 1 : 0);          // trailing fragments handled 4 columns at a time
+    constexpr bool NATP = NAT && FM % 2 == 0;                  // natural order, fragment rows paired through v_permlane16_swap: 8 columns per lane
+    constexpr int NLONE = NATP ? 0 : (NAT ? FN : (LONE ? 1 : 0));          // trailing fragments handled 4 columns at a time
     const int ncol_n = p.out_t ? p.t_col0 : p.N;     // columns below this go to out / out_f32
     h2_t* __restrict__ out = (h2_t*)p.out;
     const float os = p.o_scale;
@@ -170,6 +171,29 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4];
             finish(IC<8>{}, m, n, x, pre_r[i % PM][jp % PP], PRE && p.res && n + 8 <= ncol_n);
+        }
+    }
+    if constexpr (NATP) {
+        // lane (fr, fg) holds, per fragment (i, j), the 4 columns 16 j + 4 fg .. + 3 of row 16 i + fr.  Swapping the ODD lane rows of fragment
+        // (i, j) with the EVEN lane rows of fragment (i + 1, j), register by register, leaves lane (fr, fg) with the 8 consecutive columns
+        // 16 j + 8 (fg >> 1) .. + 7 of row 16 (i + (fg & 1)) + fr: first half in acc[i][j], second half in acc[i + 1][j]
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = nw + j * 16 + (fg >> 1) * 8;
+#pragma unroll
+            for (int i = 0; i < FM; i += 2) {
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[i][j][e]), __builtin_bit_cast(unsigned, acc[i + 1][j][e]), false, false);
+                    x[e] = __builtin_bit_cast(float, sw[0]);
+                    x[4 + e] = __builtin_bit_cast(float, sw[1]);
+                }
+                const int m = mw + (i + (fg & 1)) * 16 + fr;
+                if (m >= p.M || n >= n_lim) continue;
+                const float none[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                finish(IC<8>{}, m, n, x, none, false);
+            }
         }
     }
 #pragma unroll

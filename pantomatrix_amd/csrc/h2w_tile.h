@@ -7,23 +7,29 @@
 //   * no two waves need the same W rows: a wave loads its W fragments global -> VGPR directly, in MFMA operand layout, from a weight image
 //     packed in FRAGMENT ORDER (`ops.split_f16_weights_h2w`: per 16-row block and K-tile 2 KB = [hi plane | lo plane], a plane = 64 lanes x
 //     16 bytes) — every load instruction is one fully coalesced 1 KB run, prefetched two K-tiles ahead into a 3-deep register ring;
-//   * only the 64-row A panel (8 KB per K-tile) goes through the LDS-DMA ring; its fragments for K-tile k+1 are read while the MFMAs of K-tile
-//     k run (two register sets), and the per-K-tile barrier guards 8 KB instead of 32;
-//   * the memory operations of an iteration (2 A DMA pieces, 2 FN W loads, 2 FM fragment reads) are spread between its 3 FM FN MFMAs.
+//   * only the 64-row A panel (8 KB per K-tile) goes through LDS — by way of REGISTERS (global -> VGPR three K-tiles ahead, ds_write one
+//     iteration before its fragments are read), not by LDS-DMA: a wave's s_waitcnt vmcnt(N) can only be counted by hand when every operation
+//     in its queue completes in issue order, and LDS-DMA pieces and VGPR-returning loads do NOT complete in order with respect to each other
+//     (the first version of this kernel mixed them: correct on a half-empty chip, stale W fragments as soon as every CU had a block);
+//     the panel's fragments for K-tile k+1 are read while the MFMAs of K-tile k run (two register sets), and the per-K-tile barrier guards
+//     8 KB instead of 32;
+//   * the memory operations of an iteration (2 A loads, 2 FN W loads, 2 FM fragment reads) are spread between its 3 FM FN MFMAs.
 // Arithmetic, K order and per-accumulator MFMA order are those of gemm_h2_tile (three sweeps: W lo x A hi, W hi x A lo, W hi x A hi), so the
-// result is BIT-IDENTICAL to the LDS-staged kernels (tests/test_kernels_gpu.py).  W fragments use the natural row order (a lane ends with 4
-// consecutive output columns per fragment: h2_tile_epilogue<NAT = true>).
+// result is BIT-IDENTICAL to the LDS-staged kernels (tests/test_kernels_gpu.py).  W fragments use the natural row order, so a lane ends the
+// K-loop with 4 consecutive output columns per fragment; the epilogue swaps accumulator halves between neighbouring lane rows
+// (v_permlane16_swap: h2_tile_epilogue<NAT = true>) and stores 8 consecutive columns per lane like the LDS-staged kernels (the 4-column
+// form was measured 2.5x slower: 29 k instead of 11.6 k cycles of epilogue — store-issue bound).
 //
-// vmcnt bookkeeping: every iteration issues exactly G = GA + 2 FN vector-memory operations in a fixed order (A DMA of K-tile st + 3, W loads of
-// K-tile st + 2); K-tiles past the end are issued with out-of-range offsets (the buffer unit returns zeros: no branch, the counts stay
-// static).  At the top of iteration st everything issued up to iteration st - 2 must have landed (A of K-tile st + 1, W of K-tile st):
-// `s_waitcnt vmcnt(G)` leaves exactly iteration st - 1's G operations in flight.
+// vmcnt bookkeeping: every iteration issues exactly G = GA + 2 FN buffer loads in a fixed order (A of K-tile st + 3, W of K-tile st + 2);
+// K-tiles past the end are issued with out-of-range offsets (the buffer unit returns zeros: no branch, the counts stay static).  At the top
+// of iteration st everything issued up to iteration st - 2 must have landed (A of K-tile st + 1, W of K-tile st): `s_waitcnt vmcnt(G)`
+// leaves exactly iteration st - 1's G operations in flight.
 #pragma once
 #include "h2_tile.h"
 
 namespace emage_dev {
 
-template <int BM, int NS> constexpr int h2w_smem_bytes() { return NS * BM * 128; }
+template <int BM, int NS = 2> constexpr int h2w_smem_bytes() { return NS * BM * 128; }
 
 // 16-byte buffer load into VGPRs the compiler does not track (its own vmcnt insertion would drain the LDS-DMA queue at the first use:
 // cdna_hip_programming.md 5.7); callers count the queue by hand and pin the consumers behind `s_waitcnt` + sched_barrier
@@ -36,7 +42,7 @@ __device__ __forceinline__ void buf_load128(u32x4& dst, const u32x4& rsrc, const
 
 template <int BM, int BN, int NW, bool ILV, bool TRACE = false>
 __device__ __forceinline__ void gemm_h2w_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem) {
-    constexpr int ES = 4, BK = 32, RB = 128, RPI = 8, NS = 3;
+    constexpr int ES = 4, BK = 32, RB = 128, RPI = 8, NS = 2;
     constexpr int WTN = BN / NW, FM = BM / 16, FN = WTN / 16;
     constexpr int GA = BM / RPI / NW, GW = 2 * FN, G = GA + GW;
     static_assert((BM / RPI) % NW == 0 && WTN % 16 == 0 && BM % 16 == 0, "tile shape");
@@ -63,7 +69,14 @@ __device__ __forceinline__ void gemm_h2w_tile(const GemmArgs& p, const int m0, c
     const int nbatch = p.M / p.Lout;
     const unsigned a_shift = (unsigned)p.pad * (unsigned)(p.lda * ES);
     const unsigned a_bytes = (unsigned)((((long)nbatch * p.Lin - 1) * p.lda + p.Cp) * ES) + a_shift;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
+    u32x4 a_rsrc;
+    {
+        const unsigned long long aa = (unsigned long long)(uintptr_t)((const char*)p.A - a_shift);
+        a_rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)aa);
+        a_rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(aa >> 32) & 0xffffu);
+        a_rsrc[2] = __builtin_amdgcn_readfirstlane(a_bytes);
+        a_rsrc[3] = 0x00020000u;
+    }
     const int lrow = lane >> 3, lslot = lane & 7;
     const bool is_conv = p.taps > 1;
     unsigned a_voff[GA]; int a_lpos[GA];
@@ -103,24 +116,33 @@ __device__ __forceinline__ void gemm_h2w_tile(const GemmArgs& p, const int m0, c
     }
 
     // issue state: K-tile of the next A stage / of the next W set (both walk 0, 1, 2, ... ; past nk - 1 the offsets go out of range)
-    int a_kt = 0, a_tap = 0, a_c0 = 0, a_slot = 0;
+    int a_kt = 0, a_tap = 0, a_c0 = 0;
     unsigned soff_a = 0;
     const unsigned tap_step = (unsigned)(p.lda - p.Cp + BK) * ES;
     int w_kt = 0;
     unsigned soff_w = 0;
-    auto issue_a_piece = [&](auto jc) {
+    struct APanel { u32x4 r[GA]; };                          // a wave's share of one K-tile of the A panel (8 rows x 128 B per piece) on its way to LDS
+    auto issue_a_piece = [&](auto jc, APanel& ap) {
         constexpr int J = decltype(jc)::value;
         unsigned vo = a_voff[J];
         if (is_conv) vo = (unsigned)(a_lpos[J] + a_tap) < (unsigned)p.Lin ? vo : OOB;
         vo = a_kt < nk ? vo : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(smem + a_slot * STAGE + (wn + NW * J) * 1024),
-                                                 16, (int)vo, (int)soff_a, 0, 0);
+        buf_load128<0>(ap.r[J], a_rsrc, vo, soff_a);
     };
     auto advance_a = [&]() {
         ++a_kt;
         a_c0 += BK;
         if (a_c0 == p.Cp) { a_c0 = 0; ++a_tap; soff_a += tap_step; } else { soff_a += BK * ES; }
-        if (++a_slot == NS) a_slot = 0;
+    };
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // the LDS image of a stage is the LDS-DMA kernels' (lane-linear per 1-KiB piece; the XOR swizzle sits in the SOURCE chunk a lane loads)
+    auto write_a = [&](const APanel& ap, const int slot) {
+        static_for<GA>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            const unsigned addr = lds0 + (unsigned)(slot * STAGE + (wn + NW * J) * 1024 + lane * 16);
+            const u32x4 v = ap.r[J];
+            asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        });
     };
     struct WSet { u32x4 h[FN], l[FN]; };
     auto issue_w_piece = [&](auto jc, WSet& ws) {          // piece 2 j: hi plane of fragment j, 2 j + 1: lo plane
@@ -139,29 +161,32 @@ __device__ __forceinline__ void gemm_h2w_tile(const GemmArgs& p, const int m0, c
 
     const bool vt_tile = p.out_t != nullptr && n0 >= p.t_col0;       // block-uniform
     WSet w0 = {}, w1 = {}, w2 = {};
+    APanel p0 = {}, p1 = {};
     struct ASet { u32x4 h[FM], l[FM]; };
     ASet a0, a1;
 
-    // ---- prologue: virtual iterations -3 (A 0), -2 (A 1, W 0), -1 (A 2, W 1): G operations each except the first ----
-    static_for<GA>([&](auto jc) { issue_a_piece(jc); });
+    // ---- prologue.  Queue order: A 0, A 1, W 0 | A 2, W 1 — the same (A of K-tile k + 3, W of K-tile k + 2) groups the iterations issue ----
+    static_for<GA>([&](auto jc) { issue_a_piece(jc, p0); });
     advance_a();
-    static_for<GA>([&](auto jc) { issue_a_piece(jc); });
+    static_for<GA>([&](auto jc) { issue_a_piece(jc, p1); });
     advance_a();
     static_for<GW>([&](auto jc) { issue_w_piece(jc, w0); });
     advance_w();
-    static_for<GA>([&](auto jc) { issue_a_piece(jc); });
+    wait_vmcnt<GA + GW>();                 // A 0 has landed
+    __builtin_amdgcn_sched_barrier(0);
+    write_a(p0, 0);
+    static_for<GA>([&](auto jc) { issue_a_piece(jc, p0); });       // A 2 into the registers A 0 has just left
     advance_a();
     static_for<GW>([&](auto jc) { issue_w_piece(jc, w1); });
     advance_w();
 
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const unsigned a_rd = lds0 + fr * RB + ((fg ^ swz<8>(fr)) << 4);       // row fr + 16 i: swz is invariant under row += 16
     auto read_a = [&](auto rc, ASet& as, const unsigned sb) {              // reads 0 .. FM-1: hi planes, FM .. 2 FM-1: lo planes
         constexpr int R = decltype(rc)::value;
         if constexpr (R < FM) as.h[R] = lds_read128_off<R * 16 * RB>(a_rd + sb);
         else as.l[R - FM] = lds_read128_off<(R - FM) * 16 * RB>((a_rd ^ 64u) + sb);
     };
-    wait_vmcnt<2 * G>();                   // A 0 has landed (A 1, W 0, A 2, W 1 may be in flight)
+    wait_lgkmcnt<0>();
     __builtin_amdgcn_s_barrier();
     static_for<2 * FM>([&](auto rc) { read_a(rc, a0, 0u); });
     wait_lgkmcnt<0>();
@@ -173,17 +198,21 @@ __device__ __forceinline__ void gemm_h2w_tile(const GemmArgs& p, const int m0, c
     constexpr int MSTEP = NM / NMEM > 0 ? NM / NMEM : 1;
     auto kloop = [&](auto vtc) __attribute__((always_inline)) {
         constexpr bool VT = decltype(vtc)::value != 0;
-        // one iteration: MFMAs of K-tile st on (acur, wcur); A fragments of K-tile st + 1 -> anxt; issues A DMA st + 3 and W st + 2 -> wnew
-        auto step = [&](const int st, const ASet& acur, ASet& anxt, const WSet& wcur, WSet& wnew) {
+        // one iteration: K-tile st + 1 of the A panel (registers pnew, landed) -> LDS; MFMAs of K-tile st on (acur, wcur); A fragments of K-tile
+        // st + 1 -> anxt; issues the loads of A st + 3 -> pnew (free again) and W st + 2 -> wnew
+        auto step = [&](const int st, const ASet& acur, ASet& anxt, const WSet& wcur, WSet& wnew, APanel& pnew) {
             tr();
             wait_vmcnt<G>();
+            __builtin_amdgcn_sched_barrier(0);
+            write_a(pnew, (st + 1) & 1);
+            wait_lgkmcnt<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             tr();
-            const unsigned sb = (unsigned)(((st + 1) % NS) * STAGE);
+            const unsigned sb = (unsigned)(((st + 1) & 1) * STAGE);
             auto mem_op = [&](auto oc) {               // memory operation O of the iteration
                 constexpr int O = decltype(oc)::value;
-                if constexpr (O < GA) issue_a_piece(IC<O>{});
+                if constexpr (O < GA) issue_a_piece(IC<O>{}, pnew);
                 else if constexpr (O < G) issue_w_piece(IC<O - GA>{}, wnew);
                 else read_a(IC<O - G>{}, anxt, sb);          // past the last K-tile: a ghost stage (zeros), never used
             };
@@ -220,12 +249,12 @@ __device__ __forceinline__ void gemm_h2w_tile(const GemmArgs& p, const int m0, c
         // trailing iterations multiply ghost operands (zeros: the accumulators do not move); the host packs a weight for this kernel
         // only when its K-tile count is a multiple of 6 (768, 1536, 2304 ...)
         for (int st = 0; st < nk; st += 6) {
-            step(st, a0, a1, w0, w2);
-            step(st + 1, a1, a0, w1, w0);
-            step(st + 2, a0, a1, w2, w1);
-            step(st + 3, a1, a0, w0, w2);
-            step(st + 4, a0, a1, w1, w0);
-            step(st + 5, a1, a0, w2, w1);
+            step(st, a0, a1, w0, w2, p1);
+            step(st + 1, a1, a0, w1, w0, p0);
+            step(st + 2, a0, a1, w2, w1, p1);
+            step(st + 3, a1, a0, w0, w2, p0);
+            step(st + 4, a0, a1, w1, w0, p1);
+            step(st + 5, a1, a0, w2, w1, p0);
         }
     };
     if (vt_tile) kloop(IC<1>{}); else kloop(IC<0>{});

@@ -102,10 +102,16 @@ class GradientBuckets:
     parameter's gradient writes straight into the message.  `reduce(i)` starts bucket i's all-reduce (async), `wait()`
     finishes all of them and divides by the world size (the DDP average, train_emage_audio.py:251)."""
 
-    def __init__(self, plan, device="cpu", group=None):
-        self.group = group
+    def __init__(self, plan, device="cpu", group=None, exchange_dtype=torch.float32):
+        """exchange_dtype: what travels.  float32 (default): the buckets themselves are the messages (555 MB per step, no copy: what DDP does
+        for the reference, T:251).  bfloat16: each bucket is cast into a bf16 message, summed over the ranks in bf16 and added back into
+        the fp32 master gradients (277.8 MB per step, SURVEY 8f1 "bf16 + fp32 master"): half the bytes on the xGMI ring for 3 significant
+        digits per summand — the update differs from the reference's at the 1e-3 level of a gradient entry, so it is opt-in."""
+        if exchange_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("exchange_dtype must be torch.float32 or torch.bfloat16")
+        self.group, self.exchange_dtype = group, exchange_dtype
         self.tags = [tag for tag, _ in plan]
-        self.flat, self.grads, self._work = [], {}, []
+        self.flat, self.grads, self._work, self._msg = [], {}, [], {}
         for _tag, params in plan:
             n = sum(p.numel() for _, p in params)
             buf = torch.zeros(n, dtype=torch.float32, device=device)
@@ -116,11 +122,16 @@ class GradientBuckets:
             self.flat.append(buf)
 
     def nbytes(self):
-        return [b.numel() * 4 for b in self.flat]
+        """Bytes each bucket puts on the wire."""
+        es = 2 if self.exchange_dtype == torch.bfloat16 else 4
+        return [b.numel() * es for b in self.flat]
 
     def reduce(self, i):
         if dist.is_available() and dist.is_initialized():
-            self._work.append(dist.all_reduce(self.flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            msg = self.flat[i]
+            if self.exchange_dtype == torch.bfloat16:
+                msg = self._msg[i] = self.flat[i].to(torch.bfloat16)
+            self._work.append(dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self, average=True):
         """Finish the all-reduces started by `reduce`; average=True divides by the world size here (False: the caller folds the
@@ -128,6 +139,9 @@ class GradientBuckets:
         for w in self._work:
             w.wait()
         self._work = []
+        for i, msg in self._msg.items():                  # bf16 messages: the summed gradient replaces the fp32 master bucket's content
+            self.flat[i].copy_(msg)
+        self._msg = {}
         if average and dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(self.group)
             for b in self.flat:
@@ -195,6 +209,43 @@ def merge_batch_stats(mean_l, var_l, rows, group=None):
     mean = (means * n).sum(0) / total
     m2 = (variances * n).sum(0) + (n * (means - mean) ** 2).sum(0)
     return mean.float().contiguous(), (m2 / total).float().contiguous(), int(round(float(total)))
+
+
+def merge_batch_stats_many(items, group=None):
+    """`merge_batch_stats` for several INDEPENDENT BatchNorms in ONE all-gather and without a host read-back: items = [(mean_l (C_i,),
+    var_l (C_i,), local rows)] -> [(mean, biased variance)] float32 over the global batch.  The message of a rank is the concatenation of
+    [mean | variance | rows] per item in float64; the global row count stays on the device (the caller knows it from host arithmetic:
+    every rank runs the same sequence lengths, `training.TrainForward._global_rows`).  This is what lets the two WavEncoders' BatchNorms of
+    a block stage share a collective: 32 exchanges per forward become 12 (train_emage_audio.py:248)."""
+    dev = items[0][0].device
+    mine = torch.cat([torch.cat([m.reshape(-1).double(), v.reshape(-1).double(), torch.full((1,), float(rows), dtype=torch.float64, device=dev)])
+                      for m, v, rows in items])
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        flat = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(flat, mine.contiguous(), group=group)
+        allv = flat.view(world, mine.numel())
+    else:
+        allv = mine.view(1, -1)
+    out, off = [], 0
+    for m, _v, _rows in items:
+        c = m.numel()
+        means, variances, n = allv[:, off:off + c], allv[:, off + c:off + 2 * c], allv[:, off + 2 * c:off + 2 * c + 1]
+        total = n.sum()
+        mean = (means * n).sum(0) / total
+        m2 = (variances * n).sum(0) + (n * (means - mean) ** 2).sum(0)
+        out.append((mean.float().contiguous(), (m2 / total).float().contiguous()))
+        off += 2 * c + 1
+    return out
+
+
+def total_over_group(value: int, device="cpu", group=None) -> int:
+    """Sum of an integer over the ranks (the clips of all ranks: exchanged once per step, the only host read-back SyncBatchNorm needs)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
 
 
 def sum_over_group(tensors, group=None):

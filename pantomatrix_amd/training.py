@@ -137,18 +137,31 @@ class _Tape:
         e = self.g.get(id(t))
         return None if e is None else e[0]
 
-    def run(self, progress=None):
+    def run(self, progress=None, base=0):
         """Run the recorded closures in reverse; `pos` counts the executed nodes (what `TrainForward._param_grad` stamps a parameter's
-        last contribution with); progress(pos) is called behind each node (the overlapped gradient exchange hangs on it)."""
-        self.pos = -1
-        if progress is not None:
+        last contribution with); progress(pos) is called behind each node (the overlapped gradient exchange hangs on it).  base: position
+        of the first node (a tape run as the continuation of another one: the step-shared WavEncoder pass behind the third backward)."""
+        self.pos = base - 1
+        if progress is not None and base == 0:
             progress(-1)
         for k, fn in enumerate(reversed(self.nodes)):
-            self.pos = k
+            self.pos = base + k
             fn()
             if progress is not None:
-                progress(k)
+                progress(base + k)
         self.nodes = []
+
+
+class StepShare:
+    """What the forwards of ONE optimisation step share.  The reference runs both WavEncoders in each of the three forwards of a step
+    (T:156-172) on the SAME audio with the SAME weights: the same features and the same batch statistics three times, and three backward
+    passes through them whose parameter gradients are summed.  Here the first forward's encoder pass is kept — features, BatchNorm
+    statistics (later forwards replay the running-buffer updates from them), and its own tape — and the encoders are differentiated ONCE,
+    behind the third backward, from the SUM of the three feature gradients (the backward is linear in them): 1/3 of the WavEncoder work of a
+    step, and 1/3 of its SyncBatchNorm exchanges."""
+
+    def __init__(self):
+        self.feats, self.tape, self.bn_log = None, None, []
 
 
 class TrainForward:
@@ -163,6 +176,8 @@ class TrainForward:
             raise ValueError("the training forward runs in the fp32-storage precisions (f16x3 / fp32)")
         self.model = model
         self.sync_bn, self.group, self._bn_count = sync_bn, group, {}
+        self._clips = {}                # local clip count -> clips of all ranks (sync_bn: exchanged once per `begin_step` / first use)
+        self._bn_log = None             # list collecting (name, mean, var, rows) of a WavEncoder pass that later forwards of the step replay
         # f16x3 precision: the backward contractions run as split-fp16 MFMA on pre-split (EMAGE_H2) operands — gradients pre-scaled by
         # a power of two so that their fp16 planes stay normal (the loss-scaling of mixed-precision training, undone exactly in the
         # GEMM epilogue); fp32 precision keeps the exact-fp32 MFMA contractions
@@ -175,6 +190,7 @@ class TrainForward:
         self.param_grads = {}
         self.grad_views = None          # name -> preallocated fp32 gradient tensor (views of the exchange buckets, training.Trainer)
         self.touch = None               # dict filled with name -> tape position of the parameter's last contribution of a backward
+        self._shared, self.last_run_nodes = None, 0
         self._pcache = None
 
     # ---- packing of what the inference pack does not hold: un-folded WavEncoder convolutions ----------------------------
@@ -201,71 +217,139 @@ class TrainForward:
         pk.finish_range_check()
 
     # ---- BatchNorm bookkeeping ----------------------------------------------------------------------------------------------
-    def _bn(self, cx, name, x, new_stats):
-        """Batch statistics of conv output `x` (M, C) for BatchNorm `name`; the running buffers advance in `new_stats`."""
-        params = self._params()
-        rm = new_stats.get(name + ".running_mean", params[name + ".running_mean"]).detach().to(cx.dev, torch.float32).clone()
-        rv = new_stats.get(name + ".running_var", params[name + ".running_var"]).detach().to(cx.dev, torch.float32).clone()
-        if self.sync_bn:                                   # nn.SyncBatchNorm (T:248): statistics over the GLOBAL batch, one small all-reduce
-            from . import dist as pdist
-            mean_l, var_l = ops.bn_stats(x, None, None, BN_MOMENTUM)
-            mean, var, n = pdist.merge_batch_stats(mean_l, var_l, x.shape[0], group=self.group)      # float64, count-weighted (Chan) merge
-            stats = (mean, var)
-            rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * stats[0])
-            rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * stats[1] * (n / max(n - 1, 1)))
-            self._bn_count[name] = n
-        else:
-            stats = ops.bn_stats(x, rm, rv, BN_MOMENTUM)
-        new_stats[name + ".running_mean"], new_stats[name + ".running_var"] = rm, rv
-        nbt = new_stats.get(name + ".num_batches_tracked", params.get(name + ".num_batches_tracked", torch.zeros((), dtype=torch.long)))
-        new_stats[name + ".num_batches_tracked"] = nbt.detach().clone() + 1
-        return stats
+    def _global_rows(self, rows, b):
+        """Rows of a BatchNorm input over the GLOBAL batch (nn.SyncBatchNorm's count): every rank runs the same sequence lengths, so it is
+        rows / b x (clips of all ranks) — host arithmetic on the clip total exchanged ONCE per forward / step (`_clip_total`), no read-back
+        of a device count per BatchNorm."""
+        return rows // b * self._clip_total(b)
 
-    def _wav_encoder(self, cx, enc, e, audio, b, new_stats):
-        """WavEncoder.forward (P:296-314) with train-mode BatchNorm -> (B*T', audio_f) fp32, T'."""
+    def _clip_total(self, b):
+        if not self.sync_bn:
+            return b
+        hit = self._clips.get(b)
+        if hit is None:
+            from . import dist as pdist
+            hit = self._clips[b] = pdist.total_over_group(b, device=self.model.device, group=self.group)
+        return hit
+
+    def _bn_many(self, cx, items, b, new_stats):
+        """Batch statistics of several INDEPENDENT BatchNorms: items = [(name, conv output x (M, C))] -> [(mean, biased var)]; the running
+        buffers advance in `new_stats`.  sync_bn (nn.SyncBatchNorm, T:248): the local (mean, variance, rows) of ALL items travel in ONE
+        all-gather and are merged count-weighted in float64 (`dist.merge_batch_stats_many`) — the two encoders' bn1 of a block, or their
+        bn2 + shortcut BatchNorms, are one collective instead of two / four."""
+        params = self._params()
+        out = []
+        if self.sync_bn:
+            from . import dist as pdist
+            local = [ops.bn_stats(x, None, None, BN_MOMENTUM) for _name, x in items]
+            merged = pdist.merge_batch_stats_many([(mean, var, x.shape[0]) for (mean, var), (_name, x) in zip(local, items)], group=self.group)
+        for k, (name, x) in enumerate(items):
+            rm = new_stats.get(name + ".running_mean", params[name + ".running_mean"]).detach().to(cx.dev, torch.float32).clone()
+            rv = new_stats.get(name + ".running_var", params[name + ".running_var"]).detach().to(cx.dev, torch.float32).clone()
+            n = x.shape[0]
+            if self.sync_bn:
+                stats = merged[k]
+                n = self._global_rows(x.shape[0], b)
+                rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * stats[0])
+                rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * stats[1] * (n / max(n - 1, 1)))
+                self._bn_count[name] = n
+            else:
+                stats = ops.bn_stats(x, rm, rv, BN_MOMENTUM)
+            new_stats[name + ".running_mean"], new_stats[name + ".running_var"] = rm, rv
+            nbt = new_stats.get(name + ".num_batches_tracked", params.get(name + ".num_batches_tracked", torch.zeros((), dtype=torch.long)))
+            new_stats[name + ".num_batches_tracked"] = nbt.detach().clone() + 1
+            if self._bn_log is not None:
+                self._bn_log.append((name, stats[0], stats[1], n))
+            out.append(stats)
+        return out
+
+    def _bn(self, cx, name, x, new_stats, b=None):
+        return self._bn_many(cx, [(name, x)], x.shape[0] if b is None else b, new_stats)[0]
+
+    def _replay_bn(self, log, new_stats):
+        """The running-buffer updates of a forward whose WavEncoder pass is SHARED with an earlier forward of the step (same audio, same
+        weights: same batch statistics): momentum update and batch counter of every BatchNorm once more, from the logged statistics."""
+        params = self._params()
+        dev = self.model.device
+        names = [e[0] for e in log]
+        rms = [new_stats.get(n + ".running_mean", params[n + ".running_mean"]).detach().to(dev, torch.float32) for n in names]
+        rvs = [new_stats.get(n + ".running_var", params[n + ".running_var"]).detach().to(dev, torch.float32) for n in names]
+        rms = torch._foreach_mul(rms, 1 - BN_MOMENTUM)
+        torch._foreach_add_(rms, [e[1] for e in log], alpha=BN_MOMENTUM)
+        rvs = torch._foreach_mul(rvs, 1 - BN_MOMENTUM)
+        torch._foreach_add_(rvs, torch._foreach_mul([e[2] for e in log], [BN_MOMENTUM * e[3] / max(e[3] - 1, 1) for e in log]))
+        for n, rm, rv in zip(names, rms, rvs):
+            new_stats[n + ".running_mean"], new_stats[n + ".running_var"] = rm, rv
+            nbt = new_stats.get(n + ".num_batches_tracked", params.get(n + ".num_batches_tracked", torch.zeros((), dtype=torch.long)))
+            new_stats[n + ".num_batches_tracked"] = nbt.detach().clone() + 1
+
+    def _wav_encoders(self, cx, encs, audio, b, new_stats):
+        """WavEncoder.forward (P:296-314) with train-mode BatchNorm for several encoders IN LOCK STEP (encs = [(name, index)]): block by
+        block, so that the BatchNorm statistics of a stage — every encoder's bn1, then every encoder's bn2 and shortcut BatchNorm — form one
+        exchange under sync_bn.  -> ([features (B*T', audio_f) fp32 per encoder], T')."""
         m = self.model
         blocks = m._wav_blocks()
         lens = m._wav_lengths(audio.shape[1])
         k, q = _WAV_TAPS, blocks[0][1]
         w_in = cx.pk.w["train.wav_in"]
-        x, lin = None, None
+        xs, lin = [None] * len(encs), None
         for i, (cin, cout, stride, pad, ds) in enumerate(blocks):
-            base = f"{enc}.feat_extractor.{i}"
+            bases = [f"{enc}.feat_extractor.{i}" for enc, _e in encs]
             lout = lens[i]
             rows = b * lout
-            if i == 0:
-                r = slice(e * 2 * q, (e + 1) * 2 * q)
-                y = torch.empty(rows, 2 * q, dtype=torch.float32, device=cx.dev)
-                ops.wav_conv_in(F32, audio, w_in["w"][r], w_in["b"][r], cx.pk.w["train.ones"][:2 * q], y, lout, stride, pad)
-            else:
-                ent = cx.pk.w[base + ".conv1.raw"]
-                y, _ = cx.gemm(x, base + ".conv1.raw", conv=(stride, pad, lin, lout), m=rows, n_store=_rup(ent["n"]))
-            c1 = y[:, :cout]
-            g1, b1 = cx.pk.w[base + ".bn1.affine"]
-            y1 = torch.empty(rows, _rup(cout), dtype=torch.float32, device=cx.dev)
-            if y1.shape[1] != cout:
-                y1.zero_()                                 # padded channels feed conv2's contraction: they must be zero
-            st1 = self._bn(cx, base + ".bn1", c1, new_stats)
-            ops.bn_apply(c1, st1, g1, b1, y1[:, :cout], slope=0.01)
-            c2, _ = cx.gemm(y1, base + ".conv2.raw", conv=(1, k // 2, lout, lout), m=rows, n_store=_rup(cout))
-            c2 = c2[:, :cout]
-            g2, b2 = cx.pk.w[base + ".bn2.affine"]
-            st2 = self._bn(cx, base + ".bn2", c2, new_stats)                           # P:287-288, before the downsample branch (P:289-290)
-            out = torch.empty(rows, cout, dtype=torch.float32, device=cx.dev)
-            cds, std = None, None
-            if ds:
-                cds = y[:, cout:2 * cout]
-                gd, bd = cx.pk.w[base + ".downsample.1.affine"]
-                std = self._bn(cx, base + ".downsample.1", cds, new_stats)
-                ops.bn_apply(c2, st2, g2, b2, out, slope=0.01, sc=cds, sc_bn=(*std, gd, bd))
-            else:
-                ops.bn_apply(c2, st2, g2, b2, out, slope=0.01, sc=x[:, :cout])
+            ys = []
+            for (enc, e), base, x in zip(encs, bases, xs):
+                if i == 0:
+                    r = slice(e * 2 * q, (e + 1) * 2 * q)
+                    y = torch.empty(rows, 2 * q, dtype=torch.float32, device=cx.dev)
+                    ops.wav_conv_in(F32, audio, w_in["w"][r], w_in["b"][r], cx.pk.w["train.ones"][:2 * q], y, lout, stride, pad)
+                else:
+                    ent = cx.pk.w[base + ".conv1.raw"]
+                    y, _ = cx.gemm(x, base + ".conv1.raw", conv=(stride, pad, lin, lout), m=rows, n_store=_rup(ent["n"]))
+                ys.append(y)
+            c1s = [y[:, :cout] for y in ys]
+            st1s = self._bn_many(cx, [(base + ".bn1", c1) for base, c1 in zip(bases, c1s)], b, new_stats)
+            c2s, y1s = [], []
+            for base, c1, st1 in zip(bases, c1s, st1s):
+                g1, b1 = cx.pk.w[base + ".bn1.affine"]
+                y1 = torch.empty(rows, _rup(cout), dtype=torch.float32, device=cx.dev)
+                if y1.shape[1] != cout:
+                    y1.zero_()                             # padded channels feed conv2's contraction: they must be zero
+                ops.bn_apply(c1, st1, g1, b1, y1[:, :cout], slope=0.01)
+                c2, _ = cx.gemm(y1, base + ".conv2.raw", conv=(1, k // 2, lout, lout), m=rows, n_store=_rup(cout))
+                c2s.append(c2[:, :cout])
+                y1s.append(y1)
+            items = []
+            for base, c2, y in zip(bases, c2s, ys):        # P:287-290: bn2, then the shortcut's BatchNorm — independent of each other
+                items.append((base + ".bn2", c2))
+                if ds:
+                    items.append((base + ".downsample.1", y[:, cout:2 * cout]))
+            sts = self._bn_many(cx, items, b, new_stats)
+            saved_all, outs = [], []
+            for j, (base, c2, y, y1, c1, st1, x) in enumerate(zip(bases, c2s, ys, y1s, c1s, st1s, xs)):
+                g2, b2 = cx.pk.w[base + ".bn2.affine"]
+                out = torch.empty(rows, cout, dtype=torch.float32, device=cx.dev)
+                cds, std = None, None
+                if ds:
+                    st2, std = sts[2 * j], sts[2 * j + 1]
+                    cds = y[:, cout:2 * cout]
+                    gd, bd = cx.pk.w[base + ".downsample.1.affine"]
+                    ops.bn_apply(c2, st2, g2, b2, out, slope=0.01, sc=cds, sc_bn=(*std, gd, bd))
+                else:
+                    st2 = sts[j]
+                    ops.bn_apply(c2, st2, g2, b2, out, slope=0.01, sc=x[:, :cout])
+                outs.append(out)
+                saved_all.append(dict(i=i, base=base, geom=(cin, cout, stride, pad, ds), x_prev=x, lin=lin, lout=lout, b=b, audio=audio, c1=c1, st1=st1,
+                                      y1=y1[:, :cout], c2=c2, st2=st2, cds=cds, std=std, out=out))
             if self.tape is not None:
-                saved = dict(i=i, base=base, geom=(cin, cout, stride, pad, ds), x_prev=x, lin=lin, lout=lout, b=b, audio=audio, c1=c1, st1=st1,
-                             y1=y1[:, :cout], c2=c2, st2=st2, cds=cds, std=std, out=out)
-                self.tape.node(lambda sv=saved: self._wav_block_backward(cx, sv))
-            x, lin = out, lout
-        return x, lens[-1]
+                self.tape.node(lambda svs=saved_all: self._wav_blocks_backward(cx, svs))
+            xs, lin = outs, lout
+        return xs, lens[-1]
+
+    def _wav_encoder(self, cx, enc, e, audio, b, new_stats):
+        """One encoder alone (tests; the step runs both in lock step through `_wav_encoders`)."""
+        xs, ta = self._wav_encoders(cx, [(enc, e)], audio, b, new_stats)
+        return xs[0], ta
 
     def _conv_backward(self, cx, x, cin, origins, dy, taps, stride, pad, lin, lout, nseq, need_dx):
         """Conv1d backward on channels-last rows through emage_gemm (exact fp32): x (nseq*lin, >= cin) the layer input, dy (nseq*lout, N)
@@ -331,35 +415,67 @@ class TrainForward:
         ops.gemm(H2, dy_h, w_t, None, None, None, None, dcol, None, n=kc, cp=np_, w_scale=wsc, a_scale=16.0 * gs)
         return ops.col2im(dcol, cin, taps, stride, pad, lin, lout, nseq)
 
-    def _bn_backward(self, name, x, stats, dy):
-        gamma = self._param(name + ".weight").float()
-        if self.sync_bn:                                   # local sums -> parameter gradients (averaged later with all the others);
-            from . import dist as pdist                    # their sum over ranks -> the input gradient
-            dg, db = ops.bn_backward_sums(x, stats, dy)
-            tot = pdist.sum_over_group([dg.clone(), db.clone()], group=self.group)
-            dx = ops.bn_backward_apply(x, stats, gamma, dy, tot, self._bn_count[name])
-        else:
-            dx, dg, db = ops.bn_backward(x, stats, gamma, dy)
-        self._param_grad(name + ".weight", slice(None), dg)
-        self._param_grad(name + ".bias", slice(None), db)
-        return dx
+    def _bn_backward_many(self, items):
+        """Training-mode BatchNorm backward of several INDEPENDENT BatchNorms: items = [(name, x, stats, dy)] -> [dx]; parameter gradients
+        are accumulated.  sync_bn: the per-channel sums of ALL items are summed over the ranks in ONE all-reduce (local sums -> parameter
+        gradients, averaged later with all the others; their sum over ranks -> the input gradients)."""
+        out = []
+        if self.sync_bn:
+            from . import dist as pdist
+            sums = [ops.bn_backward_sums(x, stats, dy) for _name, x, stats, dy in items]
+            tot = pdist.sum_over_group([t.clone() for pair in sums for t in pair], group=self.group)
+        for k, (name, x, stats, dy) in enumerate(items):
+            gamma = self._param(name + ".weight").float()
+            if self.sync_bn:
+                dg, db = sums[k]
+                dx = ops.bn_backward_apply(x, stats, gamma, dy, (tot[2 * k], tot[2 * k + 1]), self._bn_count[name])
+            else:
+                dx, dg, db = ops.bn_backward(x, stats, gamma, dy)
+            self._param_grad(name + ".weight", slice(None), dg)
+            self._param_grad(name + ".bias", slice(None), db)
+            out.append(dx)
+        return out
 
-    def _wav_block_backward(self, cx, sv):
-        """BasicBlock.forward (P:283-294) backwards: LeakyReLU, bn2 / the (batch-normalised) shortcut, conv2, LeakyReLU, bn1, conv1 (+ shortcut conv)."""
+    def _bn_backward(self, name, x, stats, dy):
+        return self._bn_backward_many([(name, x, stats, dy)])[0]
+
+    def _wav_blocks_backward(self, cx, svs):
+        """BasicBlock.forward (P:283-294) backwards for the same block of several encoders in lock step: LeakyReLU, [bn2 and the
+        (batch-normalised) shortcut of every encoder: one exchange], conv2, LeakyReLU, [bn1 of every encoder: one exchange], conv1
+        (+ shortcut conv)."""
         tape = self.tape
-        d_out = tape.get(sv["out"])
-        if d_out is None:
+        svs = [sv for sv in svs if tape.get(sv["out"]) is not None]
+        if not svs:
             return
+        k = _WAV_TAPS
+        dvs = [ops.act_backward(tape.get(sv["out"]), sv["out"], 0.01) for sv in svs]
+        items = []
+        for sv, dv in zip(svs, dvs):
+            items.append((sv["base"] + ".bn2", sv["c2"], sv["st2"], dv))
+            if sv["geom"][4]:
+                items.append((sv["base"] + ".downsample.1", sv["cds"], sv["std"], dv))
+        dxs = iter(self._bn_backward_many(items))
+        dc2s, dcdss = [], []
+        for sv, dv in zip(svs, dvs):
+            cin, cout, stride, pad, ds = sv["geom"]
+            dc2s.append(next(dxs))
+            dcdss.append(next(dxs) if ds else None)
+            if not ds:
+                tape.add(sv["x_prev"], dv, cols=cout)
+        pre1 = []
+        for sv, dc2 in zip(svs, dc2s):
+            cin, cout, stride, pad, ds = sv["geom"]
+            base, b, lout = sv["base"], sv["b"], sv["lout"]
+            dy1 = self._conv_backward(cx, sv["y1"], cout, [(base + ".conv2.weight", base + ".conv2.bias")], dc2, k, 1, k // 2, lout, lout, b, True)
+            pre1.append(ops.act_backward(dy1, sv["y1"], 0.01))
+        dc1s = self._bn_backward_many([(sv["base"] + ".bn1", sv["c1"], sv["st1"], g) for sv, g in zip(svs, pre1)])
+        for sv, dc1, dcds in zip(svs, dc1s, dcdss):
+            self._wav_block_conv1_backward(cx, sv, dc1, dcds)
+
+    def _wav_block_conv1_backward(self, cx, sv, dc1, dcds):
+        tape = self.tape
         cin, cout, stride, pad, ds = sv["geom"]
         base, k, b, lin, lout = sv["base"], _WAV_TAPS, sv["b"], sv["lin"], sv["lout"]
-        dv = ops.act_backward(d_out, sv["out"], 0.01)
-        dc2 = self._bn_backward(base + ".bn2", sv["c2"], sv["st2"], dv)
-        if ds:
-            dcds = self._bn_backward(base + ".downsample.1", sv["cds"], sv["std"], dv)
-        else:
-            tape.add(sv["x_prev"], dv, cols=cout)
-        dy1 = self._conv_backward(cx, sv["y1"], cout, [(base + ".conv2.weight", base + ".conv2.bias")], dc2, k, 1, k // 2, lout, lout, b, True)
-        dc1 = self._bn_backward(base + ".bn1", sv["c1"], sv["st1"], ops.act_backward(dy1, sv["y1"], 0.01))
         origins = [(base + ".conv1.weight", base + ".conv1.bias")]
         dys = dc1
         if ds:
@@ -681,11 +797,12 @@ class TrainForward:
         return rows
 
     # ---- the forward --------------------------------------------------------------------------------------------------------
-    def __call__(self, audio, speaker_id, masked_motion, mask, dropout_masks=None, use_audio=True, new_stats=None, tape=False, rng=None):
+    def __call__(self, audio, speaker_id, masked_motion, mask, dropout_masks=None, use_audio=True, new_stats=None, tape=False, rng=None, share=None):
         """-> (dict of the 8 (B, T, 256) fp32 outputs, new_stats).  `new_stats` carries the BatchNorm running buffers from one
         forward of a step to the next (as oracle.emage_train_oracle.forward_train does); it is not written into the model.
         tape=True keeps what `backward()` needs (see there).  dropout_masks None: the masks are drawn on the device from
-        rng = (seed, step, first mask id) — see `_Masks`."""
+        rng = (seed, step, first mask id) — see `_Masks`.  share: the `StepShare` of the optimisation step this forward belongs to
+        (same audio and weights as the step's other forwards): the WavEncoder pass is computed by the first of them only."""
         model = self.model
         c = model.config
         cx = _Ctx(model._engine(h2=False))       # the training forward keeps float32 activations (split inside the GEMMs in f16x3)
@@ -725,9 +842,23 @@ class TrainForward:
         self._lin(cx, hh_face, "bodyhints_face.fc2", out=hint_face)
         hint_body = self._lin(cx, hh_body, "bodyhints_body.fc2")
 
-        # the two WavEncoders, batch statistics (M:275-281)
-        a_face, ta = self._wav_encoder(cx, "audio_encoder_face", 0, audio, b, new_stats)
-        a_body, _ = self._wav_encoder(cx, "audio_encoder_body", 1, audio, b, new_stats)
+        # the two WavEncoders, batch statistics (M:275-281), block by block in lock step; shared by the forwards of a step
+        self._shared = share
+        if share is not None and share.feats is not None:
+            a_face, a_body, ta = share.feats
+            self._replay_bn(share.bn_log, new_stats)
+        else:
+            main = self.tape
+            if share is not None:
+                self._bn_log = share.bn_log
+                if main is not None:
+                    self.tape = share.tape = _Tape(dev)      # the encoders' backward waits for the gradients of all the step's forwards
+            try:
+                (a_face, a_body), ta = self._wav_encoders(cx, [("audio_encoder_face", 0), ("audio_encoder_body", 1)], audio, b, new_stats)
+            finally:
+                self.tape, self._bn_log = main, None
+            if share is not None:
+                share.feats = (a_face, a_body, ta)
         if ta < t:
             raise RuntimeError(f"Sizes of tensors must match: audio features {ta} frames vs motion {t} frames")
         memcat[:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)                # M:278-281: the FACE features are trimmed to T
@@ -808,8 +939,26 @@ class TrainForward:
             # parameters receive exact-zero gradients and an Adam state — kept that way
             tape.add(logits, ops.nll_loss_grad(logits, index_gt[q].reshape(-1).contiguous().to(logits.device), getattr(cfg, "c" + q[0])))
         tape.run(progress)
+        self.last_run_nodes = tape.pos + 1
+        share = self._shared
+        if share is not None and share.tape is not None:           # the feature gradients of this forward join the shared encoder pass
+            for feat in share.feats[:2]:
+                g = tape.get(feat)
+                if g is not None:
+                    share.tape.add(feat, g)
         self.tape = None
         return self.param_grads
+
+    def finish_shared(self, share, progress=None, base=0):
+        """Backward of the step-shared WavEncoder pass from the summed feature gradients (call behind the step's last `backward`)."""
+        if share is None or share.tape is None:
+            return
+        self.tape = share.tape
+        try:
+            share.tape.run(progress, base=base)
+        finally:
+            self.tape = None
+        share.tape = None
 
     def backward_from(self, tape, out2d, grad_outputs):
         """Backward of ONE recorded forward from the gradients of its outputs (the autograd bridge of the model classes' train-mode
@@ -939,7 +1088,7 @@ class Trainer:
     `grad_hook(param_grads)` still runs between backward and the update (tests spy on it)."""
 
     def __init__(self, model, vq, lr=1.5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, sync_bn=False, group=None, seed=0, exchange=True,
-                 on_nonfinite="raise"):
+                 on_nonfinite="raise", share_encoders=True, exchange_dtype=torch.float32):
         """exchange=False: no built-in gradient all-reduce even in a multi-process run (a `grad_hook` may do it: `dist.gradient_allreduce_hook`).
 
         Health of a step (the f16x3 backward runs on fp16 planes of `grad_scale` x dY and of scaled weights: an overflow turns into
@@ -954,6 +1103,9 @@ class Trainer:
         if on_nonfinite not in ("raise", "skip"):
             raise ValueError("on_nonfinite must be 'raise' or 'skip'")
         self.on_nonfinite, self.skipped_steps, self.rescaled = on_nonfinite, 0, 0
+        # share_encoders: the WavEncoder pass of a step is computed (and differentiated) once for its three forwards — see `StepShare`;
+        # False = the reference's schedule, three passes (same losses; gradients equal up to fp32 summation order)
+        self.share_encoders = bool(share_encoders)
         self.exchange = bool(exchange)
         self.fwd, self.vq = TrainForward(model, sync_bn=sync_bn, group=group), vq
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -961,7 +1113,7 @@ class Trainer:
         self.state = {}                                   # name -> dict(step, exp_avg, exp_avg_sq)
         named = [(k, v) for k, v in model.named_parameters() if v.requires_grad]
         plan, self.unused = pdist.emage_bucket_plan(named)
-        self.buckets = pdist.GradientBuckets(plan, device=model.device, group=group)
+        self.buckets = pdist.GradientBuckets(plan, device=model.device, group=group, exchange_dtype=exchange_dtype)       # bfloat16: half the bytes on the wire
         self.fwd.grad_views = self.buckets.grads
         self.bucket_of = {name: i for i, (_tag, params) in enumerate(plan) for name, _p in params}
         self.schedule = None                              # bucket -> tape position (third backward) behind which it is complete
@@ -999,10 +1151,11 @@ class Trainer:
         learning = self.schedule is None
         step_for_rng = step_counter if step_counter is not None else self.steps_done + 1
         dm = dropout_masks if dropout_masks is not None else (None, None, None)
+        share = StepShare() if self.share_encoders else None
         for f, (tag, mask, use_audio, masks) in enumerate((("seed", seed_mask, True, dm[0]), ("audio", random_mask, True, dm[1]),
                                                             ("mask", random_mask, False, dm[2]))):
             pred, stats = fwd(batch["audio"], speaker_id, masked_motion, mask, masks, use_audio=use_audio, new_stats=stats, tape=True,
-                              rng=self._rng(f, step_for_rng))
+                              rng=self._rng(f, step_for_rng), share=share)
             out["rec_" + tag], out["cls_" + tag] = losses(cfg, pred, index, latent, ws)
             progress = None
             if f == 2:
@@ -1018,6 +1171,8 @@ class Trainer:
                             log.append(("reduce", i, pos))
                             buckets.reduce(i)
             fwd.backward(index, latent, progress)
+            if f == 2:                                    # the shared WavEncoder pass: the tail of the third backward
+                fwd.finish_shared(share, progress, base=fwd.last_run_nodes)
             log.append(("backward_done", f))
         if learning:
             last = {}

@@ -65,6 +65,17 @@ def _train_exchange_worker(rank, world, port, q):
     for i in range(len(buckets.flat)):                            # backward order: heads first, encoders last
         buckets.reduce(i)
     buckets.wait()
+    # the bf16 exchange (SURVEY 8f1 "bf16 + fp32 master", VERDICT round 3 next #6c): half the bytes, the sum to bf16 accuracy
+    half = pd.GradientBuckets(plan, exchange_dtype=torch.bfloat16)
+    assert sum(half.nbytes()) * 2 == sum(buckets.nbytes())
+    for k, v in local.items():
+        half.grads[k].copy_(v)
+    for i in range(len(half.flat)):
+        half.reduce(i)
+    half.wait()
+    for k in local:                                               # buckets.grads holds the fp32 average of the same local gradients
+        want = buckets.grads[k]
+        assert float((half.grads[k] - want).abs().max()) <= 2e-2 * float(want.abs().max()) + 1e-6, k
     # SyncBatchNorm statistics of two layers in one message
     x = [torch.randn(5 + rank, 64, generator=g), torch.randn(7, 128, generator=g) + rank]
     means, variances = pd.sync_batch_stats([t.sum(0) for t in x], [(t * t).sum(0) for t in x], [t.shape[0] for t in x])
@@ -187,8 +198,30 @@ def _sync_worker(rank, world, port, q):
     def spy(grads):                                        # the trainer has summed the buckets over ranks: the data-parallel average is / world
         got.update({k: (v / world).clone().numpy() for k, v in grads.items()})
 
-    with fake_ops.installed(), torch.no_grad():
-        trainer.step({k: v[lo:hi] for k, v in batch.items()}, 0, [tc.shard_masks(m, lo, hi, bs) for m in masks], random_mask[lo:hi], grad_hook=spy)
+    import torch.distributed as tdist
+    calls = {"all_gather": 0, "all_reduce_small": 0, "all_reduce_bucket": 0}
+    real_gather, real_reduce = tdist.all_gather_into_tensor, tdist.all_reduce
+
+    def count_gather(*a, **k):
+        calls["all_gather"] += 1
+        return real_gather(*a, **k)
+
+    def count_reduce(t, *a, **k):
+        calls["all_reduce_bucket" if t.numel() > 1_000_000 else "all_reduce_small"] += 1
+        return real_reduce(t, *a, **k)
+
+    tdist.all_gather_into_tensor, tdist.all_reduce = count_gather, count_reduce
+    try:
+        with fake_ops.installed(), torch.no_grad():
+            trainer.step({k: v[lo:hi] for k, v in batch.items()}, 0, [tc.shard_masks(m, lo, hi, bs) for m in masks], random_mask[lo:hi], grad_hook=spy)
+    finally:
+        tdist.all_gather_into_tensor, tdist.all_reduce = real_gather, real_reduce
+    # VERDICT round 3, next #6b/d: the SyncBatchNorm exchanges of a step.  Round 3: one all-gather per BatchNorm and forward (32 x 3) + one
+    # all-reduce per BatchNorm and backward (32 x 3) = 192, each followed by a host read of the row count.  Now: the step's three forwards share
+    # ONE WavEncoder pass, whose blocks run the two encoders in lock step — per block one exchange for the bn1 pair and one for the bn2 +
+    # shortcut BatchNorms: 12 all-gathers forward, 12 all-reduces backward (the BatchNorms of consecutive stages depend on each other: no
+    # further merging keeps nn.SyncBatchNorm's arithmetic), plus ONE integer all-reduce (the clips of all ranks) per step
+    assert calls == {"all_gather": 12, "all_reduce_small": 12 + 1, "all_reduce_bucket": 4}, calls
     keep = ("audio_encoder_face.feat_extractor.0.bn1.weight", "audio_encoder_body.feat_extractor.4.conv2.weight", "face_out_proj.weight",
             "audio_motion_cross_attn.layers.3.linear1.bias", "mask_embedding", "motion_encoder.main.0.weight", "speaker_embedding_body.weight")
     rv = model._flat_params()["audio_encoder_body.feat_extractor.2.bn2.running_var"].clone().numpy()

@@ -334,3 +334,36 @@ def test_nonfinite_gradients_never_reach_the_parameters(golden_dir):
         assert all(torch.equal(model._flat_params()[k], before[k]) for k in before)
     with pytest.raises(ValueError, match="on_nonfinite"):
         training.Trainer(model, vq, on_nonfinite="ignore")
+
+
+def test_step_shared_encoder_pass_equals_three_passes(golden_dir):
+    """`Trainer(share_encoders=True)` (the default: the WavEncoder pass of a step computed and differentiated ONCE for its three forwards,
+    `training.StepShare`) against the reference's schedule (three passes): the same losses, BatchNorm buffers and step counters, gradients
+    equal up to fp32 summation order — and a third of the WavEncoder launches."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    batch, _, masks, random_mask, _ = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
+    res = {}
+    for share in (True, False):
+        model, vq = common.product_models(precision="fp32")
+        got = {}
+        with fake_ops.installed(), torch.no_grad():
+            losses = training.Trainer(model, vq, share_encoders=share).step(batch, 0, masks, random_mask, grad_hook=lambda gr: got.update({k: v.clone() for k, v in gr.items()}))
+            n_in = fake_ops.CALLS.count("wav_conv_in")
+        res[share] = (losses, got, {k: v.clone() for k, v in model._flat_params().items() if "running_" in k or "num_batches" in k}, n_in)
+    (la, ga, ba, na), (lb, gb, bb, nb) = res[True], res[False]
+    assert nb == 3 * na and na == 2                              # first-layer launches: 2 encoders x 1 pass vs x 3 passes
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(lb[k])), k
+    for k in bb:
+        assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-6, atol=1e-7), k
+    assert int(ba["audio_encoder_face.feat_extractor.0.bn1.num_batches_tracked"]) == int(bb["audio_encoder_face.feat_extractor.0.bn1.num_batches_tracked"])
+    assert set(ga) == set(gb)
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    for k in gb:                                                 # conv biases in front of a train-mode BatchNorm: true gradient 0, fp32 noise either way
+        scale = float(gb[k].abs().max())
+        if scale < 1e-5 * gmax:
+            assert float(ga[k].abs().max()) < 1e-4 * gmax, k
+            continue
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * scale + 1e-7 * gmax, (k, float((ga[k] - gb[k]).abs().max()), scale, gmax)

@@ -121,15 +121,16 @@ def wav_encoder_backward_check(model, dev, enc="audio_encoder_body", batch=2):
 
     fwd = training.TrainForward(model)
     seen, flips = {}, {}
-    orig = fwd._wav_block_backward
+    orig = fwd._wav_blocks_backward
 
-    def spy(cx, sv):
-        seen[sv["i"]] = fwd.tape.get(sv["out"]).clone()
-        ref_out = outs[sv["i"]].detach().permute(0, 2, 1).reshape(sv["out"].shape).to(sv["out"].device)
-        flips[sv["i"]] = int(((sv["out"] > 0) != (ref_out > 0)).sum())
-        return orig(cx, sv)
+    def spy(cx, svs):
+        for sv in svs:
+            seen[sv["i"]] = fwd.tape.get(sv["out"]).clone()
+            ref_out = outs[sv["i"]].detach().permute(0, 2, 1).reshape(sv["out"].shape).to(sv["out"].device)
+            flips[sv["i"]] = int(((sv["out"] > 0) != (ref_out > 0)).sum())
+        return orig(cx, svs)
 
-    fwd._wav_block_backward = spy
+    fwd._wav_blocks_backward = spy
     with torch.no_grad():
         cx = _Ctx(model._engine(h2=False))
         fwd._train_pack(cx.pk)
