@@ -8,9 +8,8 @@
 //     packed in FRAGMENT ORDER (`ops.split_f16_weights_h2w`: per 16-row block and K-tile 2 KB = [hi plane | lo plane], a plane = 64 lanes x
 //     16 bytes) — every load instruction is one fully coalesced 1 KB run, prefetched two K-tiles ahead into a 3-deep register ring;
 //   * only the 64-row A panel (8 KB per K-tile) goes through LDS — by way of REGISTERS (global -> VGPR three K-tiles ahead, ds_write one
-//     iteration before its fragments are read), not by LDS-DMA: a wave's s_waitcnt vmcnt(N) can only be counted by hand when every operation
-//     in its queue completes in issue order, and LDS-DMA pieces and VGPR-returning loads do NOT complete in order with respect to each other
-//     (the first version of this kernel mixed them: correct on a half-empty chip, stale W fragments as soon as every CU had a block);
+//     iteration before its fragments are read), not by LDS-DMA, so that every operation in a wave's vector-memory queue is of one kind
+//     (a VGPR-returning buffer load) and `s_waitcnt vmcnt(N)` can be counted by hand without assuming an order between kinds;
 //     the panel's fragments for K-tile k+1 are read while the MFMAs of K-tile k run (two register sets), and the per-K-tile barrier guards
 //     8 KB instead of 32;
 //   * the memory operations of an iteration (2 A loads, 2 FN W loads, 2 FM fragment reads) are spread between its 3 FM FN MFMAs.
@@ -190,6 +189,11 @@ __device__ __forceinline__ void gemm_h2w_tile(const GemmArgs& p, const int m0, c
     __builtin_amdgcn_s_barrier();
     static_for<2 * FM>([&](auto rc) { read_a(rc, a0, 0u); });
     wait_lgkmcnt<0>();
+    // Everything issued so far must have LANDED before the loop is entered: the compiler gives the register sets their loop homes here
+    // (v_mov copies in the pre-header), and a copy of a register with a load still in flight carries stale data — the bug of the first
+    // two versions of this kernel: right on a half-empty chip, wrong as soon as every CU had a block.  Inside the loop the sets keep one
+    // home ("+v" ties; checked in the ISA: no instruction but MFMA / ds_write reads a load destination).  Cost: the prologue's latency, once
+    wait_vmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
     tr();
 
