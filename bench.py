@@ -543,8 +543,6 @@ def build(precision, device, args):
     for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.concurrent = not args.no_concurrent
         part.group_gemms = not args.no_group_gemms
-        if args.w_direct >= 0:
-            part.w_direct = bool(args.w_direct)
     n_samples = synthetic.samples_for_frames(args.frames)
     runner = ClipRunner(model, vq, args.batch, n_samples, use_graph=not args.no_graph, main_priority=args.main_priority)
     return model, vq, runner, n_samples
@@ -572,7 +570,6 @@ def main():
     ap.add_argument("--no-split-acts", action="store_true", help="A/B: float32 activations split inside every GEMM (EMAGE_F16X3) instead of pre-split EMAGE_H2 storage")
     ap.add_argument("--pipeline", type=int, default=1, help="also time the step with this many batches in flight (runtime.ClipPipeline)")
     ap.add_argument("--f32-residual", action="store_true", help="A/B: float32 residual twins beside the EMAGE_H2 images (round 3's default) instead of residuals read from the images")
-    ap.add_argument("--w-direct", type=int, default=-1, help="A/B: 1 = the wide layer contractions through the W-from-global kernel (EMAGE_H2W), 0 = through the LDS-staged kernels; -1 = the classes' default")
     ap.add_argument("--no-group-gemms", action="store_true", help="A/B: one stream lane per part-wise chain and one launch per contraction instead of lock-step chains with grouped launches")
     ap.add_argument("--attn-variant", type=int, default=0, help="experiments: emage_set_tuning key 6 (1 = split-f16 attention without the LDS-staged K / V^T)")
     ap.add_argument("--h2-variant", type=int, default=0, help="experiments: emage_set_tuning key 5 (EMAGE_H2 tile-heuristic variant)")

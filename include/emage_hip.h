@@ -39,7 +39,6 @@ extern "C" {
 #define EMAGE_BF16 1
 #define EMAGE_F16X3 2
 #define EMAGE_H2 3
-#define EMAGE_H2W 4   /* emage_gemm only: EMAGE_H2 operands with the WEIGHT image in MFMA fragment order (see emage_gemm) */
 
 #define EMAGE_EINVAL (-1)   /* unsupported size / alignment / null pointer */
 
@@ -120,12 +119,6 @@ int emage_gather_rows(const float* table, const int64_t* idx, int idx_rows, long
  *        that the fp16 planes stay in the normal range (|A*a_scale| must stay below 65504).  Other dtypes ignore them.
  * EMAGE_H2:  A / out / (res_is_f32 = 0) res are pre-split images (csrc/h2.h: per 8 columns 32 bytes [8 fp16 hi | 8 fp16 lo] of 16 x),
  *        out_f32 / out_t float32; W is the same image of W * w_scale, rows K-contiguous.
- * EMAGE_H2W: everything as EMAGE_H2 except the WEIGHT image, which is stored in MFMA FRAGMENT ORDER: rows in blocks of 16 (the last
- *        block zero-padded), per block and per 32-k K-tile 2048 bytes = [hi plane | lo plane], a plane = 64 x 16 bytes, entry
- *        l = 16 fg + fr holding the 8 fp16 of row (16 block + fr), k = 32 tile + 8 fg .. + 7.  The kernel behind it (csrc/h2w_tile.h)
- *        loads W fragments global -> VGPR directly and keeps only the A panel in LDS; it multiplies whole groups of 6 K-tiles, so
- *        pack a weight this way when taps * Cp / 32 is a multiple of 6 (any other length is computed correctly, with idle iterations).
- *        Bit-identical to EMAGE_H2 on the same values.
  */
 int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
                const void* res, int ldr, int res_is_f32, int res_first,

@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 TOOLS_LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip_tools.so")   # -DEMAGE_TOOLS twin: every tile configuration + emage_set_tuning
 
-F32, BF16, F16X3, H2, H2W = 0, 1, 2, 3, 4       # H2W: EMAGE_H2 for emage_gemm with the weight image in MFMA fragment order
-ABI_VERSION = 14
+F32, BF16, F16X3, H2 = 0, 1, 2, 3
+ABI_VERSION = 15
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 

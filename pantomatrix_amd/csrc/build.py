@@ -14,7 +14,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "gemm_h2.hip", "attention.hip", "vq.hip", "elementwise.hip", "motion.hip", "wavconv.hip", "convslab.hip", "lstm.hip", "lstmseq.hip", "train.hip", "version.hip"]
-HEADERS = ["common.h", "gemm_tile.h", "h2_tile.h", "h2w_tile.h", "h2.h", "attn_tile.h", "ln_row.h", "rot_math.h"]
+HEADERS = ["common.h", "gemm_tile.h", "h2_tile.h", "h2.h", "attn_tile.h", "ln_row.h", "rot_math.h"]
 LIB = os.path.join(HERE, "libemage_hip.so")
 TOOLS_LIB = os.path.join(HERE, "libemage_hip_tools.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]

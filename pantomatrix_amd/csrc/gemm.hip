@@ -16,7 +16,6 @@ extern int g_h2_force_config, g_h2_variant;         // csrc/gemm_h2.hip
 extern int g_attn_variant;                          // csrc/attention.hip
 #endif
 int gemm_h2_dispatch(GemmArgs& a, hipStream_t s);   // csrc/gemm_h2.hip: the EMAGE_H2 (pre-split operands) tile kernels
-int gemm_h2w_dispatch(GemmArgs& a, hipStream_t s);  // EMAGE_H2W: the weight image in fragment order (csrc/h2w_tile.h)
 int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only);   // several independent problems, same-configuration ones in shared launches
 }
 
@@ -323,8 +322,8 @@ int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, con
               int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout, float a_scale, float w_scale) {
     const int epc = dtype == EMAGE_BF16 ? 8 : 4;
     if (!A || !W || M <= 0 || N <= 0 || taps <= 0 || Cp <= 0 || Cp % 64 != 0) return EMAGE_EINVAL;
-    if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3 && dtype != EMAGE_H2 && dtype != EMAGE_H2W) return EMAGE_EINVAL;
-    if (dtype == EMAGE_H2 || dtype == EMAGE_H2W) {       // 32-byte groups of 8 logical columns: every row of every h2 operand starts on a group
+    if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3 && dtype != EMAGE_H2) return EMAGE_EINVAL;
+    if (dtype == EMAGE_H2) {       // 32-byte groups of 8 logical columns: every row of every h2 operand starts on a group
         if (lda % 8 || (res && ldr % (res_is_f32 ? 4 : 8)) || (res && ((uintptr_t)res & 15))) return EMAGE_EINVAL;
         if (out && (ldo % 8 || ((uintptr_t)out & 15) || ldo < ((((out_t ? t_col0 : N) > n_store ? (out_t ? t_col0 : N) : n_store) + 7) & ~7))) return EMAGE_EINVAL;
         if ((bias && ((uintptr_t)bias & 15)) || (slope && ((uintptr_t)slope & 15))) return EMAGE_EINVAL;
@@ -334,11 +333,11 @@ int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, con
     if (Lout <= 0 || Lin <= 0 || M % Lout != 0 || stride <= 0) return EMAGE_EINVAL;
     if (!out && !out_f32 && !out_t) return EMAGE_EINVAL;
     if (out_t && (t_rows <= 0 || M % t_rows != 0 || t_ld < t_rows || t_col0 < 0 || t_col0 > N)) return EMAGE_EINVAL;
-    if ((dtype == EMAGE_F16X3 || dtype == EMAGE_H2 || dtype == EMAGE_H2W) && !(a_scale > 0.f && w_scale > 0.f)) return EMAGE_EINVAL;
+    if ((dtype == EMAGE_F16X3 || dtype == EMAGE_H2) && !(a_scale > 0.f && w_scale > 0.f)) return EMAGE_EINVAL;
     {   // operands are addressed through 32-bit buffer offsets: each must span less than 2 GiB (the host splits larger batches)
         const long es = dtype == EMAGE_BF16 ? 2 : 4;
         const long a_span = ((((long)(M / Lout)) * Lin - 1) * lda + Cp + (long)pad * lda) * es;
-        if (a_span >= (1L << 31) || (long)((N + 15) / 16 * 16) * taps * Cp * es >= (1L << 31)) return EMAGE_EINVAL;
+        if (a_span >= (1L << 31) || (long)N * taps * Cp * es >= (1L << 31)) return EMAGE_EINVAL;
     }
     a.A = A; a.W = W; a.bias = bias; a.slope = slope; a.res = res; a.out = out; a.out_f32 = out_f32; a.out_t = out_t;
     a.lda = lda; a.ldr = ldr; a.ldo = ldo; a.ldf = ldf; a.res_is_f32 = res_is_f32; a.res_first = res_first; a.n_store = out ? n_store : 0;
@@ -347,7 +346,7 @@ int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, con
     a.dbg = g_debug_skip;
     a.trace = nullptr; a.cstate = nullptr; a.ldc = 0; a.ksplit = 1; a.nk_split = 0;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
-    const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2 || dtype == EMAGE_H2W;
+    const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2;
     a.a_scale = split ? a_scale : 1.f;
     a.o_scale = split ? 1.f / (a_scale * w_scale) : 1.f;
     return 0;
@@ -355,7 +354,6 @@ int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, con
 
 int dispatch_one(int dtype, GemmArgs& a, hipStream_t s) {
     if (dtype == EMAGE_H2) return gemm_h2_dispatch(a, s);
-    if (dtype == EMAGE_H2W) return gemm_h2w_dispatch(a, s);
     if (dtype == EMAGE_F16X3) return dispatch<float, true>(a, s);
     return dtype == EMAGE_BF16 ? dispatch<bf16_t, false>(a, s) : dispatch<float, false>(a, s);
 }

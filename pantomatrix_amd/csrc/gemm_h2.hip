@@ -4,7 +4,6 @@
 #include "common.h"
 #include <utility>
 #include "h2_tile.h"
-#include "h2w_tile.h"
 
 namespace emage_dev {
 #ifdef EMAGE_TOOLS
@@ -64,47 +63,6 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
     return launch_status();
-}
-
-// ---- EMAGE_H2W: weight fragments global -> VGPR from a fragment-order image, A panel alone in the LDS ring (h2w_tile.h) ----
-template <int BM, int BN, int NW, bool ILV, bool TRACE, int OCC>
-__global__ __launch_bounds__(NW * 64, OCC) void gemm_h2w_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(128))) unsigned char smem[h2w_smem_bytes<BM, 3>()];
-    const int nblk = p.tiles_m * p.tiles_n;
-    int bid = (int)blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-    gemm_h2w_tile<BM, BN, NW, ILV, TRACE>(p, tile_m * BM, tile_n * BN, smem);
-}
-
-template <int BM, int BN, int NW, bool ILV, bool TRACE = false, int OCC = 1>
-int launch_h2w(GemmArgs& a, hipStream_t s) {
-    if (a.out_t && a.t_col0 % BN != 0) return EMAGE_EINVAL;      // a tile is either row-major or transposed
-    a.tiles_m = (a.M + BM - 1) / BM;
-    const int ncols = a.n_store > a.N ? a.n_store : a.N;
-    a.tiles_n = (ncols + BN - 1) / BN;
-    a.trace = TRACE ? g_h2_trace : nullptr;
-    a.ksplit = 1;
-    hipLaunchKernelGGL((gemm_h2w_kernel<BM, BN, NW, ILV, TRACE, OCC>), dim3(a.tiles_m * a.tiles_n), dim3(NW * 64), 0, s, a);
-    return launch_status();
-}
-
-int run_config_h2w(int cfg, GemmArgs& a, hipStream_t s) {
-    switch (cfg) {
-        case 160: return launch_h2w<64, 192, 4, true>(a, s);       // 4 waves 64x48, memory operations spread between the MFMAs
-        case 162: return launch_h2w<64, 256, 4, true>(a, s);       // 4 waves 64x64
-#ifdef EMAGE_TOOLS
-        case 161: return launch_h2w<64, 192, 4, false>(a, s);      // memory operations in front of the MFMAs
-        case 163: return launch_h2w<64, 128, 4, true>(a, s);       // 4 waves 64x32
-        case 165: return launch_h2w<64, 128, 4, true, false, 2>(a, s);     // 163 with <= 256 registers: two blocks per CU may be resident
-        case 260: return launch_h2w<64, 192, 4, true, true>(a, s); // instrumented twin of 160
-#endif
-        default: break;
-    }
-    return EMAGE_EINVAL;
 }
 
 // ---- grouped launch: several independent problems of ONE tile configuration in one grid (emage_gemm_grouped) ----
@@ -267,15 +225,6 @@ static int h2_config_for(const GemmArgs& a) {
     }
     if (a.out_t && a.t_col0 % 64 != 0) return EMAGE_EINVAL;
     return (v & 8) ? 130 : 120;
-}
-
-// dtype EMAGE_H2W (fragment-order weight image): 64 x 192 tiles; 64 x 256 where 192 does not divide the width and 256 does
-int gemm_h2w_dispatch(GemmArgs& a, hipStream_t s) {
-    if (a.ksplit > 1) return EMAGE_EINVAL;
-    if (g_h2_force_config >= 160) return run_config_h2w(g_h2_force_config, a, s);
-    const int ncols = a.n_store > a.N ? a.n_store : a.N;
-    if (ncols % 192 != 0 && ncols % 256 == 0 && (!a.out_t || a.t_col0 % 256 == 0)) return run_config_h2w(162, a, s);
-    return run_config_h2w(160, a, s);
 }
 
 // called by emage_gemm (gemm.hip) for dtype EMAGE_H2 after the common argument checks

@@ -26,7 +26,7 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 
 template <int BM, int BN, int NS> constexpr int h2_smem_bytes() { return NS * (BM + BN) * 128; }
 
-// ---- the epilogue of an EMAGE_H2 tile, shared by gemm_h2_tile and gemm_h2w_tile (h2w_tile.h) ----
+// ---- the epilogue of an EMAGE_H2 tile (gemm_h2_tile; kept separate for fused kernels that end in the same stores) ----
 // acc: the wave's FM x FN accumulator fragments; (mw, nw): first row / column of the wave tile.  NAT = false: W rows were fed to the MFMAs in
 // the pair-permuted order (a lane ends with 8 consecutive columns per fragment pair; an odd last fragment in natural order); NAT = true:
 // every fragment in natural row order (a lane holds 4 consecutive columns per fragment).  Swapped MFMA operands (row-major tiles): lane
@@ -36,8 +36,7 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
                                                  const bool vt_tile, const float (&pre_r)[PM][PP][8]) {
     constexpr int FP = NAT ? 0 : FN / 2;
     constexpr bool LONE = !NAT && (FN & 1) != 0;
-    constexpr bool NATP = NAT && FM % 2 == 0;                  // natural order, fragment rows paired through v_permlane16_swap: 8 columns per lane
-    constexpr int NLONE = NATP ? 0 : (NAT ? FN : (LONE ? 1 : 0));          // trailing fragments handled 4 columns at a time
+    constexpr int NLONE = NAT ? FN : (LONE ? 1 : 0);          // trailing fragments handled 4 columns at a time
     const int ncol_n = p.out_t ? p.t_col0 : p.N;     // columns below this go to out / out_f32
     h2_t* __restrict__ out = (h2_t*)p.out;
     const float os = p.o_scale;
@@ -86,9 +85,7 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
     // n0 + wn*WTN + jp*32 + fg*8 + e (e < 4 from acc[i][2jp], e >= 4 from acc[i][2jp+1]); lone fragment -> 4 columns ----
     const int n_lim = ncol_n > p.n_store ? ncol_n : p.n_store;   // columns any store may touch (`out` zero-fills [N, n_store))
     const bool f32_vec = p.out_f32 && (p.ldf % 4 == 0) && (((uintptr_t)p.out_f32 & 15) == 0);
-    // bs_pre (NATP path): bias / slope of the 8 columns fetched ahead of the first store, [0] = bias, [1] = slope; else they are loaded here
-    auto finish = [&](auto wc, const int m, const int n, float (&x)[decltype(wc)::value], const float (&rpre)[decltype(wc)::value], const bool have_pre,
-                      const float (*bs_pre)[decltype(wc)::value] = nullptr) {
+    auto finish = [&](auto wc, const int m, const int n, float (&x)[decltype(wc)::value], const float (&rpre)[decltype(wc)::value], const bool have_pre) {
         // x: accumulators (already scaled) of W consecutive columns n.. of row m -> bias, residual, activation, stores
         constexpr int W = decltype(wc)::value;
         const bool full = n + W <= ncol_n;
@@ -96,13 +93,8 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
 #pragma unroll
         for (int e = 0; e < W; ++e) { bv[e] = 0.f; sv[e] = 1.f; rv[e] = 0.f; }
         if (full) {
-            if (bs_pre) {
-#pragma unroll
-                for (int e = 0; e < W; ++e) { bv[e] = bs_pre[0][e]; sv[e] = bs_pre[1][e]; }
-            } else {
-                if (p.bias) { if constexpr (W == 8) load8<float>(p.bias + n, bv); else { const float4 t = *(const float4*)(p.bias + n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; } }
-                if (p.slope) { if constexpr (W == 8) load8<float>(p.slope + n, sv); else { const float4 t = *(const float4*)(p.slope + n); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; } }
-            }
+            if (p.bias) { if constexpr (W == 8) load8<float>(p.bias + n, bv); else { const float4 t = *(const float4*)(p.bias + n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; } }
+            if (p.slope) { if constexpr (W == 8) load8<float>(p.slope + n, sv); else { const float4 t = *(const float4*)(p.slope + n); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; } }
             if (have_pre) {
 #pragma unroll
                 for (int e = 0; e < W; ++e) rv[e] = rpre[e];
@@ -178,53 +170,6 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4];
             finish(IC<8>{}, m, n, x, pre_r[i % PM][jp % PP], PRE && p.res && n + 8 <= ncol_n);
-        }
-    }
-    if constexpr (NATP) {
-        // lane (fr, fg) holds, per fragment (i, j), the 4 columns 16 j + 4 fg .. + 3 of row 16 i + fr.  Swapping the ODD lane rows of fragment
-        // (i, j) with the EVEN lane rows of fragment (i + 1, j), register by register, leaves lane (fr, fg) with the 8 consecutive columns
-        // 16 j + 8 (fg >> 1) .. + 7 of row 16 (i + (fg & 1)) + fr: first half in acc[i][j], second half in acc[i + 1][j].
-        // One wave per SIMD runs this epilogue alone, and a store may alias a later load as far as the compiler knows: EVERY load of the
-        // epilogue (bias, slope, residual) is therefore issued ahead of the first store — one memory latency instead of one per 8 columns
-        // (the W register sets of the K-loop are dead by now: the registers are there)
-        float bs[FN][2][8], rs[FM / 2][FN][8];
-        bool pre_ok[FM / 2][FN];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = nw + j * 16 + (fg >> 1) * 8;
-            const bool full = n + 8 <= ncol_n;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bs[j][0][e] = 0.f; bs[j][1][e] = 1.f; }
-            if (full && p.bias) load8<float>(p.bias + n, bs[j][0]);
-            if (full && p.slope) load8<float>(p.slope + n, bs[j][1]);
-#pragma unroll
-            for (int ip = 0; ip < FM / 2; ++ip) {
-                const int m = mw + (2 * ip + (fg & 1)) * 16 + fr;
-                pre_ok[ip][j] = full && p.res != nullptr && m < p.M;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rs[ip][j][e] = 0.f;
-                if (pre_ok[ip][j]) {
-                    if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, rs[ip][j]);
-                    else h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, rs[ip][j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = nw + j * 16 + (fg >> 1) * 8;
-#pragma unroll
-            for (int i = 0; i < FM; i += 2) {
-                float x[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, acc[i][j][e]), __builtin_bit_cast(unsigned, acc[i + 1][j][e]), false, false);
-                    x[e] = __builtin_bit_cast(float, sw[0]);
-                    x[4 + e] = __builtin_bit_cast(float, sw[1]);
-                }
-                const int m = mw + (i + (fg & 1)) * 16 + fr;
-                if (m >= p.M || n >= n_lim) continue;
-                finish(IC<8>{}, m, n, x, rs[i / 2][j], pre_ok[i / 2][j], n + 8 <= ncol_n ? bs[j] : nullptr);
-            }
         }
     }
 #pragma unroll

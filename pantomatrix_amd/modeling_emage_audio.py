@@ -26,7 +26,7 @@ import torch
 
 from . import ops, spec, synthetic
 from .streams import Fork
-from ._lib import BF16, F32, F16X3, H2, H2W
+from ._lib import BF16, F32, F16X3, H2
 from .configuration_emage_audio import EmageAudioConfig, EmageVAEConvConfig, EmageVQVAEConvConfig
 
 OUT_KEYS = ("rec_face", "rec_upper", "rec_hands", "rec_lower", "cls_face", "cls_upper", "cls_hands", "cls_lower")
@@ -78,8 +78,6 @@ class _EmageModule(torch.nn.Module):
                                                # 25 instead of 12.6 MB per LayerNorm at 64 clips).  Parity-green on every golden in both forms
         self.split_acts = True                 # f16x3 precision: activations that feed a contraction are stored PRE-SPLIT (EMAGE_H2,
                                                # csrc/h2.h) by their producers; False = float32 activations split inside every GEMM
-        self.w_direct = False                  # EMAGE_H2 mode: the 768 / 1536 / 2304-wide layer contractions through the W-from-global kernel
-                                               # (EMAGE_H2W, csrc/h2w_tile.h: weight fragments global -> VGPR, A panel alone in LDS; same bits)
         self.group_gemms = True                # part-wise stacks (VQ part decoders, refinement layers + heads, ...) walk in lock step and
                                                # their contractions share launches (ops.lockstep / emage_gemm_grouped); False = one stream
                                                # lane per chain, one launch per contraction (the round-3 form; same bits)
@@ -221,7 +219,6 @@ class _EmageModule(torch.nn.Module):
                 cache = self.__dict__.setdefault("_scale_caches", {}).setdefault((str(dev), dt), {})
                 pk = _Packed(self._flat_params(), dev, dt, cache)
                 pk.stamp = stamp
-                pk.w_direct = bool(self.w_direct)
                 self._pack(pk)
                 pk.finish_range_check()
                 # a weight that left the range its cached power-of-two scale was chosen for (it grew / shrank 4x since the first packing, or
@@ -252,7 +249,6 @@ class _Packed:
         # every re-packing (after an optimiser step: a pure sequence of launches, capturable); cleared when a state dict is loaded
         self.scale_cache = {} if scale_cache is None else scale_cache
         self._n_operands = 0
-        self.w_direct = False        # EMAGE_H2 mode: wide layer contractions packed for the W-from-global kernel (set by `_engine` from the model)
         self.stamp = None            # `_EmageModule._version_stamp()` of the parameters this set was packed from
         # int32 device counter of operands packed with a CACHED scale whose max |w * scale| has left [2^10, 2^14) (chosen into
         # [2^12, 2^13): the fp16 hi plane overflows at 2^16); None until such a packing happens
@@ -284,34 +280,24 @@ class _Packed:
     def _operand(self, w2d, dt=None):
         """(N, K) fp32 with K already padded -> the MFMA operand image of precision `dt` (default: the model's) and its scale."""
         dt = self.dt if dt is None else dt
-        if dt in (H2, H2W, F16X3):
+        if dt in (H2, F16X3):
             key = (dt, self._n_operands, tuple(w2d.shape))
             self._n_operands += 1
             cached = self.scale_cache.get(key)
-            pack = {H2: ops.split_f16_weights_h2, H2W: ops.split_f16_weights_h2w, F16X3: ops.split_f16_weights}[dt]
-            img, scale = pack(w2d.contiguous(), cached)
+            img, scale = (ops.split_f16_weights_h2 if dt == H2 else ops.split_f16_weights)(w2d.contiguous(), cached)
             self.scale_cache[key] = scale
             if cached is not None and w2d.numel():
                 self._range_pending.append((w2d, scale))          # checked together by `finish_range_check` (a few launches for all of them)
             return img, scale
         return w2d.to(ops.TORCH_DTYPE[dt]).contiguous(), 1.0
 
-    def _mat_dt(self, n, kp):
-        """Operand packing of an (n, kp) Linear weight: in the EMAGE_H2 mode the wide layer contractions (N a multiple of 192: the 768 /
-        1536 / 2304-wide projections of the transformer layers; a K-tile count that the kernel's 6-K-tile loop body divides) take the
-        fragment-order image of the W-from-global kernel (EMAGE_H2W, csrc/h2w_tile.h) when `w_direct` is set; everything else stays EMAGE_H2."""
-        if self.dt == H2 and self.w_direct and n % 192 == 0 and n <= 2304 and (kp // 32) % 6 == 0:
-            return H2W
-        return self.dt
-
     def _pack_mat(self, w2d):
         n, k = w2d.shape
         kp = _rup(k)
         if kp != k:
             w2d = torch.nn.functional.pad(w2d, (0, kp - k))
-        dt = self._mat_dt(n, kp)
-        w, ws = self._operand(w2d, dt)
-        return w, kp, ws, dt
+        w, ws = self._operand(w2d)
+        return w, kp, ws
 
     def linear(self, key, names, rows=None):
         """Stack nn.Linear weights along N (optionally row-slices `rows[i]` of each) -> entry `key`."""
@@ -324,8 +310,8 @@ class _Packed:
             bs.append(b)
         k_real = ws[0].shape[1]
         wcat = torch.cat(ws, 0).float()
-        w, kp, wsc, wdt = self._pack_mat(wcat)
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=wdt)
+        w, kp, wsc = self._pack_mat(wcat)
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt)
         self.origin[key] = [(nm + ".weight", nm + ".bias", rows[i] if rows is not None else slice(0, self.p[nm + ".weight"].shape[0]))
                             for i, nm in enumerate(names)]
 
@@ -343,8 +329,8 @@ class _Packed:
                 self.origin[key].append((nm + ".in_proj_weight", nm + ".in_proj_bias", sl[part]))
         k_real = ws[0].shape[1]
         wcat = torch.cat(ws, 0).float()
-        w, kp, wsc, wdt = self._pack_mat(wcat)
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=wdt)
+        w, kp, wsc = self._pack_mat(wcat)
+        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt)
 
     def folded(self, cname, bn=None):
         """Raw Conv1d (weight (Cout,Cin,k), bias) with an eval-mode BatchNorm1d folded in:
@@ -456,7 +442,7 @@ class _Ctx:
             kw = dict(taps=e["taps"], stride=stride, pad=pad, lin=lin, lout=lout)
         ops.gemm(dt, a, e["w"], e["b"], sl, res, out, out_f32, out_t, n=n, cp=e["cp"], n_store=n_store,
                  t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, k_real=e.get("k_real"), w_scale=e.get("ws", 1.0),
-                 res_h2=bool(res_h2 and dt in (H2, H2W)), **kw)
+                 res_h2=bool(res_h2 and dt == H2), **kw)
         return out, out_f32
 
     # ---- the two forms of an activation: `.a` feeds contractions (storage type of the mode), `.r` carries the residual stream

@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, F16X3, H2, H2W, check, EmageKernelError
+from ._lib import F32, BF16, F16X3, H2, check, EmageKernelError
 
 _LIBRARY = torch.library.Library("emage", "DEF")
 
@@ -158,7 +158,7 @@ def lockstep(enabled=True):
 
 # storage type of activations per precision code; F16X3 is a GEMM-only operand mode over float32 storage
 # H2: the pre-split storage of the split-fp16 mode (csrc/h2.h) — float32-sized elements, 32-byte groups of 8 columns = [8 fp16 hi | 8 fp16 lo]
-TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32, H2: torch.float32, H2W: torch.float32}
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32, H2: torch.float32}
 A_SCALE_F16X3 = 16.0    # activations are multiplied by this power of two before the fp16 hi/lo split (|x| < 4094 stays finite)
 
 
@@ -242,36 +242,6 @@ def split_f16_weights_h2(w2d, scale=None):
     w = w2d.to(torch.float32)
     scale = _f16_scale(w) if scale is None else scale
     return h2_pack(w, scale), scale
-
-
-def split_f16_weights_h2w(w2d, scale=None):
-    """Host packing of an (N, K) fp32 weight matrix for EMAGE_H2W (include/emage_hip.h: emage_gemm), K % 32 == 0: the split-fp16 planes
-    of W * w_scale in MFMA FRAGMENT ORDER — rows in blocks of 16 (zero rows up to a multiple of 16), per block and 32-k K-tile 2 KB =
-    [hi plane | lo plane], a plane = 64 entries of 16 bytes, entry 16 fg + fr = the 8 fp16 of row (16 block + fr), k = 32 tile + 8 fg ...
-    Returns (packed (ceil16(N), K) float32-typed, w_scale); `scale` as for `split_f16_weights`."""
-    n, k = w2d.shape
-    assert k % 32 == 0
-    w = w2d.to(torch.float32)
-    scale = _f16_scale(w) if scale is None else scale
-    np_ = round_up(n, 16)
-    if np_ != n:
-        w = torch.nn.functional.pad(w, (0, 0, 0, np_ - n))
-    ws = w * scale
-    hi = ws.to(torch.float16)
-    lo = (ws - hi.to(torch.float32)).to(torch.float16)
-
-    def frag(plane):      # (np_, k) -> [block][tile][fg][fr][e]
-        return plane.view(np_ // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4)
-
-    packed = torch.stack([frag(hi), frag(lo)], dim=2).reshape(np_, 2 * k).contiguous()      # [block][tile][plane][fg][fr][e]
-    return packed.view(torch.float32), scale
-
-
-def unsplit_f16_weights_h2w(packed, n, k):
-    """Inverse of `split_f16_weights_h2w` (tests, CPU stand-ins): -> (hi, lo) fp32 planes (n, k) of W * w_scale in natural order."""
-    np_ = round_up(n, 16)
-    t = packed.contiguous().view(torch.float16).reshape(np_ // 16, k // 32, 2, 4, 16, 8).permute(2, 0, 4, 1, 3, 5).reshape(2, np_, k).float()
-    return t[0, :n], t[1, :n]
 
 
 def _ptr(t):
@@ -456,8 +426,7 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
     """See include/emage_hip.h:emage_gemm.  `a` (rows, lda) and `w` (n, taps*cp) are in `dtype`.  `k_real` (the
     unpadded contraction length) is bookkeeping for bench.py's algorithmic-flop count; the kernel ignores it.
     dtype F16X3: `a` is float32, `w` / `w_scale` come from `split_f16_weights`.  dtype H2: `a` / `out` are H2 images
-    (float32-typed), `w` / `w_scale` from `split_f16_weights_h2`, `res` fp32 or (res_h2) an H2 image, `out_f32` / `out_t` fp32.
-    dtype H2W: as H2 with `w` from `split_f16_weights_h2w` (fragment order; the W-from-global kernel)."""
+    (float32-typed), `w` / `w_scale` from `split_f16_weights_h2`, `res` fp32 or (res_h2) an H2 image, `out_f32` / `out_t` fp32."""
     _dev(a)
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin

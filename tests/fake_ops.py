@@ -14,9 +14,9 @@ import torch
 
 from pantomatrix_amd import modeling_emage_audio as M
 from pantomatrix_amd import ops
-from pantomatrix_amd._lib import BF16, F32, F16X3, H2, H2W
+from pantomatrix_amd._lib import BF16, F32, F16X3, H2
 
-TD = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32, H2: torch.float32, H2W: torch.float32}
+TD = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32, H2: torch.float32}
 CALLS = []
 
 
@@ -57,11 +57,6 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin
     lout = m if lout is None else lout
-    w_frag = None
-    if dtype == H2W:             # EMAGE_H2 arithmetic on a weight image in fragment order: decode it, then the H2 restatement
-        assert w.shape == ((n + 15) // 16 * 16, taps * cp)
-        w_frag = ops.unsplit_f16_weights_h2w(w, n, taps * cp)
-        dtype, w = H2, torch.empty(n, taps * cp)
     assert a.dtype == TD[dtype] and w.dtype == TD[dtype] and w.shape == (n, taps * cp), (a.dtype, w.shape, n, taps, cp)
     assert a.stride(1) == 1 and a.stride(0) >= cp and m % lout == 0 and cp % 64 == 0
     assert a.data_ptr() % 16 == 0 and (a.stride(0) * a.element_size()) % 16 == 0
@@ -88,7 +83,7 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         sa = ops.A_SCALE_F16X3 if a_scale is None else a_scale
         xt = x.view(m, taps, 2, cp)
         xh, xl = xt[:, :, 0].reshape(m, taps * cp).double(), xt[:, :, 1].reshape(m, taps * cp).double()
-        wh, wl = h2_planes(w, taps * cp) if w_frag is None else w_frag
+        wh, wl = h2_planes(w, taps * cp)
         wh, wl = wh.double(), wl.double()
         v = ((xh @ wh.t() + (xh @ wl.t() + xl @ wh.t())) / (sa * w_scale)).float()
     elif dtype == F16X3:

@@ -601,9 +601,8 @@ GROUP_CASES = H2_GEMM_CASES + [
 ]
 
 
-def _h2_problem(case, h2w=False):
-    """Device operands + keyword arguments of one EMAGE_H2 `ops.gemm` call and a maker of fresh (poisoned) output buffers.
-    h2w: the weight image in fragment order (dtype EMAGE_H2W) instead."""
+def _h2_problem(case):
+    """Device operands + keyword arguments of one EMAGE_H2 `ops.gemm` call and a maker of fresh (poisoned) output buffers."""
     name, (nb, lin, lout), cin, n, taps, stride, pad, fl = case
     g = _g(hash(name) % 1000)
     cp = ops.round_up(cin, 64)
@@ -612,7 +611,7 @@ def _h2_problem(case, h2w=False):
     a[:, :cin] = torch.randn(nb * lin, cin, generator=g)
     w = torch.zeros(n, taps, cp)
     w[:, :, :cin] = torch.randn(n, taps, cin, generator=g) / math.sqrt(cin * taps)
-    w_h2, ws = (ops.split_f16_weights_h2w if h2w else ops.split_f16_weights_h2)(w.reshape(n, taps * cp))
+    w_h2, ws = ops.split_f16_weights_h2(w.reshape(n, taps * cp))
     bias = torch.randn(n, generator=g) * 0.1 if fl.get("bias") else None
     slope = torch.full((n,), float(fl["slope"])) if "slope" in fl else None
     n8 = ops.round_up(n, 8)
@@ -678,58 +677,3 @@ def test_gemm_grouped_is_bit_identical_to_single_launches():
     operands, kw, outputs = probs[0]
     with pytest.raises(EmageKernelError):
         ops.gemm_grouped(H2, [dict(a=operands[0], w=operands[1], out=outputs()[0], **{**kw, "cp": kw["cp"] + 8})] * 2)
-
-
-# ---- EMAGE_H2W: the W-from-global kernel (csrc/h2w_tile.h) ---------------------------------------------------------------------------
-H2W_CASES = [
-    ("w_out_proj", (64, 64, 64), 768, 768, 1, 1, 0, dict(bias=True, res="f32", want="both")),
-    ("w_out_proj_h2res", (64, 64, 64), 768, 768, 1, 1, 0, dict(bias=True, res="h2", want="f32")),
-    ("w_ffn1", (64, 64, 64), 768, 1536, 1, 1, 0, dict(bias=True, slope=0.0)),
-    ("w_ffn2", (64, 64, 64), 1536, 768, 1, 1, 0, dict(bias=True, res="h2", want="f32")),
-    ("w_qkv", (64, 64, 64), 768, 2304, 1, 1, 0, dict(bias=True, vt=1536, want="f32")),
-    ("w_kv", (3, 65, 65), 768, 1536, 1, 1, 0, dict(bias=True, vt=768, want="f32")),
-    ("w_ragged", (1, 4100, 4100), 768, 768, 1, 1, 0, dict(bias=True, res="f32", want="both")),
-    ("w_n200_k192", (5, 33, 33), 192, 200, 1, 1, 0, dict(bias=True, slope=0.1, n_store=256)),
-    ("w_k256_ghost", (4, 64, 64), 256, 768, 1, 1, 0, dict(bias=True, slope=0.1)),
-    ("w_k64", (2, 40, 40), 64, 192, 1, 1, 0, dict(bias=True)),
-    ("w_conv3", (64, 17, 17), 256, 256, 3, 1, 1, dict(bias=True, slope=0.2, n_store=256)),
-    ("w_conv3_337", (3, 64, 64), 337, 256, 3, 1, 1, dict(bias=True, res="h2", n_store=256)),
-    ("w_conv15_s6", (2, 1241, 205), 64, 128, 15, 6, 0, dict(bias=True, slope=0.01, want="f32")),
-]
-
-
-@pytest.mark.parametrize("cfg", [None, 160, 161, 162, 163, 165])
-def test_gemm_h2w_is_bit_identical_to_h2(cfg):
-    """the W-from-global kernel (weight fragments global -> VGPR from the fragment-order image, the A panel alone
-    in the LDS ring, register-pipelined A fragments, a 6-K-tile branch-free loop body with ghost iterations) writes exactly the bytes the
-    LDS-staged EMAGE_H2 kernels write — linear / conv (taps, stride), V^T tiles, residual forms, ragged M, N not a multiple of 16, K-tile
-    counts that are not a multiple of 6 — in the dispatch's choice (None) and in every compiled configuration (tools library)."""
-    from pantomatrix_amd import _lib
-    from pantomatrix_amd._lib import H2W
-    lib = _lib.use_tools(True) if cfg is not None else None
-    try:
-        for case in H2W_CASES:
-            if cfg is not None:
-                width = {160: 192, 161: 192, 162: 256, 163: 128, 165: 128}[cfg]
-                vt0 = case[7].get("vt")
-                if vt0 and vt0 % width:
-                    continue                            # a tile is either row-major or transposed
-            operands, kw, outputs = _h2_problem(case)
-            ref = outputs()
-            if lib is not None:
-                lib.emage_set_tuning(4, -1)
-            ops.gemm(H2, *operands, *ref, **kw)
-            wop, wkw, _ = _h2_problem(case, h2w=True)
-            got = outputs()
-            if lib is not None:
-                lib.emage_set_tuning(4, cfg)
-            ops.gemm(H2W, *wop, *got, **wkw)
-            torch.cuda.synchronize()
-            for nm, a, b in zip(("out", "out_f32", "out_t"), ref, got):
-                if a is not None:
-                    same = torch.equal(a.view(torch.int32), b.view(torch.int32))
-                    assert same, (case[0], cfg, nm, float((a - b).abs().max()))
-    finally:
-        if lib is not None:
-            lib.emage_set_tuning(4, -1)
-            _lib.use_tools(False)

@@ -12,7 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pantomatrix_amd import _lib, ops  # noqa: E402
-from pantomatrix_amd._lib import F16X3, H2, H2W  # noqa: E402
+from pantomatrix_amd._lib import F16X3, H2  # noqa: E402
 
 SHAPES = [
     # name, (nb, lin, lout), cin, n, taps, stride, pad, extras
@@ -37,7 +37,7 @@ SHAPES = [
     ("ragged M=4100 768->768", (1, 4100, 4100), 768, 768, 1, 1, 0, dict(res=True)),
 ]
 CONFIGS = [100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 115, 116, 118, 119, 120, 121, 122, 123, 124, 125, 126, 127, 128,
-           129, 130, 131, 132, 160, 161, 162, 163, 165]          # >= 160: the W-from-global kernels (EMAGE_H2W: weight image in fragment order)
+           129, 130, 131, 132]
 
 
 def main():
@@ -88,7 +88,6 @@ def main():
         a_h2 = ops.h2_pack(a)
         w_h2, ws_h2 = ops.split_f16_weights_h2(w)
         w_x3, ws_x3 = ops.split_f16_weights(w)
-        w_hw, ws_hw = ops.split_f16_weights_h2w(w)
         ldo = ops.round_up(max(ncol, n_store), 8)
 
         def run(cfg):
@@ -97,10 +96,7 @@ def main():
             out = None if ex.get("f32only") else torch.zeros(m, ldo, device=dev)
             out_f = torch.zeros(m, ncol, device=dev) if (res is not None or ex.get("f32only")) else None
             out_t = torch.zeros(nb, n - vt0, ops.round_up(lout, 32), device=dev) if vt0 else None
-            if h2 and cfg >= 160:
-                call = lambda: ops.gemm(H2W, a_h2, w_hw, bias, slope, res, out, out_f, out_t, n=n, cp=cp, n_store=n_store, t_col0=vt0 or 0,
-                                        t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m, w_scale=ws_hw)
-            elif h2:
+            if h2:
                 call = lambda: ops.gemm(H2, a_h2, w_h2, bias, slope, res, out, out_f, out_t, n=n, cp=cp, n_store=n_store, t_col0=vt0 or 0,
                                         t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m, w_scale=ws_h2)
             else:

@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pantomatrix_amd import _lib, ops
-from pantomatrix_amd._lib import H2, H2W
+from pantomatrix_amd._lib import H2
 
 lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
 raw = lib
@@ -14,9 +14,7 @@ dev = "cuda"
 m, k, n = 4096, 768, 768
 g = torch.Generator().manual_seed(0)
 a = ops.h2_pack(torch.randn(m, k, generator=g).to(dev))
-w32 = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
-w, ws = ops.split_f16_weights_h2(w32)
-w_frag, ws_frag = ops.split_f16_weights_h2w(w32)          # configs >= 260: the instrumented W-from-global kernel (EMAGE_H2W)
+w, ws = ops.split_f16_weights_h2((torch.randn(n, k, generator=g) / k ** 0.5).to(dev))
 bias = torch.randn(n, generator=g).to(dev)
 res = torch.randn(m, n, generator=g).to(dev)
 out, outf = torch.zeros(m, n, device=dev), torch.zeros(m, n, device=dev)
@@ -25,10 +23,7 @@ for cfg in [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "201,203,205,
     raw.emage_h2_set_trace(C.c_void_p(trace.data_ptr()))
     lib.emage_set_tuning(4, cfg)
     for _ in range(3):
-        if cfg >= 260:
-            ops.gemm(H2W, a, w_frag, bias, None, res, out, outf, None, n=n, cp=k, w_scale=ws_frag)
-        else:
-            ops.gemm(H2, a, w, bias, None, res, out, outf, None, n=n, cp=k, w_scale=ws)
+        ops.gemm(H2, a, w, bias, None, res, out, outf, None, n=n, cp=k, w_scale=ws)
     torch.cuda.synchronize()
     t = trace.cpu().view(16, 512)
     print(f"== config {cfg}")
