@@ -85,9 +85,7 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
     // n0 + wn*WTN + jp*32 + fg*8 + e (e < 4 from acc[i][2jp], e >= 4 from acc[i][2jp+1]); lone fragment -> 4 columns ----
     const int n_lim = ncol_n > p.n_store ? ncol_n : p.n_store;   // columns any store may touch (`out` zero-fills [N, n_store))
     const bool f32_vec = p.out_f32 && (p.ldf % 4 == 0) && (((uintptr_t)p.out_f32 & 15) == 0);
-    // bs_pre: bias / slope of the W columns already in registers ([0] = bias, [1] = slope: the batched fetch below), else loaded here
-    auto finish = [&](auto wc, const int m, const int n, float (&x)[decltype(wc)::value], const float (&rpre)[decltype(wc)::value], const bool have_pre,
-                      const float (*bs_pre)[decltype(wc)::value] = nullptr) {
+    auto finish = [&](auto wc, const int m, const int n, float (&x)[decltype(wc)::value], const float (&rpre)[decltype(wc)::value], const bool have_pre) {
         // x: accumulators (already scaled) of W consecutive columns n.. of row m -> bias, residual, activation, stores
         constexpr int W = decltype(wc)::value;
         const bool full = n + W <= ncol_n;
@@ -95,13 +93,8 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
 #pragma unroll
         for (int e = 0; e < W; ++e) { bv[e] = 0.f; sv[e] = 1.f; rv[e] = 0.f; }
         if (full) {
-            if (bs_pre) {
-#pragma unroll
-                for (int e = 0; e < W; ++e) { bv[e] = bs_pre[0][e]; sv[e] = bs_pre[1][e]; }
-            } else {
-                if (p.bias) { if constexpr (W == 8) load8<float>(p.bias + n, bv); else { const float4 t = *(const float4*)(p.bias + n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; } }
-                if (p.slope) { if constexpr (W == 8) load8<float>(p.slope + n, sv); else { const float4 t = *(const float4*)(p.slope + n); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; } }
-            }
+            if (p.bias) { if constexpr (W == 8) load8<float>(p.bias + n, bv); else { const float4 t = *(const float4*)(p.bias + n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; } }
+            if (p.slope) { if constexpr (W == 8) load8<float>(p.slope + n, sv); else { const float4 t = *(const float4*)(p.slope + n); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; } }
             if (have_pre) {
 #pragma unroll
                 for (int e = 0; e < W; ++e) rv[e] = rpre[e];
@@ -165,40 +158,6 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
             }
         }
     };
-    // Every load of the paired fragments' epilogue — bias, slope, residual — is issued AHEAD of the first store (round 4).  A store may
-    // alias a later load as far as the compiler can tell, so the straightforward form runs FM * FP dependent [load -> compute -> store]
-    // chains per lane, one memory latency each (~1-2 k cycles with every CU draining its tile at once).  The K-loop's fragment
-    // registers are dead by now: the batch costs no register the loop has not already paid for (unlike PRE, which fetched the residual ahead
-    // of the K-loop and lost the co-resident block).  Tools build: emage_set_tuning key 1 bit 5 restores the chained form for A/B.
-    constexpr int FPA = FP > 0 ? FP : 1;
-    constexpr bool POST_BS = FP == 1;             // bias / slope join the batch only where that costs no resident block (64 x 192: 131 VGPRs > 128 with them)
-    float post_bs[POST_BS ? FPA : 1][2][8], post_r[FM][FPA][8];
-    bool post_ok[FM][FPA];
-    const bool post = !PRE && !EMAGE_DBG(p, 32);
-    if (post) {
-#pragma unroll
-        for (int jp = 0; jp < FP; ++jp) {
-            const int n = nw + jp * 32 + fg * 8;
-            const bool full = n + 8 <= ncol_n;
-            if constexpr (POST_BS) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { post_bs[jp][0][e] = 0.f; post_bs[jp][1][e] = 1.f; }
-                if (full && p.bias) load8<float>(p.bias + n, post_bs[jp][0]);
-                if (full && p.slope) load8<float>(p.slope + n, post_bs[jp][1]);
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = mw + i * 16 + fr;
-                post_ok[i][jp] = full && p.res != nullptr && m < p.M;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) post_r[i][jp][e] = 0.f;
-                if (post_ok[i][jp]) {
-                    if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, post_r[i][jp]);
-                    else h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, post_r[i][jp]);
-                }
-            }
-        }
-    }
 #pragma unroll
     for (int jp = 0; jp < FP; ++jp) {
         const int n = nw + jp * 32 + fg * 8;
@@ -210,8 +169,7 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4];
-            if (post) finish(IC<8>{}, m, n, x, post_r[i][jp], post_ok[i][jp], POST_BS && n + 8 <= ncol_n ? post_bs[POST_BS ? jp : 0] : nullptr);
-            else finish(IC<8>{}, m, n, x, pre_r[i % PM][jp % PP], PRE && p.res && n + 8 <= ncol_n);
+            finish(IC<8>{}, m, n, x, pre_r[i % PM][jp % PP], PRE && p.res && n + 8 <= ncol_n);
         }
     }
 #pragma unroll
