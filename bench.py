@@ -424,13 +424,12 @@ def bench_lstm_models(dev, steps=3, cpu=True):
         gx = torch.randn(batch, tt, 8 * hid, generator=g).to(dev)
         hseq = torch.empty(batch, tt, 2 * hid, device=dev)
         sync = ops.lstm_layer_sync(batch, hid, dev)
-        hx = ops.lstm_layer_exchange(batch, tt, hid, dev)
-        ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync, hx=hx)
+        ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
-            ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync, hx=hx)
+            ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
         e1.record()
         torch.cuda.synchronize()
         ops.lstm_layer_check(sync)

@@ -302,9 +302,6 @@ int emage_lstm_step_pair(int dtype, const float* h_prev0, const float* h_prev1, 
  *            stream has been synchronised, word EMAGE_LSTM_SYNC_ERROR_WORD of each EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH-word
  *            record is non-zero if a block gave up waiting for its group (~1 s: blocks not co-resident) — the output
  *            is then invalid; the Python layer raises.
- *   hx       NULL, or a scratch of B * T * 2H 32-bit words (16-byte aligned, contiguous): the blocks then hand h_t over PRE-SPLIT — one
- *            word per element = the two fp16 planes of h_t * a_scale the consumers' MFMAs take — through this buffer instead of through
- *            hseq (same bits; the consumers' staging loses its scale / convert / subtract VALU work, hseq becomes a plain store).
  */
 #define EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH 544
 #define EMAGE_LSTM_SYNC_ERROR_WORD 512
@@ -316,7 +313,7 @@ int emage_lstm_layer_sync_words(int B, int H);
 int emage_lstm_layer_health(const unsigned* sync, int sync_words, int* counter, void* stream);
 int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, int ld_gx_t, const void* w_hh0, const void* w_hh1,
                      float w_scale0, float w_scale1, float a_scale, float* hseq, long ld_h_b, int ld_h_t,
-                     int B, int T, int H, unsigned* sync, int sync_words, unsigned* hx, void* stream);
+                     int B, int T, int H, unsigned* sync, int sync_words, void* stream);
 
 /* DisCo's content blend (D:244-247): out = softmax(sel[:, 0:2])[0] * c1 + softmax(...)[1] * c2, rows of C channels. */
 int emage_softmax2_mix(const float* sel, int ld_sel, const float* c1, int ld1, const float* c2, int ld2,

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 TOOLS_LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip_tools.so")   # -DEMAGE_TOOLS twin: every tile configuration + emage_set_tuning
 
 F32, BF16, F16X3, H2 = 0, 1, 2, 3
-ABI_VERSION = 16
+ABI_VERSION = 15
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -77,7 +77,7 @@ SIGNATURES = {
     "emage_lstm_step_pair": [_i, _p, _p, _i, _i, _p, _p, _f, _f, _f, _p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_lstm_layer_sync_words": [_i, _i],
     "emage_lstm_layer_health": [_p, _i, _p, _p],
-    "emage_lstm_layer": [_i, _p, _l, _i, _p, _p, _f, _f, _f, _p, _l, _i, _i, _i, _i, _p, _i, _p, _p],
+    "emage_lstm_layer": [_i, _p, _l, _i, _p, _p, _f, _f, _f, _p, _l, _i, _i, _i, _i, _p, _i, _p],
     "emage_softmax2_mix": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_lstm_inputs": [_p, _p, _i, _p, _l, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "emage_rot6d_scatter": [_p, _i, _p, _p, _i, _i, _p],

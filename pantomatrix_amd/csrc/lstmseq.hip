@@ -37,7 +37,6 @@ struct SeqArgs {
     const float* gx; long ld_gx_b; int ld_gx_t;        // gates_x[b][t][dir * 4H + 4u + g]: the input projection incl. both biases
     float* hseq; long ld_h_b; int ld_h_t;              // layer output [b][t][dir * H + u]
     const unsigned char* w[2]; float os[2]; float a_scale;
-    unsigned* hx; long ld_x_b;                         // PX: exchange buffer [b][t][dir * H + u] of packed (fp16 hi | fp16 lo << 16) words of h * a_scale
     unsigned* sync;                                    // this launch's record: arrival counter of group g at word 32 g (one 128-B line each), error word at 32 * 16
     int B, T, slices;
     int dbg;                                           // emage_set_tuning key 3 (tools): timing-only
@@ -59,12 +58,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// PX (round 4): h_t travels between the blocks PRE-SPLIT — the producer, which has the value in a register anyway, stores the two fp16
-// planes of h_t * a_scale as ONE 32-bit word per element into a separate exchange buffer (write-through; the float32 layer output becomes a
-// plain store off the serial path), and the consumer's staging is 8 v_perm_b32 per 8 elements instead of 8 x (scale, 2 conversions,
-// subtract, conversion): the split-and-stage share of a step was 3.9 us of 8-9 (profiles/r03_lstm_layer_breakdown.json).  Same planes, same
-// MFMAs: bit-identical to the fp32 exchange.  The sentinel (0xFFFFFFFF) cannot be a split pair: its hi half would be a NaN.
-template <int H, int HALVES, bool LL, bool PX>
+template <int H, int HALVES, bool LL>
 __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
     constexpr int KT = H / 32, WPG = H / 16;           // K-tiles; blocks per group
     constexpr unsigned PLANE = KT * 64 * 64;           // one fp16 plane of the 64 x H slice: [kt][row][4 chunks of 16 B]
@@ -147,12 +141,10 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
 
             // stage h_{t-1}[b_base .. +64][dir * H .. +H] as split fp16 planes
             const int tp = dir ? t + 1 : t - 1;
-            const long ld_b = PX ? p.ld_x_b : p.ld_h_b;
-            const void* hp = PX ? (const void*)(p.hx + (long)b_base * p.ld_x_b + (long)tp * (2 * H) + dir * H)
-                                : (const void*)(p.hseq + (long)b_base * p.ld_h_b + (long)tp * p.ld_h_t + dir * H);      // row 0 of the block's slice at step tp
+            const float* hp = p.hseq + (long)b_base * p.ld_h_b + (long)tp * p.ld_h_t + dir * H;      // row 0 of the block's slice at step tp
             // rows past the batch end lie beyond num_records: the buffer load returns zeros for them, no branch per load
             const int rows_in = p.B - b_base < 64 ? p.B - b_base : 64;
-            const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hp, 0, (int)((long)(rows_in - 1) * ld_b * 4) + H * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hp, 0, (int)((long)(rows_in - 1) * p.ld_h_b * 4) + H * 4, 0x00020000);
             // staging role: iteration `it` of this wave moves rows 16 * (it & 3) + (lane >> 2), chunk lane & 3 of K-tile
             // kt_of(it); with HALVES = 2 (A/B only: measured equal, 9.5 vs 9.4 us per step) iterations [0, KT/2) cover the first K half, the rest the
             // second, and the MFMAs of the first half run while the second half is still arriving
@@ -163,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
 #pragma unroll
                 for (int it = 0; it < KT; ++it) {
                     const int row = 16 * (it & 3) + st_row, kt = kt_of(it);
-                    const int off = (int)((long)row * ld_b * 4) + (kt * 32 + st_g * 4) * 4;         // < 2^31: checked by the host entry
+                    const int off = (int)((long)row * p.ld_h_b * 4) + (kt * 32 + st_g * 4) * 4;         // < 2^31: checked by the host entry
                     c0[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 16));      // aux 16 = sc1: agent-coherent reads
                     c1[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 64, 0, 16));
                 }
@@ -209,17 +201,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
                         const int it = half * KH + i2;
                         const int row = 16 * (it & 3) + st_row, kt = kt_of(it);
                         f16x8 hi, lo;
-                        if constexpr (PX) {                 // words (hi | lo << 16) -> the hi chunk and the lo chunk: two byte permutes per pair
-                            u32x4 h4, l4;
-                            h4[0] = __builtin_amdgcn_perm(c0[it].y, c0[it].x, 0x05040100u); l4[0] = __builtin_amdgcn_perm(c0[it].y, c0[it].x, 0x07060302u);
-                            h4[1] = __builtin_amdgcn_perm(c0[it].w, c0[it].z, 0x05040100u); l4[1] = __builtin_amdgcn_perm(c0[it].w, c0[it].z, 0x07060302u);
-                            h4[2] = __builtin_amdgcn_perm(c1[it].y, c1[it].x, 0x05040100u); l4[2] = __builtin_amdgcn_perm(c1[it].y, c1[it].x, 0x07060302u);
-                            h4[3] = __builtin_amdgcn_perm(c1[it].w, c1[it].z, 0x05040100u); l4[3] = __builtin_amdgcn_perm(c1[it].w, c1[it].z, 0x07060302u);
-                            hi = __builtin_bit_cast(f16x8, h4);
-                            lo = __builtin_bit_cast(f16x8, l4);
-                        } else {
-                            split_f16(c0[it], c1[it], as, hi, lo);
-                        }
+                        split_f16(c0[it], c1[it], as, hi, lo);
                         const unsigned off = kt * 4096 + row * 64 + ((st_g ^ swz4(row)) << 4);
                         *(f16x8*)(smem + off) = hi;
                         *(f16x8*)(smem + PLANE + off) = lo;
@@ -262,17 +244,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
             c[fb] = cn;
             if (b < p.B) {
                 float* dst = p.hseq + (long)b * p.ld_h_b + (long)t * p.ld_h_t + dir * H + unit;
-                const float hval = go * lstm_tanh<true>(cn);
-                if constexpr (PX) {
-                    const float xs = hval * as;             // split_f16's arithmetic, once per element instead of once per consuming block
-                    const _Float16 hh = (_Float16)xs;
-                    const _Float16 ll = (_Float16)(xs - (float)hh);
-                    const unsigned word = (unsigned)__builtin_bit_cast(unsigned short, hh) | ((unsigned)__builtin_bit_cast(unsigned short, ll) << 16);
-                    __hip_atomic_store(p.hx + (long)b * p.ld_x_b + (long)t * (2 * H) + dir * H + unit, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
-                    *dst = hval;
-                } else {
-                    __hip_atomic_store(dst, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
-                }
+                __hip_atomic_store(dst, go * lstm_tanh<true>(cn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
             }
         }
 
@@ -313,33 +285,31 @@ int max_slices_for(int H) {                            // co-resident blocks: on
     return m > MAX_GROUPS / 2 ? MAX_GROUPS / 2 : m;
 }
 
-template <int H, int HALVES, bool LL, bool PX = false>
+template <int H, int HALVES, bool LL>
 int launch_seq(SeqArgs a, int B, int max_slices, unsigned* sync, hipStream_t s) {
     constexpr int KT = H / 32, WPG = H / 16;
     constexpr size_t LDS = 2 * (size_t)KT * 64 * 64 + 128;
-    static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES, LL, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (configured != hipSuccess) return (int)configured;
     // the group barrier needs every block of a launch resident at once: one block per CU (LDS), so the occupancy query must admit >= 1
     // block per CU for this kernel's register / LDS footprint (a plain launch has the residency of a cooperative one, without its check)
     static const int blocks_per_cu = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)lstm_seq_kernel<H, HALVES, LL, PX>, 256, LDS) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)lstm_seq_kernel<H, HALVES, LL>, 256, LDS) != hipSuccess) return 0;
         return n;
     }();
     if (blocks_per_cu < 1 || 2 * max_slices * WPG > blocks_per_cu * device_cus()) return EMAGE_EINVAL;
     const float* gx = a.gx;
     float* hseq = a.hseq;
-    unsigned* hx = a.hx;
     int chunk = 0;
     for (int b0 = 0; b0 < B; b0 += 64 * max_slices, ++chunk) {
         const int nb = B - b0 < 64 * max_slices ? B - b0 : 64 * max_slices;
         a.gx = gx + (long)b0 * a.ld_gx_b;
         a.hseq = hseq + (long)b0 * a.ld_h_b;
-        a.hx = hx ? hx + (long)b0 * a.ld_x_b : nullptr;
         a.B = nb;
         a.slices = (nb + 63) / 64;
         a.sync = sync + chunk * EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH;
-        hipLaunchKernelGGL((lstm_seq_kernel<H, HALVES, LL, PX>), dim3(2 * a.slices * WPG), dim3(256), LDS, s, a);
+        hipLaunchKernelGGL((lstm_seq_kernel<H, HALVES, LL>), dim3(2 * a.slices * WPG), dim3(256), LDS, s, a);
         const int rc = launch_status();
         if (rc) return rc;
     }
@@ -374,9 +344,8 @@ extern "C" int emage_lstm_layer_sync_words(int B, int H) {
 
 extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, int ld_gx_t, const void* w_hh0, const void* w_hh1,
                                 float w_scale0, float w_scale1, float a_scale, float* hseq, long ld_h_b, int ld_h_t,
-                                int B, int T, int H, unsigned* sync, int sync_words, unsigned* hx, void* stream) {
+                                int B, int T, int H, unsigned* sync, int sync_words, void* stream) {
     if (dtype != EMAGE_F16X3 || !gates_x || !w_hh0 || !w_hh1 || !hseq || !sync || B <= 0 || T <= 0) return EMAGE_EINVAL;
-    if (hx && (((uintptr_t)hx & 15) || 64L * T * 2 * H * 4 + 4096 >= (1L << 31))) return EMAGE_EINVAL;
     if (H != 256 && H != 512) return EMAGE_EINVAL;
     if (!(a_scale > 0.f && w_scale0 > 0.f && w_scale1 > 0.f)) return EMAGE_EINVAL;
     if (ld_gx_t % 4 || ld_gx_t < 8 * H || ld_gx_b % 4 || ld_h_t % 4 || ld_h_t < 2 * H || ld_h_b % 4) return EMAGE_EINVAL;
@@ -389,11 +358,7 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
     hipError_t e = hipMemsetAsync(sync, 0, (size_t)need * sizeof(unsigned), s);
     if (e != hipSuccess) return (int)e;
     const bool ll = !(emage_dev::g_lstm_layer_dbg & 32);
-    if (ll && hx) {
-        // pre-split exchange: the sentinel fills the exchange buffer (contiguous), the layer output needs no preparation
-        e = hipMemsetAsync(hx, 0xFF, (size_t)B * T * 2 * H * sizeof(unsigned), s);
-        if (e != hipSuccess) return (int)e;
-    } else if (ll) {
+    if (ll) {
         // the hand-over protocol: every word of the layer output starts as the sentinel (0xFFFFFFFF), "not written yet"
         if (ld_h_t == 2 * H && ld_h_b == (long)T * ld_h_t) e = hipMemsetAsync(hseq, 0xFF, (size_t)B * T * 2 * H * sizeof(float), s);
         else if (ld_h_b == (long)T * ld_h_t) e = hipMemset2DAsync(hseq, (size_t)ld_h_t * sizeof(float), 0xFF, (size_t)2 * H * sizeof(float), (size_t)B * T, s);
@@ -408,7 +373,6 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
     a.w[0] = (const unsigned char*)w_hh0; a.w[1] = (const unsigned char*)w_hh1;
     a.os[0] = 1.f / (a_scale * w_scale0); a.os[1] = 1.f / (a_scale * w_scale1);
     a.a_scale = a_scale;
-    a.hx = ll ? hx : nullptr; a.ld_x_b = (long)T * 2 * H;
     a.T = T;
     a.dbg = emage_dev::g_lstm_layer_dbg;
 #ifdef EMAGE_TOOLS
@@ -417,6 +381,5 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
         return H == 512 ? launch_seq<512, 1, false>(a, B, max_slices, sync, s) : launch_seq<256, 1, false>(a, B, max_slices, sync, s);
     }
 #endif
-    if (a.hx) return H == 512 ? launch_seq<512, 1, true, true>(a, B, max_slices, sync, s) : launch_seq<256, 1, true, true>(a, B, max_slices, sync, s);
     return H == 512 ? launch_seq<512, 1, true>(a, B, max_slices, sync, s) : launch_seq<256, 1, true>(a, B, max_slices, sync, s);
 }

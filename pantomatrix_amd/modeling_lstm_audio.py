@@ -42,7 +42,6 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         self.pose_rep = getattr(config, "pose_rep", "smplx")
         self.pair_convs = True                 # WavEncoder: 32-channel blocks through the 64-channel kernels on position pairs (A/B switch)
         self.persistent_lstm = True            # one launch per LSTM layer (csrc/lstmseq.hip) instead of one per time step; same bits
-        self.presplit_exchange = True          # persistent recurrence: h_t handed over between the blocks as packed fp16 hi | lo words (same bits)
         self._sync = {}                        # scratch of the persistent recurrences, see _lstm_sync
 
     def set_precision(self, precision: str):
@@ -137,8 +136,7 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
             w0, w1 = cx.pk.w[f"{name}.hh.{k}.0"], cx.pk.w[f"{name}.hh.{k}.1"]
             if persistent:
                 sync = self._lstm_sync(name, k, b, hid, cx.dev)
-                hx = self._lstm_exchange(b, t, hid, cx.dev) if self.presplit_exchange else None
-                ops.lstm_layer(cx.gdt, g3, (w0["w"], w1["w"]), (w0["ws"], w1["ws"]), h3, sync, hx=hx)
+                ops.lstm_layer(cx.gdt, g3, (w0["w"], w1["w"]), (w0["ws"], w1["ws"]), h3, sync)
                 x = hseq
                 continue
             cstate = torch.zeros(2, b, hid, dtype=torch.float32, device=cx.dev)
@@ -158,15 +156,6 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         if key not in self._sync:
             self._sync[key] = ops.lstm_layer_sync(b, hid, dev)
         return self._sync[key]
-
-    def _lstm_exchange(self, b, t, hid, dev):
-        """The pre-split exchange scratch of the persistent recurrence: ONE buffer per (batch, length), used by every layer in turn (a
-        layer's launch is finished with it before the next one starts on the same stream)."""
-        key = (b, t, hid, str(dev))
-        cache = self.__dict__.setdefault("_xch", {})
-        if key not in cache:
-            cache[key] = ops.lstm_layer_exchange(b, t, hid, dev)
-        return cache[key]
 
     def _checked(self, result):
         """End of an eager forward: surface a lost block of the persistent recurrence (under graph capture the runner checks)."""

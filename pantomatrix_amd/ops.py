@@ -1178,30 +1178,22 @@ def lstm_layer_sync(b, hidden, device):
 
 
 @_op("lstm_layer", "(int dtype, Tensor gates_x, Tensor w_hh0, Tensor w_hh1, float w_scale0, float w_scale1, float a_scale, Tensor(a!) hseq, "
-                   "Tensor(b!) sync, Tensor(c!)? hx) -> ()")
-def _lstm_layer(dtype, gates_x, w_hh0, w_hh1, w_scale0, w_scale1, a_scale, hseq, sync, hx):
+                   "Tensor(b!) sync) -> ()")
+def _lstm_layer(dtype, gates_x, w_hh0, w_hh1, w_scale0, w_scale1, a_scale, hseq, sync):
     b, t, h2 = hseq.shape
     assert gates_x.dim() == 3 and gates_x.shape[0] == b and gates_x.shape[1] == t and gates_x.stride(2) == 1 and hseq.stride(2) == 1
     check(_lib.load().emage_lstm_layer(dtype, _ptr(gates_x), gates_x.stride(0), gates_x.stride(1), _ptr(w_hh0), _ptr(w_hh1), w_scale0, w_scale1, a_scale,
-                                       _ptr(hseq), hseq.stride(0), hseq.stride(1), b, t, h2 // 2, _ptr(sync), sync.numel(), _ptr(hx), _stream()), "lstm_layer")
+                                       _ptr(hseq), hseq.stride(0), hseq.stride(1), b, t, h2 // 2, _ptr(sync), sync.numel(), _stream()), "lstm_layer")
 
 
-def lstm_layer(dtype, gates_x, w_hh, w_scale, hseq, sync, *, a_scale=None, hx=None):
+def lstm_layer(dtype, gates_x, w_hh, w_scale, hseq, sync, *, a_scale=None):
     """The whole recurrence of one bidirectional LSTM layer (zero initial state) in one launch per <= 256 clips:
     gates_x (B, T, 8H) fp32 (input projection incl. biases, columns dir * 4H + 4u + g), w_hh / w_scale the two directions'
     packed recurrent weights, hseq (B, T, 2H) fp32 out.  Bit-identical to T `lstm_step_pair` launches.  `sync` from
-    `lstm_layer_sync`; call `lstm_layer_check(sync)` once the stream is synchronised.  hx: an int32 scratch of B * T * 2H words
-    (`lstm_layer_exchange`): the blocks hand h_t over pre-split through it (same bits, less staging work per step)."""
+    `lstm_layer_sync`; call `lstm_layer_check(sync)` once the stream is synchronised."""
     _dev(gates_x)
-    if hx is not None:
-        assert hx.dtype == torch.int32 and hx.is_contiguous() and hx.numel() >= hseq.shape[0] * hseq.shape[1] * hseq.shape[2]
-    _lstm_layer(dtype, gates_x, w_hh[0], w_hh[1], float(w_scale[0]), float(w_scale[1]), float(A_SCALE_F16X3 if a_scale is None else a_scale), hseq, sync, hx)
+    _lstm_layer(dtype, gates_x, w_hh[0], w_hh[1], float(w_scale[0]), float(w_scale[1]), float(A_SCALE_F16X3 if a_scale is None else a_scale), hseq, sync)
     return hseq
-
-
-def lstm_layer_exchange(b, t, hidden, device):
-    """The exchange scratch of `lstm_layer(hx=...)` for (B, T, 2H) hidden states; one scratch serves every layer of a model in turn."""
-    return torch.empty(b * t * 2 * hidden, dtype=torch.int32, device=device)
 
 
 @_op("lstm_layer_health", "(Tensor sync, Tensor(a!) counter) -> ()")

@@ -613,7 +613,7 @@ def lstm_layer_check(sync):
     assert not bool(sync.any())
 
 
-def lstm_layer(dtype, gates_x, w_hh, w_scale, hseq, sync, *, a_scale=None, hx=None):
+def lstm_layer(dtype, gates_x, w_hh, w_scale, hseq, sync, *, a_scale=None):
     """The persistent recurrence == T paired steps from a zero state (csrc/lstmseq.hip is bit-identical to that sequence)."""
     assert lstm_layer_supported(dtype, hseq.shape[2] // 2) and sync.dtype == torch.int32
     b, t, h2 = hseq.shape

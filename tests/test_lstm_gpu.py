@@ -119,15 +119,6 @@ def test_lstm_layer_kernel(b, t, hid):
     assert torch.equal(got, steps(ops, DEV))
     if b <= 130:
         assert float((got - steps(F, "cpu")).abs().max()) < 2e-5
-    # round 4: h_t handed over between the blocks PRE-SPLIT (one packed fp16 hi | lo word per element in a separate exchange scratch):
-    # the same bits again — also on a poisoned output buffer and a scratch reused from another call
-    hx = ops.lstm_layer_exchange(b, t, hid, DEV)
-    for _ in range(2):
-        hseq2 = torch.full((b, t, 2 * hid), float("nan"), device=DEV)
-        ops.lstm_layer(F16X3, gxd, wp, ws, hseq2, sync, hx=hx)
-        torch.cuda.synchronize()
-        ops.lstm_layer_check(sync)
-        assert torch.equal(hseq2.cpu(), got)
 
 
 def test_lstm_layer_long_sequence_and_replay():
@@ -143,14 +134,13 @@ def test_lstm_layer_long_sequence_and_replay():
     gx = torch.randn(b, t, 8 * hid, generator=g).to(DEV)
     sync = ops.lstm_layer_sync(b, hid, DEV)
     outs = []
-    hx = ops.lstm_layer_exchange(b, t, hid, DEV)
-    for rep in range(3):                       # twice through the float32 exchange, once through the pre-split exchange scratch
+    for _ in range(2):
         hseq = torch.empty(b, t, 2 * hid, device=DEV)
-        ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync, hx=hx if rep == 2 else None)
+        ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
         torch.cuda.synchronize()
         ops.lstm_layer_check(sync)
         outs.append(hseq)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and bool(torch.isfinite(outs[0]).all())
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
     # spot-check the last forward step and the last backward step of a few clips against per-step launches of those clips
     sel = torch.tensor([0, 63, 64, 200, 255], device=DEV)
     ref = torch.empty(len(sel), t, 2 * hid, device=DEV)

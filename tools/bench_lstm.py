@@ -67,7 +67,6 @@ def main():
             gx = torch.randn(batch, tt, 8 * hid, generator=g).to(dev)
             hseq = torch.empty(batch, tt, 2 * hid, device=dev)
             sync = ops.lstm_layer_sync(batch, hid, dev)
-            hx = ops.lstm_layer_exchange(batch, tt, hid, dev)
             from pantomatrix_amd import _lib
             lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
             names = {0: "shipped (data-as-flag hand-over)", 32: "round 2's arrival-counter protocol", 2: "no MFMA phase", 4: "no h load / staging",
@@ -75,27 +74,17 @@ def main():
             line["lstm_layer_us_per_step"] = {}
             for dbg in (0, 32, 64, 2, 4, 8, 14):
                 lib.emage_set_tuning(3, dbg)
-                ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync, hx=hx)
+                ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
-                    ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync, hx=hx)
+                    ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
                 e1.record()
                 torch.cuda.synchronize()
                 ops.lstm_layer_check(sync)
                 line["lstm_layer_us_per_step"][names[dbg]] = round(1e3 * e0.elapsed_time(e1) / 3 / tt, 2)
             lib.emage_set_tuning(3, 0)
-            ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)        # A/B: round 3's hand-over through the float32 layer output (the consumers split h themselves)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
-            e1.record()
-            torch.cuda.synchronize()
-            ops.lstm_layer_check(sync)
-            line["lstm_layer_us_per_step"]["round 3: float32 exchange through the layer output"] = round(1e3 * e0.elapsed_time(e1) / 3 / tt, 2)
         if not args.no_cpu:
             torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
             sd = weights(kind)
