@@ -137,6 +137,7 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
     switch (cfg) {
         //                       BM   BN  WM WN NS NLW PIPE  PRE  OCC
         case 100: return launch_h2<64, 192, 4, 2, 2, 0, false>(a, s);              // 8 waves 16x96 (the F16X3 shape)
+        case 170: return launch_h2<128, 192, 2, 4, 2, 0, false>(a, s);             // 8 waves 64x48: grids of many tiles per CU (round 4)
 #ifdef EMAGE_TOOLS
         case 101: return launch_h2<64, 192, 4, 2, 3, 0, false>(a, s);
         case 102: return launch_h2<64, 192, 2, 4, 3, 0, false>(a, s);              // 8 waves 32x48
@@ -189,6 +190,19 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 153: return launch_h2<64, 128, 2, 4, 3, 0, false, false, 1, true>(a, s);     // 8 waves 32x32
         case 155: return launch_h2<64, 192, 4, 2, 4, 0, false, false, 1, true>(a, s);
         case 156: return launch_h2<128, 128, 2, 4, 3, 0, false, false, 1, true>(a, s);    // 8 waves 64x32
+        // round 4: FEWER waves with larger wave tiles (LDS fragment bytes per MFMA fall with the wave tile: a 32x32 wave tile reads 8 KB per
+        // 12 MFMAs, a 64x48 one 14 KB per 36), several blocks per CU
+        case 160: return launch_h2<64, 96, 1, 2, 3, 0, false, false, 2>(a, s);            // 2 waves 64x48, two blocks per CU
+        case 161: return launch_h2<64, 96, 1, 2, 3, 0, true, false, 2>(a, s);
+        case 162: return launch_h2<64, 64, 1, 2, 3, 0, false, false, 3>(a, s);            // 2 waves 64x32, three blocks per CU
+        case 163: return launch_h2<64, 64, 2, 1, 3, 0, false, false, 3>(a, s);            // 2 waves 32x64
+        case 164: return launch_h2<64, 64, 1, 1, 3, 0, true, false, 3>(a, s);             // 1 wave 64x64, pipelined
+        case 165: return launch_h2<64, 64, 1, 1, 3, 0, false, false, 3>(a, s);
+        case 166: return launch_h2<128, 96, 2, 2, 3, 0, false>(a, s);                     // 4 waves 64x48, one block per CU
+        case 167: return launch_h2<128, 96, 2, 2, 3, 0, true>(a, s);
+        case 168: return launch_h2<64, 192, 1, 4, 3, 0, false>(a, s);                     // 4 waves 64x48 side by side
+        case 169: return launch_h2<64, 192, 1, 4, 3, 0, true>(a, s);
+        case 171: return launch_h2<128, 256, 2, 4, 2, 0, false>(a, s);                    // 8 waves 64x64
         // instrumented twins (TRACE) of 101 / 103 / 105 / 141
         case 201: return launch_h2<64, 192, 4, 2, 3, 0, false, false, 1, false, true>(a, s);
         case 203: return launch_h2<64, 192, 2, 2, 3, 0, true, false, 1, false, true>(a, s);
@@ -217,8 +231,17 @@ static int h2_config_for(const GemmArgs& a) {
     const int v = g_h2_variant;
     if ((v & 1) && ncols < 1024 && ncols % 192 == 0 && a.M >= 2048 && !a.out_t) return 101;       // one 8-wave block per CU
     if ((v & 4) && ncols < 1024 && ncols % 192 == 0 && a.M >= 2048 && !a.out_t) return 124;       // 64x96, two 4-wave blocks per CU
+    if ((v & 16) && ncols < 1024 && ncols % 96 == 0 && a.M >= 2048 && !a.out_t) return 160;      // 64x96, two 2-wave blocks per CU
+    if ((v & 32) && ncols < 1024 && ncols % 96 == 0 && a.M >= 2048 && !a.out_t) return 161;
+    if ((v & 64) && ncols < 1024 && !a.out_t) return 162;
+    if ((v & 128) && ncols < 1024 && !a.out_t) return 163;
+    if ((v & 256) && ncols < 1024 && !a.out_t) return 164;
     if (ncols >= 1024 && a.M >= 1024) {
         const long t128x256 = (long)((a.M + 127) / 128) * ((ncols + 255) / 256);
+        // many tiles per CU (the K/V projections of all cross-attention layers, N = 12288): 64x48 wave tiles read 14 KB of fragments per 36
+        // MFMAs (the 32x128 ones of 119: 20 KB per 48) and two 80 KB blocks fit a CU: 239 vs 270 us (profiles/r04_gemm_h2_sweep_fewer_waves_wide.txt)
+        const long t128x192 = (long)((a.M + 127) / 128) * ((ncols + 191) / 192);
+        if (!(v & 512) && t128x192 >= 1024 && ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return 170;
         if (!(v & 2) && t128x256 >= 512 && ncols % 256 == 0 && (!a.out_t || a.t_col0 % 256 == 0)) return 119;
         if (ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return 100;
         if (!a.out_t || a.t_col0 % 128 == 0) return 113;
@@ -251,6 +274,11 @@ int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only) {
             case 113: return !h2_wants_split_k<128, 128>(a[i]);
             case 119: return !h2_wants_split_k<128, 256>(a[i]);
             case 120: return !h2_wants_split_k<64, 64>(a[i]);
+            case 170: return !h2_wants_split_k<128, 192>(a[i]);
+#ifdef EMAGE_TOOLS
+            case 160: case 161: return !h2_wants_split_k<64, 96>(a[i]);
+            case 162: case 163: case 164: return !h2_wants_split_k<64, 64>(a[i]);
+#endif
             default: return false;
         }
     };
@@ -272,6 +300,14 @@ int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only) {
                 case 100: rc = launch_h2_group<64, 192, 4, 2, 2, 0, false>(grp, m, s); break;
                 case 113: rc = launch_h2_group<128, 128, 4, 2, 3, 0, false>(grp, m, s); break;
                 case 119: rc = launch_h2_group<128, 256, 4, 2, 2, 0, false>(grp, m, s); break;
+                case 170: rc = launch_h2_group<128, 192, 2, 4, 2, 0, false>(grp, m, s); break;
+#ifdef EMAGE_TOOLS
+                case 160: rc = launch_h2_group<64, 96, 1, 2, 3, 0, false, false, 2>(grp, m, s); break;
+                case 161: rc = launch_h2_group<64, 96, 1, 2, 3, 0, true, false, 2>(grp, m, s); break;
+                case 162: rc = launch_h2_group<64, 64, 1, 2, 3, 0, false, false, 3>(grp, m, s); break;
+                case 163: rc = launch_h2_group<64, 64, 2, 1, 3, 0, false, false, 3>(grp, m, s); break;
+                case 164: rc = launch_h2_group<64, 64, 1, 1, 3, 0, true, false, 3>(grp, m, s); break;
+#endif
                 default: rc = launch_h2_group<64, 64, 2, 2, 3, 0, false, false, 2>(grp, m, s); break;
             }
         } else {

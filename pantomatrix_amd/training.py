@@ -183,6 +183,7 @@ class TrainForward:
         # GEMM epilogue); fp32 precision keeps the exact-fp32 MFMA contractions
         self.h2_backward = model.precision == "f16x3"
         self.grad_scale = 1024.0
+        self.conv_backward_rows = 1 << 17                 # output rows per piece of a long convolution's backward (_conv_backward_h2)
         self._w_scale, self._wt_cache = {}, {}
         self.range_flag = None          # int32 device counter: transposed-weight operands (backward dX) whose cached scale no longer fits
         self._range_pending, self._range_seen = [], set()
@@ -385,14 +386,50 @@ class TrainForward:
 
     def _conv_backward_h2(self, cx, x, cin, origins, ws, dy, n, m, mp, taps, stride, pad, lin, lout, nseq, need_dx):
         """`_conv_backward` with both contractions as split-fp16 MFMA on EMAGE_H2 operands: dW = (gs dY)^T im2col(X) with the im2col matrix
-        written directly as an H2 image, dcol = (gs dY) W with the flattened weights converted once per forward."""
+        written directly as an H2 image, dcol = (gs dY) W with the flattened weights converted once per forward.  Long inputs (the first
+        WavEncoder blocks: 56 clips x 6 827 positions) are walked in pieces of whole sequences of about `conv_backward_rows` output rows, so
+        the im2col image, the transposed dY and dcol exist for one piece at a time (0.5 GB instead of 1.5 GB each); dW is summed over the pieces."""
         gs = self.grad_scale
         kc = taps * cin
-        dy_t = ops.h2_cast(dy, mp, scale=gs, transpose=True)                               # (N, mp)
-        col_t = ops.im2col_t_h2(x, cin, taps, stride, pad, lin, lout, nseq, mp)            # (taps*cin, mp)
-        dw = torch.empty(n, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
-        ops.gemm(H2, dy_t, col_t, None, None, None, None, dw, None, n=kc, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
-        del col_t
+        per = max(1, self.conv_backward_rows // max(lout, 1))
+        pieces = [(s0, min(s0 + per, nseq)) for s0 in range(0, nseq, per)]
+        w_t = wsc = None
+        np_ = _rup(n)
+        if need_dx:
+            key = ("conv",) + tuple(wn for wn, _ in origins)
+            hit = self._wt_cache.get(key)
+            if hit is None:
+                wflat = torch.cat([w.permute(0, 2, 1).reshape(w.shape[0], kc) for w in ws], 0).contiguous()          # (N, taps*cin), taps major
+                wsc = self._backward_scale(key, wflat)
+                hit = self._wt_cache[key] = (ops.h2_cast(wflat, np_, scale=wsc / 16.0, transpose=True), wsc)           # (taps*cin, rup64(N))
+            w_t, wsc = hit
+        dw = dx = None
+        for s0, s1 in pieces:
+            whole = len(pieces) == 1
+            xs = x if whole else x[s0 * lin:s1 * lin]
+            dys = dy if whole else dy[s0 * lout:s1 * lout]
+            ms = (s1 - s0) * lout
+            mps = _rup(ms)
+            dy_t = ops.h2_cast(dys, mps, scale=gs, transpose=True)                          # (N, mps)
+            col_t = ops.im2col_t_h2(xs, cin, taps, stride, pad, lin, lout, s1 - s0, mps)    # (taps*cin, mps)
+            dwp = torch.empty(n, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
+            ops.gemm(H2, dy_t, col_t, None, None, None, None, dwp, None, n=kc, cp=mps, w_scale=16.0, a_scale=16.0 * gs)
+            del col_t, dy_t
+            dw = dwp if dw is None else dw.add_(dwp)
+            if need_dx:
+                dy_h = ops.h2_cast(dys, np_, scale=gs)
+                dcol = torch.empty(ms, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
+                ops.gemm(H2, dy_h, w_t, None, None, None, None, dcol, None, n=kc, cp=np_, w_scale=wsc, a_scale=16.0 * gs)
+                del dy_h
+                part = ops.col2im(dcol, cin, taps, stride, pad, lin, lout, s1 - s0)
+                del dcol
+                if whole:
+                    dx = part
+                else:
+                    if dx is None:
+                        dx = torch.empty(nseq * lin, cin, dtype=torch.float32, device=cx.dev)
+                    dx[s0 * lin:s1 * lin].copy_(part)
+                del part
         db = ops.col_sum(dy)
         r0 = 0
         for (wn, bn), w in zip(origins, ws):
@@ -400,20 +437,7 @@ class TrainForward:
             self._param_grad(wn, slice(None), dw[r0:r0 + rows].reshape(rows, taps, cin).permute(0, 2, 1))
             self._param_grad(bn, slice(None), db[r0:r0 + rows])
             r0 += rows
-        if not need_dx:
-            return None
-        key = ("conv",) + tuple(wn for wn, _ in origins)
-        hit = self._wt_cache.get(key)
-        if hit is None:
-            wflat = torch.cat([w.permute(0, 2, 1).reshape(w.shape[0], kc) for w in ws], 0).contiguous()          # (N, taps*cin), taps major
-            wsc = self._backward_scale(key, wflat)
-            hit = self._wt_cache[key] = (ops.h2_cast(wflat, _rup(n), scale=wsc / 16.0, transpose=True), wsc)       # (taps*cin, rup64(N))
-        w_t, wsc = hit
-        np_ = _rup(n)
-        dy_h = ops.h2_cast(dy, np_, scale=gs)
-        dcol = torch.empty(m, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
-        ops.gemm(H2, dy_h, w_t, None, None, None, None, dcol, None, n=kc, cp=np_, w_scale=wsc, a_scale=16.0 * gs)
-        return ops.col2im(dcol, cin, taps, stride, pad, lin, lout, nseq)
+        return dx
 
     def _bn_backward_many(self, items):
         """Training-mode BatchNorm backward of several INDEPENDENT BatchNorms: items = [(name, x, stats, dy)] -> [dx]; parameter gradients

@@ -68,16 +68,19 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         af = torch.cat([a_hi, a_lo], dim=1)          # both planes ride through the row gather below
     else:
         af = torch.as_strided(a, (nb * lin, cp), (a.stride(0), 1)).float()
-    assert torch.isfinite(af).all(), "padded channels of A must be finite"
-    rows = torch.arange(m)
-    b_, l_ = rows // lout, rows % lout
-    cols = []
-    for tap in range(taps):
-        pos = l_ * stride + tap - pad
-        valid = (pos >= 0) & (pos < lin)
-        r = (b_ * lin + pos.clamp(0, lin - 1))
-        cols.append(af[r] * valid[:, None].float())
-    x = torch.cat(cols, dim=1)                                   # (M, taps*cp)
+    assert bool(torch.isfinite(af.sum())), "padded channels of A must be finite"          # an inf / NaN anywhere reaches the sum
+    if taps == 1 and stride == 1 and pad == 0 and lin == lout:
+        x = af[:m]                                               # a Linear: the rows as they are
+    else:
+        rows = torch.arange(m)
+        b_, l_ = rows // lout, rows % lout
+        cols = []
+        for tap in range(taps):
+            pos = l_ * stride + tap - pad
+            valid = (pos >= 0) & (pos < lin)
+            r = (b_ * lin + pos.clamp(0, lin - 1))
+            cols.append(af[r] * valid[:, None].float())
+        x = torch.cat(cols, dim=1)                               # (M, taps*cp)
     if dtype == H2:
         # both operands arrive pre-split: A planes hold x * 16, W planes w * w_scale (natural k order)
         sa = ops.A_SCALE_F16X3 if a_scale is None else a_scale

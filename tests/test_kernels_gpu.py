@@ -465,7 +465,7 @@ def test_gemm_h2(case):
             _cmp(f"{case[0]}.{nm}", gt[..., :width], rf[..., :width], atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("cfg", [100, 101, 102, 103, 105, 107, 108, 110, 111, 113, 115, 116, 119, 120, 121, 122, 123, 124, 125, 127, 130, 131, 141, 144, 148, 150])
+@pytest.mark.parametrize("cfg", [100, 101, 102, 103, 105, 107, 108, 110, 111, 113, 115, 116, 119, 120, 121, 122, 123, 124, 125, 127, 130, 131, 141, 144, 148, 150, 160, 164, 166, 170, 171])
 def test_gemm_h2_every_tile_configuration(cfg):
     """Every EMAGE_H2 tile configuration (wave grids, loader waves, register-pipelined / interleaved K-loops, odd fragment
     counts) on a ragged shape with a transposed tail and on a convolution with a zero-filled channel tail."""
@@ -594,6 +594,8 @@ GROUP_CASES = H2_GEMM_CASES + [
     ("g_ffn1_b", (64, 64, 64), 768, 1536, 1, 1, 0, dict(bias=True, slope=0.0)),
     ("g_kv", (64, 64, 64), 768, 1536, 1, 1, 0, dict(bias=True, vt=768, want="f32")),
     ("g_kv_b", (64, 64, 64), 768, 1536, 1, 1, 0, dict(bias=True, vt=768, want="f32")),
+    ("g_kv_all", (64, 64, 64), 768, 6144, 1, 1, 0, dict(bias=True, vt=3072, want="f32")),        # many tiles per CU: the 128x192 configuration
+    ("g_kv_all_b", (64, 64, 64), 768, 6144, 1, 1, 0, dict(bias=True, vt=3072, want="f32")),
     ("g_dec_a", (64, 120, 120), 256, 256, 3, 1, 1, dict(bias=True, slope=0.2, n_store=256)),
     ("g_dec_b", (64, 120, 120), 256, 256, 3, 1, 1, dict(bias=True, slope=0.2, n_store=256)),
     ("g_dec_c", (64, 12, 12), 256, 256, 3, 1, 1, dict(bias=True, res="h2", n_store=256)),

@@ -367,3 +367,37 @@ def test_step_shared_encoder_pass_equals_three_passes(golden_dir):
             assert float(ga[k].abs().max()) < 1e-4 * gmax, k
             continue
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * scale + 1e-7 * gmax, (k, float((ga[k] - gb[k]).abs().max()), scale, gmax)
+
+
+def test_long_convolution_backward_in_pieces():
+    """`_conv_backward_h2` walks a long input in pieces of whole sequences (bounded im2col / dcol buffers): the input gradient and the
+    summed weight / bias gradients equal the one-piece form, and equal fp64 autograd of the convolution to split-fp16 (fp32-grade) accuracy."""
+    import types
+    import torch.nn.functional as Fn
+    model, _ = common.product_models(precision="f16x3")
+    base = "audio_encoder_body.feat_extractor.2.conv2"              # stride 1, 15 taps
+    w, b = model._flat_params()[base + ".weight"], model._flat_params()[base + ".bias"]
+    cout, cin, k = w.shape
+    nseq, lin = 7, 23
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(nseq * lin, cin, generator=g)
+    dy = torch.randn(nseq * lin, cout, generator=g) * 1e-2
+    res = {}
+    with fake_ops.installed(), torch.no_grad():
+        for rows in (1 << 17, 2 * lin):
+            fwd = training.TrainForward(model)
+            fwd.conv_backward_rows = rows
+            n0 = fake_ops.CALLS.count("im2col_t_h2")
+            dx = fwd._conv_backward(types.SimpleNamespace(dev=torch.device("cpu")), x, cin, [(base + ".weight", base + ".bias")], dy, k, 1, k // 2, lin, lin, nseq, True)
+            res[rows] = (dx, fwd.param_grads[base + ".weight"].clone(), fwd.param_grads[base + ".bias"].clone(), fake_ops.CALLS.count("im2col_t_h2") - n0)
+    (dx1, dw1, db1, n1), (dx4, dw4, db4, n4) = res[1 << 17], res[2 * lin]
+    assert n1 == 1 and n4 == 4                                      # 7 sequences in pieces of 2
+    assert torch.allclose(dx4, dx1, rtol=1e-6, atol=1e-7 * float(dx1.abs().max())) and torch.equal(db4, db1)
+    assert torch.allclose(dw4, dw1, rtol=1e-5, atol=1e-6 * float(dw1.abs().max()))
+    xd = x.double().reshape(nseq, lin, cin).permute(0, 2, 1).requires_grad_(True)
+    wd = w.detach().double().requires_grad_(True)
+    out = Fn.conv1d(xd, wd, b.detach().double(), stride=1, padding=k // 2)
+    out.backward(dy.double().reshape(nseq, lin, cout).permute(0, 2, 1))
+    ref_dx = xd.grad.permute(0, 2, 1).reshape(nseq * lin, cin)
+    assert float((dx4.double() - ref_dx).abs().max()) < 2e-5 * float(ref_dx.abs().max())
+    assert float((dw4.double() - wd.grad).abs().max()) < 2e-5 * float(wd.grad.abs().max())
