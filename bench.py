@@ -144,7 +144,8 @@ def profile_kernels(runner, model, vq):
         dtype, A, n, cp, taps, m = a[0], a[1], a[9], a[10], a[15], a[20]
         es = 2 if dtype == BF16 else 4
         kk = meta.get("k_real") or taps * cp                 # unpadded contraction length
-        return ("emage_gemm", 2.0 * m * n * kk, float(m * cp * es + n * taps * cp * es + m * n * es))
+        io = sum(t.numel() * t.element_size() for t in a[5:9] if torch.is_tensor(t))      # residual read + every output written
+        return ("emage_gemm", 2.0 * m * n * kk, float(m * cp * es + n * taps * cp * es + io))
 
     def attn_cost(a, meta):
         dtype, b, h, tq, tk, hd = a[0], a[6], a[7], a[8], a[9], a[10]
@@ -303,7 +304,8 @@ def roofline_report(records, precision, ms_per_step, serial_ms=None):
                               + "); PMC counters cannot be collected from inside the timed process")
     roof.update({
         "traffic": traffic, "traffic_source": traffic_source, "kernel": name, "launches_per_step": cnt, "avg_launch_us": 1e3 * ms / cnt,
-        "algorithmic_gflop_per_launch": flops / cnt / 1e9,
+        "algorithmic_gflop_per_launch": flops / cnt / 1e9, "algorithmic_mb_per_launch": byts / cnt / 1e6,
+        "traffic_over_algorithmic": (traffic / (byts / cnt)) if (traffic and byts > 0) else None,
         "note": "algorithmic flops (2*M*N*K, unpadded K) / serialized kernel time; in f16x3 every product issues 3 MFMAs, so the "
                 "MFMA pipes are busy for about 3x this fraction",
         "how": "the timed launch sequence captured as a SINGLE-stream hipGraph and timed (serialized_kernel_ms = its wall time per step = "

@@ -85,17 +85,27 @@ def _accumulate(dst, g, out=None):
 
 class _Tape:
     """Reverse-mode bookkeeping of one forward: backward closures in launch order, gradient buffers keyed by the forward tensor
-    (or token) they belong to, column-slice views routed into their parent's buffer.  Gradients are fp32 (rows, cols)."""
+    (or token) they belong to, column-slice views routed into their parent's buffer.  Gradients are fp32 (rows, cols).
+    Memory: a gradient buffer lives from its first contribution until the node that PRODUCED its tensor has run (every consumer of a
+    tensor runs before its producer in reverse order, and a tensor has one producer); a closure — and with it the activations it saved —
+    is dropped as soon as it has run.  So the live set shrinks as the backward walks instead of doubling until its end."""
 
     def __init__(self, dev):
-        self.dev, self.nodes, self.g, self.views, self.keep, self.pos = dev, [], {}, {}, [], -1
+        self.dev, self.nodes, self.g, self.views, self.keep, self.kids, self.pos = dev, [], {}, {}, {}, {}, -1
+        self._fetched = None            # ids whose gradient the running node has taken (dropped behind the node)
+        self.pinned = set()
 
     def node(self, fn):
         self.nodes.append(fn)
 
-    def view(self, parent, view, c0):
+    def view(self, parent, view, c0, written=False):
+        """`view` = parent[:, c0:c0 + width] takes part in the forward under its own identity.  written: the view is the OUTPUT of a node
+        (the parent is assembled in pieces, so it has several producers): its gradient buffer then stays until the tape is dropped."""
         self.views[id(view)] = (parent, c0, view.shape[1])
-        self.keep.append(view)
+        self.keep[id(view)] = view                       # ids are keys: the objects must stay alive while their entries exist
+        self.kids.setdefault(id(parent), []).append(id(view))
+        if written:
+            self.pinned.add(id(parent))
 
     def buffer(self, t):
         """The zero-initialised, tape-owned gradient buffer of `t` (created on first use)."""
@@ -103,7 +113,7 @@ class _Tape:
         if e is None:
             e = [torch.zeros(tuple(t.shape), dtype=torch.float32, device=self.dev), True]
             self.g[id(t)] = e
-            self.keep.append(t)
+            self.keep[id(t)] = t
         elif not e[1]:
             e[0], e[1] = e[0].clone(), True
         return e[0]
@@ -121,7 +131,7 @@ class _Tape:
             _accumulate(dst, g)
         elif e is None:
             self.g[id(t)] = [g, False]
-            self.keep.append(t)
+            self.keep[id(t)] = t
         elif e[1]:
             _accumulate(e[0], g)
         else:
@@ -135,7 +145,20 @@ class _Tape:
             e = self.g.get(id(parent))
             return None if e is None else e[0][:, c0:c0 + n]
         e = self.g.get(id(t))
-        return None if e is None else e[0]
+        if e is None:
+            return None
+        if self._fetched is not None:
+            self._fetched.append(id(t))
+        return e[0]
+
+    def _drop(self, i):
+        if i in self.pinned:
+            return
+        self.g.pop(i, None)
+        self.keep.pop(i, None)
+        for v in self.kids.pop(i, ()):
+            self.views.pop(v, None)
+            self.keep.pop(v, None)
 
     def run(self, progress=None, base=0):
         """Run the recorded closures in reverse; `pos` counts the executed nodes (what `TrainForward._param_grad` stamps a parameter's
@@ -144,12 +167,21 @@ class _Tape:
         self.pos = base - 1
         if progress is not None and base == 0:
             progress(-1)
-        for k, fn in enumerate(reversed(self.nodes)):
+        k = 0
+        while self.nodes:
+            fn = self.nodes.pop()
             self.pos = base + k
-            fn()
+            self._fetched = []
+            try:
+                fn()
+            finally:
+                fetched, self._fetched = self._fetched, None
+            del fn
+            for i in fetched:
+                self._drop(i)
             if progress is not None:
                 progress(base + k)
-        self.nodes = []
+            k += 1
 
 
 class StepShare:
@@ -862,7 +894,7 @@ class TrainForward:
         if self.tape is not None:
             self.tape.view(hh, hh_face, 0)
             self.tape.view(hh, hh_body, d)
-            self.tape.view(memcat, hint_face, af)
+            self.tape.view(memcat, hint_face, af, written=True)
         self._lin(cx, hh_face, "bodyhints_face.fc2", out=hint_face)
         hint_body = self._lin(cx, hh_body, "bodyhints_body.fc2")
 
