@@ -399,6 +399,16 @@ int emage_col_sum(const float* x, int ldx, const float* y, int ldy, int M, int C
 /* out = dy * (y > 0 ? 1 : slope): LeakyReLU / ReLU backward from the saved OUTPUT y of the activation. */
 int emage_act_backward(const float* dy, int ld_dy, const float* y, int ld_y, float slope, float* out, int ldo, int M, int C, void* stream);
 
+/* The gradient operands of one nn.Linear's backward (what loss.backward() computes per layer, train_emage_audio.py:174) from the gradient dy
+ * (M, C) of its output in ONE pass: dpre = dy * (y > 0 ? 1 : slope) when the layer's saved output y is given (else dpre = dy);
+ *   out_h (M, n_store >= C, % 8): EMAGE_H2 image of scale * dpre, zero tail columns            (operand of dX = dpre W)
+ *   out_t (C, m_store >= M, % 8): EMAGE_H2 image of scale * dpre^T, zero tail columns          (operand of dW = dpre^T X)
+ *   bias_grad[c] (+)= sum_m dpre[m][c] (float64 partials per 64 rows in `workspace`, >= ceil(M / 64) * C * 8 bytes, added in row order)
+ * any of the three outputs may be NULL; scale a power of two (the loss scale of the split-fp16 backward). */
+int emage_grad_prep(const float* dy, int ld_dy, const float* y, int ld_y, float slope, int M, int C, float scale,
+                    void* out_h, int ldh, int n_store, void* out_t, int ldt, int m_store,
+                    float* bias_grad, int accumulate, void* workspace, long workspace_bytes, void* stream);
+
 /* nn.LayerNorm backward for input rows x (M, C): dx, and dy_xhat = dy * (x - mean) * rstd (column sums of dy_xhat / dy are
  * the weight / bias gradients: emage_col_sum). */
 int emage_layernorm_backward(const float* x, int ldx, const float* gamma, const float* dy, int ld_dy, float eps,
@@ -455,6 +465,12 @@ int emage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * normal).  transpose = 0: out (M, n_store), zero tail [C, n_store);  transpose != 0: out (C, n_store) with out[c][m] = src[m][c] * scale
  * and a zero tail [M, n_store) — the operands of the backward contractions of a training step (dW = dY^T X contracts over the rows). */
 int emage_h2_cast(const float* src, int lds, void* out, int ldo, int n_store, int M, int C, float scale, int transpose, void* stream);
+
+/* fp32 (N, K) weight rows (K % 32 == 0, 16-byte aligned rows) -> the EMAGE_F16X3 weight operand of w * scale (scale a power of two), the image
+ * emage_gemm takes as `w` in that mode: per row and 32-k K-tile 128 bytes = [16 x 4 fp16 hi | 16 x 4 fp16 lo], 16-byte chunk g of a plane holding
+ * k = 4g..4g+3, 16+4g..16+4g+3.  out: (N, ldo) 4-byte elements, ldo >= K.  A training step re-packs every weight behind each Adam update
+ * (train_emage_audio.py:174-176 changes them): one launch per operand instead of the host-side tensor arithmetic. */
+int emage_f16x3_pack_weights(const float* w, int ldw, void* out, int ldo, int N, int K, float scale, void* stream);
 
 /* Multi-tensor Adam: ONE launch over every parameter.  table: per tensor five 64-bit words {param, grad, exp_avg, exp_avg_sq, n} (device
  * pointers / element count); block b updates elements [block_chunk[b] * C, +C) of tensor block_tensor[b], C = emage_adam_multi_chunk().

@@ -45,6 +45,7 @@ SIGNATURES = {
     "emage_transpose_f32": [_p, _i, _p, _i, _i, _i, _p],
     "emage_col_sum": [_p, _i, _p, _i, _i, _i, _p, _i, _p, _l, _p],
     "emage_act_backward": [_p, _i, _p, _i, _f, _p, _i, _i, _i, _p],
+    "emage_grad_prep": [_p, _i, _p, _i, _f, _i, _i, _f, _p, _i, _i, _p, _i, _i, _p, _i, _p, _l, _p],
     "emage_layernorm_backward": [_p, _i, _p, _p, _i, _f, _p, _i, _p, _i, _i, _i, _p],
     "emage_attention_backward": [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_mse_loss_grad": [_p, _i, _p, _i, _i, _i, _f, _p, _i, _p],
@@ -69,6 +70,7 @@ SIGNATURES = {
     "emage_pack_motion": [_i, _p, _p, _l, _p, _p, _l, _i, _p, _i, _i, _i, _i, _i, _p],
     "emage_cast_pad": [_i, _p, _i, _p, _i, _i, _i, _i, _p],
     "emage_h2_cast": [_p, _i, _p, _i, _i, _i, _i, _f, _i, _p],
+    "emage_f16x3_pack_weights": [_p, _i, _p, _i, _i, _i, _f, _p],
     "emage_rot6d_to_axis_angle": [_p, _p, _i, _p],
     "emage_axis_angle_to_rot6d": [_p, _p, _i, _p],
     "emage_merge_parts": [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p],

@@ -161,6 +161,27 @@ __global__ __launch_bounds__(256) void h2_cast_kernel(const float* src, int lds_
     }
 }
 
+// fp32 (N, K) weights -> the EMAGE_F16X3 weight image of w * scale (ops.split_f16_weights): per row and 32-k K-tile 128 bytes =
+// [hi plane | lo plane], each plane 4 chunks of 16 bytes, chunk g = k 4g..4g+3 and 16+4g..16+4g+3 (the order the X3 tiles' LDS-DMA lands).
+// One thread per chunk pair.  scale_16 = scale / 16 (h2_split8 multiplies by H2_SCALE): powers of two, so the planes are those of w * scale.
+__global__ __launch_bounds__(256) void f16x3_pack_kernel(const float* __restrict__ w, int ldw, unsigned char* __restrict__ out, long ldo_bytes, int N, int K, float scale_16) {
+    const int nkt = K >> 5;
+    const long total = (long)N * nkt * 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i & 3);
+        const long r = i >> 2;
+        const int kt = (int)(r % nkt), n = (int)(r / nkt);
+        const float* src = w + (long)n * ldw + 32 * kt + 4 * g;
+        const float4 a = *(const float4*)src, b = *(const float4*)(src + 16);
+        const float v[8] = {a.x * scale_16, a.y * scale_16, a.z * scale_16, a.w * scale_16, b.x * scale_16, b.y * scale_16, b.z * scale_16, b.w * scale_16};
+        uint4 hi, lo;
+        h2_split8(v, hi, lo);
+        unsigned char* dst = out + (long)n * ldo_bytes + 128 * kt + 16 * g;
+        *(uint4*)dst = hi;
+        *(uint4*)(dst + 64) = lo;
+    }
+}
+
 inline int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -238,6 +259,13 @@ extern "C" int emage_h2_cast(const float* src, int lds, void* out, int ldo, int 
         if (n_store < C) return EMAGE_EINVAL;
         hipLaunchKernelGGL(h2_cast_kernel, dim3(grid_for((long)M * n_store / 8)), dim3(256), 0, s, src, lds, (h2_t*)out, ldo, n_store, M, C, scale);
     }
+    return launch_status();
+}
+
+extern "C" int emage_f16x3_pack_weights(const float* w, int ldw, void* out, int ldo, int N, int K, float scale, void* stream) {
+    if (!w || !out || N <= 0 || K <= 0 || K % 32 || ldw < K || ldw % 4 || ldo < K || ((uintptr_t)w & 15) || ((uintptr_t)out & 15) || ldo % 4 || !(scale > 0.f)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(f16x3_pack_kernel, dim3(grid_for((long)N * (K / 32) * 4)), dim3(256), 0, (hipStream_t)stream, w, ldw, (unsigned char*)out, (long)ldo * 4, N, K,
+                       scale * H2_INV);
     return launch_status();
 }
 

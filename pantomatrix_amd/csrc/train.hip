@@ -308,6 +308,55 @@ __global__ __launch_bounds__(256) void col_sum_finalize_kernel(const double* __r
     out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
+// Everything a Linear's backward needs from the gradient of its output, in ONE pass over dY (64 x 64 tiles through LDS):
+//   dpre = dy * (y > 0 ? 1 : slope)            (y given: the activation's backward from its saved output, as act_backward_kernel)
+//   out_h (M, n_store)  = EMAGE_H2 image of scale * dpre                  — the A operand of dX = dpre W
+//   out_t (C, m_store)  = EMAGE_H2 image of scale * dpre^T, zero tail     — the A operand of dW = dpre^T X (contraction over the rows)
+//   partial[tile_m][c]  = float64 column sums of the tile's 64 rows       — the bias gradient (col_sum_finalize_kernel adds the tiles in order)
+// instead of act_backward + h2_cast + h2_cast(transpose) + col_sum_partial: four reads of dY and a round trip of dpre become one read.
+__global__ __launch_bounds__(256) void grad_prep_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy, float slope,
+                                                        emage_dev::h2_t* __restrict__ out_h, int ldh, int n_store, emage_dev::h2_t* __restrict__ out_t, int ldt, int m_store,
+                                                        double* __restrict__ partial, float scale, int M, int C) {
+    __shared__ float tile[64][65];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        float v = 0.f;
+        if (m0 + r < M && c0 + c < C) {
+            v = dy[(long)(m0 + r) * ldd + c0 + c];
+            if (y) v = v * (y[(long)(m0 + r) * ldy + c0 + c] > 0.f ? 1.f : slope);
+        }
+        tile[r][c] = v;
+    }
+    __syncthreads();
+    if (out_h)
+        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+            const int r = i >> 3, g = i & 7;
+            if (m0 + r < M && c0 + 8 * g < n_store) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[r][8 * g + e] * scale;
+                emage_dev::h2_store8(out_h + (long)(m0 + r) * ldh + c0 + 8 * g, v);
+            }
+        }
+    if (out_t)
+        for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+            const int c = i >> 3, g = i & 7;
+            if (c0 + c < C && m0 + 8 * g < m_store) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[8 * g + e][c] * scale;
+                emage_dev::h2_store8(out_t + (long)(c0 + c) * ldt + m0 + 8 * g, v);
+            }
+        }
+    if (partial && threadIdx.x < 64 && c0 + (int)threadIdx.x < C && m0 < M) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) s += (double)tile[r][threadIdx.x];
+        partial[(long)blockIdx.x * C + c0 + threadIdx.x] = s;
+    }
+}
+
 // dpre = dy * (y > 0 ? 1 : slope): backward of LeakyReLU / ReLU from the saved OUTPUT (same sign as the pre-activation)
 __global__ __launch_bounds__(256) void act_backward_kernel(const float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy, float slope,
                                                            float* __restrict__ out, int ldo, int M, int C) {
@@ -571,6 +620,24 @@ extern "C" int emage_col_sum(const float* x, int ldx, const float* y, int ldy, i
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(col_sum_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, C, out, accumulate);
+    return launch_status();
+}
+
+extern "C" int emage_grad_prep(const float* dy, int ld_dy, const float* y, int ld_y, float slope, int M, int C, float scale,
+                               void* out_h, int ldh, int n_store, void* out_t, int ldt, int m_store,
+                               float* bias_grad, int accumulate, void* workspace, long workspace_bytes, void* stream) {
+    if (!dy || M <= 0 || C <= 0 || ld_dy < C || (y && ld_y < C) || !(scale > 0.f) || (!out_h && !out_t && !bias_grad)) return EMAGE_EINVAL;
+    if (out_h && (n_store < C || n_store % 8 || ldh % 8 || ldh < n_store || ((uintptr_t)out_h & 15))) return EMAGE_EINVAL;
+    if (out_t && (m_store < M || m_store % 8 || ldt % 8 || ldt < m_store || ((uintptr_t)out_t & 15))) return EMAGE_EINVAL;
+    const int tiles_m = ((out_t && m_store > M ? m_store : M) + 63) / 64, chunks = (M + 63) / 64;
+    const int tiles_c = ((out_h && n_store > C ? n_store : C) + 63) / 64;
+    if (bias_grad && (!workspace || ((uintptr_t)workspace & 7) || workspace_bytes < (long)chunks * C * (long)sizeof(double))) return EMAGE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(grad_prep_kernel, dim3(tiles_m, tiles_c), dim3(256), 0, s, dy, ld_dy, y, ld_y, slope, (emage_dev::h2_t*)out_h, ldh, n_store, (emage_dev::h2_t*)out_t, ldt, m_store,
+                       bias_grad ? (double*)workspace : (double*)nullptr, scale, M, C);
+    int rc = launch_status();
+    if (rc || !bias_grad) return rc;
+    hipLaunchKernelGGL(col_sum_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, C, bias_grad, accumulate);
     return launch_status();
 }
 

@@ -81,6 +81,9 @@ class _EmageModule(torch.nn.Module):
         self.group_gemms = True                # part-wise stacks (VQ part decoders, refinement layers + heads, ...) walk in lock step and
                                                # their contractions share launches (ops.lockstep / emage_gemm_grouped); False = one stream
                                                # lane per chain, one launch per contraction (the round-3 form; same bits)
+        self.group_face_body = False           # forward(): the 4 face decoder layers walk in lock step with the first 4 audio cross-attention
+                                               # layers of the body (same shapes, different weights: 6 contractions per layer pair share
+                                               # launches) instead of running on two stream lanes; same bits (A/B switch)
         self._templates = {}                   # cached default motion / mask of inference() per (batch, length, device)
         self._spec = type(self)._spec_fn(config)
         init = synthetic.state_dict_from_spec(self._spec, seed=int(getattr(config, "init_seed", 0)), cfg=config,
@@ -205,27 +208,31 @@ class _EmageModule(torch.nn.Module):
             raise RuntimeError("the EMAGE model classes run only on an MI355X device: call .to('cuda') first "
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests only)")
 
-    def _engine(self, h2=None):
+    def _engine(self, h2=None, train_only=False):
         """The packed operand set of the current precision.  h2 (f16x3 only): pre-split EMAGE_H2 operands (default: `split_acts`);
-        the training forward asks for h2=False (float32 activations, weights in the EMAGE_F16X3 packing)."""
+        the training forward asks for h2=False (float32 activations, weights in the EMAGE_F16X3 packing) and train_only=True: `_pack` may
+        then leave out operands only the eval-mode forward reads (a training step re-packs behind every update); such a set is never
+        handed to an eval-mode caller."""
         dev = self.device
         self._require_device(dev)
         want_h2 = self._dt == F16X3 and self._supports_h2 and (self.split_acts if h2 is None else h2)
         dt = H2 if want_h2 else self._dt
         stamp = self._version_stamp()
-        if self._packed is None or self._packed.device != dev or self._packed.dt != dt or self._packed.stamp != stamp:
+        if (self._packed is None or self._packed.device != dev or self._packed.dt != dt or self._packed.stamp != stamp
+                or (self._packed.train_only and not train_only)):
             capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
             for attempt in (0, 1):
-                cache = self.__dict__.setdefault("_scale_caches", {}).setdefault((str(dev), dt), {})
+                # the scale cache is keyed by packing ORDER: a train-only set (fewer operands) keeps its own
+                cache = self.__dict__.setdefault("_scale_caches", {}).setdefault((str(dev), dt, bool(train_only)), {})
                 pk = _Packed(self._flat_params(), dev, dt, cache)
-                pk.stamp = stamp
+                pk.stamp, pk.train_only = stamp, bool(train_only)
                 self._pack(pk)
                 pk.finish_range_check()
                 # a weight that left the range its cached power-of-two scale was chosen for (it grew / shrank 4x since the first packing, or
                 # was replaced): choose the scales afresh.  Outside a stream capture only (the flag is read on the host); a training step
                 # (`training.Trainer`, eager or captured) leaves the flag unread here and reads it with its losses
                 if attempt == 0 and not capturing and not self.__dict__.get("_defer_range_check") and pk.range_flag is not None and int(pk.range_flag) != 0:
-                    self.__dict__["_scale_caches"].pop((str(dev), dt), None)
+                    self.__dict__["_scale_caches"].pop((str(dev), dt, bool(train_only)), None)
                     continue
                 break
             self._packed = pk
@@ -250,6 +257,7 @@ class _Packed:
         self.scale_cache = {} if scale_cache is None else scale_cache
         self._n_operands = 0
         self.stamp = None            # `_EmageModule._version_stamp()` of the parameters this set was packed from
+        self.train_only = False      # packed for the training forward alone (`_engine(train_only=True)`): eval-only operands may be missing
         # int32 device counter of operands packed with a CACHED scale whose max |w * scale| has left [2^10, 2^14) (chosen into
         # [2^12, 2^13): the fp16 hi plane overflows at 2^16); None until such a packing happens
         self.range_flag = None
@@ -289,7 +297,8 @@ class _Packed:
             if cached is not None and w2d.numel():
                 self._range_pending.append((w2d, scale))          # checked together by `finish_range_check` (a few launches for all of them)
             return img, scale
-        return w2d.to(ops.TORCH_DTYPE[dt]).contiguous(), 1.0
+        out = w2d.to(ops.TORCH_DTYPE[dt]).contiguous()
+        return (out.clone() if out.data_ptr() == w2d.data_ptr() else out), 1.0          # never a view of the parameter itself
 
     def _pack_mat(self, w2d):
         n, k = w2d.shape
@@ -309,7 +318,7 @@ class _Packed:
             ws.append(w)
             bs.append(b)
         k_real = ws[0].shape[1]
-        wcat = torch.cat(ws, 0).float()
+        wcat = (torch.cat(ws, 0) if len(ws) > 1 else ws[0]).float()       # one source: the operand packing reads the parameter itself
         w, kp, wsc = self._pack_mat(wcat)
         self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt)
         self.origin[key] = [(nm + ".weight", nm + ".bias", rows[i] if rows is not None else slice(0, self.p[nm + ".weight"].shape[0]))
@@ -328,7 +337,7 @@ class _Packed:
                 bs.append(self.p[nm + ".in_proj_bias"][sl[part]])
                 self.origin[key].append((nm + ".in_proj_weight", nm + ".in_proj_bias", sl[part]))
         k_real = ws[0].shape[1]
-        wcat = torch.cat(ws, 0).float()
+        wcat = (torch.cat(ws, 0) if len(ws) > 1 else ws[0]).float()
         w, kp, wsc = self._pack_mat(wcat)
         self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt)
 
@@ -963,7 +972,8 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             self._pack_layer(pk, nm, cross=True)
         pk.in_proj("cross.kv_all", [n + ".multihead_attn" for n in cross], "kv")
         pk.in_proj("face.kv_all", [n + ".multihead_attn" for n in face], "kv")
-        self._pack_wav_encoders(pk, ("audio_encoder_face", "audio_encoder_body"))
+        if not pk.train_only:        # eval-mode WavEncoders (BatchNorms folded into the convolutions); training packs the raw ones (`_train_pack`)
+            self._pack_wav_encoders(pk, ("audio_encoder_face", "audio_encoder_body"))
         pk.w["pe"] = pk.f32("position_embeddings.pe")[0].contiguous()                 # (2*pose_length, d)
         pk.w["spk_body"] = pk.f32("speaker_embedding_body.weight")
         pk.w["spk_face"] = pk.f32("speaker_embedding_face.weight")
@@ -1167,17 +1177,24 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
 
             # face branch (M:288-294) on lane 1, once the hints (lane 0) are there
             fk.after(1, 0)
+            def face_layer(i, face):
+                return self._decoder_layer(cx, f"face_motion_decoder.layers.{i}", face, b, t,
+                                           fkk[:, i * d:(i + 1) * d], fvt[:, i * d:], nf * d, t)
+
+            def cross_layer(i, x, base):
+                return self._decoder_layer(cx, f"audio_motion_cross_attn.layers.{i}", x, b, t,
+                                           bk[:, i * d:(i + 1) * d], bvt[:, i * d:], nc * d, ta,
+                                           post_add=base.r if i == nc - 1 else None)               # motion_fea + cross
+
+            # the two decoder stacks side by side: lock step (one lane, shared launches) or two lanes
+            paired = self.group_face_body and self.group_gemms and use_audio and dev.type == "cuda" and nf < nc
             with fk.lane(1):
                 mem_face, _ = cx.gemm(memcat, "audio_face_motion_proj")
                 fkk, fvt = self._memory_kv(cx, "face.kv_all", mem_face, b, t, nf)
                 face = face0
-                for i in range(nf):
-                    face = self._decoder_layer(cx, f"face_motion_decoder.layers.{i}", face, b, t,
-                                               fkk[:, i * d:(i + 1) * d], fvt[:, i * d:], nf * d, t)
-                rec_lo, out["rec_face"] = cx.gemm(face.a, "face_out_proj", want="both")
-                if not (_lean and c_of["face"] == 0):
-                    hc, _ = cx.gemm(rec_lo, "face_cls.fc1", slope=0.1)
-                    _, out["cls_face"] = cx.gemm(hc, "face_cls.fc2", want="f32")
+                if not paired:
+                    for i in range(nf):
+                        face = face_layer(i, face)
 
             with fk.lane(0):
                 # body branch: temporal self-attention (M:297-300)
@@ -1185,14 +1202,33 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                 x = self._encoder_layer(cx, "motion_self_encoder.layers.0", x, b, t, post_add=pos_spk,   # + speaker + pe (M:304-305)
                                         want_f32=use_audio)          # `base`: added behind the last cross-attention layer's norm
             # audio cross-attention stack (M:303-312) needs lane 2's projected memory
+            first = 0
             if use_audio:
                 fk.after(0, 2)
+                base = x
+            if paired:
+                fk.after(0, 1)                  # the face memory (lane 1) feeds the lock-step walk on lane 0
+                pair = {}
+                with fk.lane(0), ops.lockstep() as ls:
+                    with ls.chain():
+                        for i in range(nf):
+                            face = face_layer(i, face)
+                        pair["face"] = face
+                    with ls.chain():
+                        for i in range(nf):
+                            x = cross_layer(i, x, base)
+                        pair["x"] = x
+                face, x, first = pair["face"], pair["x"], nf
+                fk.after(1, 0)
+            with fk.lane(1):
+                rec_lo, out["rec_face"] = cx.gemm(face.a, "face_out_proj", want="both")
+                if not (_lean and c_of["face"] == 0):
+                    hc, _ = cx.gemm(rec_lo, "face_cls.fc1", slope=0.1)
+                    _, out["cls_face"] = cx.gemm(hc, "face_cls.fc2", want="f32")
+            if use_audio:
                 with fk.lane(0):
-                    base = x
-                    for i in range(nc):
-                        x = self._decoder_layer(cx, f"audio_motion_cross_attn.layers.{i}", x, b, t,
-                                                bk[:, i * d:(i + 1) * d], bvt[:, i * d:], nc * d, ta,
-                                                post_add=base.r if i == nc - 1 else None)           # motion_fea + cross
+                    for i in range(first, nc):
+                        x = cross_layer(i, x, base)
             with fk.lane(0):
                 # part latents (M:315-317)
                 hl, _ = cx.gemm(x.a, "motion2latent.fc1", slope=0.1)             # (M, 3d)

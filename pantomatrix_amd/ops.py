@@ -173,6 +173,8 @@ def split_f16_weights(w2d, scale=None):
     w = w2d.to(torch.float32)
     if scale is None:
         scale = _f16_scale(w)
+    if w.is_cuda and n:                  # on the device: ONE launch, the same bits as the tensor arithmetic below (tests/test_kernels_gpu.py)
+        return pack_f16x3_weights(w, scale), scale
     ws = w * scale
     hi = ws.to(torch.float16)
     lo = (ws - hi.to(torch.float32)).to(torch.float16)
@@ -241,6 +243,8 @@ def split_f16_weights_h2(w2d, scale=None):
     assert k % 32 == 0
     w = w2d.to(torch.float32)
     scale = _f16_scale(w) if scale is None else scale
+    if w.is_cuda and n:                  # on the device: the activation-cast kernel (h2 images carry a fixed x16: the rest of the scale goes in front)
+        return h2_cast(w if w.stride(1) == 1 else w.contiguous(), k, scale=scale / A_SCALE_F16X3), scale
     return h2_pack(w, scale), scale
 
 
@@ -647,7 +651,8 @@ def col_sum(x, y=None, out=None, accumulate=False):
     """out[c] (+)= sum_m x[m, c] (* y[m, c]) over fp32 (M, C) views."""
     _dev(x)
     m, c = x.shape
-    out = torch.zeros(c, dtype=torch.float32, device=x.device) if out is None else out
+    if out is None:                       # the finalize launch WRITES every column unless `accumulate`: no zero fill
+        out, accumulate = torch.empty(c, dtype=torch.float32, device=x.device), False
     ws = torch.empty(((m + 63) // 64) * c, dtype=torch.float64, device=x.device)         # one partial per chunk of >= 64 rows (csrc/train.hip STAT_CHUNK)
     _col_sum(x, y, out, accumulate, ws)
     return out
@@ -667,6 +672,37 @@ def act_backward(dy, y, slope, out=None):
     return out
 
 
+@_op("grad_prep", "(Tensor dy, Tensor? y, float slope, float scale, Tensor(a!)? out_h, Tensor(b!)? out_t, Tensor(c!)? bias_grad, bool accumulate, "
+                  "Tensor(d!)? workspace) -> ()")
+def _grad_prep(dy, y, slope, scale, out_h, out_t, bias_grad, accumulate, workspace):
+    m, c = dy.shape
+    check(_lib.load().emage_grad_prep(_ptr(dy), _ld(dy), _ptr(y), _ld(y) if y is not None else 0, slope, m, c, scale,
+                                      _ptr(out_h), _ld(out_h) if out_h is not None else 0, out_h.shape[1] if out_h is not None else 0,
+                                      _ptr(out_t), _ld(out_t) if out_t is not None else 0, out_t.shape[1] if out_t is not None else 0,
+                                      _ptr(bias_grad), int(accumulate), _ptr(workspace), workspace.numel() * 8 if workspace is not None else 0, _stream()),
+          "grad_prep")
+
+
+def grad_prep(dy, y=None, slope=0.0, scale=1.0, n_store=None, m_store=None, bias_grad=None, accumulate=False, want_bias=True):
+    """One pass over the gradient dy (M, C) of a Linear's output -> (dpre_h, dpre_t, bias gradient): the EMAGE_H2 images of
+    scale * dpre (M, n_store) and of its transpose (C, m_store), dpre = dy * (y > 0 ? 1 : slope) when the saved output `y` is given, and
+    the column sums of dpre — written to / added to (`accumulate`) `bias_grad`, or to a fresh tensor.  n_store / m_store None: that image
+    is not wanted.  Replaces act_backward + two h2_cast + col_sum (four reads of dy) in the split-fp16 backward."""
+    _dev(dy)
+    m, c = dy.shape
+    out_h = torch.empty(m, n_store, dtype=torch.float32, device=dy.device) if n_store is not None else None
+    out_t = torch.empty(c, m_store, dtype=torch.float32, device=dy.device) if m_store is not None else None
+    ws = None
+    if want_bias:
+        if bias_grad is None:
+            bias_grad, accumulate = torch.empty(c, dtype=torch.float32, device=dy.device), False
+        ws = torch.empty(((m + 63) // 64) * c, dtype=torch.float64, device=dy.device)
+    else:
+        bias_grad = None
+    _grad_prep(dy, y, float(slope), float(scale), out_h, out_t, bias_grad, bool(accumulate), ws)
+    return out_h, out_t, bias_grad
+
+
 @_op("layernorm_backward", "(Tensor x, Tensor gamma, Tensor dy, float eps, Tensor(a!) dx, Tensor(b!) dy_xhat) -> ()")
 def _layernorm_backward(x, gamma, dy, eps, dx, dy_xhat):
     m, c = x.shape
@@ -674,12 +710,15 @@ def _layernorm_backward(x, gamma, dy, eps, dx, dy_xhat):
                                                m, c, _stream()), "layernorm_backward")
 
 
-def layernorm_backward(x, gamma, dy, eps=1e-5):
-    """-> (dx, dgamma, dbeta) of LayerNorm(x) * gamma + beta for fp32 (M, C) rows."""
+def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None):
+    """-> (dx, dgamma, dbeta) of LayerNorm(x) * gamma + beta for fp32 (M, C) rows.  dgamma / dbeta given: the affine gradients are ADDED
+    to them (the parameter's gradient accumulator: no temporary, no separate add)."""
     _dev(x)
     dx, t = torch.empty(x.shape, dtype=torch.float32, device=x.device), torch.empty(x.shape, dtype=torch.float32, device=x.device)
     _layernorm_backward(x, gamma, dy, float(eps), dx, t)
-    return dx, col_sum(t), col_sum(dy)
+    if dgamma is None:
+        return dx, col_sum(t), col_sum(dy)
+    return dx, col_sum(t, out=dgamma, accumulate=True), col_sum(dy, out=dbeta, accumulate=True)
 
 
 @_op("attention_backward", "(Tensor q, Tensor k, Tensor vt, int vt_rows, Tensor? pmask, Tensor d_out, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) dv, "
@@ -1059,6 +1098,22 @@ def h2_cast(src2d, n_store, scale=1.0, transpose=False):
     m, c = src2d.shape
     out = torch.empty(c if transpose else m, n_store, dtype=torch.float32, device=src2d.device)
     _h2_cast(src2d, out, float(scale), bool(transpose))
+    return out
+
+
+@_op("f16x3_pack_weights", "(Tensor w, Tensor(a!) out, float scale) -> ()")
+def _f16x3_pack_weights(w, out, scale):
+    n, k = w.shape
+    check(_lib.load().emage_f16x3_pack_weights(_ptr(w), _ld(w), _ptr(out), _ld(out), n, k, scale, _stream()), "f16x3_pack_weights")
+
+
+def pack_f16x3_weights(w2d, scale):
+    """fp32 (N, K) device weights, K % 32 == 0 -> the EMAGE_F16X3 operand image of w * scale (what `split_f16_weights` builds with
+    tensor arithmetic), float32-typed (N, K)."""
+    _dev(w2d)
+    w = w2d if (w2d.stride(1) == 1 and w2d.stride(0) % 4 == 0 and w2d.data_ptr() % 16 == 0) else w2d.contiguous()
+    out = torch.empty(w.shape[0], w.shape[1], dtype=torch.float32, device=w.device)
+    _f16x3_pack_weights(w, out, float(scale))
     return out
 
 

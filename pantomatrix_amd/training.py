@@ -38,6 +38,9 @@ def dropout_mask_count():
     return 3 + 6 * (spec.N_FACE_LAYERS + spec.N_CROSS_LAYERS + 3) + 4
 
 
+_ZERO_LONG = torch.zeros((), dtype=torch.long)           # stands for a missing `num_batches_tracked` buffer
+
+
 class _Masks:
     """The dropout masks of one forward: a given list (the parity tests: the reference's recorded draws), or — masks None — drawn on
     the device as they are needed (`ops.dropout_mask`: Philox keyed by rng = (seed, step, first mask id); step may be a device scalar)."""
@@ -107,11 +110,13 @@ class _Tape:
         if written:
             self.pinned.add(id(parent))
 
-    def buffer(self, t):
-        """The zero-initialised, tape-owned gradient buffer of `t` (created on first use)."""
+    def buffer(self, t, zero=True):
+        """The zero-initialised, tape-owned gradient buffer of `t` (created on first use).  zero=False: the caller (and its siblings)
+        OVERWRITE every column block before anyone reads the buffer — the attention backward's dQ / dK / dV blocks of a projection."""
         e = self.g.get(id(t))
         if e is None:
-            e = [torch.zeros(tuple(t.shape), dtype=torch.float32, device=self.dev), True]
+            alloc = torch.zeros if zero else torch.empty
+            e = [alloc(tuple(t.shape), dtype=torch.float32, device=self.dev), True]
             self.g[id(t)] = e
             self.keep[id(t)] = t
         elif not e[1]:
@@ -217,10 +222,12 @@ class TrainForward:
         self.grad_scale = 1024.0
         self.conv_backward_rows = 1 << 17                 # output rows per piece of a long convolution's backward (_conv_backward_h2)
         self._w_scale, self._wt_cache = {}, {}
+        self._wt_keep = False           # True inside `Trainer._device_step`: the transposed weight images (`_weight_t_h2`) serve all three forwards
         self.range_flag = None          # int32 device counter: transposed-weight operands (backward dX) whose cached scale no longer fits
         self._range_pending, self._range_seen = [], set()
         self.tape = None
-        self.param_grads = {}
+        self._pgrads = {}               # name -> gradient accumulator (`param_grads` is the flushed view of it)
+        self._pg_dst, self._pg_src, self._pg_spans, self._pg_bytes = [], [], {}, 0       # queued parameter-gradient contributions (_param_grad)
         self.grad_views = None          # name -> preallocated fp32 gradient tensor (views of the exchange buckets, training.Trainer)
         self.touch = None               # dict filled with name -> tape position of the parameter's last contribution of a backward
         self._shared, self.last_run_nodes = None, 0
@@ -276,9 +283,14 @@ class TrainForward:
             from . import dist as pdist
             local = [ops.bn_stats(x, None, None, BN_MOMENTUM) for _name, x in items]
             merged = pdist.merge_batch_stats_many([(mean, var, x.shape[0]) for (mean, var), (_name, x) in zip(local, items)], group=self.group)
+        # fresh copies of the running buffers (updated in place below) and the advanced batch counters of ALL items: three multi-tensor launches
+        src = lambda nm, sfx: new_stats.get(nm + sfx, params[nm + sfx]).detach()
+        rms = torch._foreach_mul([src(name, ".running_mean").to(cx.dev, torch.float32) for name, _x in items], 1.0)
+        rvs = torch._foreach_mul([src(name, ".running_var").to(cx.dev, torch.float32) for name, _x in items], 1.0)
+        nbts = torch._foreach_add([new_stats.get(name + ".num_batches_tracked", params.get(name + ".num_batches_tracked", _ZERO_LONG)).detach().to(cx.dev)
+                                   for name, _x in items], 1)
         for k, (name, x) in enumerate(items):
-            rm = new_stats.get(name + ".running_mean", params[name + ".running_mean"]).detach().to(cx.dev, torch.float32).clone()
-            rv = new_stats.get(name + ".running_var", params[name + ".running_var"]).detach().to(cx.dev, torch.float32).clone()
+            rm, rv = rms[k], rvs[k]
             n = x.shape[0]
             if self.sync_bn:
                 stats = merged[k]
@@ -289,8 +301,7 @@ class TrainForward:
             else:
                 stats = ops.bn_stats(x, rm, rv, BN_MOMENTUM)
             new_stats[name + ".running_mean"], new_stats[name + ".running_var"] = rm, rv
-            nbt = new_stats.get(name + ".num_batches_tracked", params.get(name + ".num_batches_tracked", torch.zeros((), dtype=torch.long)))
-            new_stats[name + ".num_batches_tracked"] = nbt.detach().clone() + 1
+            new_stats[name + ".num_batches_tracked"] = nbts[k]
             if self._bn_log is not None:
                 self._bn_log.append((name, stats[0], stats[1], n))
             out.append(stats)
@@ -311,10 +322,9 @@ class TrainForward:
         torch._foreach_add_(rms, [e[1] for e in log], alpha=BN_MOMENTUM)
         rvs = torch._foreach_mul(rvs, 1 - BN_MOMENTUM)
         torch._foreach_add_(rvs, torch._foreach_mul([e[2] for e in log], [BN_MOMENTUM * e[3] / max(e[3] - 1, 1) for e in log]))
-        for n, rm, rv in zip(names, rms, rvs):
-            new_stats[n + ".running_mean"], new_stats[n + ".running_var"] = rm, rv
-            nbt = new_stats.get(n + ".num_batches_tracked", params.get(n + ".num_batches_tracked", torch.zeros((), dtype=torch.long)))
-            new_stats[n + ".num_batches_tracked"] = nbt.detach().clone() + 1
+        nbts = torch._foreach_add([new_stats.get(n + ".num_batches_tracked", params.get(n + ".num_batches_tracked", _ZERO_LONG)).detach().to(dev) for n in names], 1)
+        for n, rm, rv, nbt in zip(names, rms, rvs, nbts):
+            new_stats[n + ".running_mean"], new_stats[n + ".running_var"], new_stats[n + ".num_batches_tracked"] = rm, rv, nbt
 
     def _wav_encoders(self, cx, encs, audio, b, new_stats):
         """WavEncoder.forward (P:296-314) with train-mode BatchNorm for several encoders IN LOCK STEP (encs = [(name, index)]): block by
@@ -609,12 +619,12 @@ class TrainForward:
         ent = cx.pk.w[key]
         n, k = ent["n"], ent["k_real"]
         m = dy.shape[0]
-        dpre = dy if slope is None else ops.act_backward(dy, y, slope)
-        if dpre.shape[1] != n or dpre.stride(1) != 1:
-            raise RuntimeError(f"{key}: gradient of shape {tuple(dpre.shape)} for an output of {n} columns")
+        if dy.shape[1] != n or dy.stride(1) != 1:
+            raise RuntimeError(f"{key}: gradient of shape {tuple(dy.shape)} for an output of {n} columns")
         if self.h2_backward:
-            self._lin_backward_h2(cx, x, key, dpre, n, k, m, need_dx)
+            self._lin_backward_h2(cx, x, key, dy, y if slope is not None else None, slope, n, k, m, need_dx)
             return
+        dpre = dy if slope is None else ops.act_backward(dy, y, slope)
         w32 = torch.cat([self._param(wn)[rs] for wn, _bn, rs in cx.pk.origin[key]], 0).float().contiguous()            # (N, K)
         mp = _rup(m)
         dpre_t = torch.zeros(n, mp, dtype=torch.float32, device=cx.dev)
@@ -623,13 +633,7 @@ class TrainForward:
         ops.transpose(x[:, :k], x_t)
         dw = torch.empty(n, k, dtype=torch.float32, device=cx.dev)
         ops.gemm(F32, dpre_t, x_t, None, None, None, dw, None, None, n=k, cp=mp)                                          # dW = dpre^T x
-        db = ops.col_sum(dpre)
-        r0 = 0
-        for wn, bn, rs in cx.pk.origin[key]:
-            rows = rs.stop - rs.start
-            self._param_grad(wn, rs, dw[r0:r0 + rows])
-            self._param_grad(bn, rs, db[r0:r0 + rows])
-            r0 += rows
+        self._lin_param_grads(cx, key, dw, dpre)
         if need_dx:
             np_ = _rup(n)
             if np_ != n:
@@ -638,6 +642,22 @@ class TrainForward:
             dx = torch.empty(m, k, dtype=torch.float32, device=cx.dev)
             ops.gemm(F32, dpre, w_t, None, None, None, dx, None, None, n=k, cp=n)                                        # dX = dpre W
             tape.add(x, dx, cols=k)
+
+    def _lin_param_grads(self, cx, key, dw, dpre):
+        """Hand dW (N, K) and the bias gradient (column sums of dpre) of the packed Linear `key` to the parameters it stacks."""
+        origin = cx.pk.origin[key]
+        if len(origin) == 1:                              # the usual case: the reduction's finalize adds into the gradient rows itself
+            wn, bn, rs = origin[0]
+            self._param_grad(wn, rs, dw)
+            self._param_grad_colsum(bn, rs, dpre)
+            return
+        db = ops.col_sum(dpre)
+        r0 = 0
+        for wn, bn, rs in origin:
+            rows = rs.stop - rs.start
+            self._param_grad(wn, rs, dw[r0:r0 + rows])
+            self._param_grad(bn, rs, db[r0:r0 + rows])
+            r0 += rows
 
     def _backward_scale(self, key, w):
         """Power-of-two scale of a backward weight operand: chosen at the first use of `key` (one read-back: max |w| into [2^11, 2^12)) and
@@ -684,28 +704,32 @@ class TrainForward:
         self._wt_cache[key] = (img, ws)
         return img, ws
 
-    def _lin_backward_h2(self, cx, x, key, dpre, n, k, m, need_dx):
-        """dW = dpre^T x, db = colsum(dpre), dX = dpre W as split-fp16 MFMA contractions (emage_gemm, EMAGE_H2) on operands converted
-        by `ops.h2_cast`; the gradient operand is pre-scaled by `grad_scale` (undone by the GEMM's output scale)."""
+    def _lin_backward_h2(self, cx, x, key, dy, y, slope, n, k, m, need_dx):
+        """dW = dpre^T x, db = colsum(dpre), dX = dpre W as split-fp16 MFMA contractions (emage_gemm, EMAGE_H2).  dpre = dy through the
+        activation's backward (y: the layer's saved output, None = no activation).  ONE pass over dy (`ops.grad_prep`) yields both
+        gradient operands — pre-scaled by `grad_scale`, undone by the GEMM's output scale — and the bias gradient, which the reduction's
+        finalize launch adds straight into the parameter's gradient rows when the packed key holds one Linear."""
         gs = self.grad_scale
         mp = _rup(m)
-        dpre_t = ops.h2_cast(dpre, mp, scale=gs, transpose=True)                      # (N, mp)
+        origin = cx.pk.origin[key]
+        single = len(origin) == 1
+        bias_dst = self._grad_rows(origin[0][1], origin[0][2])[0] if single else None
+        dpre_h, dpre_t, db = ops.grad_prep(dy, y, 0.0 if slope is None else slope, gs, n_store=_rup(n) if need_dx else None, m_store=mp,
+                                           bias_grad=bias_dst, accumulate=single)                # (M, rup64(N)), (N, mp)
         x_t = ops.h2_cast(x[:, :k], mp, scale=1.0, transpose=True)                    # (K, mp)
         dw = torch.empty(n, k, dtype=torch.float32, device=cx.dev)
         ops.gemm(H2, dpre_t, x_t, None, None, None, None, dw, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
-        db = ops.col_sum(dpre)
         r0 = 0
-        for wn, bn, rs in cx.pk.origin[key]:
+        for wn, bn, rs in origin:
             rows = rs.stop - rs.start
             self._param_grad(wn, rs, dw[r0:r0 + rows])
-            self._param_grad(bn, rs, db[r0:r0 + rows])
+            if not single:
+                self._param_grad(bn, rs, db[r0:r0 + rows])
             r0 += rows
         if need_dx:
             w_t, ws = self._weight_t_h2(cx, key, n, k)
-            np_ = _rup(n)
-            dpre_h = ops.h2_cast(dpre, np_, scale=gs)                                 # (M, rup64(N))
             dx = torch.empty(m, k, dtype=torch.float32, device=cx.dev)
-            ops.gemm(H2, dpre_h, w_t, None, None, None, None, dx, None, n=k, cp=np_, w_scale=ws, a_scale=16.0 * gs)
+            ops.gemm(H2, dpre_h, w_t, None, None, None, None, dx, None, n=k, cp=_rup(n), w_scale=ws, a_scale=16.0 * gs)
             self.tape.add(x, dx, cols=k)
 
     def _params(self):
@@ -719,15 +743,56 @@ class TrainForward:
     def _param(self, name):
         return self._params()[name]
 
-    def _param_grad(self, name, rows, g):
-        full = self.param_grads.get(name)
+    @property
+    def param_grads(self):
+        """name -> fp32 gradient accumulated so far (queued contributions applied first: reading is always consistent)."""
+        self.flush_param_grads()
+        return self._pgrads
+
+    @param_grads.setter
+    def param_grads(self, value):
+        self.flush_param_grads()          # contributions queued for the previous accumulators belong to them
+        self._pgrads = value
+
+    def _grad_rows(self, name, rows):
+        """The rows `rows` of parameter `name`'s gradient accumulator (the exchange bucket's view under a `Trainer`) as the destination of
+        one more contribution: a queued contribution to overlapping rows is applied first; the tape position is stamped."""
+        full = self._pgrads.get(name)
         if full is None:
             full = self.grad_views[name] if self.grad_views is not None else torch.zeros_like(self._param(name), dtype=torch.float32)
-            self.param_grads[name] = full
-        dst = full[rows]
-        dst += g.reshape(dst.shape)                    # parameter-sized accumulation across the forwards of a step
+            self._pgrads[name] = full
+        n0 = full.shape[0] if full.dim() else 1
+        lo, hi = (0 if rows.start is None else rows.start), (n0 if rows.stop is None else rows.stop)
+        spans = self._pg_spans.get(name)
+        if spans is not None and any(lo < b and a < hi for a, b in spans):
+            self.flush_param_grads()
         if self.touch is not None:
             self.touch[name] = self.tape.pos
+        return full[rows], (lo, hi)
+
+    def _param_grad(self, name, rows, g):
+        """grad(name)[rows] += g — parameter-sized accumulation across the forwards of a step.  The contributions are QUEUED and applied
+        in batches (`flush_param_grads`: one multi-tensor add for up to 256 of them instead of one small launch each, ~1 200 per step);
+        every element still receives its contributions one by one in issue order, so the sums are the same bits."""
+        dst, span = self._grad_rows(name, rows)
+        g = g.reshape(dst.shape)
+        self._pg_spans.setdefault(name, []).append(span)
+        self._pg_dst.append(dst)
+        self._pg_src.append(g)
+        self._pg_bytes += g.numel() * 4
+        if len(self._pg_dst) >= 256 or self._pg_bytes >= (96 << 20):
+            self.flush_param_grads()
+
+    def _param_grad_colsum(self, name, rows, x, y=None):
+        """grad(name)[rows] += column sums of x (* y): the bias / affine gradients, accumulated by the reduction's own finalize launch."""
+        dst, _span = self._grad_rows(name, rows)
+        ops.col_sum(x, y, out=dst, accumulate=True)
+
+    def flush_param_grads(self):
+        """Apply the queued parameter-gradient contributions (call before anything reads or exchanges the accumulators)."""
+        if self._pg_dst:
+            torch._foreach_add_(self._pg_dst, self._pg_src)
+        self._pg_dst, self._pg_src, self._pg_spans, self._pg_bytes = [], [], {}, 0
 
     def _add(self, cx, a, bb, mod_b=0, grad_b=True):
         out = cx.lo(*a.shape)
@@ -765,9 +830,9 @@ class TrainForward:
                 g = self.tape.get(y)
                 if g is None:
                     return
-                dx, dg, db = ops.layernorm_backward(s_in, n["g"], g)
-                self._param_grad(key + ".weight", slice(None), dg)
-                self._param_grad(key + ".bias", slice(None), db)
+                dg, _ = self._grad_rows(key + ".weight", slice(None))
+                db, _ = self._grad_rows(key + ".bias", slice(None))
+                dx, _, _ = ops.layernorm_backward(s_in, n["g"], g, dgamma=dg, dbeta=db)      # d gamma / d beta += inside
                 self.tape.add(s_in, dx)
             self.tape.node(bw)
         return y
@@ -792,9 +857,11 @@ class TrainForward:
                 g = self.tape.get(att)
                 if g is None:
                     return
-                gq = self.tape.buffer(q_src[0])[:, q_src[1]:q_src[1] + d]
-                gk = self.tape.buffer(k_src[0])[:, k_src[1]:k_src[1] + d]
-                gv = self.tape.buffer(v_src[0])[:, v_src[1]:v_src[1] + d]
+                # tokens (projections whose column blocks are all attention operands) are covered block by block by the attention
+                # backwards of their layers: no zero fill; a real tensor (the cross-attention query) may have other consumers
+                gq = self.tape.buffer(q_src[0], zero=not isinstance(q_src[0], _Token))[:, q_src[1]:q_src[1] + d]
+                gk = self.tape.buffer(k_src[0], zero=not isinstance(k_src[0], _Token))[:, k_src[1]:k_src[1] + d]
+                gv = self.tape.buffer(v_src[0], zero=not isinstance(v_src[0], _Token))[:, v_src[1]:v_src[1] + d]
                 ops.attention_backward(q, k, vt, vt_rows, pm, g, gq, gk, gv, b, h, tq, tk, d // h)
             self.tape.node(bw)
         return att
@@ -861,13 +928,16 @@ class TrainForward:
         (same audio and weights as the step's other forwards): the WavEncoder pass is computed by the first of them only."""
         model = self.model
         c = model.config
-        cx = _Ctx(model._engine(h2=False))       # the training forward keeps float32 activations (split inside the GEMMs in f16x3)
+        # the training forward keeps float32 activations (split inside the GEMMs in f16x3); train_only: the operand set leaves out what
+        # only the eval-mode forward reads (the WavEncoder convolutions with their BatchNorms folded in)
+        cx = _Ctx(model._engine(h2=False, train_only=True))
         pk, dev = cx.pk, cx.dev
         self._train_pack(pk)
         self.tape = _Tape(dev) if tape else None
         self._cx = cx
         self._pcache = None
-        self._wt_cache = {}
+        if not self._wt_keep:                    # inside a `Trainer` step the weights are those of the step's first forward: keep the images
+            self._wt_cache = {}
         new_stats = {} if new_stats is None else new_stats
         masks = _Masks(dropout_masks, dev, rng)
         b, t, cm = masked_motion.shape
@@ -995,6 +1065,7 @@ class TrainForward:
             # parameters receive exact-zero gradients and an Adam state — kept that way
             tape.add(logits, ops.nll_loss_grad(logits, index_gt[q].reshape(-1).contiguous().to(logits.device), getattr(cfg, "c" + q[0])))
         tape.run(progress)
+        self.flush_param_grads()
         self.last_run_nodes = tape.pos + 1
         share = self._shared
         if share is not None and share.tape is not None:           # the feature gradients of this forward join the shared encoder pass
@@ -1012,6 +1083,7 @@ class TrainForward:
         self.tape = share.tape
         try:
             share.tape.run(progress, base=base)
+            self.flush_param_grads()
         finally:
             self.tape = None
         share.tape = None
@@ -1029,7 +1101,8 @@ class TrainForward:
             tape.run()
             return self.param_grads
         finally:
-            self.param_grads, self.tape = saved, None
+            self._pg_dst, self._pg_src, self._pg_spans, self._pg_bytes = [], [], {}, 0       # (an exception mid-walk: drop what was queued)
+            self._pgrads, self.tape = saved, None
 
 
 # ======================================================================================
@@ -1199,6 +1272,15 @@ class Trainer:
         seed_mask = torch.ones_like(masked_motion)
         seed_mask[:, :cfg.seed_frames] = 0
         fwd.param_grads = {}
+        fwd._wt_cache, fwd._wt_keep = {}, True            # the parameters move at the END of the step: one set of transposed weight images
+        try:
+            return self._device_step_body(batch, dropout_masks, random_mask, grad_hook, step_counter, index, latent, masked_motion, speaker_id, seed_mask)
+        finally:
+            fwd._wt_cache, fwd._wt_keep = {}, False
+
+    def _device_step_body(self, batch, dropout_masks, random_mask, grad_hook, step_counter, index, latent, masked_motion, speaker_id, seed_mask):
+        fwd, model = self.fwd, self.fwd.model
+        cfg = model.config
         stats, out = {}, {}
         ws = ops.loss_workspace(masked_motion.device)
         world = self._world()
@@ -1224,6 +1306,7 @@ class Trainer:
 
                     def progress(pos, ready=ready):
                         for i in ready.get(pos, ()):         # every gradient of bucket i is final: its all-reduce overlaps the rest of the backward
+                            fwd.flush_param_grads()          # ... once its queued contributions have been applied
                             log.append(("reduce", i, pos))
                             buckets.reduce(i)
             fwd.backward(index, latent, progress)
@@ -1266,9 +1349,14 @@ class Trainer:
         ops.adam_multi(self._adam, self.steps_done if step_counter is None else step_counter, self.lr, self.betas[0], self.betas[1], self.eps,
                        self.weight_decay, grad_scale=1.0 / world, zero_grad=True, skip=self.health)
         skipped = self.health[0] > 0                      # device scalar: the buffers below keep their values in a skipped step
+        by_dtype = {}
         for name, v in stats.items():                     # BatchNorm running statistics after the three forwards
             if name in params:
-                params[name].copy_(torch.where(skipped, params[name], v.to(params[name].dtype)))
+                by_dtype.setdefault(params[name].dtype, []).append((params[name], v.to(device=params[name].device, dtype=params[name].dtype)))
+        for pairs in by_dtype.values():                   # per dtype: gather, ONE select on the skip word, ONE multi-tensor copy back (96 buffers)
+            olds, news = [p for p, _v in pairs], [v for _p, v in pairs]
+            sel = torch.where(skipped, torch.cat([p.reshape(-1) for p in olds]), torch.cat([v.reshape(-1) for v in news]))
+            torch._foreach_copy_(olds, [c.view(p.shape) for c, p in zip(sel.split([p.numel() for p in olds]), olds)])
         if step_counter is not None:                      # a skipped step does not count (Adam's bias correction, the mask generator's step)
             step_counter.sub_(skipped.to(step_counter.dtype))
         return out, ws

@@ -192,14 +192,32 @@ def act_backward(dy, y, slope, out=None):
     return r
 
 
-def layernorm_backward(x, gamma, dy, eps=1e-5):
+def grad_prep(dy, y=None, slope=0.0, scale=1.0, n_store=None, m_store=None, bias_grad=None, accumulate=False, want_bias=True):
+    CALLS.append("grad_prep")
+    dpre = dy if y is None else dy * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+    out_h = h2_cast(dpre, n_store, scale) if n_store is not None else None
+    out_t = h2_cast(dpre, m_store, scale, transpose=True) if m_store is not None else None
+    if not want_bias:
+        return out_h, out_t, None
+    s = dpre.double().sum(0).float()
+    if bias_grad is None:
+        return out_h, out_t, s
+    bias_grad.copy_(bias_grad + s if accumulate else s)
+    return out_h, out_t, bias_grad
+
+
+def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None):
     CALLS.append("layernorm_backward")
     mu = x.mean(1, keepdim=True)
     rstd = 1.0 / torch.sqrt(((x - mu) ** 2).mean(1, keepdim=True) + eps)
     xh = (x - mu) * rstd
     g = dy * gamma
     dx = rstd * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
-    return dx, (dy * xh).sum(0), dy.sum(0)
+    if dgamma is None:
+        return dx, (dy * xh).sum(0), dy.sum(0)
+    dgamma += (dy * xh).sum(0)
+    dbeta += dy.sum(0)
+    return dx, dgamma, dbeta
 
 
 def attention_backward(q, k, vt, vt_rows, pmask, d_out, dq, dk, dv, b, h, tq, tk, hd):
@@ -671,7 +689,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["im2col_t_h2", "h2_cast", "adam_multi", "dropout_mask", "count_nonfinite", "loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["im2col_t_h2", "grad_prep", "h2_cast", "adam_multi", "dropout_mask", "count_nonfinite", "loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

@@ -679,3 +679,68 @@ def test_gemm_grouped_is_bit_identical_to_single_launches():
     operands, kw, outputs = probs[0]
     with pytest.raises(EmageKernelError):
         ops.gemm_grouped(H2, [dict(a=operands[0], w=operands[1], out=outputs()[0], **{**kw, "cp": kw["cp"] + 8})] * 2)
+
+
+def test_weight_packing_on_the_device_equals_the_tensor_arithmetic():
+    """`ops.split_f16_weights` / `split_f16_weights_h2` on device tensors run as ONE launch per operand (`emage_f16x3_pack_weights`, the
+    activation-cast kernel) — a training step re-packs every weight behind each Adam update.  The images must be the bits the host-side
+    tensor arithmetic produces (what the CPU tests and every earlier golden were built on): random weights, a given and a derived scale,
+    strided rows, zeros, values that overflow the fp16 hi plane (inf, and inf - inf = NaN in the lo plane) and NaN."""
+    def same_planes(got, want):                  # fp16 planes bit for bit; a NaN is a NaN (payload / sign differ between CPU and device)
+        a, b = got.cpu().view(torch.float16), want.view(torch.float16)
+        na, nb = torch.isnan(a), torch.isnan(b)
+        return torch.equal(na, nb) and torch.equal(torch.where(na, torch.zeros_like(a), a).view(torch.int16), torch.where(nb, torch.zeros_like(b), b).view(torch.int16))
+
+    g = _g(5)
+    for n, k in ((1, 32), (40, 192), (768, 768), (256, 1536), (67, 64)):
+        w = torch.randn(n, k, generator=g) / math.sqrt(k)
+        w[0, 0], w[-1, -1] = 0.0, 1e-30
+        if n > 2:
+            w[1, 3], w[2, 5], w[2, 6] = 1e9, float("nan"), -float("inf")
+        for scale in (None, 2.0 ** 14):
+            for fn in (ops.split_f16_weights, ops.split_f16_weights_h2):
+                if scale is None and n > 2:                        # the derived scale needs a finite maximum
+                    wc = torch.nan_to_num(w, nan=0.0, posinf=1.0, neginf=-1.0).clamp(-4.0, 4.0)
+                else:
+                    wc = w
+                want, s_cpu = fn(wc, scale)
+                got, s_dev = fn(wc.to(DEV), scale)
+                assert s_cpu == s_dev and got.shape == want.shape and got.dtype == torch.float32
+                assert same_planes(got, want), (fn.__name__, n, k, scale)
+        base = torch.randn(n, k + 64, generator=g)
+        view = base.to(DEV)[:, 32:32 + k]                              # rows strided and offset by 128 bytes
+        for fn in (ops.split_f16_weights, ops.split_f16_weights_h2):
+            want, _ = fn(base[:, 32:32 + k].contiguous(), 2.0 ** 10)
+            got, _ = fn(view, 2.0 ** 10)
+            assert same_planes(got, want), (fn.__name__, "strided", n, k)
+
+
+def test_grad_prep_equals_the_separate_launches():
+    """`emage_grad_prep` (one pass over a Linear's output gradient: activation backward, both EMAGE_H2 gradient operands, the bias
+    gradient) against the launches it replaces — `act_backward`, `h2_cast`, `h2_cast(transpose=True)`, `col_sum`: the two images bit for
+    bit (zero tails included), the column sums to float64-summation-order accuracy, with and without an activation, ragged sizes,
+    strided views, accumulation into an existing gradient, and each output on its own."""
+    g = _g(11)
+    for m, c, slope in ((3584, 768, None), (130, 256, 0.1), (70, 337, 0.0), (64, 64, None), (1, 8, 0.2), (200, 1536, 0.0)):
+        base = torch.randn(m, c + 24, generator=g).to(DEV)
+        dy = base[:, 8:8 + c]                                            # strided rows
+        y = torch.randn(m, c, generator=g).to(DEV)
+        y[0, 0] = 0.0                                                    # y == 0 takes the slope, as in act_backward
+        n_store, m_store, scale = ops.round_up(c, 64), ops.round_up(m, 64), 1024.0
+        dpre = dy if slope is None else ops.act_backward(dy.contiguous(), y, slope)
+        want_h = ops.h2_cast(dpre, n_store, scale=scale)
+        want_t = ops.h2_cast(dpre, m_store, scale=scale, transpose=True)
+        want_b = ops.col_sum(dpre.contiguous())
+        got_h, got_t, got_b = ops.grad_prep(dy, None if slope is None else y, 0.0 if slope is None else slope, scale, n_store=n_store, m_store=m_store)
+        torch.cuda.synchronize()
+        assert torch.equal(got_h.view(torch.int32), want_h.view(torch.int32)), (m, c, "row-major image")
+        assert torch.equal(got_t.view(torch.int32), want_t.view(torch.int32)), (m, c, "transposed image")
+        tol = 1e-6 * float(dpre.abs().sum(0).max()) + 1e-30
+        assert float((got_b - want_b).abs().max()) <= tol, (m, c, "bias gradient")
+        acc = torch.full((c,), 3.0, device=DEV)
+        only_t = ops.grad_prep(dy, None if slope is None else y, 0.0 if slope is None else slope, scale, m_store=m_store, bias_grad=acc, accumulate=True)
+        assert only_t[0] is None and torch.equal(only_t[1].view(torch.int32), want_t.view(torch.int32))
+        assert float((acc - 3.0 - want_b).abs().max()) <= tol + 1e-6
+        only_h = ops.grad_prep(dy, None, 0.0, scale, n_store=n_store, want_bias=False)
+        assert only_h[1] is None and only_h[2] is None
+        assert torch.equal(only_h[0].view(torch.int32), ops.h2_cast(dy, n_store, scale=scale).view(torch.int32))
