@@ -490,6 +490,12 @@ int emage_adam_multi(const long long* table, const int* block_tensor, const int*
  * library's own (csrc/train.hip), not torch's. */
 int emage_dropout_mask(float* out, long n, float p, unsigned long long seed, unsigned mask_id, const int* step_dev, int step, void* stream);
 
+/* emage_mul_add with the mask of emage_dropout_mask(seed, mask_id, step) drawn inside the kernel instead of read from memory: out = a * keep (+ b),
+ * keep = element (mask row, c) of that (M, C) mask (mask_t_rows as in emage_mul_add), C % 4 == 0.  The same bits as the two calls; the forward
+ * and the backward of a dropout site (F.dropout inside nn.Transformer*Layer, train_emage_audio.py:156-172) draw the mask from the key each. */
+int emage_mul_add_philox(const float* a, int lda, float p, unsigned long long seed, unsigned mask_id, const int* step_dev, int step, int mask_t_rows,
+                         const float* b, int ldb, float* out, int ldo, int M, int C, void* stream);
+
 /* emage_adam_step with the 1-based step count read from device memory (`step`: one int32), for a step captured in a hipGraph. */
 int emage_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, const int* step,
                         float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);

@@ -65,6 +65,7 @@ SIGNATURES = {
     "emage_adam_multi": [_p, _p, _p, _i, _p, _i, _f, _f, _f, _f, _f, _f, _i, _p, _p],
     "emage_dropout_mask": [_p, _l, _f, C.c_ulonglong, C.c_uint, _p, _i, _p],
     "emage_mul_add": [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p],
+    "emage_mul_add_philox": [_p, _i, _f, C.c_ulonglong, C.c_uint, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p],
     "emage_layernorm": [_i, _p, _i, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p],
     "emage_add": [_i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _i, _i, _p],
     "emage_pack_motion": [_i, _p, _p, _l, _p, _p, _l, _i, _p, _i, _i, _i, _i, _i, _p],

@@ -1011,6 +1011,32 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
+// out = a * keep (+ b) with the keep mask DRAWN IN PLACE: element (mask row mr, column c) is element mr * C + c of the mask
+// dropout_mask_kernel would have written for the same key — the same bits as emage_dropout_mask + emage_mul_add, without the mask in
+// memory (a training forward holds ~0.9 GB of (T, B, d) masks for its backward otherwise; the backward draws them again from the key).
+__global__ __launch_bounds__(256) void mul_add_philox_kernel(const float* __restrict__ a, int lda, float p, float keep_value, unsigned seed_lo, unsigned seed_hi,
+                                                             unsigned mask_id, const int* __restrict__ step_dev, int step, int t_rows,
+                                                             const float* __restrict__ b, int ldb, float* __restrict__ out, int ldo, int M, int C) {
+    const unsigned st = step_dev ? (unsigned)*step_dev : (unsigned)step;
+    const int c4 = C >> 2;
+    const long total = (long)M * c4;
+    const int nb = t_rows > 0 ? M / t_rows : 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / c4;
+        const int cq = (int)(i - m * c4);
+        const long mr = t_rows > 0 ? (m % t_rows) * nb + m / t_rows : m;          // row (b, t) of the stream <-> row (t, b) of the mask
+        const long blk = mr * c4 + cq;                                             // (mr * C + 4 cq) / 4
+        unsigned c[4] = {(unsigned)blk, (unsigned)(blk >> 32), mask_id, st};
+        philox4x32_10(c, seed_lo, seed_hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float k = ((float)(c[e] >> 8) * (1.0f / 16777216.0f) >= p) ? keep_value : 0.f;
+            float v = a[m * lda + 4 * cq + e] * k;
+            if (b) v += b[m * ldb + 4 * cq + e];
+            out[m * ldo + 4 * cq + e] = v;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, float p, float keep_value,
                                                            unsigned seed_lo, unsigned seed_hi, unsigned mask_id, const int* __restrict__ step_dev, int step) {
     const unsigned st = step_dev ? (unsigned)*step_dev : (unsigned)step;
@@ -1031,6 +1057,14 @@ extern "C" int emage_dropout_mask(float* out, long n, float p, unsigned long lon
     if (!out || n <= 0 || !(p >= 0.f && p < 1.f)) return EMAGE_EINVAL;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n, p, 1.0f / (1.0f - p),
                        (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), mask_id, step_dev, step);
+    return launch_status();
+}
+
+extern "C" int emage_mul_add_philox(const float* a, int lda, float p, unsigned long long seed, unsigned mask_id, const int* step_dev, int step, int mask_t_rows,
+                                    const float* b, int ldb, float* out, int ldo, int M, int C, void* stream) {
+    if (!a || !out || M <= 0 || C <= 0 || C % 4 || lda < C || ldo < C || (b && ldb < C) || !(p >= 0.f && p < 1.f) || (mask_t_rows > 0 && M % mask_t_rows)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(mul_add_philox_kernel, dim3(grid_for((long)M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, lda, p, 1.0f / (1.0f - p),
+                       (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), mask_id, step_dev, step, mask_t_rows, b, ldb, out, ldo, M, C);
     return launch_status();
 }
 

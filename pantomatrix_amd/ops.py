@@ -574,10 +574,50 @@ def _mul_add(a, mask, mask_t_rows, b, out):
                                     m, c, _stream()), "mul_add")
 
 
+class PhiloxMask:
+    """A dropout keep mask that exists as its KEY only: the tensor `dropout_mask(empty(shape), p, seed, mask_id, step)` would hold.
+    `mul_add` draws it inside its kernel (forward and backward alike), so the mask never occupies memory; `materialize()` for consumers
+    that need the tensor.  `view(m, c)` re-shapes like a contiguous tensor (the element order is the key's)."""
+
+    def __init__(self, shape, p, seed, mask_id, step, device):
+        self.shape, self.p, self.seed, self.mask_id, self.step, self.device = tuple(shape), float(p), int(seed), int(mask_id), step, device
+
+    def view(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        m = 1
+        for d in self.shape:
+            m *= d
+        assert n == m, (shape, self.shape)
+        return PhiloxMask(shape, self.p, self.seed, self.mask_id, self.step, self.device)
+
+    def materialize(self):
+        return dropout_mask(torch.empty(self.shape, dtype=torch.float32, device=self.device), self.p, self.seed, self.mask_id, self.step)
+
+
+@_op("mul_add_philox", "(Tensor a, float p, int seed, int mask_id, Tensor? step_dev, int step, int mask_t_rows, Tensor? b, Tensor(a!) out) -> ()")
+def _mul_add_philox(a, p, seed, mask_id, step_dev, step, mask_t_rows, b, out):
+    m, c = a.shape
+    check(_lib.load().emage_mul_add_philox(_ptr(a), _ld(a), p, seed & 0xFFFFFFFFFFFFFFFF, mask_id & 0xFFFFFFFF, _ptr(step_dev), step, mask_t_rows,
+                                           _ptr(b), _ld(b) if b is not None else 0, _ptr(out), _ld(out), m, c, _stream()), "mul_add_philox")
+
+
 def mul_add(a, mask, b=None, out=None, *, mask_t_rows=0):
     """out = a * mask (+ b) on fp32 (M, C) views: dropout with a given mask, and the residual add behind it.  mask_t_rows = T:
-    the mask rows are stored (T, B) while a / b / out run (B, T)."""
+    the mask rows are stored (T, B) while a / b / out run (B, T).  mask may be a `PhiloxMask` (C % 4 == 0): drawn inside the kernel."""
     _dev(a)
+    if isinstance(mask, PhiloxMask):
+        assert mask.shape == tuple(a.shape) and a.shape[1] % 4 == 0
+        out = torch.empty_like(a) if out is None else out
+        seed = mask.seed & 0xFFFFFFFFFFFFFFFF
+        if seed >= 1 << 63:           # the op schema's `int` is a signed 64-bit word: the same 64 bits in two's complement
+            seed -= 1 << 64
+        if torch.is_tensor(mask.step):
+            _mul_add_philox(a, mask.p, seed, mask.mask_id, mask.step, 0, int(mask_t_rows), b, out)
+        else:
+            _mul_add_philox(a, mask.p, seed, mask.mask_id, None, int(mask.step), int(mask_t_rows), b, out)
+        return out
     assert mask.dtype == torch.float32 and mask.dim() == 2 and mask.shape == a.shape and mask.stride(1) == 1
     out = torch.empty_like(a) if out is None else out
     _mul_add(a, mask, int(mask_t_rows), b, out)

@@ -45,17 +45,22 @@ class _Masks:
     """The dropout masks of one forward: a given list (the parity tests: the reference's recorded draws), or — masks None — drawn on
     the device as they are needed (`ops.dropout_mask`: Philox keyed by rng = (seed, step, first mask id); step may be a device scalar)."""
 
-    def __init__(self, masks, dev, rng=None):
-        self.masks, self.i, self.dev, self.rng = (None if masks is None else list(masks)), 0, dev, rng
+    def __init__(self, masks, dev, rng=None, lazy=True):
+        self.masks, self.i, self.dev, self.rng, self.lazy = (None if masks is None else list(masks)), 0, dev, rng, lazy
         if masks is None and rng is None:
             raise RuntimeError("train-mode forward: pass dropout_masks or an rng (seed, step, first mask id)")
 
     def consumed_all(self):
         return self.masks is None or self.i == len(self.masks)
 
-    def take(self, shape):
+    def take(self, shape, lazy=False):
+        """The next mask of the forward, of logical shape `shape`.  lazy (device-drawn masks only): the caller consumes it through
+        `ops.mul_add` alone, which draws the mask inside its kernel — return the key (`ops.PhiloxMask`) instead of a tensor."""
         if self.masks is None:
             seed, step, base = self.rng
+            if lazy and self.lazy and shape[-1] % 4 == 0:
+                self.i += 1
+                return ops.PhiloxMask(shape, DROPOUT_P, seed, base + self.i - 1, step, self.dev)
             m = torch.empty(tuple(shape), dtype=torch.float32, device=self.dev)
             ops.dropout_mask(m, DROPOUT_P, seed, base + self.i, step)
             self.i += 1
@@ -222,6 +227,7 @@ class TrainForward:
         self.grad_scale = 1024.0
         self.conv_backward_rows = 1 << 17                 # output rows per piece of a long convolution's backward (_conv_backward_h2)
         self._w_scale, self._wt_cache = {}, {}
+        self.lazy_masks = True          # device-drawn (T, B, d) dropout masks live as Philox keys: drawn inside `mul_add`, forward and backward (-0.9 GB per forward)
         self._wt_keep = False           # True inside `Trainer._device_step`: the transposed weight images (`_weight_t_h2`) serve all three forwards
         self.range_flag = None          # int32 device counter: transposed-weight operands (backward dX) whose cached scale no longer fits
         self._range_pending, self._range_seen = [], set()
@@ -698,7 +704,8 @@ class TrainForward:
         hit = self._wt_cache.get(key)
         if hit is not None:
             return hit
-        w32 = torch.cat([self._param(wn)[rs] for wn, _bn, rs in cx.pk.origin[key]], 0).float().contiguous()            # (N, K)
+        rows = [self._param(wn)[rs] for wn, _bn, rs in cx.pk.origin[key]]
+        w32 = (torch.cat(rows, 0) if len(rows) > 1 else rows[0]).float().contiguous()                                    # (N, K); one source: no copy
         ws = self._backward_scale(key, w32)
         img = ops.h2_cast(w32, _rup(n), scale=ws / 16.0, transpose=True)              # h2 images carry a fixed x16: the rest of the scale goes in front
         self._wt_cache[key] = (img, ws)
@@ -840,7 +847,7 @@ class TrainForward:
     def _drop_add(self, cx, o, masks, t, res=None):
         """res + dropout(o) with the mask the reference draws on the (T, B, C) tensor."""
         m, c = o.shape
-        mk = masks.take((t, m // t, c)).view(m, c)
+        mk = masks.take((t, m // t, c), lazy=True).view(m, c)
         return self._mul_add(o, mk, res, t_rows=t)
 
     def _mha(self, cx, masks, q_src, k_src, v_src, k_rows, vt, vt_rows, b, tq, tk):
@@ -904,7 +911,7 @@ class TrainForward:
         """PeriodicPositionalEncoding.forward (P:341-343): dropout(x + pe[:, :T]) on (B*T, d) rows."""
         m, d = x.shape
         y = self._add(cx, x, cx.pk.w["pe"][:t], mod_b=t)
-        return self._mul_add(y, masks.take((b, t, d)).view(m, d))
+        return self._mul_add(y, masks.take((b, t, d), lazy=True).view(m, d))
 
     def _speaker(self, cx, key, name, sid):
         rows = ops.gather_rows(cx.pk.w[key], sid, F32)
@@ -939,7 +946,7 @@ class TrainForward:
         if not self._wt_keep:                    # inside a `Trainer` step the weights are those of the step's first forward: keep the images
             self._wt_cache = {}
         new_stats = {} if new_stats is None else new_stats
-        masks = _Masks(dropout_masks, dev, rng)
+        masks = _Masks(dropout_masks, dev, rng, lazy=self.lazy_masks)
         b, t, cm = masked_motion.shape
         m = b * t
         d, mf, af = c.hidden_size, c.motion_f, c.audio_f

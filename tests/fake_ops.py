@@ -408,6 +408,13 @@ def bn_apply(x, stats, gamma, beta, out, *, slope=1.0, sc=None, sc_bn=None, eps=
 def mul_add(a, mask, b=None, out=None, *, mask_t_rows=0):
     CALLS.append("mul_add")
     m, c = a.shape
+    if isinstance(mask, ops.PhiloxMask):                  # drawn inside the kernel on the device: the same mask as `dropout_mask` with its key
+        mark, key = len(CALLS), mask
+        mask = dropout_mask(torch.empty(mask.shape), mask.p, mask.seed, mask.mask_id, mask.step)
+        del CALLS[mark:]
+        if not getattr(key, "_logged", False):            # one "dropout_mask" per mask SITE (forward and backward share the key object)
+            key._logged = True
+            CALLS.append("dropout_mask")
     mk = mask
     if mask_t_rows:
         mk = mask.view(mask_t_rows, m // mask_t_rows, c).transpose(0, 1).reshape(m, c)

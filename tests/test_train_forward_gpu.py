@@ -413,6 +413,35 @@ def test_device_drawn_masks_step_and_capture():
     fresh, _ = common.product_models(precision="fp32", device=DEV)
     l_same = training.Trainer(fresh, vq, seed=11).step(batch, random_mask=random_mask)
     assert l_same == l_first and l_same != l_other          # a fresh trainer with seed 11 repeats the first eager step exactly
+    # the (T, B, d) masks as Philox KEYS drawn inside `mul_add` (the default) against masks written to memory first: the same bits
+    stored, _ = common.product_models(precision="fp32", device=DEV)
+    tr = training.Trainer(stored, vq, seed=11)
+    tr.fwd.lazy_masks = False
+    assert tr.step(batch, random_mask=random_mask) == l_first
+    ps = stored._flat_params()
+    one, _ = common.product_models(precision="fp32", device=DEV)
+    training.Trainer(one, vq, seed=11).step(batch, random_mask=random_mask)
+    assert all(torch.equal(v, ps[k]) for k, v in one._flat_params().items())
+
+
+def test_mul_add_with_the_mask_drawn_inside_the_kernel():
+    """`emage_mul_add_philox` (dropout with the keep mask drawn from its Philox key inside the kernel) equals `emage_dropout_mask` +
+    `emage_mul_add` bit for bit: both row orders ((B, T) rows against a (T, B, d) mask), with and without the residual, strided
+    operands, the step as a host integer and read from device memory."""
+    from pantomatrix_amd import ops
+    g = torch.Generator().manual_seed(17)
+    for m, c, t_rows, seed, mid, step in ((128, 768, 64, 5, 3, 1), (3584, 1536, 64, 1234567890123456789, 200, 77), (6, 8, 0, 2 ** 64 - 3, 0, 0), (130, 256, 0, 9, 41, 3)):
+        a = torch.randn(m, c + 8, generator=g).to(DEV)[:, 4:4 + c]
+        b = torch.randn(m, c, generator=g).to(DEV)
+        shape = (t_rows, m // t_rows, c) if t_rows else (m, c)
+        mask = ops.dropout_mask(torch.empty(shape, device=DEV), 0.1, seed, mid, step).view(m, c)
+        for res in (None, b):
+            want = ops.mul_add(a, mask, res, mask_t_rows=t_rows)
+            key = ops.PhiloxMask(shape, 0.1, seed, mid, step, DEV).view(m, c)
+            assert torch.equal(ops.mul_add(a, key, res, mask_t_rows=t_rows), want), (m, c, t_rows, res is None)
+            key_dev = ops.PhiloxMask(shape, 0.1, seed, mid, torch.tensor([step], dtype=torch.int32, device=DEV), DEV).view(m, c)
+            assert torch.equal(ops.mul_add(a, key_dev, res, mask_t_rows=t_rows), want)
+        assert torch.equal(ops.PhiloxMask(shape, 0.1, seed, mid, step, DEV).materialize().view(m, c), mask)
 
 
 def test_sync_batchnorm_on_one_device_equals_plain_batchnorm(golden_dir):
