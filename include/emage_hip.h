@@ -118,7 +118,9 @@ int emage_gather_rows(const float* table, const int64_t* idx, int idx_rows, long
  *        split and the accumulators by 1/(a_scale*w_scale) after the K-loop — both scales are powers of two chosen so
  *        that the fp16 planes stay in the normal range (|A*a_scale| must stay below 65504).  Other dtypes ignore them.
  * EMAGE_H2:  A / out / (res_is_f32 = 0) res are pre-split images (csrc/h2.h: per 8 columns 32 bytes [8 fp16 hi | 8 fp16 lo] of 16 x),
- *        out_f32 / out_t float32; W is the same image of W * w_scale, rows K-contiguous.
+ *        out_f32 / out_t float32; W is the same image of W * w_scale, rows K-contiguous.  res == out_f32 (fp32, ldr == ldf) accumulates:
+ *        out_f32 += contraction (a weight gradient added straight into the parameter's gradient, loss.backward()'s accumulation T:174).
+ *        A bare contraction (no bias / slope / out / out_t) with few tiles and K >= 2048 is cut into K-slices added with fp32 atomics.
  */
 int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
                const void* res, int ldr, int res_is_f32, int res_first,

@@ -35,6 +35,11 @@ __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) vo
     gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE>(p, tile_m * BM, tile_n * BN, smem, split);
 }
 
+constexpr long H2_SPLIT_K_TILES = 384;
+static inline bool h2_accumulates_in_place(const GemmArgs& a) {
+    return a.res && a.res_is_f32 && a.out_f32 && (const void*)a.res == (const void*)a.out_f32 && a.ldr == a.ldf;
+}
+
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false, bool TRACE = false>
 int launch_h2(GemmArgs& a, hipStream_t s) {
     if (a.out_t && a.t_col0 % BN != 0) return EMAGE_EINVAL;      // a tile is either row-major or transposed
@@ -43,11 +48,15 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
     a.tiles_n = (ncols + BN - 1) / BN;
     a.trace = TRACE ? g_h2_trace : nullptr;
     // split-K: a bare contraction (only out_f32, no bias / activation / residual — the weight gradients of a training step: few output
-    // tiles, a very long K) with too few tiles to fill the chip is cut into K-slices whose partial tiles are atomically added in memory
+    // tiles, a very long K) with too few tiles to fill the chip is cut into K-slices whose partial tiles are atomically added in memory.
+    // H2_SPLIT_K_TILES: up to 384 tiles (the 768 x 1536 FFN weight gradients are 288 tiles of 64 x 64 on 768 block slots: two slices)
     a.ksplit = 1;
     const long tiles = (long)a.tiles_m * a.tiles_n;
     const int nk_all = a.K / 32;
-    if (a.taps == 1 && !a.out && !a.out_t && !a.res && !a.bias && !a.slope && a.out_f32 && tiles < 192 && nk_all >= 64) {
+    // res == out_f32 (fp32, same pitch): "out_f32 += contraction" — a weight gradient accumulated straight into the parameter's gradient.
+    // One slice: the epilogue's residual add does it in place.  Split-K: the atomics land on the existing contents (no clearing, no residual)
+    const bool accumulate = h2_accumulates_in_place(a);
+    if (a.taps == 1 && !a.out && !a.out_t && (!a.res || accumulate) && !a.bias && !a.slope && a.out_f32 && tiles <= H2_SPLIT_K_TILES && nk_all >= 64) {
         int want = (int)((512 + tiles - 1) / tiles);
         const int most = nk_all / 16;                  // >= 16 K-tiles (512 k) per slice
         if (want > most) want = most;
@@ -57,8 +66,12 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
             per = (per + 1) & ~1;                      // the register-pipelined loops take K-tiles in pairs
             a.nk_split = per;
             a.ksplit = (nk_all + per - 1) / per;
-            const hipError_t e = hipMemset2DAsync(a.out_f32, (size_t)a.ldf * sizeof(float), 0, (size_t)a.N * sizeof(float), (size_t)a.M, s);
-            if (e != hipSuccess) return (int)e;
+            if (accumulate) {
+                a.res = nullptr;
+            } else {
+                const hipError_t e = hipMemset2DAsync(a.out_f32, (size_t)a.ldf * sizeof(float), 0, (size_t)a.N * sizeof(float), (size_t)a.M, s);
+                if (e != hipSuccess) return (int)e;
+            }
         }
     }
     hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
@@ -108,7 +121,7 @@ void h2_tiles(GemmArgs& a) {
 template <int BM, int BN>
 bool h2_wants_split_k(const GemmArgs& a) {
     const long tiles = (long)((a.M + BM - 1) / BM) * (((a.n_store > a.N ? a.n_store : a.N) + BN - 1) / BN);
-    return a.taps == 1 && !a.out && !a.out_t && !a.res && !a.bias && !a.slope && a.out_f32 && tiles < 192 && a.K / 32 >= 64;
+    return a.taps == 1 && !a.out && !a.out_t && (!a.res || h2_accumulates_in_place(a)) && !a.bias && !a.slope && a.out_f32 && tiles <= H2_SPLIT_K_TILES && a.K / 32 >= 64;
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false>

@@ -112,13 +112,14 @@ class GradientBuckets:
         self.group, self.exchange_dtype = group, exchange_dtype
         self.tags = [tag for tag, _ in plan]
         self.flat, self.grads, self._work, self._msg = [], {}, [], {}
-        for _tag, params in plan:
-            n = sum(p.numel() for _, p in params)
+        pad = lambda k: (k + 7) // 8 * 8                  # every view starts on a 32-byte boundary: the backward contractions accumulate into
+        for _tag, params in plan:                         # them with 16-byte accesses (the few padding words stay zero and travel along)
+            n = sum(pad(p.numel()) for _, p in params)
             buf = torch.zeros(n, dtype=torch.float32, device=device)
             off = 0
             for name, p in params:
                 self.grads[name] = buf[off:off + p.numel()].view(p.shape)
-                off += p.numel()
+                off += pad(p.numel())
             self.flat.append(buf)
 
     def nbytes(self):

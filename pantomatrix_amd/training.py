@@ -724,15 +724,24 @@ class TrainForward:
         dpre_h, dpre_t, db = ops.grad_prep(dy, y, 0.0 if slope is None else slope, gs, n_store=_rup(n) if need_dx else None, m_store=mp,
                                            bias_grad=bias_dst, accumulate=single)                # (M, rup64(N)), (N, mp)
         x_t = ops.h2_cast(x[:, :k], mp, scale=1.0, transpose=True)                    # (K, mp)
-        dw = torch.empty(n, k, dtype=torch.float32, device=cx.dev)
-        ops.gemm(H2, dpre_t, x_t, None, None, None, None, dw, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
-        r0 = 0
-        for wn, bn, rs in origin:
-            rows = rs.stop - rs.start
-            self._param_grad(wn, rs, dw[r0:r0 + rows])
-            if not single:
+        wdst = self._grad_rows(origin[0][0], origin[0][2])[0] if single else None
+        if wdst is not None and wdst.dim() == 2 and wdst.stride(1) == 1 and wdst.stride(0) % 4 == 0 and wdst.data_ptr() % 16 == 0:
+            # dW added by the contraction itself (res == out_f32: the epilogue's residual add in place, or split-K atomics onto the contents)
+            ops.gemm(H2, dpre_t, x_t, None, None, wdst, None, wdst, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
+        else:
+            dw = torch.empty(n, k, dtype=torch.float32, device=cx.dev)
+            ops.gemm(H2, dpre_t, x_t, None, None, None, None, dw, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
+            r0 = 0
+            for wn, bn, rs in origin:
+                rows = rs.stop - rs.start
+                self._param_grad(wn, rs, dw[r0:r0 + rows])
+                r0 += rows
+        if not single:
+            r0 = 0
+            for wn, bn, rs in origin:
+                rows = rs.stop - rs.start
                 self._param_grad(bn, rs, db[r0:r0 + rows])
-            r0 += rows
+                r0 += rows
         if need_dx:
             w_t, ws = self._weight_t_h2(cx, key, n, k)
             dx = torch.empty(m, k, dtype=torch.float32, device=cx.dev)
