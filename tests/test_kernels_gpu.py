@@ -590,7 +590,8 @@ def test_attention_lds_staged_kv_is_bit_identical_to_the_register_path(b, tq, tk
 
 
 # ---- emage_gemm_grouped: independent problems of one tile configuration in one launch (csrc/gemm_h2.hip: gemm_h2_group_kernel) -----------
-GROUP_CASES = H2_GEMM_CASES + [
+# (split-K contractions add their slices with fp32 atomics: launched one by one, not bit-reproducible — not part of the bit-identity list)
+GROUP_CASES = [c for c in H2_GEMM_CASES if not c[0].startswith("h2_splitk")] + [
     ("g_out_proj", (64, 64, 64), 768, 768, 1, 1, 0, dict(bias=True, res="f32", want="both")),
     ("g_out_proj_h2res", (64, 64, 64), 768, 768, 1, 1, 0, dict(bias=True, res="h2", want="f32")),
     ("g_ffn1", (64, 64, 64), 768, 1536, 1, 1, 0, dict(bias=True, slope=0.0)),

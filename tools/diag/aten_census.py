@@ -1,7 +1,7 @@
 """Which ATen launches does a training step issue OUTSIDE the emage kernels, and from where?  Runs `Trainer.step` on the CPU stand-ins
 (tests/fake_ops.py) under a TorchDispatchMode and attributes every non-view ATen call to the innermost pantomatrix_amd frame (calls made
 inside a stand-in are the kernel itself and are skipped).  No GPU needed: the host logic is the same as on the device.
-usage: python tools/diag/aten_census.py [f16x3|fp32] [top]"""
+usage: python tools/diag/aten_census.py [f16x3|fp32] [top] [cuda]"""
 import collections
 import os
 import sys
@@ -53,6 +53,7 @@ class Census(TorchDispatchMode):
 def main():
     precision = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    on_gpu = len(sys.argv) > 3 and sys.argv[3] == "cuda"          # the real operators on the device: also sees what the op wrappers allocate / fill
     import common
     import fake_ops
     import train_common as tc
@@ -60,9 +61,14 @@ def main():
     from pantomatrix_amd import training
     g = np.load(os.path.join(ROOT, "tests", "golden", "train_step_b2.npz"))
     batch, _, masks, random_mask, _ = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
-    model, vq = common.product_models(precision=precision)
+    import contextlib
+    if on_gpu:
+        dev = torch.device("cuda", 0)
+        batch = {k: v.to(dev) for k, v in batch.items()}
+        masks, random_mask = None, random_mask.to(dev)
+    model, vq = common.product_models(precision=precision, **({"device": torch.device("cuda", 0)} if on_gpu else {}))
     trainer = training.Trainer(model, vq)
-    with fake_ops.installed(), torch.no_grad():
+    with (contextlib.nullcontext() if on_gpu else fake_ops.installed()), torch.no_grad():
         trainer.step(batch, 0, masks, random_mask)          # first step: lazy initialisation, schedule learning
         c = Census()
         with c:
