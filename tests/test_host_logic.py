@@ -262,11 +262,11 @@ def test_operand_scales_are_rederived_when_a_weight_leaves_their_range():
         model.face_cls.fc2.weight.mul_(1.5)
         out1 = model.forward(audio, spk, motion, mask)
         assert model._packed.range_flag is not None and int(model._packed.range_flag) == 0       # re-packed with the cached scales, all in range
-        scales1 = dict(model.__dict__["_scale_caches"][(str(model.device), model._packed.dt)])
+        scales1 = dict(model.__dict__["_scale_caches"][(str(model.device), model._packed.dt, False)])
         model.face_cls.fc2.weight.mul_(64.0)
         model.face_cls.fc2.bias.mul_(0.0)
         out2 = model.forward(audio, spk, motion, mask)
-        scales2 = model.__dict__["_scale_caches"][(str(model.device), model._packed.dt)]
+        scales2 = model.__dict__["_scale_caches"][(str(model.device), model._packed.dt, False)]
         changed = [k for k in scales1 if scales1[k] != scales2[k]]
         assert len(changed) == 1 and scales2[changed[0]] in (scales1[changed[0]] / 64, scales1[changed[0]] / 128)      # the weight grew 96x
         assert torch.isfinite(out2["cls_face"]).all()
