@@ -462,7 +462,7 @@ def bench_lstm_models(dev, steps=3, cpu=True):
     return out
 
 
-def bench_train_step(dev, steps=3, cpu=True, batch=56):
+def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw=None):
     """One EMAGE optimisation step at BASELINE configs[2]'s per-GPU batch (56 clips x 64 frames): targets through the frozen VQ-VAEs, three
     train-mode forwards (batch-statistics BatchNorm, dropout masks drawn on the device), six losses, three backward passes, multi-tensor
     Adam, BatchNorm buffers — `training.Trainer.capture` / `replay`: the whole step is ONE hipGraph.  `roofline`: the step's algorithmic
@@ -475,7 +475,10 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56):
     data = {k: v.to(dev) for k, v in common.train_batch(bs=batch, t=t).items()}
     random_mask = (torch.rand(batch, t, 337, generator=torch.Generator().manual_seed(6)) < 0.5).float().to(dev)
     torch.cuda.reset_peak_memory_stats()
-    trainer = training.Trainer(model, vq, seed=1).capture(data, random_mask)
+    trainer = training.Trainer(model, vq, seed=1)
+    if accumulate_dw is not None:                 # tools/bench_train_step.py A/B
+        trainer.fwd.accumulate_dw = bool(accumulate_dw)
+    trainer.capture(data, random_mask)
     losses = trainer.replay()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -496,6 +499,8 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56):
     torch.cuda.empty_cache()
     # the EAGER step — the path a multi-process run takes (a collective cannot sit inside the captured graph): same model, same inputs
     try:
+        if not eager:
+            raise RuntimeError("not timed in this run")
         eager = training.Trainer(model, vq, seed=1)
         eager.step(data, random_mask=random_mask)
         torch.cuda.synchronize()

@@ -35,7 +35,10 @@ __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) vo
     gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE>(p, tile_m * BM, tile_n * BN, smem, split);
 }
 
-constexpr long H2_SPLIT_K_TILES = 384;
+// most tiles a split-K launch may have.  Raising it to 384 (the 768 x 1536 FFN weight gradients: 288 tiles -> two slices of 576 blocks) made
+// the training step SLOWER, 105.2 -> 109.6 ms in an A/B on one box (profiles/r04_train_step_ab_splitk_accumulate.txt): the second slice's
+// atomic epilogue costs more than the idle block slots.  Tools build: emage_set_tuning key 5 bit 1024 selects 384 for such A/B runs
+static inline long h2_split_k_tiles() { return (g_h2_variant & 1024) ? 384 : 191; }
 static inline bool h2_accumulates_in_place(const GemmArgs& a) {
     return a.res && a.res_is_f32 && a.out_f32 && (const void*)a.res == (const void*)a.out_f32 && a.ldr == a.ldf;
 }
@@ -49,14 +52,13 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
     a.trace = TRACE ? g_h2_trace : nullptr;
     // split-K: a bare contraction (only out_f32, no bias / activation / residual — the weight gradients of a training step: few output
     // tiles, a very long K) with too few tiles to fill the chip is cut into K-slices whose partial tiles are atomically added in memory.
-    // H2_SPLIT_K_TILES: up to 384 tiles (the 768 x 1536 FFN weight gradients are 288 tiles of 64 x 64 on 768 block slots: two slices)
     a.ksplit = 1;
     const long tiles = (long)a.tiles_m * a.tiles_n;
     const int nk_all = a.K / 32;
     // res == out_f32 (fp32, same pitch): "out_f32 += contraction" — a weight gradient accumulated straight into the parameter's gradient.
     // One slice: the epilogue's residual add does it in place.  Split-K: the atomics land on the existing contents (no clearing, no residual)
     const bool accumulate = h2_accumulates_in_place(a);
-    if (a.taps == 1 && !a.out && !a.out_t && (!a.res || accumulate) && !a.bias && !a.slope && a.out_f32 && tiles <= H2_SPLIT_K_TILES && nk_all >= 64) {
+    if (a.taps == 1 && !a.out && !a.out_t && (!a.res || accumulate) && !a.bias && !a.slope && a.out_f32 && tiles <= h2_split_k_tiles() && nk_all >= 64) {
         int want = (int)((512 + tiles - 1) / tiles);
         const int most = nk_all / 16;                  // >= 16 K-tiles (512 k) per slice
         if (want > most) want = most;
@@ -121,7 +123,7 @@ void h2_tiles(GemmArgs& a) {
 template <int BM, int BN>
 bool h2_wants_split_k(const GemmArgs& a) {
     const long tiles = (long)((a.M + BM - 1) / BM) * (((a.n_store > a.N ? a.n_store : a.N) + BN - 1) / BN);
-    return a.taps == 1 && !a.out && !a.out_t && (!a.res || h2_accumulates_in_place(a)) && !a.bias && !a.slope && a.out_f32 && tiles <= H2_SPLIT_K_TILES && a.K / 32 >= 64;
+    return a.taps == 1 && !a.out && !a.out_t && (!a.res || h2_accumulates_in_place(a)) && !a.bias && !a.slope && a.out_f32 && tiles <= h2_split_k_tiles() && a.K / 32 >= 64;
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false>

@@ -227,6 +227,7 @@ class TrainForward:
         self.grad_scale = 1024.0
         self.conv_backward_rows = 1 << 17                 # output rows per piece of a long convolution's backward (_conv_backward_h2)
         self._w_scale, self._wt_cache = {}, {}
+        self.accumulate_dw = True       # Linear weight gradients are added into the gradient rows by their contraction (A/B switch; False: a temporary + a queued add)
         self.lazy_masks = True          # device-drawn (T, B, d) dropout masks live as Philox keys: drawn inside `mul_add`, forward and backward (-0.9 GB per forward)
         self._wt_keep = False           # True inside `Trainer._device_step`: the transposed weight images (`_weight_t_h2`) serve all three forwards
         self.range_flag = None          # int32 device counter: transposed-weight operands (backward dX) whose cached scale no longer fits
@@ -725,7 +726,7 @@ class TrainForward:
                                            bias_grad=bias_dst, accumulate=single)                # (M, rup64(N)), (N, mp)
         x_t = ops.h2_cast(x[:, :k], mp, scale=1.0, transpose=True)                    # (K, mp)
         wdst = self._grad_rows(origin[0][0], origin[0][2])[0] if single else None
-        if wdst is not None and wdst.dim() == 2 and wdst.stride(1) == 1 and wdst.stride(0) % 4 == 0 and wdst.data_ptr() % 16 == 0:
+        if self.accumulate_dw and wdst is not None and wdst.dim() == 2 and wdst.stride(1) == 1 and wdst.stride(0) % 4 == 0 and wdst.data_ptr() % 16 == 0:
             # dW added by the contraction itself (res == out_f32: the epilogue's residual add in place, or split-K atomics onto the contents)
             ops.gemm(H2, dpre_t, x_t, None, None, wdst, None, wdst, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
         else:

@@ -10,7 +10,16 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 cpu = "--cpu" in sys.argv
+quick = "--quick" in sys.argv                   # captured step only (A/B runs): no eager timing
+acc = None if "--accumulate-dw" not in sys.argv else int(sys.argv[sys.argv.index("--accumulate-dw") + 1])
+variant = 0 if "--h2-variant" not in sys.argv else int(sys.argv[sys.argv.index("--h2-variant") + 1])
 sys.argv = ["bench.py"]
 import bench  # noqa: E402
 
-print(json.dumps(bench.bench_train_step(torch.device("cuda", 0), cpu=cpu)))
+if variant:                                     # tools library: emage_set_tuning key 5 (EMAGE_H2 dispatch-heuristic variant)
+    from pantomatrix_amd import _lib
+    _lib.use_tools(True)
+    _lib.load().emage_set_tuning(5, variant)
+line = bench.bench_train_step(torch.device("cuda", 0), cpu=cpu, eager=not quick, accumulate_dw=acc)
+line["ab"] = {"accumulate_dw": acc, "h2_variant": variant}
+print(json.dumps(line))
