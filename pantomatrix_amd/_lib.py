@@ -45,6 +45,8 @@ SIGNATURES = {
     "emage_transpose_f32": [_p, _i, _p, _i, _i, _i, _p],
     "emage_col_sum": [_p, _i, _p, _i, _i, _i, _p, _i, _p, _l, _p],
     "emage_act_backward": [_p, _i, _p, _i, _f, _p, _i, _i, _i, _p],
+    "emage_layernorm_backward_affine_workspace_bytes": [_i, _i],
+    "emage_layernorm_backward_affine": [_p, _i, _p, _p, _i, _f, _p, _i, _p, _p, _i, _i, _i, _p, _l, _p],
     "emage_grad_prep": [_p, _i, _p, _i, _f, _i, _i, _f, _p, _i, _i, _p, _i, _i, _p, _i, _p, _l, _p],
     "emage_layernorm_backward": [_p, _i, _p, _p, _i, _f, _p, _i, _p, _i, _i, _i, _p],
     "emage_attention_backward": [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -85,7 +87,7 @@ SIGNATURES = {
     "emage_lstm_inputs": [_p, _p, _i, _p, _l, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "emage_rot6d_scatter": [_p, _i, _p, _p, _i, _i, _p],
 }
-RESTYPES = {"emage_bn_stats_workspace_bytes": _l, "emage_wav_conv_in_backward_workspace_bytes": _l}
+RESTYPES = {"emage_bn_stats_workspace_bytes": _l, "emage_wav_conv_in_backward_workspace_bytes": _l, "emage_layernorm_backward_affine_workspace_bytes": _l}
 
 _lib = None
 _tools = None

@@ -400,6 +400,79 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
     }
 }
 
+// LayerNorm backward WITH its affine gradients: a block takes LNB_ROWS rows (one wave per row at a time, the arithmetic and its order exactly
+// those of layernorm_backward_kernel: the same dx bits), every lane keeps float64 running sums of dy * xhat and dy for the columns it owns, the
+// four waves add theirs in LDS in wave order, and the block writes ONE partial per column: partial[(block * 2 + {0: sum dy, 1: sum dy xhat}) * C + c].
+// ln_bwd_finalize_kernel adds the blocks in order.  Replaces layernorm_backward + 2 x (col_sum_partial + col_sum_finalize): the (M, C) product
+// dy * xhat is never written, five launches become two.
+constexpr int LNB_ROWS = 16, LNB_MAXJ = 16;                  // C <= 64 * LNB_MAXJ
+__global__ __launch_bounds__(256) void layernorm_backward_affine_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ dy, int ldd,
+                                                                        float eps, float* __restrict__ dx, int ldo, double* __restrict__ partial, int M, int C) {
+    __shared__ double red[2][64 * LNB_MAXJ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int J = (C + 63) >> 6;
+    double ab[LNB_MAXJ], ag[LNB_MAXJ];
+#pragma unroll
+    for (int j = 0; j < LNB_MAXJ; ++j) { ab[j] = 0.0; ag[j] = 0.0; }
+    for (int r = wave; r < LNB_ROWS; r += 4) {
+        const long m = (long)blockIdx.x * LNB_ROWS + r;
+        if (m >= M) break;
+        const float* xr = x + m * ldx;
+        const float* dr = dy + m * ldd;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += xr[c];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mu = s / C;
+        float v = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = xr[c] - mu; v += d * d; }
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float rstd = 1.0f / sqrtf(v / C + eps);
+        float sg = 0.f, sgx = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float xh = (xr[c] - mu) * rstd, g = dr[c] * gamma[c];
+            sg += g;
+            sgx += g * xh;
+        }
+        for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o); sgx += __shfl_xor(sgx, o); }
+        const float mg = sg / C, mgx = sgx / C;
+#pragma unroll
+        for (int j = 0; j < LNB_MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (j < J && c < C) {
+                const float xh = (xr[c] - mu) * rstd, g = dr[c] * gamma[c];
+                dx[m * ldo + c] = rstd * (g - mg - xh * mgx);
+                ab[j] += (double)dr[c];
+                ag[j] += (double)(dr[c] * xh);
+            }
+        }
+    }
+    for (int w = 0; w < 4; ++w) {                            // the waves add their sums in wave order: a fixed summation order
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < LNB_MAXJ; ++j) {
+                const int c = lane + 64 * j;
+                if (j < J && c < C) {
+                    red[0][c] = (w ? red[0][c] : 0.0) + ab[j];
+                    red[1][c] = (w ? red[1][c] : 0.0) + ag[j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        partial[((long)blockIdx.x * 2 + 0) * C + c] = red[0][c];
+        partial[((long)blockIdx.x * 2 + 1) * C + c] = red[1][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const double* __restrict__ partial, int chunks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    double tot[2];
+    int c;
+    if (!finalize_sums<2>(partial, chunks, C, tot, c)) return;
+    dbeta[c] = accumulate ? dbeta[c] + (float)tot[0] : (float)tot[0];
+    dgamma[c] = accumulate ? dgamma[c] + (float)tot[1] : (float)tot[1];
+}
+
 struct AttnBwdArgs {
     const float* q; const float* k; const float* vt; const float* pmask; const float* d_out;
     float* dq; float* dk; float* dv;
@@ -651,6 +724,25 @@ extern "C" int emage_layernorm_backward(const float* x, int ldx, const float* ga
                                         float* dx, int ld_dx, float* dy_xhat, int ld_t, int M, int C, void* stream) {
     if (!x || !gamma || !dy || !dx || !dy_xhat || M <= 0 || C <= 0 || ldx < C || ld_dy < C || ld_dx < C || ld_t < C) return EMAGE_EINVAL;
     hipLaunchKernelGGL(layernorm_backward_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, dy, ld_dy, eps, dx, ld_dx, dy_xhat, ld_t, M, C);
+    return launch_status();
+}
+
+extern "C" long emage_layernorm_backward_affine_workspace_bytes(int M, int C) {
+    if (M <= 0 || C <= 0) return EMAGE_EINVAL;
+    return (long)((M + LNB_ROWS - 1) / LNB_ROWS) * 2 * C * (long)sizeof(double);
+}
+
+extern "C" int emage_layernorm_backward_affine(const float* x, int ldx, const float* gamma, const float* dy, int ld_dy, float eps, float* dx, int ld_dx,
+                                               float* dgamma, float* dbeta, int accumulate, int M, int C, void* workspace, long workspace_bytes, void* stream) {
+    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || C > 64 * LNB_MAXJ || ldx < C || ld_dy < C || ld_dx < C || ((uintptr_t)workspace & 7))
+        return EMAGE_EINVAL;
+    const int chunks = (M + LNB_ROWS - 1) / LNB_ROWS;
+    if (workspace_bytes < (long)chunks * 2 * C * (long)sizeof(double)) return EMAGE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(layernorm_backward_affine_kernel, dim3(chunks), dim3(256), 0, s, x, ldx, gamma, dy, ld_dy, eps, dx, ld_dx, (double*)workspace, M, C);
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, C, dgamma, dbeta, accumulate);
     return launch_status();
 }
 

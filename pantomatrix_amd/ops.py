@@ -750,11 +750,32 @@ def _layernorm_backward(x, gamma, dy, eps, dx, dy_xhat):
                                                m, c, _stream()), "layernorm_backward")
 
 
+FUSED_LAYERNORM_BACKWARD = True          # A/B switch (tools/bench_train_step.py --ln-fused 0): False = dx, dy * xhat and two column sums as separate launches
+
+
+@_op("layernorm_backward_affine", "(Tensor x, Tensor gamma, Tensor dy, float eps, Tensor(a!) dx, Tensor(b!) dgamma, Tensor(c!) dbeta, bool accumulate, "
+                                  "Tensor(d!) workspace) -> ()")
+def _layernorm_backward_affine(x, gamma, dy, eps, dx, dgamma, dbeta, accumulate, workspace):
+    m, c = x.shape
+    check(_lib.load().emage_layernorm_backward_affine(_ptr(x), _ld(x), _ptr(gamma), _ptr(dy), _ld(dy), eps, _ptr(dx), _ld(dx), _ptr(dgamma), _ptr(dbeta),
+                                                      int(accumulate), m, c, _ptr(workspace), workspace.numel() * 8, _stream()), "layernorm_backward_affine")
+
+
 def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None):
     """-> (dx, dgamma, dbeta) of LayerNorm(x) * gamma + beta for fp32 (M, C) rows.  dgamma / dbeta given: the affine gradients are ADDED
-    to them (the parameter's gradient accumulator: no temporary, no separate add)."""
+    to them (the parameter's gradient accumulator: no temporary, no separate add).  C <= 1024: dx and the float64 partials of both affine
+    gradients come from ONE kernel (emage_layernorm_backward_affine) + a finalize launch; wider rows: dx, dy * xhat, two column sums."""
     _dev(x)
-    dx, t = torch.empty(x.shape, dtype=torch.float32, device=x.device), torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    m, c = x.shape
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if c <= 1024 and FUSED_LAYERNORM_BACKWARD:
+        accumulate = dgamma is not None
+        if not accumulate:
+            dgamma, dbeta = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = torch.empty(((m + 15) // 16) * 2 * c, dtype=torch.float64, device=x.device)
+        _layernorm_backward_affine(x, gamma, dy, float(eps), dx, dgamma, dbeta, accumulate, ws)
+        return dx, dgamma, dbeta
+    t = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     _layernorm_backward(x, gamma, dy, float(eps), dx, t)
     if dgamma is None:
         return dx, col_sum(t), col_sum(dy)

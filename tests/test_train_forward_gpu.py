@@ -134,6 +134,20 @@ def test_backward_kernels():
     torch.nn.functional.layer_norm(xs, (c,), gamma, beta, 1e-5).backward(dy)
     dx, dg, db = ops.layernorm_backward(xs.detach().to(DEV), gamma.detach().to(DEV), dy.to(DEV))
     assert float((dx.cpu() - xs.grad).abs().max()) < 2e-5 and float((dg.cpu() - gamma.grad).abs().max()) < 2e-4 and float((db.cpu() - beta.grad).abs().max()) < 2e-4
+    # the fused form (dx + float64 partials of both affine gradients in one kernel) against the separate launches: the same dx bits, the
+    # same sums to summation order; accumulation into existing gradients; ragged row counts
+    from pantomatrix_amd.ops import _layernorm_backward
+    for rows in (130, 16, 1, 77):
+        xd, dyd, gd = xs.detach()[:rows].to(DEV), dy[:rows].to(DEV), gamma.detach().to(DEV)
+        dx_old, t_old = torch.empty(rows, c, device=DEV), torch.empty(rows, c, device=DEV)
+        _layernorm_backward(xd, gd, dyd, 1e-5, dx_old, t_old)
+        dx_new, dg_new, db_new = ops.layernorm_backward(xd, gd, dyd)
+        assert torch.equal(dx_new, dx_old), rows
+        assert float((dg_new - ops.col_sum(t_old)).abs().max()) < 1e-5 * max(1.0, float(t_old.abs().sum(0).max())), rows
+        assert float((db_new - ops.col_sum(dyd)).abs().max()) < 1e-5 * max(1.0, float(dyd.abs().sum(0).max())), rows
+        acc_g, acc_b = torch.full((c,), 2.0, device=DEV), torch.full((c,), -1.0, device=DEV)
+        ops.layernorm_backward(xd, gd, dyd, dgamma=acc_g, dbeta=acc_b)
+        assert float((acc_g - 2.0 - dg_new).abs().max()) < 1e-5 and float((acc_b + 1.0 - db_new).abs().max()) < 1e-5, rows
     # attention (with probability dropout), Tk != Tq
     b, h, tq, tk, hd = 2, 4, 64, 65, 192
     q = torch.randn(b * tq, h * hd, generator=g)

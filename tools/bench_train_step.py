@@ -13,6 +13,7 @@ cpu = "--cpu" in sys.argv
 quick = "--quick" in sys.argv                   # captured step only (A/B runs): no eager timing
 acc = None if "--accumulate-dw" not in sys.argv else int(sys.argv[sys.argv.index("--accumulate-dw") + 1])
 variant = 0 if "--h2-variant" not in sys.argv else int(sys.argv[sys.argv.index("--h2-variant") + 1])
+ln_fused = None if "--ln-fused" not in sys.argv else int(sys.argv[sys.argv.index("--ln-fused") + 1])
 sys.argv = ["bench.py"]
 import bench  # noqa: E402
 
@@ -20,6 +21,9 @@ if variant:                                     # tools library: emage_set_tunin
     from pantomatrix_amd import _lib
     _lib.use_tools(True)
     _lib.load().emage_set_tuning(5, variant)
+if ln_fused is not None:
+    from pantomatrix_amd import ops
+    ops.FUSED_LAYERNORM_BACKWARD = bool(ln_fused)
 line = bench.bench_train_step(torch.device("cuda", 0), cpu=cpu, eager=not quick, accumulate_dw=acc)
-line["ab"] = {"accumulate_dw": acc, "h2_variant": variant}
+line["ab"] = {"accumulate_dw": acc, "h2_variant": variant, "ln_fused": ln_fused}
 print(json.dumps(line))
