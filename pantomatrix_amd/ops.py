@@ -750,7 +750,11 @@ def _layernorm_backward(x, gamma, dy, eps, dx, dy_xhat):
                                                m, c, _stream()), "layernorm_backward")
 
 
-FUSED_LAYERNORM_BACKWARD = True          # A/B switch (tools/bench_train_step.py --ln-fused 0): False = dx, dy * xhat and two column sums as separate launches
+# LayerNorm backward as ONE kernel that also reduces the affine gradients (emage_layernorm_backward_affine, 16 rows per block) + a finalize
+# launch, instead of dx / dy * xhat from the row kernel and two column sums: built, equal (tests), and SLOWER — the captured training step
+# 103.5 -> 106.4 ms in an A/B on one box (profiles/r04_train_step_ab_fused_layernorm_backward.txt): 224 blocks of 4 waves walking 4 rows each
+# are a longer dependent chain than 896 blocks of one row per wave plus two bandwidth-bound reductions.  Off; tools/bench_train_step.py --ln-fused 1
+FUSED_LAYERNORM_BACKWARD = False
 
 
 @_op("layernorm_backward_affine", "(Tensor x, Tensor gamma, Tensor dy, float eps, Tensor(a!) dx, Tensor(b!) dgamma, Tensor(c!) dbeta, bool accumulate, "

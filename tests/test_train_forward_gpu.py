@@ -137,6 +137,8 @@ def test_backward_kernels():
     # the fused form (dx + float64 partials of both affine gradients in one kernel) against the separate launches: the same dx bits, the
     # same sums to summation order; accumulation into existing gradients; ragged row counts
     from pantomatrix_amd.ops import _layernorm_backward
+    monkey = ops.FUSED_LAYERNORM_BACKWARD
+    ops.FUSED_LAYERNORM_BACKWARD = True                     # (off by default: measured slower end to end; kept equal all the same)
     for rows in (130, 16, 1, 77):
         xd, dyd, gd = xs.detach()[:rows].to(DEV), dy[:rows].to(DEV), gamma.detach().to(DEV)
         dx_old, t_old = torch.empty(rows, c, device=DEV), torch.empty(rows, c, device=DEV)
@@ -148,6 +150,7 @@ def test_backward_kernels():
         acc_g, acc_b = torch.full((c,), 2.0, device=DEV), torch.full((c,), -1.0, device=DEV)
         ops.layernorm_backward(xd, gd, dyd, dgamma=acc_g, dbeta=acc_b)
         assert float((acc_g - 2.0 - dg_new).abs().max()) < 1e-5 and float((acc_b + 1.0 - db_new).abs().max()) < 1e-5, rows
+    ops.FUSED_LAYERNORM_BACKWARD = monkey
     # attention (with probability dropout), Tk != Tq
     b, h, tq, tk, hd = 2, 4, 64, 65, 192
     q = torch.randn(b * tq, h * hd, generator=g)
