@@ -551,8 +551,6 @@ def build(precision, device, args):
     for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.concurrent = not args.no_concurrent
         part.group_gemms = not args.no_group_gemms
-    if args.stagger_audio is not None:
-        model.stagger_audio = bool(args.stagger_audio)
     if args.group_face_body is not None:
         model.group_face_body = bool(args.group_face_body)
     n_samples = synthetic.samples_for_frames(args.frames)
@@ -582,7 +580,6 @@ def main():
     ap.add_argument("--no-split-acts", action="store_true", help="A/B: float32 activations split inside every GEMM (EMAGE_F16X3) instead of pre-split EMAGE_H2 storage")
     ap.add_argument("--pipeline", type=int, default=1, help="also time the step with this many batches in flight (runtime.ClipPipeline)")
     ap.add_argument("--f32-residual", action="store_true", help="A/B: float32 residual twins beside the EMAGE_H2 images (round 3's default) instead of residuals read from the images")
-    ap.add_argument("--stagger-audio", type=int, default=None, help="A/B (default: the class default): 1 = waveform-only features window by window (window i + 1's beside window i's transformer stack); 0 = all windows ahead of the loop")
     ap.add_argument("--group-face-body", type=int, default=None, help="A/B (default: the class default): 1 = the face decoder layers walk in lock step with the first cross-attention layers (shared launches, one lane); 0 = two stream lanes")
     ap.add_argument("--no-group-gemms", action="store_true", help="A/B: one stream lane per part-wise chain and one launch per contraction instead of lock-step chains with grouped launches")
     ap.add_argument("--attn-variant", type=int, default=0, help="experiments: emage_set_tuning key 6 (1 = split-f16 attention without the LDS-staged K / V^T)")

@@ -70,8 +70,6 @@ class _EmageModule(torch.nn.Module):
         self._packed = None
         self.concurrent = True                 # issue independent launch chains on side streams (streams.py)
         self.hoist_audio = True                # inference(): waveform-only features of all full windows in one pass
-        self.stagger_audio = False             # ... or window by window: window 0's ahead of the loop, window i + 1's on a side lane BESIDE window i's
-                                               # transformer stack (the first cross-attention layer then waits for one window's features, not all)
         self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
         self.health_counter = None             # optional int32 device counter of non-finite logits / latents met by infer_codes (runtime.ClipRunner)
         self.slab_convs = True                 # WavEncoder: LDS-resident-slab convolutions + fused block 0 (A/B switch; same bits)
@@ -1396,9 +1394,7 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
         hoisted = None
         open_fork = None
         tables = self._speaker_tables(_Ctx(self._engine()), speaker_id, bs, window) if rounds > 0 else None
-        staggered = {}                               # window index -> its waveform-only features (stagger_audio)
         try:
-            stagger = rounds > 0 and self.hoist_audio and self.stagger_audio and dev.type == "cuda" and self.concurrent
             if rounds > 0 and self.hoist_audio:
                 cx = _Ctx(self._engine())
                 # Issued on the side streams the first window's forward() will use for its own lanes 1 and 2 and NOT
@@ -1406,42 +1402,15 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                 # queue behind this work by stream order, and forward()'s join closes the fork.
                 open_fork = Fork(dev, 3, self.concurrent)
                 open_fork.__enter__()
-                if stagger:                          # window 0 alone; the later windows follow one by one (`issue_next_feats`)
-                    hoisted = self._audio_features(cx, audio[:, :window * spf], bs, window, True, open_fork, 1, 2)
-                else:
-                    hoisted = self._audio_features(cx, audio, rounds * bs, window, True, open_fork, 1, 2,
-                                                   nwin=rounds, hop=hop * spf, win_len=window * spf)       # M:393-394
+                hoisted = self._audio_features(cx, audio, rounds * bs, window, True, open_fork, 1, 2,
+                                               nwin=rounds, hop=hop * spf, win_len=window * spf)           # M:393-394
                 if hoisted["ta"] != window:
                     open_fork.__exit__(None, None, None)
-                    open_fork, hoisted, stagger = None, None, False
-                elif stagger:
-                    staggered[0] = hoisted
-
-            def fork_before_window(i):
-                """stagger_audio: a fork entered BEFORE window i's forward() is issued — its side lanes wait for the main lane's position at
-                the END of window i - 1 and no later."""
-                if not stagger or i + 1 >= rounds:
-                    return None
-                fk = Fork(dev, 3, self.concurrent)
-                fk.__enter__()
-                return fk
-
-            def issue_next_feats(i, fk):
-                """stagger_audio: the features of full window i on side lane 2 of `fork_before_window(i - 1)`, issued on the host BEHIND window
-                i - 1's forward(): on the device (a captured graph orders by dependencies only) they wait for the end of window i - 2 — whose
-                feature buffers are free by then — and for the lane's earlier work, so they run BESIDE window i - 1's transformer stack;
-                window i's first cross-attention layer waits for them (`fk.after(0, 2)`), and window i's own fork joins the lane."""
-                if fk is None or i >= rounds or i in staggered:
-                    return
-                start = i * hop * spf
-                staggered[i] = self._audio_features(_Ctx(self._engine()), audio[:, start:start + window * spf], bs, window, True, fk, 2, 2)
+                    open_fork, hoisted = None, None
 
             def window_feats(i):
                 if hoisted is None:
                     return None
-                if stagger:
-                    f = staggered.pop(i)
-                    return dict(memcat=f["memcat"], ta=f["ta"], bk=f["bk"], bvt=f["bvt"], _keep=f.get("_keep"))
                 ta, mrows = hoisted["ta"], bs * window
                 return dict(memcat=hoisted["memcat"][i * mrows:(i + 1) * mrows], ta=ta,
                             bk=hoisted["bk"][i * bs * ta:(i + 1) * bs * ta], bvt=hoisted["bvt"][i * bs:(i + 1) * bs])
@@ -1451,11 +1420,9 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                 t = end - start
                 a = audio[:, start * spf:start * spf + t * spf]                                      # M:393-394
                 # the seed splice (M:386-391) happens inside the packing kernel: frames < pre take `last` where masked
-                next_fk = fork_before_window(start // hop) if feats is not None else None             # (None unless stagger_audio)
                 net = self.forward(a, speaker_id, motion[:, start:end], full_mask[:, start:end], use_audio=True,
                                    _audio_feats=feats, _tables=tables, _lean=want_codes, _seed=last)
                 open_fork = None                        # forward()'s own fork joined the side streams
-                issue_next_feats(start // hop + 1, next_fk)                                           # joined by the NEXT forward()'s fork
                 seed = None
                 if want_codes:
                     self._window_codes(net, vq_model, codes, start, bs, t)
@@ -1488,5 +1455,3 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
         finally:
             if open_fork is not None:                   # abandoned before the first window ran: join the side streams
                 open_fork.__exit__(None, None, None)
-            elif staggered:                             # features issued for a window that never ran: join their lane
-                Fork(dev, 3, self.concurrent).__exit__(None, None, None)

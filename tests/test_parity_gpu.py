@@ -475,30 +475,3 @@ def test_grouped_launches_change_no_bit(golden_dir):
         if ca[k] is not None:
             assert torch.equal(ca[k], cb[k]), k
             assert torch.equal(ca[k], cc[k]), k
-
-
-@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
-def test_staggered_audio_features_change_no_bit(precision):
-    """`model.stagger_audio`: the waveform-only features (WavEncoders, audio projection, cross-attention K / V) window by window — window
-    0's ahead of the loop, window i + 1's on a side lane beside window i's transformer stack — instead of all windows in one set of
-    launches: the same kernels on the same rows, so every output of a 310-frame clip (5 windows + a tail window; the feature buffers of
-    three windows are recycled while later ones are computed) and the hipGraph-captured 128-frame batch are equal bit for bit, replay after replay."""
-    from pantomatrix_amd.runtime import ClipRunner
-    a_model, a_vq = common.product_models(precision=precision, device=DEV)
-    b_model, b_vq = common.product_models(precision=precision, device=DEV)
-    b_model.stagger_audio = True
-    clip = synthetic.synthetic_audio(2, synthetic.samples_for_frames(310)).to(DEV)
-    (pa, ea, ta), _ = common.product_infer_clip(a_model, a_vq, clip)
-    (pb, eb, tb), _ = common.product_infer_clip(b_model, b_vq, clip)
-    assert np.array_equal(pa, pb) and np.array_equal(ea, eb) and np.array_equal(ta, tb)
-    spk = torch.zeros(2, 1, dtype=torch.long, device=DEV)
-    with torch.no_grad():
-        na, nb = a_model.inference(clip, spk, a_vq), b_model.inference(clip, spk, b_vq)
-    for k in orc.OUT_KEYS:
-        assert torch.equal(na[k], nb[k]), k
-    n = synthetic.samples_for_frames(128)
-    a1, a2 = synthetic.synthetic_audio(4, n).to(DEV), synthetic.synthetic_audio(4, n, seed=77).to(DEV)
-    plain, stag = ClipRunner(a_model, a_vq, 4, n, use_graph=True), ClipRunner(b_model, b_vq, 4, n, use_graph=True)
-    for a in (a1, a2, a1):
-        for x, y in zip([v.copy() for v in plain(a)], [v.copy() for v in stag(a)]):
-            assert x.shape == y.shape and np.array_equal(x, y)
