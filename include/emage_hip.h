@@ -417,11 +417,13 @@ int emage_layernorm_backward(const float* x, int ldx, const float* gamma, const 
                              float* dx, int ld_dx, float* dy_xhat, int ld_t, int M, int C, void* stream);
 
 /* nn.LayerNorm backward with its affine gradients in two launches: dx as emage_layernorm_backward (the same bits), and
- * dgamma[c] (+)= sum_m dy[m][c] * xhat[m][c], dbeta[c] (+)= sum_m dy[m][c] (float64 partials per 16 rows in `workspace`, added in row order;
- * `accumulate`: into the parameters' gradient accumulators, loss.backward()'s accumulation over the three forwards of a step, T:174).  C <= 1024. */
-long emage_layernorm_backward_affine_workspace_bytes(int M, int C);
+ * dgamma[c] (+)= sum_m dy[m][c] * xhat[m][c], dbeta[c] (+)= sum_m dy[m][c] (float64 partials per `rows_per_block` rows — 4 or 16 — in
+ * `workspace`, added in row order; `accumulate`: into the parameters' gradient accumulators, loss.backward()'s accumulation over the three
+ * forwards of a step, T:174).  C <= 1024. */
+long emage_layernorm_backward_affine_workspace_bytes(int M, int C, int rows_per_block);
 int emage_layernorm_backward_affine(const float* x, int ldx, const float* gamma, const float* dy, int ld_dy, float eps, float* dx, int ld_dx,
-                                    float* dgamma, float* dbeta, int accumulate, int M, int C, void* workspace, long workspace_bytes, void* stream);
+                                    float* dgamma, float* dbeta, int accumulate, int M, int C, int rows_per_block,
+                                    void* workspace, long workspace_bytes, void* stream);
 
 /* Backward of emage_attention / emage_attention_dropout (same operand layouts; pmask may be NULL): dq (B*Tq, .), dk, dv (B*Tk, .)
  * in row layout with head h at columns [h*hd, (h+1)*hd).  The probabilities are recomputed. */

@@ -45,8 +45,8 @@ SIGNATURES = {
     "emage_transpose_f32": [_p, _i, _p, _i, _i, _i, _p],
     "emage_col_sum": [_p, _i, _p, _i, _i, _i, _p, _i, _p, _l, _p],
     "emage_act_backward": [_p, _i, _p, _i, _f, _p, _i, _i, _i, _p],
-    "emage_layernorm_backward_affine_workspace_bytes": [_i, _i],
-    "emage_layernorm_backward_affine": [_p, _i, _p, _p, _i, _f, _p, _i, _p, _p, _i, _i, _i, _p, _l, _p],
+    "emage_layernorm_backward_affine_workspace_bytes": [_i, _i, _i],
+    "emage_layernorm_backward_affine": [_p, _i, _p, _p, _i, _f, _p, _i, _p, _p, _i, _i, _i, _i, _p, _l, _p],
     "emage_grad_prep": [_p, _i, _p, _i, _f, _i, _i, _f, _p, _i, _i, _p, _i, _i, _p, _i, _p, _l, _p],
     "emage_layernorm_backward": [_p, _i, _p, _p, _i, _f, _p, _i, _p, _i, _i, _i, _p],
     "emage_attention_backward": [_p, _i, _p, _i, _p, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -400,12 +400,13 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
     }
 }
 
-// LayerNorm backward WITH its affine gradients: a block takes LNB_ROWS rows (one wave per row at a time, the arithmetic and its order exactly
+// LayerNorm backward WITH its affine gradients: a block takes LNB_ROWS (16 or 4) rows (one wave per row at a time, the arithmetic and its order exactly
 // those of layernorm_backward_kernel: the same dx bits), every lane keeps float64 running sums of dy * xhat and dy for the columns it owns, the
 // four waves add theirs in LDS in wave order, and the block writes ONE partial per column: partial[(block * 2 + {0: sum dy, 1: sum dy xhat}) * C + c].
 // ln_bwd_finalize_kernel adds the blocks in order.  Replaces layernorm_backward + 2 x (col_sum_partial + col_sum_finalize): the (M, C) product
 // dy * xhat is never written, five launches become two.
-constexpr int LNB_ROWS = 16, LNB_MAXJ = 16;                  // C <= 64 * LNB_MAXJ
+constexpr int LNB_MAXJ = 16;                                 // C <= 64 * LNB_MAXJ
+template <int LNB_ROWS>                                      // 16: four rows per wave, few partials; 4: one row per wave (the row kernel's parallelism), 4x the partials
 __global__ __launch_bounds__(256) void layernorm_backward_affine_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ dy, int ldd,
                                                                         float eps, float* __restrict__ dx, int ldo, double* __restrict__ partial, int M, int C) {
     __shared__ double red[2][64 * LNB_MAXJ];
@@ -727,19 +728,24 @@ extern "C" int emage_layernorm_backward(const float* x, int ldx, const float* ga
     return launch_status();
 }
 
-extern "C" long emage_layernorm_backward_affine_workspace_bytes(int M, int C) {
-    if (M <= 0 || C <= 0) return EMAGE_EINVAL;
-    return (long)((M + LNB_ROWS - 1) / LNB_ROWS) * 2 * C * (long)sizeof(double);
+extern "C" long emage_layernorm_backward_affine_workspace_bytes(int M, int C, int rows_per_block) {
+    if (M <= 0 || C <= 0 || (rows_per_block != 4 && rows_per_block != 16)) return EMAGE_EINVAL;
+    return (long)((M + rows_per_block - 1) / rows_per_block) * 2 * C * (long)sizeof(double);
 }
 
 extern "C" int emage_layernorm_backward_affine(const float* x, int ldx, const float* gamma, const float* dy, int ld_dy, float eps, float* dx, int ld_dx,
-                                               float* dgamma, float* dbeta, int accumulate, int M, int C, void* workspace, long workspace_bytes, void* stream) {
+                                               float* dgamma, float* dbeta, int accumulate, int M, int C, int rows_per_block,
+                                               void* workspace, long workspace_bytes, void* stream) {
     if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || C > 64 * LNB_MAXJ || ldx < C || ld_dy < C || ld_dx < C || ((uintptr_t)workspace & 7))
         return EMAGE_EINVAL;
-    const int chunks = (M + LNB_ROWS - 1) / LNB_ROWS;
+    if (rows_per_block != 4 && rows_per_block != 16) return EMAGE_EINVAL;
+    const int chunks = (M + rows_per_block - 1) / rows_per_block;
     if (workspace_bytes < (long)chunks * 2 * C * (long)sizeof(double)) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(layernorm_backward_affine_kernel, dim3(chunks), dim3(256), 0, s, x, ldx, gamma, dy, ld_dy, eps, dx, ld_dx, (double*)workspace, M, C);
+    if (rows_per_block == 4)
+        hipLaunchKernelGGL(layernorm_backward_affine_kernel<4>, dim3(chunks), dim3(256), 0, s, x, ldx, gamma, dy, ld_dy, eps, dx, ld_dx, (double*)workspace, M, C);
+    else
+        hipLaunchKernelGGL(layernorm_backward_affine_kernel<16>, dim3(chunks), dim3(256), 0, s, x, ldx, gamma, dy, ld_dy, eps, dx, ld_dx, (double*)workspace, M, C);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, C, dgamma, dbeta, accumulate);

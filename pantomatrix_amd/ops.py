@@ -754,15 +754,16 @@ def _layernorm_backward(x, gamma, dy, eps, dx, dy_xhat):
 # launch, instead of dx / dy * xhat from the row kernel and two column sums: built, equal (tests), and SLOWER — the captured training step
 # 103.5 -> 106.4 ms in an A/B on one box (profiles/r04_train_step_ab_fused_layernorm_backward.txt): 224 blocks of 4 waves walking 4 rows each
 # are a longer dependent chain than 896 blocks of one row per wave plus two bandwidth-bound reductions.  Off; tools/bench_train_step.py --ln-fused 1
-FUSED_LAYERNORM_BACKWARD = False
+FUSED_LAYERNORM_BACKWARD = False         # False | 16 (= True) | 4: rows per block of the fused kernel
 
 
 @_op("layernorm_backward_affine", "(Tensor x, Tensor gamma, Tensor dy, float eps, Tensor(a!) dx, Tensor(b!) dgamma, Tensor(c!) dbeta, bool accumulate, "
-                                  "Tensor(d!) workspace) -> ()")
-def _layernorm_backward_affine(x, gamma, dy, eps, dx, dgamma, dbeta, accumulate, workspace):
+                                  "int rows_per_block, Tensor(d!) workspace) -> ()")
+def _layernorm_backward_affine(x, gamma, dy, eps, dx, dgamma, dbeta, accumulate, rows_per_block, workspace):
     m, c = x.shape
     check(_lib.load().emage_layernorm_backward_affine(_ptr(x), _ld(x), _ptr(gamma), _ptr(dy), _ld(dy), eps, _ptr(dx), _ld(dx), _ptr(dgamma), _ptr(dbeta),
-                                                      int(accumulate), m, c, _ptr(workspace), workspace.numel() * 8, _stream()), "layernorm_backward_affine")
+                                                      int(accumulate), m, c, rows_per_block, _ptr(workspace), workspace.numel() * 8, _stream()),
+          "layernorm_backward_affine")
 
 
 def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None):
@@ -776,8 +777,9 @@ def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None):
         accumulate = dgamma is not None
         if not accumulate:
             dgamma, dbeta = torch.empty(c, dtype=torch.float32, device=x.device), torch.empty(c, dtype=torch.float32, device=x.device)
-        ws = torch.empty(((m + 15) // 16) * 2 * c, dtype=torch.float64, device=x.device)
-        _layernorm_backward_affine(x, gamma, dy, float(eps), dx, dgamma, dbeta, accumulate, ws)
+        rows = 4 if int(FUSED_LAYERNORM_BACKWARD) == 4 else 16
+        ws = torch.empty(((m + rows - 1) // rows) * 2 * c, dtype=torch.float64, device=x.device)
+        _layernorm_backward_affine(x, gamma, dy, float(eps), dx, dgamma, dbeta, accumulate, rows, ws)
         return dx, dgamma, dbeta
     t = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     _layernorm_backward(x, gamma, dy, float(eps), dx, t)

@@ -138,8 +138,8 @@ def test_backward_kernels():
     # same sums to summation order; accumulation into existing gradients; ragged row counts
     from pantomatrix_amd.ops import _layernorm_backward
     monkey = ops.FUSED_LAYERNORM_BACKWARD
-    ops.FUSED_LAYERNORM_BACKWARD = True                     # (off by default: measured slower end to end; kept equal all the same)
-    for rows in (130, 16, 1, 77):
+    for per_block, rows in ((16, 130), (16, 16), (16, 1), (16, 77), (4, 130), (4, 3), (4, 77)):
+        ops.FUSED_LAYERNORM_BACKWARD = per_block            # (the default is measured, see ops.py; both forms are kept equal all the same)
         xd, dyd, gd = xs.detach()[:rows].to(DEV), dy[:rows].to(DEV), gamma.detach().to(DEV)
         dx_old, t_old = torch.empty(rows, c, device=DEV), torch.empty(rows, c, device=DEV)
         _layernorm_backward(xd, gd, dyd, 1e-5, dx_old, t_old)

@@ -23,7 +23,7 @@ if variant:                                     # tools library: emage_set_tunin
     _lib.load().emage_set_tuning(5, variant)
 if ln_fused is not None:
     from pantomatrix_amd import ops
-    ops.FUSED_LAYERNORM_BACKWARD = bool(ln_fused)
+    ops.FUSED_LAYERNORM_BACKWARD = {0: False, 1: 16}.get(ln_fused, ln_fused)
 line = bench.bench_train_step(torch.device("cuda", 0), cpu=cpu, eager=not quick, accumulate_dw=acc)
 line["ab"] = {"accumulate_dw": acc, "h2_variant": variant, "ln_fused": ln_fused}
 print(json.dumps(line))
