@@ -753,7 +753,9 @@ def _layernorm_backward(x, gamma, dy, eps, dx, dy_xhat):
 # LayerNorm backward as ONE kernel that also reduces the affine gradients (emage_layernorm_backward_affine, 16 rows per block) + a finalize
 # launch, instead of dx / dy * xhat from the row kernel and two column sums: built, equal (tests), and SLOWER — the captured training step
 # 103.5 -> 106.4 ms in an A/B on one box (profiles/r04_train_step_ab_fused_layernorm_backward.txt): 224 blocks of 4 waves walking 4 rows each
-# are a longer dependent chain than 896 blocks of one row per wave plus two bandwidth-bound reductions.  Off; tools/bench_train_step.py --ln-fused 1
+# are a longer dependent chain than 896 blocks of one row per wave plus two bandwidth-bound reductions.  With 4 rows per block (one per wave:
+# the row kernel's parallelism, 4x the partials) it is still 0.6 ms behind the separate launches (105.0 vs 105.7 ms).  Off;
+# tools/bench_train_step.py --ln-fused {0, 4, 16}
 FUSED_LAYERNORM_BACKWARD = False         # False | 16 (= True) | 4: rows per block of the fused kernel
 
 
