@@ -401,3 +401,45 @@ def test_long_convolution_backward_in_pieces():
     ref_dx = xd.grad.permute(0, 2, 1).reshape(nseq * lin, cin)
     assert float((dx4.double() - ref_dx).abs().max()) < 2e-5 * float(ref_dx.abs().max())
     assert float((dw4.double() - wd.grad).abs().max()) < 2e-5 * float(wd.grad.abs().max())
+
+
+def test_queued_parameter_gradients_equal_immediate_adds(monkeypatch):
+    """`TrainForward._param_grad` queues `grad[rows] += g` and applies the queue as multi-tensor adds.  Every element must still receive its
+    contributions one by one in issue order (fp32 addition is not associative: 1e8 + 1 - 1e8 is 0 or 1 depending on the order), so a
+    contribution to rows that overlap a queued one flushes first; disjoint row blocks of one parameter (the q / k / v blocks of an in_proj
+    weight) share a batch; reading `param_grads` always sees everything; a direct accumulation (`_grad_rows`, the reductions that add into
+    the gradient themselves) is ordered behind what was queued for its rows."""
+    model, _ = common.product_models(precision="fp32")
+    fwd = training.TrainForward(model)
+    views = {"w": torch.zeros(12, 4), "b": torch.zeros(12), "other": torch.zeros(3)}
+    fwd.grad_views = views
+    fwd.param_grads = {}
+    calls = []
+    real = torch._foreach_add_
+    monkeypatch.setattr(torch, "_foreach_add_", lambda dst, src: (calls.append(len(dst)), real(dst, src))[1])
+    ref = {k: v.clone() for k, v in views.items()}
+    seq = [("w", slice(0, 4), torch.full((4, 4), 1e8)), ("w", slice(4, 8), torch.full((4, 4), 2.0)), ("w", slice(8, 12), torch.full((4, 4), 3.0)),
+           ("b", slice(None), torch.arange(12.0)),
+           ("w", slice(2, 6), torch.full((4, 4), 1.0)),          # overlaps the first two: they are applied first
+           ("w", slice(0, 4), torch.full((4, 4), -1e8)),         # overlaps the previous one
+           ("other", slice(None), torch.ones(3)), ("b", slice(0, 6), torch.ones(6))]
+    for name, rows, g in seq:
+        fwd._param_grad(name, rows, g)
+        ref[name][rows] += g
+    assert calls == [4, 1]                                         # two flushes so far (in front of the two overlapping contributions), three still queued
+    got = fwd.param_grads                                          # reading flushes
+    assert sum(calls) == len(seq)
+    for k in views:
+        assert torch.equal(got[k], ref[k]), k
+    assert float(views["w"][2, 0]) == 0.0                          # (1e8 + 1) - 1e8 in issue order; any other order of the three gives 1
+    # a direct accumulation into rows with a queued contribution: the queue goes first
+    fwd._param_grad("b", slice(0, 4), torch.full((4,), 1e8))
+    dst, _span = fwd._grad_rows("b", slice(2, 8))
+    dst += 1.0
+    ref["b"][0:4] += 1e8
+    ref["b"][2:8] += 1.0
+    assert torch.equal(fwd.param_grads["b"], ref["b"])
+    # a new accumulator dict (the next step) starts with an empty queue
+    fwd._param_grad("other", slice(None), torch.ones(3))
+    fwd.param_grads = {}
+    assert not fwd._pg_dst and float(views["other"][0]) == 2.0
