@@ -35,6 +35,16 @@ SHAPES = [
     ("conv3 128->106 f32out", (64, 64, 64), 106, 106, 3, 1, 1, dict(f32only=True)),
     ("cls fc 256->256", (64, 64, 64), 256, 256, 1, 1, 0, dict(slope=0.1)),
     ("ragged M=4100 768->768", (1, 4100, 4100), 768, 768, 1, 1, 0, dict(res=True)),
+    # the backward contractions of a training step at 56 clips (M = 3 584 rows; DESIGN 7 #2 — never swept so far): dX = dpre W (fp32 result),
+    # dW = dpre^T X (bare: no bias, fp32 result only — few tiles and a 3 584-long contraction: split-K below 192 tiles)
+    ("bwd dX 768<-768", (56, 64, 64), 768, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dX 768<-1536", (56, 64, 64), 1536, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dX 1536<-768", (56, 64, 64), 768, 1536, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dX 768<-2304", (56, 64, 64), 2304, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dW 768x768", (12, 64, 64), 3584, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dW 1536x768", (24, 64, 64), 3584, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dW 768x1536", (12, 64, 64), 3584, 1536, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dW 2304x768", (36, 64, 64), 3584, 768, 1, 1, 0, dict(f32only=True, bare=True)),
 ]
 CONFIGS = [100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 115, 116, 118, 119, 120, 121, 122, 123, 124, 125, 126, 127, 128,
            129, 130, 131, 132]
@@ -63,7 +73,7 @@ def main():
         w = torch.zeros(n, taps, cp)
         w[:, :, :cin] = torch.randn(n, taps, cin, generator=g) / (cin * taps) ** 0.5
         a, w = a.to(dev), w.reshape(n, taps * cp).to(dev)
-        bias = (torch.randn(n, generator=g) * 0.1).to(dev)
+        bias = None if ex.get("bare") else (torch.randn(n, generator=g) * 0.1).to(dev)
         slope = torch.full((n,), float(ex["slope"]), device=dev) if "slope" in ex else None
         res = torch.randn(m, n, generator=g).to(dev) if ex.get("res") else None
         vt0 = ex.get("vt")
@@ -78,7 +88,7 @@ def main():
             pos = l_ * stride + tap - pad
             valid = ((pos >= 0) & (pos < lin)).double()[:, None]
             cols.append(a.double()[b_ * lin + pos.clamp(0, lin - 1)] * valid)
-        ref = torch.cat(cols, 1) @ w.double().t() + bias.double()
+        ref = torch.cat(cols, 1) @ w.double().t() + (bias.double() if bias is not None else 0.0)
         if slope is not None:
             ref = torch.where(ref > 0, ref, ref * slope.double())
         if res is not None:
