@@ -37,8 +37,8 @@ __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) vo
 
 // most tiles a split-K launch may have.  Raising it to 384 (the 768 x 1536 FFN weight gradients: 288 tiles -> two slices of 576 blocks) made
 // the training step SLOWER, 105.2 -> 109.6 ms in an A/B on one box (profiles/r04_train_step_ab_splitk_accumulate.txt): the second slice's
-// atomic epilogue costs more than the idle block slots.  Tools build: emage_set_tuning key 5 bit 1024 selects 384 for such A/B runs
-static inline long h2_split_k_tiles() { return (g_h2_variant & 1024) ? 384 : 191; }
+// atomic epilogue costs more than the idle block slots.  Tools build: emage_set_tuning key 5 bit 1024 selects 384, bit 2048 no split-K at all, bit 4096 at most 100 tiles (A/B runs)
+static inline long h2_split_k_tiles() { return (g_h2_variant & 1024) ? 384 : (g_h2_variant & 2048) ? -1 : (g_h2_variant & 4096) ? 100 : 191; }
 static inline bool h2_accumulates_in_place(const GemmArgs& a) {
     return a.res && a.res_is_f32 && a.out_f32 && (const void*)a.res == (const void*)a.out_f32 && a.ldr == a.ldf;
 }
