@@ -35,10 +35,15 @@ __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) vo
     gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE>(p, tile_m * BM, tile_n * BN, smem, split);
 }
 
-// most tiles a split-K launch may have.  Raising it to 384 (the 768 x 1536 FFN weight gradients: 288 tiles -> two slices of 576 blocks) made
-// the training step SLOWER, 105.2 -> 109.6 ms in an A/B on one box (profiles/r04_train_step_ab_splitk_accumulate.txt): the second slice's
-// atomic epilogue costs more than the idle block slots.  Tools build: emage_set_tuning key 5 bit 1024 selects 384, bit 2048 no split-K at all, bit 4096 at most 100 tiles (A/B runs)
-static inline long h2_split_k_tiles() { return (g_h2_variant & 1024) ? 384 : (g_h2_variant & 2048) ? -1 : (g_h2_variant & 4096) ? 100 : 191; }
+// most tiles a split-K launch may have: 100.  Measured on the captured training step (A/Bs on one box each, tools library variants):
+//   * 384 instead of 191 (the 768 x 1536 FFN weight gradients: 288 tiles -> two slices of 576 blocks): 105.2 -> 109.6 ms
+//     (profiles/r04_train_step_ab_splitk_accumulate.txt) — the second slice's atomic epilogue costs more than the idle block slots;
+//   * no split-K at all: 103.4 -> 119.0 ms (the 48- / 96-tile gradients of the heads and narrow MLPs need it);
+//   * 100 instead of 191: 103.4 -> 98.4 ms (profiles/r04_train_step_ab_splitk_limit.txt) — the 144-tile 768 x 768 weight gradients (three
+//     per decoder layer) run 80 us as four atomically-added slices and ~45 us as one slice per block on 144 CUs
+//     (profiles/r04_gemm_h2_sweep_backward_shapes.txt: the 288-tile gradient, twice the work and never split, takes 47.5 us).
+// Tools build: emage_set_tuning key 5 bit 1024 selects 384, bit 2048 no split-K, bit 4096 round 3's 191 (A/B runs)
+static inline long h2_split_k_tiles() { return (g_h2_variant & 1024) ? 384 : (g_h2_variant & 2048) ? -1 : (g_h2_variant & 4096) ? 191 : 100; }
 static inline bool h2_accumulates_in_place(const GemmArgs& a) {
     return a.res && a.res_is_f32 && a.out_f32 && (const void*)a.res == (const void*)a.out_f32 && a.ldr == a.ldf;
 }

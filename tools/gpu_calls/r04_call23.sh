@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-4 GPU call 23 (the last 2 GPU-minutes): split-K at all?  The backward sweep (profiles/r04_gemm_h2_sweep_backward_shapes.txt) has the 144-tile
 # split-K weight gradient at 80 us while the 288-tile one, twice the work and NOT split, takes 47.5 us.  A/B of the captured step, tools library:
-# key 5 bit 8192 = neutral (191 tiles, as shipped), 2048 = never split, 4096 = split below 100 tiles only
+# key 5 bit 8192 = neutral (191 tiles, as shipped THEN), 2048 = never split, 4096 = split below 100 tiles only (as run; the tree now ships 100 and bit 4096 selects 191)
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04_c23; mkdir -p $O
