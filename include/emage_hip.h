@@ -60,9 +60,6 @@ const char* emage_target_arch(void);
 #ifdef EMAGE_TOOLS
 int emage_set_tuning(int key, int value);
 int emage_h2_set_trace(void* buf);
-/* Experiment (never run on a device yet): a float workspace the split-K launches of this process may use to store their K-slices as partial
- * planes that a reduce kernel adds in slice order, instead of fp32 atomics (emage_set_tuning key 5 bit 16384 switches it on; one stream only). */
-int emage_h2_set_splitk_workspace(void* buf, long floats);
 #endif
 
 /*

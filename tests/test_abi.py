@@ -50,7 +50,7 @@ def test_product_library_has_no_tuning_hooks_and_the_tools_twin_does():
     exports them (and everything the product exports)."""
     import ctypes
     tools_only = _declared(tools=True)
-    assert set(tools_only) == set(_lib.TOOLS_SIGNATURES) == {"emage_set_tuning", "emage_h2_set_trace", "emage_h2_set_splitk_workspace"}
+    assert set(tools_only) == set(_lib.TOOLS_SIGNATURES) == {"emage_set_tuning", "emage_h2_set_trace"}
     product = ctypes.CDLL(_lib.LIB_PATH)
     for name in tools_only:
         assert not hasattr(product, name), f"{name} must not be exported by the product library"
