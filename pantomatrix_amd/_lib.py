@@ -23,7 +23,7 @@ class GemmProblem(C.Structure):
 
 
 # name -> argtypes, exactly the prototypes of include/emage_hip.h
-TOOLS_SIGNATURES = {"emage_set_tuning": [_i, _i], "emage_h2_set_trace": [_p], "emage_h2_set_splitk_workspace": [_p, _l]}      # exported by the tools build only
+TOOLS_SIGNATURES = {"emage_set_tuning": [_i, _i], "emage_h2_set_trace": [_p]}      # exported by the tools build only
 SIGNATURES = {
     "emage_vq_argmin_f32": [_p, _i, _p, _p, _i, _l, _i, _i, _i, _p],
     "emage_argmax_logsoftmax_f32": [_p, _i, _p, _i, _l, _i, _i, _p],

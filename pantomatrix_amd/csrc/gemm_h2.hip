@@ -9,8 +9,6 @@ namespace emage_dev {
 #ifdef EMAGE_TOOLS
 int g_h2_force_config = -1;      // tools build (emage_set_tuning key 4): fixed tile configuration for sweeps
 int g_h2_variant = 0;            // tools build: dispatch-heuristic variant for A/B runs (emage_set_tuning key 5)
-float* g_h2_splitk_ws = nullptr;  // tools build: workspace of the two-pass split-K experiment (emage_h2_set_splitk_workspace)
-long g_h2_splitk_ws_floats = 0;
 unsigned long long* g_h2_trace = nullptr;   // tools build: device buffer of (waves x 512) s_memtime stamps (emage_h2_set_trace)
 #else
 constexpr int g_h2_force_config = -1, g_h2_variant = 0;
@@ -50,21 +48,6 @@ static inline bool h2_accumulates_in_place(const GemmArgs& a) {
     return a.res && a.res_is_f32 && a.out_f32 && (const void*)a.res == (const void*)a.out_f32 && a.ldr == a.ldf;
 }
 
-#ifdef EMAGE_TOOLS
-// two-pass split-K (tools experiment): out[m][n] (+)= sum over slices of plane[s][m][n], added in slice order (a fixed order: bit-reproducible)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int slices, long plane, int ld, float* __restrict__ out, int ldo,
-                                                            int M, int N, int accumulate) {
-    const long total = (long)M * N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long m = i / N;
-        const int n = (int)(i - m * N);
-        float v = accumulate ? out[m * ldo + n] : 0.f;
-        for (int sidx = 0; sidx < slices; ++sidx) v += ws[(long)sidx * plane + m * ld + n];
-        out[m * ldo + n] = v;
-    }
-}
-#endif
-
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false, bool TRACE = false>
 int launch_h2(GemmArgs& a, hipStream_t s) {
     if (a.out_t && a.t_col0 % BN != 0) return EMAGE_EINVAL;      // a tile is either row-major or transposed
@@ -90,23 +73,6 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
             per = (per + 1) & ~1;                      // the register-pipelined loops take K-tiles in pairs
             a.nk_split = per;
             a.ksplit = (nk_all + per - 1) / per;
-#ifdef EMAGE_TOOLS
-            // experiment (emage_set_tuning key 5 bit 16384 + a workspace): the slices store plain partial planes, a reduce kernel adds them
-            const long plane = (long)a.M * a.ldf;
-            if ((g_h2_variant & 16384) && g_h2_splitk_ws && plane * a.ksplit <= g_h2_splitk_ws_floats && plane < (1L << 31)) {
-                float* const dst = a.out_f32;
-                a.res = nullptr;
-                a.cstate = g_h2_splitk_ws;
-                a.ldc = (int)plane;
-                hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
-                int rc = launch_status();
-                if (rc) return rc;
-                const long total = (long)a.M * a.N;
-                const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)g_h2_splitk_ws, a.ksplit, plane, a.ldf, dst, a.ldf, a.M, a.N, accumulate ? 1 : 0);
-                return launch_status();
-            }
-#endif
             if (accumulate) {
                 a.res = nullptr;
             } else {
@@ -272,8 +238,6 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
 
 #ifdef EMAGE_TOOLS
 extern "C" int emage_h2_set_trace(void* buf) { emage_dev::g_h2_trace = (unsigned long long*)buf; return 0; }
-// two-pass split-K experiment: a float workspace of `floats` elements the split-K launches of THIS process may use (single stream only)
-extern "C" int emage_h2_set_splitk_workspace(void* buf, long floats) { emage_dev::g_h2_splitk_ws = (float*)buf; emage_dev::g_h2_splitk_ws_floats = buf ? floats : 0; return 0; }
 #endif
 
 namespace emage_dev {

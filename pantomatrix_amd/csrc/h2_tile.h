@@ -501,17 +501,6 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     if (!is_compute) { if constexpr (TRACE) { if (p.trace && blockIdx.x == 0 && lane == 0) p.trace[wave * 512] = (unsigned long long)tr_n; } __syncthreads(); return; }
     if constexpr (PRE && NLW > 0) wait_vmcnt<0>();
 
-#ifdef EMAGE_TOOLS
-    // tools build, experiment "two-pass split-K" (gemm_h2.hip: launch_h2): slice `split` stores its partial tile with plain stores into its
-    // own plane of a workspace (passed in the otherwise unused `cstate` / `ldc` fields: plane pointer, plane stride in floats); a reduce
-    // kernel adds the planes in slice order.  The product build has neither the branch nor the copy of the argument block.
-    if (p.ksplit > 1 && p.cstate) {
-        GemmArgs q = p;
-        q.out_f32 = p.cstate + (long)split * p.ldc;
-        q.ksplit = 1;
-        h2_tile_epilogue<FM, FN, false, PRE, PM, PP>(q, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r);
-    } else
-#endif
     h2_tile_epilogue<FM, FN, false, PRE, PM, PP>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r);
     if (vt_tile) { __syncthreads(); return; }
     tr();

@@ -56,18 +56,9 @@ def main():
     ap.add_argument("--configs", default="")
     ap.add_argument("--shapes", default="", help="comma-separated substrings of shape names")
     ap.add_argument("--loop", type=int, default=0, help="no sweep: run the first selected shape / config this many times eagerly (profiling)")
-    ap.add_argument("--h2-variant", type=int, default=0, help="emage_set_tuning key 5 (dispatch-heuristic variant: 1024 / 2048 / 4096 = split-K limit 384 / none / 191; "
-                                                              "16384 = two-pass split-K through --splitk-ws-mb)")
-    ap.add_argument("--splitk-ws-mb", type=int, default=0, help="workspace of the two-pass split-K experiment (tools library; with --h2-variant 16384 [+ limit bits])")
     args = ap.parse_args()
     lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
     dev = "cuda"
-    if args.h2_variant:
-        lib.emage_set_tuning(5, args.h2_variant)
-    splitk_ws = None
-    if args.splitk_ws_mb:           # slices of a split-K launch store partial planes here, a reduce kernel adds them in slice order (csrc/gemm_h2.hip, tools only)
-        splitk_ws = torch.empty(args.splitk_ws_mb * 262144, dtype=torch.float32, device=dev)
-        lib.emage_h2_set_splitk_workspace(splitk_ws.data_ptr(), splitk_ws.numel())
     configs = [int(c) for c in args.configs.split(",")] if args.configs else CONFIGS
     want = [s for s in args.shapes.split(",") if s]
     g = torch.Generator().manual_seed(0)
