@@ -56,9 +56,12 @@ def main():
     ap.add_argument("--configs", default="")
     ap.add_argument("--shapes", default="", help="comma-separated substrings of shape names")
     ap.add_argument("--loop", type=int, default=0, help="no sweep: run the first selected shape / config this many times eagerly (profiling)")
+    ap.add_argument("--h2-variant", type=int, default=0, help="emage_set_tuning key 5 (dispatch-heuristic variant; 1024 / 2048 / 4096 = split-K limit 384 / none / 191 instead of 100)")
     args = ap.parse_args()
     lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
     dev = "cuda"
+    if args.h2_variant:
+        lib.emage_set_tuning(5, args.h2_variant)
     configs = [int(c) for c in args.configs.split(",")] if args.configs else CONFIGS
     want = [s for s in args.shapes.split(",") if s]
     g = torch.Generator().manual_seed(0)
