@@ -1292,6 +1292,9 @@ class Trainer:
         fwd._wt_cache, fwd._wt_keep = {}, True            # the parameters move at the END of the step: one set of transposed weight images
         try:
             return self._device_step_body(batch, dropout_masks, random_mask, grad_hook, step_counter, index, latent, masked_motion, speaker_id, seed_mask)
+        except BaseException:
+            fwd._pg_dst, fwd._pg_src, fwd._pg_spans, fwd._pg_bytes = [], [], {}, 0       # a step that died mid-backward: its queued contributions die with it
+            raise
         finally:
             fwd._wt_cache, fwd._wt_keep = {}, False
 
