@@ -277,3 +277,27 @@ def test_operand_scales_are_rederived_when_a_weight_leaves_their_range():
         # invalidate_packed(reset_scales=True): the explicit form for weights replaced behind the module's back
         model.invalidate_packed(reset_scales=True)
         assert model.__dict__["_scale_caches"] == {}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_train_only_operand_set_is_never_handed_to_an_eval_forward(precision):
+    """A training step re-packs the MFMA operands behind every update and leaves out what only the eval-mode forward reads (the WavEncoder
+    convolutions with their BatchNorms folded in): `_engine(train_only=True)`.  Such a set must never serve an eval-mode caller — in fp32
+    precision both forwards ask for the same operand type, so only the flag tells them apart — while a FULL set may serve the training
+    forward; the two keep separate scale caches (the cache is keyed by packing order)."""
+    model, _ = common.product_models(precision=precision)
+    audio, spk, motion, mask = common.window_inputs(1)
+    with fake_ops.installed(), torch.no_grad():
+        lean = model._engine(h2=False, train_only=True)
+        assert lean.train_only and "audio_encoder_face.feat_extractor.1.conv2" not in lean.w and "moton_proj" in lean.w
+        assert model._engine(h2=False, train_only=True) is lean                  # nothing changed: the training forward keeps its set
+        out = model.forward(audio, spk, motion, mask)                            # eval mode: a full set is packed
+        full = model._packed
+        assert full is not lean and not full.train_only and "audio_encoder_face.feat_extractor.1.conv2" in full.w
+        if precision == "fp32":                                                  # same operand type: the full set also serves the training forward
+            assert model._engine(h2=False, train_only=True) is full
+        caches = model.__dict__.get("_scale_caches", {})
+        if precision == "f16x3":
+            assert {k[2] for k in caches} == {False, True}                       # one cache per kind of set
+            assert (str(model.device), lean.dt, True) in caches and (str(model.device), full.dt, False) in caches
+        assert all(torch.isfinite(v).all() for v in out.values() if v is not None)
