@@ -138,19 +138,21 @@ def test_backward_kernels():
     # same sums to summation order; accumulation into existing gradients; ragged row counts
     from pantomatrix_amd.ops import _layernorm_backward
     monkey = ops.FUSED_LAYERNORM_BACKWARD
-    for per_block, rows in ((16, 130), (16, 16), (16, 1), (16, 77), (4, 130), (4, 3), (4, 77)):
-        ops.FUSED_LAYERNORM_BACKWARD = per_block            # (the default is measured, see ops.py; both forms are kept equal all the same)
-        xd, dyd, gd = xs.detach()[:rows].to(DEV), dy[:rows].to(DEV), gamma.detach().to(DEV)
-        dx_old, t_old = torch.empty(rows, c, device=DEV), torch.empty(rows, c, device=DEV)
-        _layernorm_backward(xd, gd, dyd, 1e-5, dx_old, t_old)
-        dx_new, dg_new, db_new = ops.layernorm_backward(xd, gd, dyd)
-        assert torch.equal(dx_new, dx_old), rows
-        assert float((dg_new - ops.col_sum(t_old)).abs().max()) < 1e-5 * max(1.0, float(t_old.abs().sum(0).max())), rows
-        assert float((db_new - ops.col_sum(dyd)).abs().max()) < 1e-5 * max(1.0, float(dyd.abs().sum(0).max())), rows
-        acc_g, acc_b = torch.full((c,), 2.0, device=DEV), torch.full((c,), -1.0, device=DEV)
-        ops.layernorm_backward(xd, gd, dyd, dgamma=acc_g, dbeta=acc_b)
-        assert float((acc_g - 2.0 - dg_new).abs().max()) < 1e-5 and float((acc_b + 1.0 - db_new).abs().max()) < 1e-5, rows
-    ops.FUSED_LAYERNORM_BACKWARD = monkey
+    try:
+        for per_block, rows in ((16, 130), (16, 16), (16, 1), (16, 77), (4, 130), (4, 3), (4, 77)):
+            ops.FUSED_LAYERNORM_BACKWARD = per_block            # (the default is measured, see ops.py; both forms are kept equal all the same)
+            xd, dyd, gd = xs.detach()[:rows].to(DEV), dy[:rows].to(DEV), gamma.detach().to(DEV)
+            dx_old, t_old = torch.empty(rows, c, device=DEV), torch.empty(rows, c, device=DEV)
+            _layernorm_backward(xd, gd, dyd, 1e-5, dx_old, t_old)
+            dx_new, dg_new, db_new = ops.layernorm_backward(xd, gd, dyd)
+            assert torch.equal(dx_new, dx_old), rows
+            assert float((dg_new - ops.col_sum(t_old)).abs().max()) < 1e-5 * max(1.0, float(t_old.abs().sum(0).max())), rows
+            assert float((db_new - ops.col_sum(dyd)).abs().max()) < 1e-5 * max(1.0, float(dyd.abs().sum(0).max())), rows
+            acc_g, acc_b = torch.full((c,), 2.0, device=DEV), torch.full((c,), -1.0, device=DEV)
+            ops.layernorm_backward(xd, gd, dyd, dgamma=acc_g, dbeta=acc_b)
+            assert float((acc_g - 2.0 - dg_new).abs().max()) < 1e-5 and float((acc_b + 1.0 - db_new).abs().max()) < 1e-5, rows
+    finally:
+        ops.FUSED_LAYERNORM_BACKWARD = monkey
     # attention (with probability dropout), Tk != Tq
     b, h, tq, tk, hd = 2, 4, 64, 65, 192
     q = torch.randn(b * tq, h * hd, generator=g)
