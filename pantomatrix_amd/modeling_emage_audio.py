@@ -135,19 +135,37 @@ class _EmageModule(torch.nn.Module):
         step re-packs without a host read-back) — for weights REPLACED other than through this module's `load_state_dict`."""
         self._packed = None
         self._templates = {}
-        self.__dict__["_version_tensors"] = None
         if reset_scales:
             self.__dict__["_scale_caches"] = {}
         return self
 
     def _version_stamp(self):
-        """In-place version counters of every parameter and buffer: what `_engine()` compares with the stamp taken at packing time, so an
-        optimiser step, a BatchNorm-buffer update of a train-mode forward, `p.data.copy_()`, a parent module's `load_state_dict` ... are
-        all followed by a re-pack — in eval mode too (train, `optimizer.step()`, `model.eval(); model(...)`)."""
-        ts = self.__dict__.get("_version_tensors")
-        if ts is None:
-            ts = self.__dict__["_version_tensors"] = list(super().state_dict(keep_vars=True).values())
-        return tuple(t._version for t in ts)
+        """Identity and in-place version counter of every parameter and buffer: what `_engine()` compares with the stamp taken at packing
+        time, so an optimiser step, a BatchNorm-buffer update of a train-mode forward, `p.data.copy_()`, a parent module's
+        `load_state_dict` ... are all followed by a re-pack — in eval mode too (ADVICE round 3: train, `optimizer.step()`, `model.eval();
+        model(...)`).  The stamp reads the CURRENT objects out of each owning module's `_parameters` / `_buffers` dict (a
+        tensor REPLACED after packing — `module.weight = nn.Parameter(...)`, a re-registered buffer — has a new identity and re-packs too);
+        only the list of (dict, key) slots is cached (the module tree is fixed at construction): ~500 dict reads, no `state_dict()` walk."""
+        slots = self.__dict__.get("_version_slots")
+        if slots is None:
+            slots = []
+            for mod in self.modules():
+                slots.extend((mod._parameters, k) for k in mod._parameters)
+                slots.extend((mod._buffers, k) for k in mod._buffers if k not in mod._non_persistent_buffers_set)
+            self.__dict__["_version_slots"] = slots
+        stamp = []
+        for d, k in slots:
+            t = d.get(k)
+            stamp.append((id(t), t._version) if t is not None else (0, 0))
+        return tuple(stamp)
+
+    @staticmethod
+    def bump_versions(tensors):
+        """Advance the version counters of tensors that were updated through raw device pointers (`emage_adam_multi`, a graph replay): the
+        staleness check of `_engine()` then sees the update without anyone having to call `invalidate_packed()`."""
+        ts = [t for t in tensors if torch.is_tensor(t)]
+        if ts:
+            torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
 
     _trainable = False       # EmageAudioModel: train() switches forward() to the differentiable train-mode forward
 
@@ -680,14 +698,19 @@ class EmageVQModel(torch.nn.Module):
         todo = (("lower", lower_index, lower_latent), ("hands", hands_index, hands_latent),
                 ("upper", upper_index, upper_latent), ("face", face_index, face_latent))
         trans = [None]
+        # every part's operand set is packed BEFORE the chains below are entered: a packing is torch arithmetic + launches
+        # of its own and must not run at record time inside a lock-step chain, where only emage ops are deferred
+        engines = {name: getattr(self, f"vq_model_{name}")._engine() for name, index, latent in todo if index is not None or latent is not None}
+        if get_global_motion:
+            self.global_motion._engine()
 
         def part_chain(name, index, latent):
             model = getattr(self, f"vq_model_{name}")
             if index is not None:
-                cx = _Ctx(model._engine())
+                cx = _Ctx(engines[name])
                 parts[name] = model._decode_idx(cx, index, bs, t)
             elif latent is not None:
-                cx = _Ctx(model._engine())
+                cx = _Ctx(engines[name])
                 idx = model._nearest(cx, latent.reshape(m, -1).float().contiguous())
                 parts[name] = model._decode_idx(cx, idx, bs, t)
             else:

@@ -20,6 +20,43 @@ _RECORDER = [None]        # the active `Lockstep` (ops issued inside one of its 
 _TRACE = [None]           # measurement hook (bench.py / tools): an object with tag() -> label of the calling scope, evaluated when an op is
                           # CALLED, and fire(kind, entries, launch) which must call launch() — it brackets every actual launch
 _META = {}                # bookkeeping the next op call carries to the hook (gemm: k_real, the unpadded contraction length)
+LOCKSTEP_CHECK = False    # debug mode of `lockstep()`: while chains are being recorded, any NON-emage torch operator that touches
+                          # the storage of a recorded (= not yet launched) emage output raises — such an op would run at record time, ahead of
+                          # its producer, and read or overwrite uninitialised memory.  Costs a TorchDispatchMode: tests only
+
+
+def _written_args(op, args):
+    """The tensor arguments an emage operator writes (its schema's `Tensor(a!)` annotations)."""
+    out = []
+    for a, v in zip(op.default._schema.arguments, args):
+        if a.alias_info is not None and a.alias_info.is_write and torch.is_tensor(v):
+            out.append(v)
+    return out
+
+
+def _storage_key(t):
+    try:
+        return t.untyped_storage().data_ptr()
+    except Exception:  # noqa: BLE001  (meta / fake tensors)
+        return None
+
+
+class _PendingGuard(torch.utils._python_dispatch.TorchDispatchMode):
+    """`LOCKSTEP_CHECK`: active between the first recorded op of a lockstep and its `run()`."""
+
+    def __init__(self, pending):
+        super().__init__()
+        self.pending = pending
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if self.pending and func.namespace != "emage" and not getattr(func, "is_view", False):
+            import torch.utils._pytree as pytree
+            for v in pytree.tree_leaves((args, kwargs)):
+                if torch.is_tensor(v) and v.numel() and _storage_key(v) in self.pending:
+                    raise RuntimeError(f"ops.lockstep: {func} touches the output of emage::{self.pending[_storage_key(v)]}, which is recorded in a "
+                                       "chain and not launched yet — only emage ops may consume a chain's tensors before the lockstep exits")
+        return func(*args, **kwargs)
 
 
 def _entry(name, op, args):
@@ -69,6 +106,7 @@ class Lockstep:
 
     def __init__(self, enabled=True):
         self.enabled, self.chains, self.cur = bool(enabled), [], None
+        self.pending = {}                 # LOCKSTEP_CHECK: storage pointer -> name of the recorded op that will write it
         self.launches = []                # (kind, count) log of the last run: ("group", n) / ("gemm", 1) / (op name, 1)
         self.groups = []                  # the recorded contractions of every grouped call of the last run (tests: `grouped_launch_count`)
 
@@ -91,6 +129,11 @@ class Lockstep:
         if self.cur is None:
             raise RuntimeError(f"ops.lockstep: emage::{entry[0]} issued outside a chain (it would overtake the recorded launches)")
         self.cur.append(entry)
+        if LOCKSTEP_CHECK:
+            for t in _written_args(entry[1], entry[2]):
+                k = _storage_key(t)
+                if k:
+                    self.pending[k] = entry[0]
 
     @staticmethod
     def _groupable(entry):
@@ -147,11 +190,14 @@ def lockstep(enabled=True):
         ls = Lockstep(enabled)
         _RECORDER[0] = ls
         ok = False
+        guard = _PendingGuard(ls.pending) if LOCKSTEP_CHECK else contextlib.nullcontext()
         try:
-            yield ls
+            with guard:
+                yield ls
             ok = True
         finally:
             _RECORDER[0] = None
+            ls.pending.clear()
             if ok:
                 ls.run()
     return cm()

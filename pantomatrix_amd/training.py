@@ -33,6 +33,11 @@ BN_MOMENTUM = 0.1          # nn.BatchNorm1d default
 DROPOUT_P = 0.1            # PeriodicPositionalEncoding (P:329) and nn.Transformer*Layer defaults
 
 
+def _capturing(device=None):
+    """True while the current stream of `device` is recording a hipGraph (no host read-back, no blocking collective result)."""
+    return bool(torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+
+
 def dropout_mask_count():
     """Masks one train-mode forward consumes: 3 positional encodings, 15 decoder layers x 6, 1 encoder layer x 4."""
     return 3 + 6 * (spec.N_FACE_LAYERS + spec.N_CROSS_LAYERS + 3) + 4
@@ -218,7 +223,7 @@ class TrainForward:
             raise ValueError("the training forward runs in the fp32-storage precisions (f16x3 / fp32)")
         self.model = model
         self.sync_bn, self.group, self._bn_count = sync_bn, group, {}
-        self._clips = {}                # local clip count -> clips of all ranks (sync_bn: exchanged once per `begin_step` / first use)
+        self._clips = {}                # local clip count -> clips of all ranks (sync_bn: exchanged at the first BatchNorm of EVERY eager forward, see `_clip_total`)
         self._bn_log = None             # list collecting (name, mean, var, rows) of a WavEncoder pass that later forwards of the step replay
         # f16x3 precision: the backward contractions run as split-fp16 MFMA on pre-split (EMAGE_H2) operands — gradients pre-scaled by
         # a power of two so that their fp16 planes stay normal (the loss-scaling of mixed-precision training, undone exactly in the
@@ -271,10 +276,19 @@ class TrainForward:
         return rows // b * self._clip_total(b)
 
     def _clip_total(self, b):
+        """Clips of all ranks for a local batch of b clips (sync_bn).  Exchanged — one small all-reduce with a host read-back — at the first
+        BatchNorm of EVERY eager forward that runs the encoders (`__call__` clears the cache; with the shared encoder pass that is once per
+        step), on every rank at the same point of the launch sequence, so the collectives always pair and a rank whose neighbour changed
+        its batch size never divides by a stale count.  Inside a graph capture the host cannot read a device count: the
+        value of the warm-up step is used, and `Trainer.capture` documents the contract that goes with it — every rank replays the batch
+        sizes it captured (a changed batch needs a re-capture on ALL ranks, as the collectives inside the graphs must pair anyway)."""
         if not self.sync_bn:
             return b
         hit = self._clips.get(b)
         if hit is None:
+            if _capturing(self.model.device):
+                raise RuntimeError("TrainForward: the global clip count of a SyncBatchNorm step must be known before a graph capture "
+                                   "(run one eager step with the same batch size first: Trainer.capture does)")
             from . import dist as pdist
             hit = self._clips[b] = pdist.total_over_group(b, device=self.model.device, group=self.group)
         return hit
@@ -956,6 +970,8 @@ class TrainForward:
         if not self._wt_keep:                    # inside a `Trainer` step the weights are those of the step's first forward: keep the images
             self._wt_cache = {}
         new_stats = {} if new_stats is None else new_stats
+        if self.sync_bn and not _capturing(dev):   # the global clip count is exchanged afresh by every eager forward (see `_clip_total`)
+            self._clips.clear()
         masks = _Masks(dropout_masks, dev, rng, lazy=self.lazy_masks)
         b, t, cm = masked_motion.shape
         m = b * t
@@ -1249,6 +1265,7 @@ class Trainer:
         if on_nonfinite not in ("raise", "skip"):
             raise ValueError("on_nonfinite must be 'raise' or 'skip'")
         self.on_nonfinite, self.skipped_steps, self.rescaled = on_nonfinite, 0, 0
+        self.nonfinite_loss_steps = 0                     # steps whose loss was inf / NaN although every gradient was finite (update applied; see `_finish`)
         # share_encoders: the WavEncoder pass of a step is computed (and differentiated) once for its three forwards — see `StepShare`;
         # False = the reference's schedule, three passes (same losses; gradients equal up to fp32 summation order)
         self.share_encoders = bool(share_encoders)
@@ -1274,6 +1291,13 @@ class Trainer:
         if not self.exchange:
             return 1
         return tdist.get_world_size(self.group) if (tdist.is_available() and tdist.is_initialized()) else 1
+
+    def _exchanging(self):
+        """True when the step runs its gradient exchange: a process group exists (and exchange=True) — ALSO at world size 1, like
+        DistributedDataParallel: the four bucket all-reduces then go through the backend (RCCL on one MI355X: the only way to run the
+        exchange on hardware without a multi-GPU node, tests/test_train_forward_gpu.py) and are the identity."""
+        import torch.distributed as tdist
+        return self.exchange and tdist.is_available() and tdist.is_initialized()
 
     def _rng(self, forward_index, step):
         return (self.seed, step, 128 * forward_index)
@@ -1303,7 +1327,7 @@ class Trainer:
         cfg = model.config
         stats, out = {}, {}
         ws = ops.loss_workspace(masked_motion.device)
-        world = self._world()
+        world, exchanging = self._world(), self._exchanging()
         buckets, log = self.buckets, []
         self.exchange_log = log
         learning = self.schedule is None
@@ -1319,7 +1343,7 @@ class Trainer:
             if f == 2:
                 if learning:
                     fwd.touch = {}
-                elif world > 1:
+                elif exchanging:
                     ready = {}
                     for i, pos in self.schedule.items():
                         ready.setdefault(pos, []).append(i)
@@ -1340,12 +1364,12 @@ class Trainer:
                 last[i] = max(last.get(i, -1), pos)
             self.schedule = {i: last.get(i, -1) for i in range(len(buckets.flat))}      # -1: complete before the third backward starts
             fwd.touch = None
-            if world > 1:
+            if exchanging:
                 for i in range(len(buckets.flat)):
                     log.append(("reduce", i, None))
                     buckets.reduce(i)
         grads = fwd.param_grads
-        if world > 1:
+        if exchanging:
             buckets.wait(average=False)                   # the 1 / world of the average is Adam's grad_scale
             log.append(("wait",))
         if grad_hook is not None:
@@ -1414,8 +1438,9 @@ class Trainer:
             self.rescaled += 1
             self.fwd.reset_scales()
             recapture = self._recapture_pending = True
-        if bad or not all(v == v and abs(v) != float("inf") for v in res.values()):
-            self.steps_done -= 1
+        finite = all(v == v and abs(v) != float("inf") for v in res.values())
+        if bad:                                           # the DEVICE skipped the update (Adam's skip word, the same on every rank: it is counted
+            self.steps_done -= 1                          # behind the gradient exchange) — the host only follows that decision
             for st in self.state.values():
                 st["step"] = self.steps_done
             msg = (f"training step {self.steps_done + 1}: {bad} non-finite gradient words (losses {res}) — the update was skipped on the device, "
@@ -1427,6 +1452,14 @@ class Trainer:
             self.skipped_steps += 1
             self.fwd.grad_scale *= 0.5
             recapture = self._recapture_pending = True
+        elif not finite:
+            # a non-finite LOSS whose gradients were all finite: the device applied the update — the health word decides, and
+            # it is the only thing all ranks share (losses are rank-local).  Nothing is rolled back, re-scaled or re-captured: host and device
+            # step counts stay equal, and no rank starts a warm-up step (with collectives) the others do not run.
+            self.nonfinite_loss_steps += 1
+            if self.on_nonfinite == "raise":
+                raise FloatingPointError(f"training step {self.steps_done}: non-finite loss {res} with finite gradients — the update WAS applied "
+                                         "(the device's health word counts gradient words only); optimiser state and step counts are consistent")
         return res, recapture
 
     def step(self, batch, iteration=0, dropout_masks=None, random_mask=None, grad_hook=None):
@@ -1434,10 +1467,19 @@ class Trainer:
         reference's train_val_fn (T:132) and unused: the caller computes the mask ratio and passes `random_mask` (T:163-165)."""
         with self._deferred_range_check():                # the operand-scale flags are read HERE with the losses, not at packing time
             out, ws = self._device_step(batch, dropout_masks, random_mask, grad_hook)
-        res, _ = self._finish(out, ws)
-        self.fwd.model.invalidate_packed()                # the MFMA operand copies are rebuilt from the updated parameters
-        self.fwd._pcache = None
+        try:
+            res, _ = self._finish(out, ws)
+        finally:
+            self._parameters_moved()                      # the MFMA operand copies are rebuilt from the updated parameters
         return res
+
+    def _parameters_moved(self):
+        """`emage_adam_multi` (and a graph replay) update the parameters through raw device pointers: advance their version counters so
+        the staleness stamp of `_engine()` sees it (correctness no longer hangs on the call below), and drop the packed set."""
+        model = self.fwd.model
+        model.bump_versions([p for p in model.parameters() if p.requires_grad])
+        model.invalidate_packed()
+        self.fwd._pcache = None
 
     # ---- the step as ONE hipGraph -------------------------------------------------------------------------------------------------
     def capture(self, batch, random_mask, dropout_masks=None):
@@ -1447,10 +1489,20 @@ class Trainer:
         become the graph's input buffers (refill them in place between replays), the parameters its state.  `replay()` then runs a
         step at device speed instead of the ~10^4 Python-level launches of `step()`.  Both fp32-storage precisions: in f16x3 the
         split-fp16 operand scales are the ones chosen by the warm-up step's packing (a re-packing with known scales is a pure sequence
-        of launches).  Needs a single process (no collective inside a capture).  One eager warm-up step is run and undone."""
+        of launches).  One eager warm-up step is run and undone.
+
+        Multi-process runs (round 5): the step is captured WITH its collectives — the four bucket all-reduces (started mid-backward on the
+        backend's own stream: they become parallel branches of the graph), SyncBatchNorm's all-gathers and small all-reduces — when the
+        backend is "nccl" (= RCCL, whose kernels are stream-capturable), so a multi-rank step is the same graph replay as a single-rank
+        one instead of ~10^4 eager launches.  Contract: every rank calls `capture()` (its warm-up step runs the collectives eagerly) and
+        then `replay()` the same number of times, with the batch sizes it captured (SyncBatchNorm's global count is the warm-up step's)."""
         fwd, model = self.fwd, self.fwd.model
-        if fwd.sync_bn or self._world() > 1:
-            raise RuntimeError("Trainer.capture: needs sync_bn=False and a single process (no collective inside a captured graph)")
+        if fwd.sync_bn or self._exchanging():
+            import torch.distributed as tdist
+            backend = tdist.get_backend(self.group) if (tdist.is_available() and tdist.is_initialized()) else None
+            if backend is not None and str(backend) != "nccl":
+                raise RuntimeError(f"Trainer.capture: the step's collectives can only be captured with the nccl (RCCL) backend, not {backend!r}; "
+                                   "use Trainer.step")
         dev = model.device
         for name, t in list(batch.items()) + [("random_mask", random_mask)]:
             if not (torch.is_tensor(t) and t.is_cuda and t.device == dev and t.dtype == torch.float32):
@@ -1511,7 +1563,7 @@ class Trainer:
         try:
             res, recapture = self._finish(self._graph_out, self._graph_ws)
         finally:
-            model.invalidate_packed()                     # a replay moves the parameters without touching their version counters: an eval
-        if recapture:                                     # forward behind it must re-pack (and never reads the graph's operand set)
+            self._parameters_moved()                      # a replay moves the parameters through raw pointers: an eval forward behind it
+        if recapture:                                     # must re-pack (and never reads the graph's operand set)
             self.capture(*self._graph_inputs)
         return res

@@ -1,0 +1,125 @@
+"""Worker of tests/test_rccl_gpu.py (its own process: a wedged collective must not take the GPU suite with it).
+
+Joins a WORLD_SIZE = 1 process group on the `nccl` backend (= RCCL on ROCm) on the one MI355X of the box, so that every collective of the
+training exchange — the four bucket all-reduces, SyncBatchNorm's all-gathers and small all-reduces (train_emage_audio.py:214, 248-251) —
+goes through RCCL on the device, and runs
+
+  1. `Trainer(sync_bn=True, exchange=True).step` (eager) against the REAL reference step's golden (tests/golden/train_step_b2.npz),
+     counting the collectives the backend was asked for;
+  2. `Trainer.capture` + `replay` of the same step WITH its collectives inside the hipGraph, against the same golden.
+
+Prints one JSON line: {"eager": {...}, "captured": {...}}; a stage that raised carries {"error": "<type>: <text>"} instead."""
+import json
+import os
+import socket
+import sys
+import time
+import traceback
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def main():
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    import torch
+    import torch.distributed as tdist
+
+    import common
+    import train_common as tc
+    import test_train_forward_gpu as ttf
+    from pantomatrix_amd import dist as pd
+    from pantomatrix_amd import training
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    res = {"torch": torch.__version__, "hip": torch.version.hip}
+    assert pd.init("nccl", device=dev) is not None
+    res["backend"], res["world"] = str(tdist.get_backend()), tdist.get_world_size()
+    try:
+        res["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:  # noqa: BLE001
+        res["rccl_version"] = f"unknown ({e})"
+
+    g = np.load(os.path.join(HERE, "golden", "train_step_b2.npz"))
+    batch, _, masks, random_mask, _ = tc.oracle_step(int(g["seed"]), int(g["iteration"]))
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    masks = [[m.to(dev).contiguous() for m in fm] for fm in masks]
+    random_mask = random_mask.to(dev)
+
+    calls = {"all_gather": 0, "all_reduce_small": 0, "all_reduce_bucket": 0, "bucket_bytes": 0}
+    real_gather, real_reduce = tdist.all_gather_into_tensor, tdist.all_reduce
+
+    def count_gather(*a, **k):
+        calls["all_gather"] += 1
+        return real_gather(*a, **k)
+
+    def count_reduce(t, *a, **k):
+        if t.numel() > 1_000_000:
+            calls["all_reduce_bucket"] += 1
+            calls["bucket_bytes"] += t.numel() * t.element_size()
+        else:
+            calls["all_reduce_small"] += 1
+        assert t.is_cuda, "the exchange must run on the device (RCCL), not on a host tensor"
+        return real_reduce(t, *a, **k)
+
+    # ---- 1. the eager step through RCCL ----
+    try:
+        model, vq = common.product_models(precision="f16x3", device=dev)
+        before = {k: v.clone() for k, v in model._flat_params().items()}
+        trainer = training.Trainer(model, vq, sync_bn=True, exchange=True)
+        seen = {}
+        tdist.all_gather_into_tensor, tdist.all_reduce = count_gather, count_reduce
+        try:
+            t0 = time.time()
+            losses = trainer.step(batch, int(g["iteration"]), masks, random_mask, grad_hook=lambda gr: seen.update({k: float(v.norm()) for k, v in gr.items()}))
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+        finally:
+            tdist.all_gather_into_tensor, tdist.all_reduce = real_gather, real_reduce
+        worst = ttf._check_step_against(g, losses, model._flat_params(), before, grads=seen, what="eager step over RCCL")
+        res["eager"] = dict(ok=True, collectives=dict(calls), worst=worst, loss_all=losses["all"], first_step_s=round(dt, 2),
+                            exchange_log=[e[0] for e in trainer.exchange_log])
+    except Exception as e:  # noqa: BLE001
+        res["eager"] = dict(error=f"{type(e).__name__}: {e}", trace=traceback.format_exc()[-1500:])
+
+    # ---- 2. the step captured WITH its collectives ----
+    try:
+        model, vq = common.product_models(precision="f16x3", device=dev)
+        before = {k: v.clone() for k, v in model._flat_params().items()}
+        trainer = training.Trainer(model, vq, sync_bn=True, exchange=True)
+        trainer.capture(batch, random_mask, masks)
+        for k, v in before.items():
+            assert torch.equal(model._flat_params()[k], v), k
+        losses = trainer.replay()
+        worst = ttf._check_step_against(g, losses, model._flat_params(), before, what="captured step with RCCL collectives inside the graph")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            trainer._graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        res["captured"] = dict(ok=True, worst=worst, loss_all=losses["all"], steps_done=trainer.steps_done, replay_ms=round(e0.elapsed_time(e1) / 3, 2))
+    except Exception as e:  # noqa: BLE001
+        res["captured"] = dict(error=f"{type(e).__name__}: {e}", trace=traceback.format_exc()[-1500:])
+    print("RCCL_WORKER " + json.dumps(res, default=float), flush=True)
+    try:
+        tdist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+
+
+if __name__ == "__main__":
+    main()
