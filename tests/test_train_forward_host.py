@@ -203,9 +203,11 @@ def test_trainer_step_host_logic(golden_dir):
 
 
 def test_capture_preconditions():
-    """Trainer.capture refuses what cannot be captured (the SyncBatchNorm exchange: a collective inside a graph)."""
+    """Trainer.capture refuses what cannot be captured: inputs that are not device buffers (round 5: the SyncBatchNorm exchange and the
+    gradient all-reduces ARE captured when the backend is RCCL — tests/test_rccl_gpu.py; a gloo group is refused —
+    tests/test_round5_host.py::test_single_rank_process_group_runs_the_exchange)."""
     model, vq = common.product_models(precision="fp32")
-    with pytest.raises(RuntimeError, match="sync_bn"):
+    with pytest.raises(RuntimeError, match="must be a float32 tensor on"):
         training.Trainer(model, vq, sync_bn=True).capture({}, None)
     with pytest.raises(ValueError, match="fp32-storage"):
         training.TrainForward(common.product_models(precision="bf16")[0])
