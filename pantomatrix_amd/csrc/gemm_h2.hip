@@ -27,11 +27,12 @@ __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) vo
     const int nblk = p.tiles_m * p.tiles_n;
     const int split = p.ksplit > 1 ? (int)blockIdx.x / nblk : 0;
     int bid = (int)blockIdx.x - split * nblk;
-    {
+    if (!EMAGE_DBG(p, 32)) {     // tools (emage_set_tuning key 1 bit 32, tools/prof_traffic_calib.py): dispatch order = tile order, no XCD remap
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    if (EMAGE_DBG(p, 64)) { tile_m = bid % p.tiles_m; tile_n = bid / p.tiles_m; }      // tools: an XCD's run walks M first (it owns a slice of N: A re-fetched per XCD, W once)
     gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE>(p, tile_m * BM, tile_n * BN, smem, split);
 }
 

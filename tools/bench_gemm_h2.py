@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--shapes", default="", help="comma-separated substrings of shape names")
     ap.add_argument("--loop", type=int, default=0, help="no sweep: run the first selected shape / config this many times eagerly (profiling)")
     ap.add_argument("--h2-variant", type=int, default=0, help="emage_set_tuning key 5 (dispatch-heuristic variant; 1024 / 2048 / 4096 = split-K limit 384 / none / 191 instead of 100)")
+    ap.add_argument("--dbg", type=int, default=0, help="emage_set_tuning key 1 for the EMAGE_H2 runs (32 = no XCD remap, 64 = an XCD's run walks M first)")
     args = ap.parse_args()
     lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
     dev = "cuda"
@@ -106,6 +107,7 @@ def main():
         def run(cfg):
             h2 = cfg is not None
             lib.emage_set_tuning(4, cfg if h2 else -1)
+            lib.emage_set_tuning(1, args.dbg if h2 else 0)
             out = None if ex.get("f32only") else torch.zeros(m, ldo, device=dev)
             out_f = torch.zeros(m, ncol, device=dev) if (res is not None or ex.get("f32only")) else None
             out_t = torch.zeros(nb, n - vt0, ops.round_up(lout, 32), device=dev) if vt0 else None
