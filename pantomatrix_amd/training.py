@@ -275,10 +275,16 @@ class TrainForward:
         of a device count per BatchNorm."""
         return rows // b * self._clip_total(b)
 
+    def begin_step(self):
+        """Start of an optimisation step (`Trainer._device_step`): outside a graph capture the global clip count of SyncBatchNorm is
+        forgotten, so the step's first BatchNorm exchanges it afresh (`_clip_total`)."""
+        if self.sync_bn and not _capturing(self.model.device):
+            self._clips.clear()
+
     def _clip_total(self, b):
         """Clips of all ranks for a local batch of b clips (sync_bn).  Exchanged — one small all-reduce with a host read-back — at the first
-        BatchNorm of EVERY eager forward that runs the encoders (`__call__` clears the cache; with the shared encoder pass that is once per
-        step), on every rank at the same point of the launch sequence, so the collectives always pair and a rank whose neighbour changed
+        BatchNorm of EVERY eager step (`begin_step`; of every eager forward outside a step: `__call__`) — with the shared encoder pass that is
+        once per step —, on every rank at the same point of the launch sequence, so the collectives always pair and a rank whose neighbour changed
         its batch size never divides by a stale count.  Inside a graph capture the host cannot read a device count: the
         value of the warm-up step is used, and `Trainer.capture` documents the contract that goes with it — every rank replays the batch
         sizes it captured (a changed batch needs a re-capture on ALL ranks, as the collectives inside the graphs must pair anyway)."""
@@ -970,8 +976,8 @@ class TrainForward:
         if not self._wt_keep:                    # inside a `Trainer` step the weights are those of the step's first forward: keep the images
             self._wt_cache = {}
         new_stats = {} if new_stats is None else new_stats
-        if self.sync_bn and not _capturing(dev):   # the global clip count is exchanged afresh by every eager forward (see `_clip_total`)
-            self._clips.clear()
+        if self.sync_bn and share is None and not _capturing(dev):      # a forward outside a `Trainer` step (the class API): the global clip
+            self._clips.clear()                                         # count is exchanged afresh (see `_clip_total`; a step: `begin_step`)
         masks = _Masks(dropout_masks, dev, rng, lazy=self.lazy_masks)
         b, t, cm = masked_motion.shape
         m = b * t
@@ -1313,6 +1319,7 @@ class Trainer:
         seed_mask = torch.ones_like(masked_motion)
         seed_mask[:, :cfg.seed_frames] = 0
         fwd.param_grads = {}
+        fwd.begin_step()
         fwd._wt_cache, fwd._wt_keep = {}, True            # the parameters move at the END of the step: one set of transposed weight images
         try:
             return self._device_step_body(batch, dropout_masks, random_mask, grad_hook, step_counter, index, latent, masked_motion, speaker_id, seed_mask)

@@ -32,7 +32,7 @@ def test_eager_step_exchanges_through_rccl_and_matches_the_reference(rccl_result
     # the collectives of ONE step with the shared encoder pass (the counts tests/test_dist_cpu.py pins on two gloo ranks)
     c = e["collectives"]
     assert (c["all_gather"], c["all_reduce_small"], c["all_reduce_bucket"]) == (12, 13, 4), c
-    assert c["bucket_bytes"] > 550_000_000, c                    # the 555 MB of fp32 gradients went through RCCL
+    assert c["bucket_bytes"] > 500_000_000, c                    # the fp32 gradients of every parameter the forward uses (508 MB) went through RCCL
     assert e["exchange_log"].count("reduce") == 4 and e["exchange_log"][-1] == "wait"
     print("eager step over RCCL:", json.dumps(e))
 
