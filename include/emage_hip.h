@@ -130,6 +130,23 @@ int emage_gemm(int dtype, const void* A, int lda, const void* W, const float* bi
                float a_scale, float w_scale, void* stream);
 
 /*
+ * emage_gemm with a caller-owned WORKSPACE (round 5; the weight-gradient contractions of the training step, train_emage_audio.py:176
+ * `loss.backward()`): same arguments, meaning and validation as emage_gemm, plus `workspace` — device memory, 16-byte aligned,
+ * `workspace_bytes` long (NULL: exactly emage_gemm).  EMAGE_H2, bare contractions (only out_f32, optionally accumulating: res == out_f32) with
+ * few tiles and K >= 2048: the contraction is cut into as many K-slices as fill the chip's block slots once; every slice stores its partial
+ * tile as a plane of the workspace (plain stores) and a second launch adds the planes IN SLICE ORDER onto the destination — a fixed
+ * association: the result is the same bits on every run, which the fp32-atomic form of emage_gemm is not.  The number of slices is limited
+ * by the workspace (M * round_up(N, 4) * 4 bytes per slice); below two slices the call falls back to emage_gemm's behaviour.  The library
+ * neither allocates nor keeps the workspace; its contents are scratch after the call.  Other dtypes / shapes ignore it.
+ */
+int emage_gemm_ws(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
+                  const void* res, int ldr, int res_is_f32, int res_first,
+                  void* out, int ldo, int n_store, float* out_f32, int ldf,
+                  void* out_t, int t_col0, int t_rows, int t_ld,
+                  int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
+                  float a_scale, float w_scale, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Several INDEPENDENT emage_gemm problems in as few launches as possible — the part-wise stacks of the model run the same shapes on
  * different weights side by side: the four VQ-VAE part decoders (M:126-193 -> P:237-261), the three refinement decoder layers and
  * their heads (M:248-263, 320-330), `motion2latent_{upper,hands,lower}.fc2` (M:315-317), the two `bodyhints_*` MLPs (M:232-233).

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 TOOLS_LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip_tools.so")   # -DEMAGE_TOOLS twin: every tile configuration + emage_set_tuning
 
 F32, BF16, F16X3, H2 = 0, 1, 2, 3
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -30,6 +30,8 @@ SIGNATURES = {
     "emage_gather_rows": [_p, _p, _i, _l, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "emage_gemm": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i,
                    _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p],
+    "emage_gemm_ws": [_i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i,
+                      _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, C.c_size_t, _p],
     "emage_gemm_grouped": [_i, C.POINTER(GemmProblem), _i, _p],
     "emage_gemm_grouped_launches": [_i, C.POINTER(GemmProblem), _i],
     "emage_wav_conv_in": [_i, _p, _l, _i, _i, _l, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

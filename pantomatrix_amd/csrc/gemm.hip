@@ -344,7 +344,7 @@ int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, con
     a.t_col0 = out_t ? t_col0 : N; a.t_rows = t_rows > 0 ? t_rows : 1; a.t_ld = t_ld;
     a.tiles_m = a.tiles_n = 0;
     a.dbg = g_debug_skip;
-    a.trace = nullptr; a.cstate = nullptr; a.ldc = 0; a.ksplit = 1; a.nk_split = 0;
+    a.trace = nullptr; a.cstate = nullptr; a.ldc = 0; a.ksplit = 1; a.nk_split = 0; a.ws = nullptr; a.ws_plane = 0; a.ldws = 0;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
     const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2;
     a.a_scale = split ? a_scale : 1.f;
@@ -369,6 +369,26 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
     const int rc = make_args(a, dtype, A, lda, W, bias, slope, res, ldr, res_is_f32, res_first, out, ldo, n_store, out_f32, ldf, out_t, t_col0, t_rows, t_ld,
                              M, N, Cp, taps, stride, pad, Lin, Lout, a_scale, w_scale);
     if (rc) return rc;
+    return dispatch_one(dtype, a, (hipStream_t)stream);
+}
+
+// emage_gemm with a caller-owned workspace: a split-K contraction (EMAGE_H2: bare weight-gradient shapes, see gemm_h2.hip) stores its
+// K-slices' partial tiles as planes of the workspace and sums them in slice order with a second launch — no atomics, bit-reproducible.
+extern "C" int emage_gemm_ws(int dtype, const void* A, int lda, const void* W, const float* bias, const float* slope,
+                             const void* res, int ldr, int res_is_f32, int res_first,
+                             void* out, int ldo, int n_store, float* out_f32, int ldf,
+                             void* out_t, int t_col0, int t_rows, int t_ld,
+                             int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
+                             float a_scale, float w_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    GemmArgs a;
+    const int rc = make_args(a, dtype, A, lda, W, bias, slope, res, ldr, res_is_f32, res_first, out, ldo, n_store, out_f32, ldf, out_t, t_col0, t_rows, t_ld,
+                             M, N, Cp, taps, stride, pad, Lin, Lout, a_scale, w_scale);
+    if (rc) return rc;
+    if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 16)) return EMAGE_EINVAL;
+    if (workspace && dtype == EMAGE_H2) {
+        a.ws = (float*)workspace;
+        a.ws_plane = (long)(workspace_bytes / sizeof(float));       // the dispatch turns the capacity (in floats) into the plane stride it uses
+    }
     return dispatch_one(dtype, a, (hipStream_t)stream);
 }
 

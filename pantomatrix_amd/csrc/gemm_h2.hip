@@ -49,6 +49,39 @@ static inline bool h2_accumulates_in_place(const GemmArgs& a) {
     return a.res && a.res_is_f32 && a.out_f32 && (const void*)a.res == (const void*)a.out_f32 && a.ldr == a.ldf;
 }
 
+// second pass of a workspace split-K: out[m][n] (+)= plane_0[m][n] + plane_1[m][n] + ... in slice order — a fixed association, so the
+// result is the same bits on every run (the atomic form adds the slices in arrival order).  4 columns per thread.
+__global__ __launch_bounds__(256) void h2_splitk_reduce_kernel(const float* __restrict__ ws, long plane, int ldws, int nslices,
+                                                               float* __restrict__ out, int ldf, int M, int N, int accumulate) {
+    const int n4 = (N + 3) >> 2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)M * n4) return;
+    const int m = (int)(t / n4), n = (int)(t - (long)m * n4) << 2;
+    const bool vec = n + 4 <= N && (ldf & 3) == 0 && (((uintptr_t)out & 15) == 0);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float* dst = out + (long)m * ldf + n;
+    if (accumulate) {
+        if (vec) { const float4 q = *(const float4*)dst; v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+        else { for (int e = 0; e < 4; ++e) if (n + e < N) v[e] = dst[e]; }
+    }
+    const float* src = ws + (long)m * ldws + n;          // ldws % 4 == 0 and the planes are 16-byte aligned: whole float4s (columns >= N hold zeros or junk, never stored)
+    for (int s = 0; s < nslices; ++s) {
+        const float4 q = *(const float4*)(src + (long)s * plane);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+    }
+    if (vec) *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+    else { for (int e = 0; e < 4; ++e) if (n + e < N) dst[e] = v[e]; }
+}
+
+// block slots of the chip for a tile configuration (LDS-bound residency x CUs): what a split-K launch should fill.  256 CUs (MI355X); the
+// count only steers how many K-slices are cut, never correctness
+template <int BM, int BN, int NS, int THREADS>
+constexpr int h2_block_slots() {
+    constexpr int by_lds = (160 * 1024) / h2_smem_bytes<BM, BN, NS>();
+    constexpr int by_waves = 32 / (THREADS / 64);
+    return 256 * (by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves);
+}
+
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false, bool TRACE = false>
 int launch_h2(GemmArgs& a, hipStream_t s) {
     if (a.out_t && a.t_col0 % BN != 0) return EMAGE_EINVAL;      // a tile is either row-major or transposed
@@ -64,7 +97,38 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
     // res == out_f32 (fp32, same pitch): "out_f32 += contraction" — a weight gradient accumulated straight into the parameter's gradient.
     // One slice: the epilogue's residual add does it in place.  Split-K: the atomics land on the existing contents (no clearing, no residual)
     const bool accumulate = h2_accumulates_in_place(a);
-    if (a.taps == 1 && !a.out && !a.out_t && (!a.res || accumulate) && !a.bias && !a.slope && a.out_f32 && tiles <= h2_split_k_tiles() && nk_all >= 64) {
+    const bool bare = a.taps == 1 && !a.out && !a.out_t && (!a.res || accumulate) && !a.bias && !a.slope && a.out_f32 && nk_all >= 64;
+    float* const ws = a.ws;
+    const long ws_floats = a.ws_plane;                 // emage_gemm_ws: capacity of the workspace in floats (gemm.hip)
+    a.ws = nullptr; a.ws_plane = 0; a.ldws = 0;
+    bool reduce = false;
+    if (bare && ws && !(g_h2_variant & 16384)) {      // tools A/B: bit 16384 = ignore the workspace (the atomic form)
+        // two-pass split-K (emage_gemm_ws): as many K-slices as fill the chip's block slots ONCE, each slice >= 16 K-tiles, partial tiles as
+        // planes of the workspace.  Cheap enough (plain stores + one streaming pass) to use up to twice the tile count of the atomic form
+        constexpr int SLOTS = h2_block_slots<BM, BN, NS, (WM * WN + NLW) * 64>();
+        const int ldws = (a.N + 3) & ~3;
+        const long plane = ((long)a.M * ldws + 3) & ~3L;
+        int want = (int)(SLOTS / tiles);
+        const int most = nk_all / 16;
+        if (want > most) want = most;
+        if (want > 16) want = 16;
+        if (plane > 0 && (long)want * plane > ws_floats) want = (int)(ws_floats / plane);
+        const long most_tiles = (g_h2_variant & 8192) ? 191 : SLOTS / 2;       // tools A/B: bit 8192 = two-pass below 192 tiles only
+        if (want > 1 && tiles <= most_tiles) {
+            int per = (nk_all + want - 1) / want;
+            per = (per + 1) & ~1;
+            a.nk_split = per;
+            a.ksplit = (nk_all + per - 1) / per;
+            if (a.ksplit > 1) {
+                a.ws = ws; a.ws_plane = plane; a.ldws = ldws;
+                a.res = nullptr;                       // an accumulating contraction: the reduce pass adds onto the destination
+                reduce = true;
+            } else {
+                a.ksplit = 1;
+            }
+        }
+    }
+    if (!reduce && bare && tiles <= h2_split_k_tiles()) {     // no workspace (emage_gemm), or one too small for two slices: K-slices met by fp32 atomics
         int want = (int)((512 + tiles - 1) / tiles);
         const int most = nk_all / 16;                  // >= 16 K-tiles (512 k) per slice
         if (want > most) want = most;
@@ -81,6 +145,15 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
                 if (e != hipSuccess) return (int)e;
             }
         }
+    }
+    if (reduce) {
+        hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
+        const int rc = launch_status();
+        if (rc) return rc;
+        const long quads = (long)a.M * ((a.N + 3) >> 2);
+        hipLaunchKernelGGL(h2_splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float*)a.ws, a.ws_plane, a.ldws, a.ksplit,
+                           a.out_f32, a.ldf, a.M, a.N, accumulate ? 1 : 0);
+        return launch_status();
     }
     hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
     return launch_status();

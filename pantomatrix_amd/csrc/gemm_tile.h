@@ -23,7 +23,9 @@ struct GemmArgs {
     int dbg;
     float a_scale, o_scale;   // split-f16 mode: A is multiplied by a_scale before the hi/lo split, accumulators by o_scale after the K-loop
     float* cstate; int ldc;   // EPI_LSTM: the (M, N/4) cell state, updated in place
-    int ksplit, nk_split;        // EMAGE_H2 split-K (gemm_h2.hip): > 1 K-slices of nk_split K-tiles each, partial tiles atomically added into out_f32
+    int ksplit, nk_split;        // EMAGE_H2 split-K (gemm_h2.hip): > 1 K-slices of nk_split K-tiles each; partial tiles atomically added into out_f32,
+    float* ws; long ws_plane; int ldws;   // ... or (ws != NULL, emage_gemm_ws) stored as plane `slice` of the workspace — (M, ldws) fp32 each, ws_plane
+                                 // elements apart — and summed in slice order by a second launch (deterministic)
     unsigned long long* trace;   // tools builds: per-wave s_memtime stamps of one block (h2_tile.h TRACE), else NULL
 };
 

@@ -33,7 +33,7 @@ template <int BM, int BN, int NS> constexpr int h2_smem_bytes() { return NS * (B
 // (fr, fg) holds row mw + 16 i + fr; V^T tiles (un-swapped): lane holds rows mw + 16 i + 4 fg + r of one column.
 template <int FM, int FN, bool NAT, bool PRE, int PM, int PP>
 __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)[FM][FN], const int mw, const int nw, const int fr, const int fg,
-                                                 const bool vt_tile, const float (&pre_r)[PM][PP][8]) {
+                                                 const bool vt_tile, const float (&pre_r)[PM][PP][8], const int split = 0) {
     constexpr int FP = NAT ? 0 : FN / 2;
     constexpr bool LONE = !NAT && (FN & 1) != 0;
     constexpr int NLONE = NAT ? FN : (LONE ? 1 : 0);          // trailing fragments handled 4 columns at a time
@@ -84,7 +84,11 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
     // ---- row-major epilogue.  Lane (fr, fg): row m0 + wm*WTM + 16 i + fr; fragment pair jp -> 8 consecutive columns
     // n0 + wn*WTN + jp*32 + fg*8 + e (e < 4 from acc[i][2jp], e >= 4 from acc[i][2jp+1]); lone fragment -> 4 columns ----
     const int n_lim = ncol_n > p.n_store ? ncol_n : p.n_store;   // columns any store may touch (`out` zero-fills [N, n_store))
-    const bool f32_vec = p.out_f32 && (p.ldf % 4 == 0) && (((uintptr_t)p.out_f32 & 15) == 0);
+    // split-K with a workspace (emage_gemm_ws): this slice's partial tile goes to ITS plane with plain stores — block-uniform scalars
+    const bool to_plane = p.ksplit > 1 && p.ws != nullptr;
+    float* __restrict__ of32 = to_plane ? p.ws + (long)split * p.ws_plane : p.out_f32;
+    const int ldf = to_plane ? p.ldws : p.ldf;
+    const bool f32_vec = of32 && (ldf % 4 == 0) && (((uintptr_t)of32 & 15) == 0);
     auto finish = [&](auto wc, const int m, const int n, float (&x)[decltype(wc)::value], const float (&rpre)[decltype(wc)::value], const bool have_pre) {
         // x: accumulators (already scaled) of W consecutive columns n.. of row m -> bias, residual, activation, stores
         constexpr int W = decltype(wc)::value;
@@ -142,9 +146,9 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
             if constexpr (W == 8) h2_store8(out + (long)m * p.ldo + n, v);
             else h2_store4(out + (long)m * p.ldo + n, n, v);
         }
-        if (p.out_f32 && n < ncol_n) {
-            float* dst = p.out_f32 + (long)m * p.ldf + n;
-            if (p.ksplit > 1) {                       // partial sums of the K-slices meet in memory (the destination was cleared by the host call)
+        if (of32 && n < ncol_n) {
+            float* dst = of32 + (long)m * ldf + n;
+            if (p.ksplit > 1 && !to_plane) {          // partial sums of the K-slices meet in memory (the destination was cleared by the host call)
 #pragma unroll
                 for (int e = 0; e < W; ++e)
                     if (n + e < ncol_n) __hip_atomic_fetch_add(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -501,7 +505,7 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     if (!is_compute) { if constexpr (TRACE) { if (p.trace && blockIdx.x == 0 && lane == 0) p.trace[wave * 512] = (unsigned long long)tr_n; } __syncthreads(); return; }
     if constexpr (PRE && NLW > 0) wait_vmcnt<0>();
 
-    h2_tile_epilogue<FM, FN, false, PRE, PM, PP>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r);
+    h2_tile_epilogue<FM, FN, false, PRE, PM, PP>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r, split);
     if (vt_tile) { __syncthreads(); return; }
     tr();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

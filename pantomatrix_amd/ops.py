@@ -407,6 +407,18 @@ def _gemm(dtype, *args):
                                  f["M"], f["N"], f["Cp"], f["taps"], f["stride"], f["pad"], f["Lin"], f["Lout"], f["a_scale"], f["w_scale"], _stream()), "gemm")
 
 
+@_op("gemm_ws", "(int dtype, Tensor a, Tensor w, Tensor? bias, Tensor? slope, Tensor? res, Tensor(a!)? out, Tensor(b!)? out_f32, "
+                "Tensor(c!)? out_t, int n, int cp, int n_store, int t_col0, int t_rows, bool res_first, int taps, int stride, int pad, "
+                "int lin, int lout, int m, float w_scale, float a_scale, bool res_h2, Tensor(d!) workspace) -> ()")
+def _gemm_ws(dtype, *args):
+    ws = args[-1]
+    f = _gemm_fields(dtype, *args[:-1])
+    check(_lib.load().emage_gemm_ws(dtype, f["A"], f["lda"], f["W"], f["bias"], f["slope"], f["res"], f["ldr"], f["res_is_f32"], f["res_first"],
+                                    f["out"], f["ldo"], f["n_store"], f["out_f32"], f["ldf"], f["out_t"], f["t_col0"], f["t_rows"], f["t_ld"],
+                                    f["M"], f["N"], f["Cp"], f["taps"], f["stride"], f["pad"], f["Lin"], f["Lout"], f["a_scale"], f["w_scale"],
+                                    _ptr(ws), ws.numel() * ws.element_size(), _stream()), "gemm_ws")
+
+
 # Descriptor-table operator: `tensors` lists every tensor the problems touch (dispatch key, aliasing: they may be written), `desc` holds
 # per problem the 26 integer words of `emage_gemm_problem` in field order (device addresses first), `scales` its (a_scale, w_scale).
 _GEMM_PROBLEM_INTS = ("A", "W", "bias", "slope", "res", "out", "out_f32", "out_t", "lda", "ldr", "res_is_f32", "res_first", "ldo", "n_store", "ldf",
@@ -472,17 +484,24 @@ def gemm_grouped(dtype, problems):
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None, w_scale=1.0, a_scale=None, res_h2=False):
+         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None):
     """See include/emage_hip.h:emage_gemm.  `a` (rows, lda) and `w` (n, taps*cp) are in `dtype`.  `k_real` (the
     unpadded contraction length) is bookkeeping for bench.py's algorithmic-flop count; the kernel ignores it.
     dtype F16X3: `a` is float32, `w` / `w_scale` come from `split_f16_weights`.  dtype H2: `a` / `out` are H2 images
-    (float32-typed), `w` / `w_scale` from `split_f16_weights_h2`, `res` fp32 or (res_h2) an H2 image, `out_f32` / `out_t` fp32."""
+    (float32-typed), `w` / `w_scale` from `split_f16_weights_h2`, `res` fp32 or (res_h2) an H2 image, `out_f32` / `out_t` fp32.
+    workspace (a contiguous device tensor, scratch): emage_gemm_ws — split-K contractions store their K-slices as planes of it and add
+    them in slice order (deterministic) instead of meeting through fp32 atomics."""
     _dev(a)
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin
     lout = m if lout is None else lout
     if k_real is not None:
         _META["k_real"] = k_real
+    if workspace is not None:
+        assert workspace.is_contiguous() and workspace.device == a.device
+        _gemm_ws(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
+                 lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2), workspace)
+        return
     _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
           lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2))
 

@@ -233,6 +233,8 @@ class TrainForward:
         self.conv_backward_rows = 1 << 17                 # output rows per piece of a long convolution's backward (_conv_backward_h2)
         self._w_scale, self._wt_cache = {}, {}
         self.accumulate_dw = True       # Linear weight gradients are added into the gradient rows by their contraction (A/B switch; False: a temporary + a queued add)
+        self.splitk_workspace_bytes = 32 << 20            # scratch of the two-pass split-K weight-gradient contractions (emage_gemm_ws: K-slices as planes, added
+        self._splitk_buf = None                           # in slice order — bit-reproducible gradients); 0: the fp32-atomic form of emage_gemm
         self.lazy_masks = True          # device-drawn (T, B, d) dropout masks live as Philox keys: drawn inside `mul_add`, forward and backward (-0.9 GB per forward)
         self._wt_keep = False           # True inside `Trainer._device_step`: the transposed weight images (`_weight_t_h2`) serve all three forwards
         self.range_flag = None          # int32 device counter: transposed-weight operands (backward dX) whose cached scale no longer fits
@@ -244,6 +246,15 @@ class TrainForward:
         self.touch = None               # dict filled with name -> tape position of the parameter's last contribution of a backward
         self._shared, self.last_run_nodes = None, 0
         self._pcache = None
+
+    def _splitk_ws(self, dev=None):
+        """The workspace of the weight-gradient contractions (one buffer per trainer: the launches of a step run in stream order)."""
+        if not self.splitk_workspace_bytes:
+            return None
+        dev = self.model.device if dev is None else dev
+        if self._splitk_buf is None or self._splitk_buf.device != dev or self._splitk_buf.numel() * 4 != self.splitk_workspace_bytes:
+            self._splitk_buf = torch.empty(self.splitk_workspace_bytes // 4, dtype=torch.float32, device=dev)
+        return self._splitk_buf
 
     # ---- packing of what the inference pack does not hold: un-folded WavEncoder convolutions ----------------------------
     def _train_pack(self, pk):
@@ -482,13 +493,13 @@ class TrainForward:
             dy_t = ops.h2_cast(dys, mps, scale=gs, transpose=True)                          # (N, mps)
             col_t = ops.im2col_t_h2(xs, cin, taps, stride, pad, lin, lout, s1 - s0, mps)    # (taps*cin, mps)
             dwp = torch.empty(n, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
-            ops.gemm(H2, dy_t, col_t, None, None, None, None, dwp, None, n=kc, cp=mps, w_scale=16.0, a_scale=16.0 * gs)
+            ops.gemm(H2, dy_t, col_t, None, None, None, None, dwp, None, n=kc, cp=mps, w_scale=16.0, a_scale=16.0 * gs, workspace=self._splitk_ws(cx.dev))
             del col_t, dy_t
             dw = dwp if dw is None else dw.add_(dwp)
             if need_dx:
                 dy_h = ops.h2_cast(dys, np_, scale=gs)
                 dcol = torch.empty(ms, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
-                ops.gemm(H2, dy_h, w_t, None, None, None, None, dcol, None, n=kc, cp=np_, w_scale=wsc, a_scale=16.0 * gs)
+                ops.gemm(H2, dy_h, w_t, None, None, None, None, dcol, None, n=kc, cp=np_, w_scale=wsc, a_scale=16.0 * gs, workspace=self._splitk_ws(cx.dev))
                 del dy_h
                 part = ops.col2im(dcol, cin, taps, stride, pad, lin, lout, s1 - s0)
                 del dcol
@@ -582,7 +593,7 @@ class TrainForward:
                 dys_t = ops.h2_cast(dys, mp, scale=self.grad_scale, transpose=True)                         # (2*cout, mp)
                 col = ops.im2col_t_h2(audio.reshape(-1, 1), 1, k, stride, pad, audio.shape[1], lout, b, mp)  # (k, mp)
                 dw = torch.empty(dys.shape[1], _rup(k, 4), dtype=torch.float32, device=cx.dev)[:, :k]
-                ops.gemm(H2, dys_t, col, None, None, None, None, dw, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * self.grad_scale)
+                ops.gemm(H2, dys_t, col, None, None, None, None, dw, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * self.grad_scale, workspace=self._splitk_ws(cx.dev))
             else:
                 dw = ops.wav_conv_in_backward(dys, sv["audio"], lout, k, stride, pad)      # (2*cout, k): conv1 rows, then the shortcut conv's
             db = ops.col_sum(dys)
@@ -748,10 +759,10 @@ class TrainForward:
         wdst = self._grad_rows(origin[0][0], origin[0][2])[0] if single else None
         if self.accumulate_dw and wdst is not None and wdst.dim() == 2 and wdst.stride(1) == 1 and wdst.stride(0) % 4 == 0 and wdst.data_ptr() % 16 == 0:
             # dW added by the contraction itself (res == out_f32: the epilogue's residual add in place, or split-K atomics onto the contents)
-            ops.gemm(H2, dpre_t, x_t, None, None, wdst, None, wdst, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
+            ops.gemm(H2, dpre_t, x_t, None, None, wdst, None, wdst, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs, workspace=self._splitk_ws())
         else:
             dw = torch.empty(n, k, dtype=torch.float32, device=cx.dev)
-            ops.gemm(H2, dpre_t, x_t, None, None, None, None, dw, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs)
+            ops.gemm(H2, dpre_t, x_t, None, None, None, None, dw, None, n=k, cp=mp, w_scale=16.0, a_scale=16.0 * gs, workspace=self._splitk_ws(cx.dev))
             r0 = 0
             for wn, bn, rs in origin:
                 rows = rs.stop - rs.start
@@ -766,7 +777,7 @@ class TrainForward:
         if need_dx:
             w_t, ws = self._weight_t_h2(cx, key, n, k)
             dx = torch.empty(m, k, dtype=torch.float32, device=cx.dev)
-            ops.gemm(H2, dpre_h, w_t, None, None, None, None, dx, None, n=k, cp=_rup(n), w_scale=ws, a_scale=16.0 * gs)
+            ops.gemm(H2, dpre_h, w_t, None, None, None, None, dx, None, n=k, cp=_rup(n), w_scale=ws, a_scale=16.0 * gs, workspace=self._splitk_ws(cx.dev))
             self.tape.add(x, dx, cols=k)
 
     def _params(self):

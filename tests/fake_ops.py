@@ -52,7 +52,7 @@ def h2_store(dst2d, values):
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None, w_scale=1.0, a_scale=None, res_h2=False):
+         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None):
     CALLS.append("gemm")
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin

@@ -686,6 +686,46 @@ def test_gemm_grouped_is_bit_identical_to_single_launches():
         ops.gemm_grouped(H2, [dict(a=operands[0], w=operands[1], out=outputs()[0], **{**kw, "cp": kw["cp"] + 8})] * 2)
 
 
+def test_gemm_ws_split_k_is_deterministic_and_fp32_grade():
+    """VERDICT round 4 next #2b: `emage_gemm_ws` — the weight-gradient shapes of the training step (bare contractions, K = 3 584 rows of a
+    56-clip batch, few tiles) cut into K-slices stored as planes of a caller-owned workspace and added in slice order: (i) fp32-grade
+    against float64, like the single-slice kernel; (ii) the SAME BITS on every run (the fp32-atomic form of emage_gemm is not);
+    (iii) accumulating form (res == out_f32): added onto the destination's contents; (iv) a workspace too small for two slices falls back
+    to emage_gemm's behaviour; ragged N; (v) shapes that are not split are untouched by the workspace."""
+    g = torch.Generator().manual_seed(5)
+    ws = torch.empty(8 << 20, dtype=torch.float32, device=DEV)
+    for n_out, k_in, kc in ((768, 768, 3584), (768, 1536, 3584), (256, 768, 3584), (768, 250, 2048), (1536, 768, 3584)):
+        a = torch.randn(n_out, kc, generator=g).to(DEV)
+        x = torch.randn(k_in, kc, generator=g).to(DEV)
+        a_h2, x_h2 = ops.h2_pack(a), ops.h2_pack(x)
+        ref = a.double() @ x.double().t()
+        tol = 2e-5 * float(ref.abs().max()) * 4
+        ldo = ops.round_up(k_in, 4)
+        outs = []
+        for rep in range(3):
+            out = torch.full((n_out, ldo), float("nan"), device=DEV)[:, :k_in]
+            ops.gemm(H2, a_h2, x_h2, None, None, None, None, out, None, n=k_in, cp=kc, w_scale=16.0, a_scale=16.0, workspace=ws)
+            outs.append(out.clone())
+        assert float((outs[0].double() - ref).abs().max()) <= tol, (n_out, k_in)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (n_out, k_in)
+        base = torch.randn(n_out, ldo, generator=g).to(DEV)[:, :k_in]
+        acc = base.clone()
+        ops.gemm(H2, a_h2, x_h2, None, None, acc, None, acc, None, n=k_in, cp=kc, w_scale=16.0, a_scale=16.0, workspace=ws)
+        assert float((acc.double() - (base.double() + ref)).abs().max()) <= tol, (n_out, k_in)
+        small = torch.empty(1024, dtype=torch.float32, device=DEV)          # not even one plane: emage_gemm's path
+        out_s = torch.empty(n_out, ldo, device=DEV)[:, :k_in]
+        ops.gemm(H2, a_h2, x_h2, None, None, None, None, out_s, None, n=k_in, cp=kc, w_scale=16.0, a_scale=16.0, workspace=small)
+        assert float((out_s.double() - ref).abs().max()) <= tol, (n_out, k_in)
+    # not a split-K shape (an activation GEMM with bias): the workspace changes no bit
+    a = ops.h2_pack(torch.randn(4096, 768, generator=g).to(DEV))
+    w, wsc = ops.split_f16_weights_h2((torch.randn(768, 768, generator=g) / 27.0).to(DEV))
+    bias = torch.randn(768, generator=g).to(DEV)
+    o1, o2 = torch.empty(4096, 768, device=DEV), torch.empty(4096, 768, device=DEV)
+    ops.gemm(H2, a, w, bias, None, None, o1, None, None, n=768, cp=768, w_scale=wsc)
+    ops.gemm(H2, a, w, bias, None, None, o2, None, None, n=768, cp=768, w_scale=wsc, workspace=ws)
+    assert torch.equal(o1.view(torch.int32), o2.view(torch.int32))
+
+
 def test_weight_packing_on_the_device_equals_the_tensor_arithmetic():
     """`ops.split_f16_weights` / `split_f16_weights_h2` on device tensors run as ONE launch per operand (`emage_f16x3_pack_weights`, the
     activation-cast kernel) — a training step re-packs every weight behind each Adam update.  The images must be the bits the host-side
