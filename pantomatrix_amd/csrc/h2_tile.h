@@ -24,7 +24,7 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     [&]<int... I>(std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }(std::make_integer_sequence<int, N>{});
 }
 
-template <int BM, int BN, int NS> constexpr int h2_smem_bytes() { return NS * (BM + BN) * 128; }
+template <int BM, int BN, int NS, int KPB = 1> constexpr int h2_smem_bytes() { return NS * KPB * (BM + BN) * 128; }
 
 // ---- the epilogue of an EMAGE_H2 tile (gemm_h2_tile; kept separate for fused kernels that end in the same stores) ----
 // acc: the wave's FM x FN accumulator fragments; (mw, nw): first row / column of the wave tile.  NAT = false: W rows were fed to the MFMAs in
@@ -194,7 +194,10 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, bool DILV = false, bool TRACE = false>
+// KPB (round 5, VERDICT next #1b "BK = 64"): K-tiles per ring slot and per s_barrier — a slot holds KPB consecutive 32-k sub-tiles (each in the
+// unchanged [4 hi | 4 lo] row image), one rendezvous and one counted wait serve KPB x (3 FM FN) MFMAs per wave; the MFMA order per
+// accumulator is that of KPB = 1, so the result is the same bits.  Plain K-loop only (not PIPE / DILV).
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, bool DILV = false, bool TRACE = false, int KPB = 1>
 __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem, const int split = 0) {
     constexpr int ES = 4, BK = 32, RB = 128, RPI = 8;
     constexpr int NCW = WM * WN, NL = NLW ? NLW : NCW;
@@ -204,7 +207,9 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     static_assert((BM / RPI) % NL == 0 && (BN / RPI) % NL == 0, "every loading wave issues the same number of DMA instructions");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0 && NS >= 2 && NS <= 4, "tile shape");
     static_assert(!PIPE || NS >= 3, "the register-pipelined K-loop reads one stage ahead: ring of >= 3");
-    constexpr int STAGE = (BM + BN) * RB;
+    static_assert(KPB == 1 || (!PIPE && !DILV && KPB == 2), "several K-tiles per slot: the plain K-loop");
+    constexpr int SUB = (BM + BN) * RB;               // one 32-k sub-tile of a slot
+    constexpr int STAGE = KPB * SUB;
     constexpr int AH = PIPE ? 1 : 0;                  // stages the fragment reads run ahead of the MFMAs
 
     const int tid = threadIdx.x;
@@ -266,13 +271,13 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     // split-K (p.ksplit > 1, Linear only): this block contracts K-tiles [kt0, kt0 + nk) and adds its partial tile into out_f32
     const int nk_all = p.K / BK;
     const int kt0 = p.ksplit > 1 ? split * p.nk_split : 0;
-    int is_tap = 0, is_c0 = kt0 * BK, is_slot = 0;
+    int is_tap = 0, is_c0 = kt0 * BK, is_slot = 0, is_sub = 0;
     unsigned soff_a = (unsigned)(kt0 * BK * ES), soff_w = (unsigned)(kt0 * BK * ES);
     const unsigned tap_step = (unsigned)(p.lda - p.Cp + BK) * ES;
     // DMA instruction J of a stage (J < GA: A rows, else W rows) and the bookkeeping that follows the last one
     auto issue_piece = [&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        unsigned char* base = smem + is_slot * STAGE;
+        unsigned char* base = smem + is_slot * STAGE + (KPB > 1 ? is_sub * SUB : 0);
         if constexpr (J < GA) {
             unsigned vo = a_voff[J];
             if (is_conv) vo = (unsigned)(a_lpos[J] + is_tap) < (unsigned)p.Lin ? vo : OOB;
@@ -287,11 +292,17 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
         soff_w += BK * ES;
         is_c0 += BK;
         if (is_c0 == p.Cp) { is_c0 = 0; ++is_tap; soff_a += tap_step; } else { soff_a += BK * ES; }
-        if (++is_slot == NS) is_slot = 0;
+        if constexpr (KPB > 1) {
+            if (++is_sub == KPB) { is_sub = 0; if (++is_slot == NS) is_slot = 0; }
+        } else {
+            if (++is_slot == NS) is_slot = 0;
+        }
     };
-    auto issue = [&]() {
-        static_for<G>([&](auto jc) { issue_piece(jc); });
-        issue_advance();
+    auto issue = [&]() {                              // one ring slot: KPB sub-tiles
+        static_for<KPB>([&](auto) {
+            static_for<G>([&](auto jc) { issue_piece(jc); });
+            issue_advance();
+        });
     };
 
     // ---- epilogue operands fetched ahead of the K-loop (compute waves; oldest entries of their memory queue) ----
@@ -324,7 +335,7 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.ksplit > 1 ? (nk_all - kt0 < p.nk_split ? nk_all - kt0 : p.nk_split) : nk_all;
+    const int nk = (p.ksplit > 1 ? (nk_all - kt0 < p.nk_split ? nk_all - kt0 : p.nk_split) : nk_all) / KPB;      // ring slots to walk (K-tiles: even, gemm_h2.hip)
     if (is_loader) {
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)
@@ -379,8 +390,8 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
             // the loading waves wait until stage st + AH has landed; stages issued after it may stay in flight
             const int last_issued = (st + NS - 2 < nk - 1) ? st + NS - 2 : nk - 1;
             const int infl = last_issued - (st + AH);
-            if (NS >= 4 && infl >= 2) wait_vmcnt<2 * G>();
-            else if (NS >= 3 && infl >= 1) wait_vmcnt<G>();
+            if (NS >= 4 && infl >= 2) wait_vmcnt<2 * G * KPB>();
+            else if (NS >= 3 && infl >= 1) wait_vmcnt<G * KPB>();
             else wait_vmcnt<0>();
         };
 
@@ -400,8 +411,10 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
                 if (!(DILV && NLW == 0) && do_issue) issue();
                 tr();
                 if (is_compute) {
+                  static_for<KPB>([&](auto subc) {
+                    constexpr int SB2 = decltype(subc)::value * SUB;
                     Frag f;
-                    static_for<NR>([&](auto rc) { read_one(rc, f, sb); });
+                    static_for<NR>([&](auto rc) { read_one(rc, f, sb + SB2); });
                     tr();
                     wait_lgkmcnt<FN + FM>();              // A hi and W lo are there: first sweep
                     __builtin_amdgcn_sched_barrier(0);
@@ -420,6 +433,8 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     });
+                    if constexpr (decltype(subc)::value + 1 < KPB) __builtin_amdgcn_sched_barrier(0);
+                  });
                     if constexpr (DILV && NLW == 0) {
                         static_for<G>([&](auto jc) {      // pieces the interleave did not reach
                             if constexpr (decltype(jc)::value >= NM / DSTEP) { if (do_issue) issue_piece(jc); }
