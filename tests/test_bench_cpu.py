@@ -114,6 +114,8 @@ def test_main_prints_one_json_line_and_reports_a_failing_extra(monkeypatch, caps
     monkeypatch.setattr(bench, "cpu_baseline", lambda frames: {"value": 2000.0, "unit": "motion-frames/s", "cores": 16, "kind": "port", "sample": "stand-in"})
     monkeypatch.setattr(bench, "bench_lstm_models", lambda dev, cpu=True: {"disco": {"ms_per_step": 9.0}, "camn": {"ms_per_step": 72.0}})
     monkeypatch.setattr(bench, "bench_train_step", failing_train_step)
+    monkeypatch.setattr(bench, "bench_config1", lambda precision, dev, args, cpu=True: {"b1_128f": {"ms": 4.0}, "b1_28s": {"ms": 25.0}})
+    monkeypatch.setattr(bench, "bench_batch_sweep", lambda precision, dev, args: {"by_batch": {"1": {}, "8": {}, "64": {}, "256": {}}})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         monkeypatch.delenv(k, raising=False)
     bench.main()
@@ -121,9 +123,10 @@ def test_main_prints_one_json_line_and_reports_a_failing_extra(monkeypatch, caps
     assert len(lines) == 1
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-                "roofline", "cpu_baseline", "pcie_inclusive", "other_precisions", "lstm_models", "train_step"):
+                "roofline", "cpu_baseline", "pcie_inclusive", "other_precisions", "lstm_models", "train_step", "config1", "batch_sweep", "host"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f16x3" and d["vs_baseline"] is None and "workload" in d["config"]
     assert d["roofline"]["vq_argmin"]["n_1m"] == {"n": 1 << 20} and set(d["other_precisions"]) == {"bf16"}
-    assert d["lstm_models"]["camn"]["ms_per_step"] == 72.0
+    assert d["lstm_models"]["camn"]["ms_per_step"] == 72.0 and d["config1"]["b1_28s"]["ms"] == 25.0 and set(d["batch_sweep"]["by_batch"]) == {"1", "8", "64", "256"}
+    assert d["host"]["usable_cores"] >= 1
     assert d["train_step"] == {"error": "RuntimeError: out of memory (stand-in)"}
