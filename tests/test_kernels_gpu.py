@@ -741,7 +741,8 @@ def test_gemm_ws_split_k_is_deterministic_and_fp32_grade():
         assert float((outs[0].double() - ref).abs().max()) <= tol, (n_out, k_in)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (n_out, k_in)
         base = torch.randn(n_out, ldo, generator=g).to(DEV)[:, :k_in]
-        acc = base.clone()
+        acc = torch.empty(n_out, ldo, device=DEV)[:, :k_in]             # rows on 16-byte boundaries, like the gradient buckets' views
+        acc.copy_(base)
         ops.gemm(H2, a_h2, x_h2, None, None, acc, None, acc, None, n=k_in, cp=kc, w_scale=16.0, a_scale=16.0, workspace=ws)
         assert float((acc.double() - (base.double() + ref)).abs().max()) <= tol, (n_out, k_in)
         small = torch.empty(1024, dtype=torch.float32, device=DEV)          # not even one plane: emage_gemm's path
