@@ -297,6 +297,13 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 168: return launch_h2<64, 192, 1, 4, 3, 0, false>(a, s);                     // 4 waves 64x48 side by side
         case 169: return launch_h2<64, 192, 1, 4, 3, 0, true>(a, s);
         case 171: return launch_h2<128, 256, 2, 4, 2, 0, false>(a, s);                    // 8 waves 64x64
+        // round 5: one fat block per CU for grids of many tiles per CU (the K / V projections of all cross-attention layers): MFMA issue per K-tile
+        // 3-4x the operand delivery (64 B/clk per CU)
+        case 172: return launch_h2<256, 256, 2, 4, 2, 0, false>(a, s);                    // 8 waves 128x64
+        case 173: return launch_h2<256, 192, 2, 4, 2, 0, false>(a, s);                    // 8 waves 128x48
+        case 174: return launch_h2<256, 192, 4, 2, 2, 0, false>(a, s);                    // 8 waves 64x96
+        case 175: return launch_h2<256, 128, 4, 2, 2, 0, false>(a, s);                    // 8 waves 64x64
+        case 187: return launch_h2<64, 64, 2, 2, 3, 0, false, true, 2>(a, s);             // 120 with the residual fetched ahead of the K-loop
         // round 5 (VERDICT next #1b, "BK = 64"): TWO K-tiles per ring slot and barrier (KPB = 2), otherwise the shipped configurations
         case 180: return launch_h2<64, 192, 4, 2, 2, 0, false, false, 1, false, false, 2>(a, s);    // 100 with 128 KB of LDS: one block per CU
         case 181: return launch_h2<128, 192, 2, 4, 2, 0, false, false, 1, false, false, 2>(a, s);   // 170 with 160 KB: one block per CU instead of two

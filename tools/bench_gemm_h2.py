@@ -45,6 +45,14 @@ SHAPES = [
     ("bwd dW 1536x768", (24, 64, 64), 3584, 768, 1, 1, 0, dict(f32only=True, bare=True)),
     ("bwd dW 768x1536", (12, 64, 64), 3584, 1536, 1, 1, 0, dict(f32only=True, bare=True)),
     ("bwd dW 2304x768", (36, 64, 64), 3584, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    # round 5: the K / V projections of all cross-attention layers in the backward (the largest contractions of the step), the narrow heads
+    ("bwd dW 12288x768", (192, 64, 64), 3584, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dW 6144x768", (96, 64, 64), 3584, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dX 768<-12288", (56, 64, 64), 12288, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dX 768<-6144", (56, 64, 64), 6144, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dW 256x768", (4, 64, 64), 3584, 768, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dW 768x256", (12, 64, 64), 3584, 256, 1, 1, 0, dict(f32only=True, bare=True)),
+    ("bwd dX 768<-256", (56, 64, 64), 256, 768, 1, 1, 0, dict(f32only=True, bare=True)),
 ]
 CONFIGS = [100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 115, 116, 118, 119, 120, 121, 122, 123, 124, 125, 126, 127, 128,
            129, 130, 131, 132]
@@ -57,6 +65,7 @@ def main():
     ap.add_argument("--shapes", default="", help="comma-separated substrings of shape names")
     ap.add_argument("--loop", type=int, default=0, help="no sweep: run the first selected shape / config this many times eagerly (profiling)")
     ap.add_argument("--h2-variant", type=int, default=0, help="emage_set_tuning key 5 (dispatch-heuristic variant; 1024 / 2048 / 4096 = split-K limit 384 / none / 191 instead of 100)")
+    ap.add_argument("--workspace-mb", type=int, default=0, help="EMAGE_H2 runs of bare contractions go through emage_gemm_ws with a workspace of this size (two-pass split-K)")
     ap.add_argument("--dbg", type=int, default=0, help="emage_set_tuning key 1 for the EMAGE_H2 runs (32 = no XCD remap, 64 = an XCD's run walks M first)")
     args = ap.parse_args()
     lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
@@ -66,6 +75,7 @@ def main():
     configs = [int(c) for c in args.configs.split(",")] if args.configs else CONFIGS
     want = [s for s in args.shapes.split(",") if s]
     g = torch.Generator().manual_seed(0)
+    wspace = torch.empty(args.workspace_mb << 18, dtype=torch.float32, device=dev) if args.workspace_mb else None
     print(f"{'shape':26s} GF  | x3    " + " ".join(f"c{c:<6d}" for c in configs) + " | best")
     for name, (nb, lin, lout), cin, n, taps, stride, pad, ex in SHAPES:
         if want and not any(w in name for w in want):
@@ -113,7 +123,8 @@ def main():
             out_t = torch.zeros(nb, n - vt0, ops.round_up(lout, 32), device=dev) if vt0 else None
             if h2:
                 call = lambda: ops.gemm(H2, a_h2, w_h2, bias, slope, res, out, out_f, out_t, n=n, cp=cp, n_store=n_store, t_col0=vt0 or 0,
-                                        t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m, w_scale=ws_h2)
+                                        t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m, w_scale=ws_h2,
+                                        workspace=wspace if ex.get("bare") else None)
             else:
                 call = lambda: ops.gemm(F16X3, a, w_x3, bias, slope, res, out, out_f, out_t, n=n, cp=cp, n_store=n_store, t_col0=vt0 or 0,
                                         t_rows=lout if vt0 else 0, taps=taps, stride=stride, pad=pad, lin=lin, lout=lout, m=m, w_scale=ws_x3)
