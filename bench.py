@@ -462,6 +462,54 @@ def bench_lstm_models(dev, steps=3, cpu=True):
     return out
 
 
+def bench_exchange_single_rank(dev, data, random_mask, steps=3):
+    """`Trainer(sync_bn=True, exchange=True)` in a WORLD_SIZE = 1 `nccl` (= RCCL) process group on this GPU: collectives per step, bytes per
+    bucket message, the eager step and the step captured WITH its collectives (VERDICT round 4, next #3c).  No multi-GPU node is needed for
+    the exchange to run on hardware; the xGMI part of a real ring (2 x 7/8 x 508 MB per GPU and step at ~150 GB/s per link pair: ~6 ms,
+    three of four buckets overlapped with the third backward) is arithmetic, stated in DESIGN.md section 8."""
+    import torch.distributed as tdist
+    from tools import workloads as common
+    from pantomatrix_amd import dist as pdist
+    from pantomatrix_amd import training
+    created = False
+    if not tdist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(free_port())
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        out = {"backend": str(tdist.get_backend()), "world": tdist.get_world_size()}
+        model, vq = common.product_models(precision="f16x3", device=dev)
+        trainer = training.Trainer(model, vq, seed=1, sync_bn=True, exchange=True)
+        with pdist.CollectiveCounter() as cc:
+            trainer.step(data, random_mask=random_mask)
+        out["collectives_per_step"] = {k: v for k, v in cc.counts.items() if k != "bucket_bytes"}
+        out["bucket_bytes"] = trainer.buckets.nbytes()
+        out["bytes_all_reduced_per_step"] = cc.counts["bucket_bytes"]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            trainer.step(data, random_mask=random_mask)
+        torch.cuda.synchronize()
+        out["eager_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 2
+        trainer.capture(data, random_mask)
+        trainer.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            losses = trainer.replay()
+        torch.cuda.synchronize()
+        out["captured_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps
+        out["loss_all_after_replays"] = losses["all"]
+        out["note"] = ("single-rank RCCL: every collective of the step runs on the device (the all-reduces are the identity); captured = the collectives "
+                       "are nodes of the step's hipGraph — what each rank of a multi-GPU run replays (Trainer.capture no longer refuses world > 1 / sync_bn)")
+        del trainer, model, vq
+        return out
+    finally:
+        if created:
+            tdist.destroy_process_group()
+
+
 def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw=None):
     """One EMAGE optimisation step at BASELINE configs[2]'s per-GPU batch (56 clips x 64 frames): targets through the frozen VQ-VAEs, three
     train-mode forwards (batch-statistics BatchNorm, dropout masks drawn on the device), six losses, three backward passes, multi-tensor
@@ -497,7 +545,8 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw
                          "note": "whole-step algorithmic flops / step time (an upper bound on the GEMM family's share) against the dense fp16 MFMA peak"}}
     del trainer
     torch.cuda.empty_cache()
-    # the EAGER step — the path a multi-process run takes (a collective cannot sit inside the captured graph): same model, same inputs
+    # the EAGER step — the same launches issued from Python (until round 4 the only form of a multi-process run; round 5 captures the collectives
+    # too: `exchange` below) — same model, same inputs, same process: the ratio is this host's (`host` in the line)
     try:
         if not eager:
             raise RuntimeError("not timed in this run")
@@ -510,11 +559,20 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw
         torch.cuda.synchronize()
         ems = 1e3 * (time.perf_counter() - t0) / 2
         line["eager"] = {"ms_per_step": ems, "ratio_to_captured": ems / ms,
-                         "note": "Trainer.step: the same launches issued from Python, one host read of losses + health word per step (the form world > 1 uses)"}
+                         "note": "Trainer.step: the same launches issued from Python, one host read of losses + health word per step; measured in the SAME process "
+                                 "as the captured figure — the ratio depends on the host CPU (`host`), not on the GPU"}
         del eager
     except Exception as exc:                      # noqa: BLE001 — an extra never costs the line
         line["eager"] = {"error": f"{type(exc).__name__}: {exc}"}
     del model, vq
+    torch.cuda.empty_cache()
+    # the exchange of BASELINE configs[2] (train_emage_audio.py:214, 248-251: DDP + SyncBatchNorm) through RCCL on THIS GPU: a process group of
+    # one rank — the four bucket all-reduces, the SyncBatchNorm all-gathers / small all-reduces run on the device, eagerly and inside the
+    # captured graph (the form every rank of a multi-GPU run replays)
+    try:
+        line["exchange"] = bench_exchange_single_rank(dev, data, random_mask, steps)
+    except Exception as exc:                      # noqa: BLE001
+        line["exchange"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
     torch.cuda.empty_cache()
     if cpu:
         torch.set_num_threads(usable_cores())

@@ -149,6 +149,39 @@ class GradientBuckets:
                 b.div_(world)
 
 
+class CollectiveCounter:
+    """Context manager: counts what the training exchange asks the backend for while it is active — all-gathers (SyncBatchNorm forward),
+    small all-reduces (SyncBatchNorm backward, the clip count) and bucket all-reduces with their bytes — by wrapping
+    `torch.distributed.all_reduce` / `all_gather_into_tensor`.  Used by bench.py's `train_step.exchange` and by the RCCL / gloo tests."""
+
+    BUCKET_ELEMENTS = 1_000_000
+
+    def __init__(self):
+        self.counts = {"all_gather": 0, "all_reduce_small": 0, "all_reduce_bucket": 0, "bucket_bytes": 0}
+
+    def __enter__(self):
+        self._gather, self._reduce = dist.all_gather_into_tensor, dist.all_reduce
+
+        def gather(*a, **k):
+            self.counts["all_gather"] += 1
+            return self._gather(*a, **k)
+
+        def reduce(t, *a, **k):
+            if t.numel() > self.BUCKET_ELEMENTS:
+                self.counts["all_reduce_bucket"] += 1
+                self.counts["bucket_bytes"] += t.numel() * t.element_size()
+            else:
+                self.counts["all_reduce_small"] += 1
+            return self._reduce(t, *a, **k)
+
+        dist.all_gather_into_tensor, dist.all_reduce = gather, reduce
+        return self
+
+    def __exit__(self, *exc):
+        dist.all_gather_into_tensor, dist.all_reduce = self._gather, self._reduce
+        return False
+
+
 def gradient_allreduce_hook(model, device=None, group=None):
     """The `grad_hook` of `training.Trainer.step` for a multi-GPU run: the step's gradients go into the four backward-ordered
     bucket messages, are summed over ranks (RCCL / gloo) and averaged (the DDP average, train_emage_audio.py:251), and come

@@ -58,36 +58,18 @@ def main():
     masks = [[m.to(dev).contiguous() for m in fm] for fm in masks]
     random_mask = random_mask.to(dev)
 
-    calls = {"all_gather": 0, "all_reduce_small": 0, "all_reduce_bucket": 0, "bucket_bytes": 0}
-    real_gather, real_reduce = tdist.all_gather_into_tensor, tdist.all_reduce
-
-    def count_gather(*a, **k):
-        calls["all_gather"] += 1
-        return real_gather(*a, **k)
-
-    def count_reduce(t, *a, **k):
-        if t.numel() > 1_000_000:
-            calls["all_reduce_bucket"] += 1
-            calls["bucket_bytes"] += t.numel() * t.element_size()
-        else:
-            calls["all_reduce_small"] += 1
-        assert t.is_cuda, "the exchange must run on the device (RCCL), not on a host tensor"
-        return real_reduce(t, *a, **k)
-
     # ---- 1. the eager step through RCCL ----
     try:
         model, vq = common.product_models(precision="f16x3", device=dev)
         before = {k: v.clone() for k, v in model._flat_params().items()}
         trainer = training.Trainer(model, vq, sync_bn=True, exchange=True)
         seen = {}
-        tdist.all_gather_into_tensor, tdist.all_reduce = count_gather, count_reduce
-        try:
+        with pd.CollectiveCounter() as cc:
             t0 = time.time()
             losses = trainer.step(batch, int(g["iteration"]), masks, random_mask, grad_hook=lambda gr: seen.update({k: float(v.norm()) for k, v in gr.items()}))
             torch.cuda.synchronize()
             dt = time.time() - t0
-        finally:
-            tdist.all_gather_into_tensor, tdist.all_reduce = real_gather, real_reduce
+        calls = cc.counts
         worst = ttf._check_step_against(g, losses, model._flat_params(), before, grads=seen, what="eager step over RCCL")
         res["eager"] = dict(ok=True, collectives=dict(calls), worst=worst, loss_all=losses["all"], first_step_s=round(dt, 2),
                             exchange_log=[e[0] for e in trainer.exchange_log])
