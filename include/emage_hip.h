@@ -411,7 +411,16 @@ int emage_nll_loss(const float* logits, int ld, const int64_t* index, int M, int
 int emage_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int M, int N, void* stream);
 
 /* out[c] (+)= sum_m x[m][c] (* y[m][c] when y is given): bias / LayerNorm-affine gradients.  float64 block partials added in
- * block order (deterministic); workspace: ceil(M / 2048) * C * 8 bytes. */
+ * block order (deterministic); workspace: emage_col_sum_chunks(M) * C * 8 bytes.  out == NULL (round 5): only the partials are
+ * written (partial[chunk * C + c]); a later emage_col_sum_finalize_multi ends this reduction together with others.
+ *
+ * emage_col_sum_finalize_multi — the finalize step of up to 64 chunked column reductions in ONE launch (a training step ends ~600 of
+ * them: bias gradients from emage_grad_prep, LayerNorm / embedding gradients from emage_col_sum).  `table`: device memory, n_entries
+ * records of 32 bytes { const double* partial; float* out; int32 chunks, C, accumulate, block0 } with block0 = the running sum of
+ * ceil(C / 16) over the earlier entries; n_blocks = that sum over all entries.  Entry by entry the arithmetic (and the bits) of the
+ * finalize launch inside emage_col_sum / emage_grad_prep.  No two entries of one call may name overlapping `out` ranges. */
+int emage_col_sum_chunks(int M);
+int emage_col_sum_finalize_multi(const void* table, int n_entries, int n_blocks, void* stream);
 int emage_col_sum(const float* x, int ldx, const float* y, int ldy, int M, int C, float* out, int accumulate,
                   void* workspace, long workspace_bytes, void* stream);
 
@@ -423,7 +432,8 @@ int emage_act_backward(const float* dy, int ld_dy, const float* y, int ld_y, flo
  *   out_h (M, n_store >= C, % 8): EMAGE_H2 image of scale * dpre, zero tail columns            (operand of dX = dpre W)
  *   out_t (C, m_store >= M, % 8): EMAGE_H2 image of scale * dpre^T, zero tail columns          (operand of dW = dpre^T X)
  *   bias_grad[c] (+)= sum_m dpre[m][c] (float64 partials per 64 rows in `workspace`, >= ceil(M / 64) * C * 8 bytes, added in row order)
- * any of the three outputs may be NULL; scale a power of two (the loss scale of the split-fp16 backward). */
+ * any of the three outputs may be NULL; scale a power of two (the loss scale of the split-fp16 backward).  `workspace` without
+ * bias_grad (round 5): the ceil(M / 64) x C partials are written and left for emage_col_sum_finalize_multi. */
 int emage_grad_prep(const float* dy, int ld_dy, const float* y, int ld_y, float slope, int M, int C, float scale,
                     void* out_h, int ldh, int n_store, void* out_t, int ldt, int m_store,
                     float* bias_grad, int accumulate, void* workspace, long workspace_bytes, void* stream);

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip.so")
 TOOLS_LIB_PATH = os.path.join(_HERE, "csrc", "libemage_hip_tools.so")   # -DEMAGE_TOOLS twin: every tile configuration + emage_set_tuning
 
 F32, BF16, F16X3, H2 = 0, 1, 2, 3
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_long
 
@@ -46,6 +46,8 @@ SIGNATURES = {
     "emage_nll_loss": [_p, _i, _p, _i, _i, _f, _p, _p, _p],
     "emage_transpose_f32": [_p, _i, _p, _i, _i, _i, _p],
     "emage_col_sum": [_p, _i, _p, _i, _i, _i, _p, _i, _p, _l, _p],
+    "emage_col_sum_chunks": [_i],
+    "emage_col_sum_finalize_multi": [_p, _i, _i, _p],
     "emage_act_backward": [_p, _i, _p, _i, _f, _p, _i, _i, _i, _p],
     "emage_layernorm_backward_affine_workspace_bytes": [_i, _i, _i],
     "emage_layernorm_backward_affine": [_p, _i, _p, _p, _i, _f, _p, _i, _p, _p, _i, _i, _i, _i, _p, _l, _p],

@@ -354,6 +354,15 @@ static int h2_config_for(const GemmArgs& a) {
         if (ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return 100;
         if (!a.out_t || a.t_col0 % 128 == 0) return 113;
     }
+    // 768-wide outputs of a LONG contraction over many rows (the K / V projections of all cross-attention layers in the backward of a training
+    // step: dW 12288 x 768 and 6144 x 768 with K = 3584, dX 3584 x 768 with K = 12288 / 6144): many 64 x 64 tiles per block slot, each re-streaming
+    // its operands — the 8-wave tiles move half the bytes per MFMA (profiles/r05_gemm_h2_sweep_backward_two_pass.txt: 187-197 vs 234-266 us,
+    // 104-116 vs 133-134 us).  Below ~20 M (rows x k) the 64 x 64 tile wins (the window shapes of inference: M = 4096, K <= 1536)
+    if (!(v & 65536) && !a.out_t && ncols % 192 == 0 && ncols >= 768 && a.taps == 1) {
+        const long mk = (long)a.M * a.K;
+        if (mk >= 40L * 1000 * 1000) return 170;
+        if (mk >= 20L * 1000 * 1000) return 100;
+    }
     if (a.out_t && a.t_col0 % 64 != 0) return EMAGE_EINVAL;
     return (v & 8) ? 130 : 120;
 }

@@ -308,6 +308,31 @@ __global__ __launch_bounds__(256) void col_sum_finalize_kernel(const double* __r
     out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
+// The finalize step of MANY chunked column reductions in one launch (round 5): a training step ends ~600 bias / affine-gradient
+// reductions with a finalize launch of 3-48 blocks each (4.8 us apiece: 2.9 ms per step).  Entry e of the device table describes one
+// reduction (its float64 partials, chunk count, width, destination, accumulate flag) and owns blocks [block0_e, block0_{e+1}); a block
+// finds its entry by a scan of the (<= 64) entries and then runs the arithmetic of col_sum_finalize_kernel: the same bits.
+struct FinEntry { const double* partial; float* out; int chunks, C, accumulate, block0; };
+__global__ __launch_bounds__(256) void col_sum_finalize_multi_kernel(const FinEntry* __restrict__ tab, int n) {
+    __shared__ double red[FIN_LANES][FIN_COLS];
+    int e = 0;
+    for (int i = 1; i < n; ++i) e += ((int)blockIdx.x >= tab[i].block0) ? 1 : 0;      // block0 ascending
+    const FinEntry t = tab[e];
+    const int cl = threadIdx.x % FIN_COLS, rl = threadIdx.x / FIN_COLS;
+    const int c = ((int)blockIdx.x - t.block0) * FIN_COLS + cl;
+    const int per = (t.chunks + FIN_LANES - 1) / FIN_LANES;
+    const int i0 = rl * per, i1 = i0 + per < t.chunks ? i0 + per : t.chunks;
+    double s = 0.0;
+    if (c < t.C)
+        for (int i = i0; i < i1; ++i) s += t.partial[(long)i * t.C + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl != 0 || c >= t.C) return;
+    double a = 0.0;
+    for (int l = 0; l < FIN_LANES; ++l) a += red[l][cl];
+    t.out[c] = t.accumulate ? t.out[c] + (float)a : (float)a;
+}
+
 // Everything a Linear's backward needs from the gradient of its output, in ONE pass over dY (64 x 64 tiles through LDS):
 //   dpre = dy * (y > 0 ? 1 : slope)            (y given: the activation's backward from its saved output, as act_backward_kernel)
 //   out_h (M, n_store)  = EMAGE_H2 image of scale * dpre                  — the A operand of dX = dpre W
@@ -686,29 +711,43 @@ extern "C" int emage_transpose_f32(const float* in, int ld_in, float* out, int l
 
 extern "C" int emage_col_sum(const float* x, int ldx, const float* y, int ldy, int M, int C, float* out, int accumulate,
                              void* workspace, long workspace_bytes, void* stream) {
-    if (!x || !out || !workspace || M <= 0 || C <= 0 || ldx < C || (y && ldy < C) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
+    if (!x || !workspace || M <= 0 || C <= 0 || ldx < C || (y && ldy < C) || ((uintptr_t)workspace & 7)) return EMAGE_EINVAL;
     const int chunk_rows = stat_rows(M), chunks = (M + chunk_rows - 1) / chunk_rows;
     if (workspace_bytes < (long)chunks * C * (long)sizeof(double)) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(col_sum_partial_kernel, dim3(chunks, (C + 63) / 64), dim3(256), 0, s, x, ldx, y, ldy, M, C, (double*)workspace, chunk_rows);
     int rc = launch_status();
-    if (rc) return rc;
+    if (rc || !out) return rc;                       // out == NULL: the partials only (emage_col_sum_chunks of them; emage_col_sum_finalize_multi ends them)
     hipLaunchKernelGGL(col_sum_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, C, out, accumulate);
+    return launch_status();
+}
+
+extern "C" int emage_col_sum_chunks(int M) {
+    if (M <= 0) return EMAGE_EINVAL;
+    const int chunk_rows = stat_rows(M);
+    return (M + chunk_rows - 1) / chunk_rows;
+}
+
+extern "C" int emage_col_sum_finalize_multi(const void* table, int n_entries, int n_blocks, void* stream) {
+    if (!table || n_entries <= 0 || n_entries > 64 || n_blocks <= 0 || ((uintptr_t)table & 7)) return EMAGE_EINVAL;
+    hipLaunchKernelGGL(col_sum_finalize_multi_kernel, dim3(n_blocks), dim3(FIN_THREADS), 0, (hipStream_t)stream, (const FinEntry*)table, n_entries);
     return launch_status();
 }
 
 extern "C" int emage_grad_prep(const float* dy, int ld_dy, const float* y, int ld_y, float slope, int M, int C, float scale,
                                void* out_h, int ldh, int n_store, void* out_t, int ldt, int m_store,
                                float* bias_grad, int accumulate, void* workspace, long workspace_bytes, void* stream) {
-    if (!dy || M <= 0 || C <= 0 || ld_dy < C || (y && ld_y < C) || !(scale > 0.f) || (!out_h && !out_t && !bias_grad)) return EMAGE_EINVAL;
+    if (!dy || M <= 0 || C <= 0 || ld_dy < C || (y && ld_y < C) || !(scale > 0.f) || (!out_h && !out_t && !bias_grad && !workspace)) return EMAGE_EINVAL;
     if (out_h && (n_store < C || n_store % 8 || ldh % 8 || ldh < n_store || ((uintptr_t)out_h & 15))) return EMAGE_EINVAL;
     if (out_t && (m_store < M || m_store % 8 || ldt % 8 || ldt < m_store || ((uintptr_t)out_t & 15))) return EMAGE_EINVAL;
     const int tiles_m = ((out_t && m_store > M ? m_store : M) + 63) / 64, chunks = (M + 63) / 64;
     const int tiles_c = ((out_h && n_store > C ? n_store : C) + 63) / 64;
-    if (bias_grad && (!workspace || ((uintptr_t)workspace & 7) || workspace_bytes < (long)chunks * C * (long)sizeof(double))) return EMAGE_EINVAL;
+    if (bias_grad && !workspace) return EMAGE_EINVAL;
+    if (workspace && (((uintptr_t)workspace & 7) || workspace_bytes < (long)chunks * C * (long)sizeof(double))) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    // workspace without bias_grad (round 5): the column partials only — ceil(M / 64) chunks of C float64 — for emage_col_sum_finalize_multi
     hipLaunchKernelGGL(grad_prep_kernel, dim3(tiles_m, tiles_c), dim3(256), 0, s, dy, ld_dy, y, ld_y, slope, (emage_dev::h2_t*)out_h, ldh, n_store, (emage_dev::h2_t*)out_t, ldt, m_store,
-                       bias_grad ? (double*)workspace : (double*)nullptr, scale, M, C);
+                       (double*)workspace, scale, M, C);
     int rc = launch_status();
     if (rc || !bias_grad) return rc;
     hipLaunchKernelGGL(col_sum_finalize_kernel, fin_grid(C), dim3(FIN_THREADS), 0, s, (const double*)workspace, chunks, C, bias_grad, accumulate);

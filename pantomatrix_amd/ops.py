@@ -745,20 +745,75 @@ def transpose(x, out=None):
     return out
 
 
-@_op("col_sum", "(Tensor x, Tensor? y, Tensor(a!) out, bool accumulate, Tensor(b!) workspace) -> ()")
+@_op("col_sum", "(Tensor x, Tensor? y, Tensor(a!)? out, bool accumulate, Tensor(b!) workspace) -> ()")
 def _col_sum(x, y, out, accumulate, workspace):
     m, c = x.shape
     check(_lib.load().emage_col_sum(_ptr(x), _ld(x), _ptr(y), _ld(y) if y is not None else 0, m, c, _ptr(out), int(accumulate), _ptr(workspace),
                                     workspace.numel() * 8, _stream()), "col_sum")
 
 
-def col_sum(x, y=None, out=None, accumulate=False):
-    """out[c] (+)= sum_m x[m, c] (* y[m, c]) over fp32 (M, C) views."""
+@_op("col_sum_finalize_multi", "(Tensor table, int n_entries, int n_blocks) -> ()")
+def _col_sum_finalize_multi(table, n_entries, n_blocks):
+    check(_lib.load().emage_col_sum_finalize_multi(_ptr(table), n_entries, n_blocks, _stream()), "col_sum_finalize_multi")
+
+
+class FinalizeQueue:
+    """The finalize steps of chunked column reductions (bias gradients out of `grad_prep`, LayerNorm / embedding gradients out of
+    `col_sum`), QUEUED and issued 64 at a time as one `emage_col_sum_finalize_multi` launch instead of one 3-48-block launch each (~600 per
+    training step).  An entry whose destination overlaps a queued one flushes first, so every element still receives its contributions in
+    issue order.  `flush()` before anything reads the destinations (training.TrainForward.flush_param_grads).  The launch reads a small
+    device table copied from pinned host memory; tables are kept alive (`keep`) for as long as a captured graph may replay the copy —
+    `new_step()` drops them outside a capture."""
+    CAP = 64
+
+    def __init__(self):
+        self.entries, self.keep = [], []
+
+    def add(self, partial, chunks, c, out, accumulate):
+        lo = out.data_ptr()
+        hi = lo + ((out.numel() - 1) * out.stride(-1) + 1) * 4 if out.numel() else lo
+        if any(lo < b and a < hi for a, b, *_ in self.entries):
+            self.flush()
+        assert out.dtype == torch.float32 and (out.dim() == 1 and out.stride(0) == 1 or out.numel() == 1), "destination: a contiguous fp32 vector"
+        self.entries.append((lo, hi, partial, int(chunks), int(c), out, bool(accumulate)))
+        if len(self.entries) >= self.CAP:
+            self.flush()
+
+    def flush(self):
+        if not self.entries:
+            return
+        words, block0 = [], 0
+        for _lo, _hi, partial, chunks, c, out, accumulate in self.entries:
+            words += [partial.data_ptr(), out.data_ptr(), chunks | (c << 32), int(accumulate) | (block0 << 32)]
+            block0 += (c + 15) // 16
+        dev = self.entries[0][5].device
+        host = torch.tensor(words, dtype=torch.int64).pin_memory()
+        table = host.to(dev, non_blocking=True)
+        _col_sum_finalize_multi(table, len(self.entries), block0)
+        self.keep.append((host, table, [e[2] for e in self.entries]))          # the partial buffers live until their finalize has been issued
+        self.entries = []
+
+    def new_step(self, capturing=False):
+        if not capturing:
+            self.keep = []
+
+
+def col_sum_chunks(m):
+    return _lib.load().emage_col_sum_chunks(int(m))
+
+
+def col_sum(x, y=None, out=None, accumulate=False, defer=None):
+    """out[c] (+)= sum_m x[m, c] (* y[m, c]) over fp32 (M, C) views.  defer (a `FinalizeQueue`, needs `out`): only the float64 chunk
+    partials are computed now; the finalize is queued."""
     _dev(x)
     m, c = x.shape
     if out is None:                       # the finalize launch WRITES every column unless `accumulate`: no zero fill
-        out, accumulate = torch.empty(c, dtype=torch.float32, device=x.device), False
+        out, accumulate, defer = torch.empty(c, dtype=torch.float32, device=x.device), False, None
     ws = torch.empty(((m + 63) // 64) * c, dtype=torch.float64, device=x.device)         # one partial per chunk of >= 64 rows (csrc/train.hip STAT_CHUNK)
+    if defer is not None:
+        _col_sum(x, y, None, False, ws)
+        defer.add(ws, col_sum_chunks(m), c, out, accumulate)
+        return out
     _col_sum(x, y, out, accumulate, ws)
     return out
 
@@ -788,7 +843,7 @@ def _grad_prep(dy, y, slope, scale, out_h, out_t, bias_grad, accumulate, workspa
           "grad_prep")
 
 
-def grad_prep(dy, y=None, slope=0.0, scale=1.0, n_store=None, m_store=None, bias_grad=None, accumulate=False, want_bias=True):
+def grad_prep(dy, y=None, slope=0.0, scale=1.0, n_store=None, m_store=None, bias_grad=None, accumulate=False, want_bias=True, defer=None):
     """One pass over the gradient dy (M, C) of a Linear's output -> (dpre_h, dpre_t, bias gradient): the EMAGE_H2 images of
     scale * dpre (M, n_store) and of its transpose (C, m_store), dpre = dy * (y > 0 ? 1 : slope) when the saved output `y` is given, and
     the column sums of dpre — written to / added to (`accumulate`) `bias_grad`, or to a fresh tensor.  n_store / m_store None: that image
@@ -804,6 +859,10 @@ def grad_prep(dy, y=None, slope=0.0, scale=1.0, n_store=None, m_store=None, bias
         ws = torch.empty(((m + 63) // 64) * c, dtype=torch.float64, device=dy.device)
     else:
         bias_grad = None
+    if defer is not None and bias_grad is not None:      # the bias gradient's finalize is queued (`FinalizeQueue`): partials only in this launch
+        _grad_prep(dy, y, float(slope), float(scale), out_h, out_t, None, False, ws)
+        defer.add(ws, (m + 63) // 64, c, bias_grad, accumulate)
+        return out_h, out_t, bias_grad
     _grad_prep(dy, y, float(slope), float(scale), out_h, out_t, bias_grad, bool(accumulate), ws)
     return out_h, out_t, bias_grad
 
@@ -833,7 +892,7 @@ def _layernorm_backward_affine(x, gamma, dy, eps, dx, dgamma, dbeta, accumulate,
           "layernorm_backward_affine")
 
 
-def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None):
+def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None, defer=None):
     """-> (dx, dgamma, dbeta) of LayerNorm(x) * gamma + beta for fp32 (M, C) rows.  dgamma / dbeta given: the affine gradients are ADDED
     to them (the parameter's gradient accumulator: no temporary, no separate add).  C <= 1024: dx and the float64 partials of both affine
     gradients come from ONE kernel (emage_layernorm_backward_affine) + a finalize launch; wider rows: dx, dy * xhat, two column sums."""
@@ -852,7 +911,7 @@ def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None):
     _layernorm_backward(x, gamma, dy, float(eps), dx, t)
     if dgamma is None:
         return dx, col_sum(t), col_sum(dy)
-    return dx, col_sum(t, out=dgamma, accumulate=True), col_sum(dy, out=dbeta, accumulate=True)
+    return dx, col_sum(t, out=dgamma, accumulate=True, defer=defer), col_sum(dy, out=dbeta, accumulate=True, defer=defer)
 
 
 @_op("attention_backward", "(Tensor q, Tensor k, Tensor vt, int vt_rows, Tensor? pmask, Tensor d_out, Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) dv, "

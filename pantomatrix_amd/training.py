@@ -233,6 +233,8 @@ class TrainForward:
         self.conv_backward_rows = 1 << 17                 # output rows per piece of a long convolution's backward (_conv_backward_h2)
         self._w_scale, self._wt_cache = {}, {}
         self.accumulate_dw = True       # Linear weight gradients are added into the gradient rows by their contraction (A/B switch; False: a temporary + a queued add)
+        self.defer_finalize = True      # bias / affine-gradient reductions end in batched finalize launches (`ops.FinalizeQueue`; A/B switch: False = one each)
+        self._fin = ops.FinalizeQueue()
         self.splitk_workspace_bytes = 32 << 20            # scratch of the two-pass split-K weight-gradient contractions (emage_gemm_ws: K-slices as planes, added
         self._splitk_buf = None                           # in slice order — bit-reproducible gradients); 0: the fp32-atomic form of emage_gemm
         self.lazy_masks = True          # device-drawn (T, B, d) dropout masks live as Philox keys: drawn inside `mul_add`, forward and backward (-0.9 GB per forward)
@@ -288,7 +290,8 @@ class TrainForward:
 
     def begin_step(self):
         """Start of an optimisation step (`Trainer._device_step`): outside a graph capture the global clip count of SyncBatchNorm is
-        forgotten, so the step's first BatchNorm exchanges it afresh (`_clip_total`)."""
+        forgotten, so the step's first BatchNorm exchanges it afresh (`_clip_total`); the finalize queue lets go of last step's tables."""
+        self._fin.new_step(_capturing(self.model.device))
         if self.sync_bn and not _capturing(self.model.device):
             self._clips.clear()
 
@@ -754,7 +757,8 @@ class TrainForward:
         single = len(origin) == 1
         bias_dst = self._grad_rows(origin[0][1], origin[0][2])[0] if single else None
         dpre_h, dpre_t, db = ops.grad_prep(dy, y, 0.0 if slope is None else slope, gs, n_store=_rup(n) if need_dx else None, m_store=mp,
-                                           bias_grad=bias_dst, accumulate=single)                # (M, rup64(N)), (N, mp)
+                                           bias_grad=bias_dst, accumulate=single,                # (M, rup64(N)), (N, mp)
+                                           defer=self._fin if (single and self.defer_finalize) else None)
         x_t = ops.h2_cast(x[:, :k], mp, scale=1.0, transpose=True)                    # (K, mp)
         wdst = self._grad_rows(origin[0][0], origin[0][2])[0] if single else None
         if self.accumulate_dw and wdst is not None and wdst.dim() == 2 and wdst.stride(1) == 1 and wdst.stride(0) % 4 == 0 and wdst.data_ptr() % 16 == 0:
@@ -834,10 +838,11 @@ class TrainForward:
     def _param_grad_colsum(self, name, rows, x, y=None):
         """grad(name)[rows] += column sums of x (* y): the bias / affine gradients, accumulated by the reduction's own finalize launch."""
         dst, _span = self._grad_rows(name, rows)
-        ops.col_sum(x, y, out=dst, accumulate=True)
+        ops.col_sum(x, y, out=dst, accumulate=True, defer=self._fin if self.defer_finalize else None)
 
     def flush_param_grads(self):
         """Apply the queued parameter-gradient contributions (call before anything reads or exchanges the accumulators)."""
+        self._fin.flush()                 # the queued finalize steps of the column reductions (bias / affine gradients)
         if self._pg_dst:
             torch._foreach_add_(self._pg_dst, self._pg_src)
         self._pg_dst, self._pg_src, self._pg_spans, self._pg_bytes = [], [], {}, 0
@@ -880,7 +885,8 @@ class TrainForward:
                     return
                 dg, _ = self._grad_rows(key + ".weight", slice(None))
                 db, _ = self._grad_rows(key + ".bias", slice(None))
-                dx, _, _ = ops.layernorm_backward(s_in, n["g"], g, dgamma=dg, dbeta=db)      # d gamma / d beta += inside
+                dx, _, _ = ops.layernorm_backward(s_in, n["g"], g, dgamma=dg, dbeta=db,      # d gamma / d beta += inside
+                                                  defer=self._fin if self.defer_finalize else None)
                 self.tape.add(s_in, dx)
             self.tape.node(bw)
         return y

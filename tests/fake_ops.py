@@ -174,7 +174,7 @@ def transpose(x, out=None):
     return r
 
 
-def col_sum(x, y=None, out=None, accumulate=False):
+def col_sum(x, y=None, out=None, accumulate=False, defer=None):
     CALLS.append("col_sum")
     s = (x.double() * (y.double() if y is not None else 1.0)).sum(0).float()
     if out is None:
@@ -192,7 +192,7 @@ def act_backward(dy, y, slope, out=None):
     return r
 
 
-def grad_prep(dy, y=None, slope=0.0, scale=1.0, n_store=None, m_store=None, bias_grad=None, accumulate=False, want_bias=True):
+def grad_prep(dy, y=None, slope=0.0, scale=1.0, n_store=None, m_store=None, bias_grad=None, accumulate=False, want_bias=True, defer=None):
     CALLS.append("grad_prep")
     dpre = dy if y is None else dy * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
     out_h = h2_cast(dpre, n_store, scale) if n_store is not None else None
@@ -206,7 +206,7 @@ def grad_prep(dy, y=None, slope=0.0, scale=1.0, n_store=None, m_store=None, bias
     return out_h, out_t, bias_grad
 
 
-def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None):
+def layernorm_backward(x, gamma, dy, eps=1e-5, dgamma=None, dbeta=None, defer=None):
     CALLS.append("layernorm_backward")
     mu = x.mean(1, keepdim=True)
     rstd = 1.0 / torch.sqrt(((x - mu) ** 2).mean(1, keepdim=True) + eps)

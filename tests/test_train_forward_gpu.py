@@ -463,6 +463,57 @@ def test_mul_add_with_the_mask_drawn_inside_the_kernel():
         assert torch.equal(ops.PhiloxMask(shape, 0.1, seed, mid, step, DEV).materialize().view(m, c), mask)
 
 
+def test_batched_finalize_launches_change_no_bit(golden_dir):
+    """Round 5: the ~600 finalize launches of a step's bias / affine-gradient reductions are queued and issued 64 at a time
+    (`emage_col_sum_finalize_multi`, `ops.FinalizeQueue`).  (i) the kernel: a mixed batch — 70 reductions of both producers
+    (`col_sum`, `grad_prep`), writing and accumulating, ragged widths — equals the one-by-one finalize launches bit for bit, and a
+    destination queued twice is flushed in between; (ii) the step: the same parameters after Adam, bit for bit, as with
+    `defer_finalize = False`."""
+    from pantomatrix_amd import ops
+    g = torch.Generator().manual_seed(11)
+    q = ops.FinalizeQueue()
+    ref, got = [], []
+    for i in range(70):
+        m, c = (3584, 768) if i % 3 == 0 else ((448, 250) if i % 3 == 1 else (3000, 1536))
+        x = torch.randn(m, c, generator=g).to(DEV)
+        base = torch.randn(c, generator=g).to(DEV)
+        acc = bool(i % 2)
+        a, b = base.clone(), base.clone()
+        if i % 4 < 2:
+            ops.col_sum(x, None, out=a, accumulate=acc)
+            ops.col_sum(x, None, out=b, accumulate=acc, defer=q)
+        else:
+            ops.grad_prep(x, None, 0.0, 1.0, None, None, bias_grad=a, accumulate=acc)
+            ops.grad_prep(x, None, 0.0, 1.0, None, None, bias_grad=b, accumulate=acc, defer=q)
+        ref.append(a)
+        got.append(b)
+    assert len(q.entries) == 70 - 64                                # one full batch went out on its own
+    q.flush()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), i
+    d = torch.zeros(768, device=DEV)
+    x = torch.randn(3584, 768, generator=g).to(DEV)
+    ops.col_sum(x, None, out=d, accumulate=True, defer=q)
+    ops.col_sum(x, None, out=d, accumulate=True, defer=q)           # the same destination again: the first entry is flushed first
+    assert len(q.entries) == 1
+    q.flush()
+    one = ops.col_sum(x)
+    assert torch.equal(d, one + one)
+    gg = np.load(os.path.join(golden_dir, "train_step_b2.npz"))
+    batch, _, masks, random_mask, _ = tc.oracle_step(int(gg["seed"]), int(gg["iteration"]))
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    ends = []
+    for defer in (True, False):
+        model, vq = common.product_models(precision="f16x3", device=DEV)
+        trainer = training.Trainer(model, vq)
+        trainer.fwd.defer_finalize = defer
+        trainer.step(batch, int(gg["iteration"]), masks, random_mask.to(DEV))
+        ends.append({k: v.clone() for k, v in model._flat_params().items() if v.is_floating_point()})
+    diff = [k for k in ends[0] if not torch.equal(ends[0][k], ends[1][k])]
+    assert not diff, diff[:8]
+
+
 def test_sync_batchnorm_on_one_device_equals_plain_batchnorm(golden_dir):
     """sync_bn=True with a world of one (no process group): the SyncBatchNorm code path of the forward and of the backward on the
     MI355X gives the step of the plain BatchNorm path (Weak #1 iii)."""
