@@ -415,12 +415,17 @@ int emage_transpose_f32(const float* in, int ld_in, float* out, int ld_out, int 
  * written (partial[chunk * C + c]); a later emage_col_sum_finalize_multi ends this reduction together with others.
  *
  * emage_col_sum_finalize_multi — the finalize step of up to 64 chunked column reductions in ONE launch (a training step ends ~600 of
- * them: bias gradients from emage_grad_prep, LayerNorm / embedding gradients from emage_col_sum).  `table`: device memory, n_entries
- * records of 32 bytes { const double* partial; float* out; int32 chunks, C, accumulate, block0 } with block0 = the running sum of
- * ceil(C / 16) over the earlier entries; n_blocks = that sum over all entries.  Entry by entry the arithmetic (and the bits) of the
- * finalize launch inside emage_col_sum / emage_grad_prep.  No two entries of one call may name overlapping `out` ranges. */
+ * them: bias gradients from emage_grad_prep, LayerNorm / embedding gradients from emage_col_sum).  `entries`: HOST memory, read during
+ * the call (the table travels by value in the kernel argument segment: nothing to allocate, and a captured launch keeps its own copy).
+ * Entry by entry the arithmetic (and the bits) of the finalize launch inside emage_col_sum / emage_grad_prep.  No two entries of one
+ * call may name overlapping `out` ranges. */
+typedef struct emage_finalize_entry {
+    const double* partial;      /* chunks x C float64 partials: partial[chunk * C + c] */
+    float* out;                 /* C floats */
+    int chunks, C, accumulate;  /* accumulate != 0: out[c] += sum, else out[c] = sum */
+} emage_finalize_entry;
 int emage_col_sum_chunks(int M);
-int emage_col_sum_finalize_multi(const void* table, int n_entries, int n_blocks, void* stream);
+int emage_col_sum_finalize_multi(const emage_finalize_entry* entries, int n_entries, void* stream);
 int emage_col_sum(const float* x, int ldx, const float* y, int ldy, int M, int C, float* out, int accumulate,
                   void* workspace, long workspace_bytes, void* stream);
 

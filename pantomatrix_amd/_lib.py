@@ -22,6 +22,11 @@ class GemmProblem(C.Structure):
                 + [("a_scale", _f), ("w_scale", _f)])
 
 
+class FinalizeEntry(C.Structure):
+    """`emage_finalize_entry` of include/emage_hip.h (emage_col_sum_finalize_multi takes a host array of them)."""
+    _fields_ = [("partial", _p), ("out", _p), ("chunks", _i), ("C", _i), ("accumulate", _i)]
+
+
 # name -> argtypes, exactly the prototypes of include/emage_hip.h
 TOOLS_SIGNATURES = {"emage_set_tuning": [_i, _i], "emage_h2_set_trace": [_p]}      # exported by the tools build only
 SIGNATURES = {
@@ -47,7 +52,7 @@ SIGNATURES = {
     "emage_transpose_f32": [_p, _i, _p, _i, _i, _i, _p],
     "emage_col_sum": [_p, _i, _p, _i, _i, _i, _p, _i, _p, _l, _p],
     "emage_col_sum_chunks": [_i],
-    "emage_col_sum_finalize_multi": [_p, _i, _i, _p],
+    "emage_col_sum_finalize_multi": [C.POINTER(FinalizeEntry), _i, _p],
     "emage_act_backward": [_p, _i, _p, _i, _f, _p, _i, _i, _i, _p],
     "emage_layernorm_backward_affine_workspace_bytes": [_i, _i, _i],
     "emage_layernorm_backward_affine": [_p, _i, _p, _p, _i, _f, _p, _i, _p, _p, _i, _i, _i, _i, _p, _l, _p],

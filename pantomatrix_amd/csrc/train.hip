@@ -313,11 +313,14 @@ __global__ __launch_bounds__(256) void col_sum_finalize_kernel(const double* __r
 // reduction (its float64 partials, chunk count, width, destination, accumulate flag) and owns blocks [block0_e, block0_{e+1}); a block
 // finds its entry by a scan of the (<= 64) entries and then runs the arithmetic of col_sum_finalize_kernel: the same bits.
 struct FinEntry { const double* partial; float* out; int chunks, C, accumulate, block0; };
-__global__ __launch_bounds__(256) void col_sum_finalize_multi_kernel(const FinEntry* __restrict__ tab, int n) {
+constexpr int FIN_MAX = 64;
+struct FinTable { FinEntry e[FIN_MAX]; int n; };        // 2 KB: travels BY VALUE in the kernel argument segment (a captured launch keeps its own copy)
+__global__ __launch_bounds__(256) void col_sum_finalize_multi_kernel(FinTable tab) {
     __shared__ double red[FIN_LANES][FIN_COLS];
     int e = 0;
-    for (int i = 1; i < n; ++i) e += ((int)blockIdx.x >= tab[i].block0) ? 1 : 0;      // block0 ascending
-    const FinEntry t = tab[e];
+    for (int i = 1; i < tab.n; ++i) e += ((int)blockIdx.x >= tab.e[i].block0) ? 1 : 0;      // block0 ascending; scalar work
+    e = __builtin_amdgcn_readfirstlane(e);
+    const FinEntry& t = tab.e[e];
     const int cl = threadIdx.x % FIN_COLS, rl = threadIdx.x / FIN_COLS;
     const int c = ((int)blockIdx.x - t.block0) * FIN_COLS + cl;
     const int per = (t.chunks + FIN_LANES - 1) / FIN_LANES;
@@ -728,9 +731,19 @@ extern "C" int emage_col_sum_chunks(int M) {
     return (M + chunk_rows - 1) / chunk_rows;
 }
 
-extern "C" int emage_col_sum_finalize_multi(const void* table, int n_entries, int n_blocks, void* stream) {
-    if (!table || n_entries <= 0 || n_entries > 64 || n_blocks <= 0 || ((uintptr_t)table & 7)) return EMAGE_EINVAL;
-    hipLaunchKernelGGL(col_sum_finalize_multi_kernel, dim3(n_blocks), dim3(FIN_THREADS), 0, (hipStream_t)stream, (const FinEntry*)table, n_entries);
+extern "C" int emage_col_sum_finalize_multi(const emage_finalize_entry* entries, int n_entries, void* stream) {
+    if (!entries || n_entries <= 0 || n_entries > FIN_MAX) return EMAGE_EINVAL;
+    FinTable tab;
+    int blocks = 0;
+    for (int i = 0; i < n_entries; ++i) {
+        const emage_finalize_entry& q = entries[i];
+        if (!q.partial || !q.out || q.chunks <= 0 || q.C <= 0 || ((uintptr_t)q.partial & 7)) return EMAGE_EINVAL;
+        tab.e[i] = FinEntry{q.partial, q.out, q.chunks, q.C, q.accumulate ? 1 : 0, blocks};
+        blocks += (q.C + FIN_COLS - 1) / FIN_COLS;
+    }
+    for (int i = n_entries; i < FIN_MAX; ++i) tab.e[i] = tab.e[0];
+    tab.n = n_entries;
+    hipLaunchKernelGGL(col_sum_finalize_multi_kernel, dim3(blocks), dim3(FIN_THREADS), 0, (hipStream_t)stream, tab);
     return launch_status();
 }
 

@@ -752,22 +752,26 @@ def _col_sum(x, y, out, accumulate, workspace):
                                     workspace.numel() * 8, _stream()), "col_sum")
 
 
-@_op("col_sum_finalize_multi", "(Tensor table, int n_entries, int n_blocks) -> ()")
-def _col_sum_finalize_multi(table, n_entries, n_blocks):
-    check(_lib.load().emage_col_sum_finalize_multi(_ptr(table), n_entries, n_blocks, _stream()), "col_sum_finalize_multi")
+@_op("col_sum_finalize_multi", "(Tensor(a!)[] outs, Tensor[] partials, int[] desc) -> ()")
+def _col_sum_finalize_multi(outs, partials, desc):
+    n = len(outs)
+    arr = (_lib.FinalizeEntry * n)()
+    for i in range(n):
+        arr[i].partial, arr[i].out = partials[i].data_ptr(), outs[i].data_ptr()
+        arr[i].chunks, arr[i].C, arr[i].accumulate = desc[3 * i], desc[3 * i + 1], desc[3 * i + 2]
+    check(_lib.load().emage_col_sum_finalize_multi(arr, n, _stream()), "col_sum_finalize_multi")
 
 
 class FinalizeQueue:
     """The finalize steps of chunked column reductions (bias gradients out of `grad_prep`, LayerNorm / embedding gradients out of
     `col_sum`), QUEUED and issued 64 at a time as one `emage_col_sum_finalize_multi` launch instead of one 3-48-block launch each (~600 per
     training step).  An entry whose destination overlaps a queued one flushes first, so every element still receives its contributions in
-    issue order.  `flush()` before anything reads the destinations (training.TrainForward.flush_param_grads).  The launch reads a small
-    device table copied from pinned host memory; tables are kept alive (`keep`) for as long as a captured graph may replay the copy —
-    `new_step()` drops them outside a capture."""
+    issue order.  `flush()` before anything reads the destinations (training.TrainForward.flush_param_grads).  The launch carries its
+    table by value in the kernel arguments: no device table, nothing whose lifetime a captured graph would depend on."""
     CAP = 64
 
     def __init__(self):
-        self.entries, self.keep = [], []
+        self.entries = []
 
     def add(self, partial, chunks, c, out, accumulate):
         lo = out.data_ptr()
@@ -782,20 +786,11 @@ class FinalizeQueue:
     def flush(self):
         if not self.entries:
             return
-        words, block0 = [], 0
-        for _lo, _hi, partial, chunks, c, out, accumulate in self.entries:
-            words += [partial.data_ptr(), out.data_ptr(), chunks | (c << 32), int(accumulate) | (block0 << 32)]
-            block0 += (c + 15) // 16
-        dev = self.entries[0][5].device
-        host = torch.tensor(words, dtype=torch.int64).pin_memory()
-        table = host.to(dev, non_blocking=True)
-        _col_sum_finalize_multi(table, len(self.entries), block0)
-        self.keep.append((host, table, [e[2] for e in self.entries]))          # the partial buffers live until their finalize has been issued
+        desc = []
+        for _lo, _hi, _partial, chunks, c, _out, accumulate in self.entries:
+            desc += [chunks, c, int(accumulate)]
+        _col_sum_finalize_multi([e[5] for e in self.entries], [e[2] for e in self.entries], desc)
         self.entries = []
-
-    def new_step(self, capturing=False):
-        if not capturing:
-            self.keep = []
 
 
 def col_sum_chunks(m):

@@ -290,8 +290,7 @@ class TrainForward:
 
     def begin_step(self):
         """Start of an optimisation step (`Trainer._device_step`): outside a graph capture the global clip count of SyncBatchNorm is
-        forgotten, so the step's first BatchNorm exchanges it afresh (`_clip_total`); the finalize queue lets go of last step's tables."""
-        self._fin.new_step(_capturing(self.model.device))
+        forgotten, so the step's first BatchNorm exchanges it afresh (`_clip_total`)."""
         if self.sync_bn and not _capturing(self.model.device):
             self._clips.clear()
 

@@ -14,6 +14,7 @@ quick = "--quick" in sys.argv                   # captured step only (A/B runs):
 acc = None if "--accumulate-dw" not in sys.argv else int(sys.argv[sys.argv.index("--accumulate-dw") + 1])
 variant = 0 if "--h2-variant" not in sys.argv else int(sys.argv[sys.argv.index("--h2-variant") + 1])
 ln_fused = None if "--ln-fused" not in sys.argv else int(sys.argv[sys.argv.index("--ln-fused") + 1])
+defer = None if "--defer-finalize" not in sys.argv else int(sys.argv[sys.argv.index("--defer-finalize") + 1])
 sys.argv = ["bench.py"]
 import bench  # noqa: E402
 
@@ -24,6 +25,6 @@ if variant:                                     # tools library: emage_set_tunin
 if ln_fused is not None:
     from pantomatrix_amd import ops
     ops.FUSED_LAYERNORM_BACKWARD = {0: False, 1: 16}.get(ln_fused, ln_fused)
-line = bench.bench_train_step(torch.device("cuda", 0), cpu=cpu, eager=not quick, accumulate_dw=acc)
-line["ab"] = {"accumulate_dw": acc, "h2_variant": variant, "ln_fused": ln_fused}
+line = bench.bench_train_step(torch.device("cuda", 0), cpu=cpu, eager=not quick, accumulate_dw=acc, defer_finalize=defer)
+line["ab"] = {"accumulate_dw": acc, "h2_variant": variant, "ln_fused": ln_fused, "defer_finalize": defer}
 print(json.dumps(line))
