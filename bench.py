@@ -510,7 +510,7 @@ def bench_exchange_single_rank(dev, data, random_mask, steps=3):
             tdist.destroy_process_group()
 
 
-def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw=None, defer_finalize=None):
+def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw=None, defer_finalize=None, exchange=True):
     """One EMAGE optimisation step at BASELINE configs[2]'s per-GPU batch (56 clips x 64 frames): targets through the frozen VQ-VAEs, three
     train-mode forwards (batch-statistics BatchNorm, dropout masks drawn on the device), six losses, three backward passes, multi-tensor
     Adam, BatchNorm buffers — `training.Trainer.capture` / `replay`: the whole step is ONE hipGraph.  `roofline`: the step's algorithmic
@@ -572,7 +572,8 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw
     # one rank — the four bucket all-reduces, the SyncBatchNorm all-gathers / small all-reduces run on the device, eagerly and inside the
     # captured graph (the form every rank of a multi-GPU run replays)
     try:
-        line["exchange"] = bench_exchange_single_rank(dev, data, random_mask, steps)
+        if exchange:
+            line["exchange"] = bench_exchange_single_rank(dev, data, random_mask, steps)
     except Exception as exc:                      # noqa: BLE001
         line["exchange"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
     torch.cuda.empty_cache()

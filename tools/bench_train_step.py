@@ -25,6 +25,6 @@ if variant:                                     # tools library: emage_set_tunin
 if ln_fused is not None:
     from pantomatrix_amd import ops
     ops.FUSED_LAYERNORM_BACKWARD = {0: False, 1: 16}.get(ln_fused, ln_fused)
-line = bench.bench_train_step(torch.device("cuda", 0), cpu=cpu, eager=not quick, accumulate_dw=acc, defer_finalize=defer)
+line = bench.bench_train_step(torch.device("cuda", 0), cpu=cpu, eager=not quick, accumulate_dw=acc, defer_finalize=defer, exchange=not quick)
 line["ab"] = {"accumulate_dw": acc, "h2_variant": variant, "ln_fused": ln_fused, "defer_finalize": defer}
 print(json.dumps(line))
