@@ -28,6 +28,7 @@
 #include "common.h"
 #include <math.h>
 #include "gemm_tile.h"
+#include "h2_tile.h"          // IC / static_for
 
 namespace {
 
@@ -151,19 +152,59 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
             constexpr int KH = KT / HALVES;                 // K-tiles per staging phase
             auto kt_of = [&](int it) { return (it / KH) * KH + wave * (KH / 4) + ((it % KH) >> 2); };
             u32x4 c0[KT], c1[KT];
-            auto load_h = [&]() {
+            auto load_part = [&](auto hc) {             // the loads of staging phase `hc` (iterations [hc * KH, (hc + 1) * KH))
+                constexpr int HF = decltype(hc)::value;
 #pragma unroll
-                for (int it = 0; it < KT; ++it) {
+                for (int i2 = 0; i2 < KH; ++i2) {
+                    const int it = HF * KH + i2;
                     const int row = 16 * (it & 3) + st_row, kt = kt_of(it);
                     const int off = (int)((long)row * p.ld_h_b * 4) + (kt * 32 + st_g * 4) * 4;         // < 2^31: checked by the host entry
                     c0[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 16));      // aux 16 = sc1: agent-coherent reads
                     c1[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 64, 0, 16));
                 }
             };
-            if constexpr (LL) {
+            auto part_ready = [&](auto hc) {            // wave-uniform: no word of the phase's loads still holds the sentinel
+                constexpr int HF = decltype(hc)::value;
+                unsigned mx = 0u;
+#pragma unroll
+                for (int i2 = 0; i2 < KH; ++i2) {
+                    const int it = HF * KH + i2;
+                    const unsigned a = max(max(c0[it].x, c0[it].y), max(c0[it].z, c0[it].w));
+                    const unsigned b2 = max(max(c1[it].x, c1[it].y), max(c1[it].z, c1[it].w));
+                    mx = max(mx, max(a, b2));
+                }
+                return __builtin_amdgcn_ballot_w64(mx == H_SENTINEL) == 0ull;
+            };
+            auto load_h = [&]() { emage_dev::static_for<HALVES>([&](auto hc) { load_part(hc); }); };
+            unsigned spins = 0;
+            int bad = 0;
+            bool gave_up = false;
+            // one polling loop of staging phase `hc`; first: the phase's loads have not been issued yet
+            auto poll_part = [&](auto hc, const bool first) {
+                bool issued = !first;
+                for (;;) {
+                    if (!issued) load_part(hc);
+                    issued = false;
+                    if (part_ready(hc)) break;
+                    ++spins;
+                    if (spins > SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { bad = 1; break; }
+                }
+            };
+            if constexpr (LL && HALVES > 1) {
+                // PIPELINED hand-over (round 5, VERDICT next #7): only phase 0 of h_{t-1} is waited for here; the loads of the later phases
+                // are issued once and checked just before their staging — they land while phase 0 is staged and multiplied
+                poll_part(emage_dev::IC<0>{}, true);
+                emage_dev::static_for<HALVES - 1>([&](auto hc) { load_part(emage_dev::IC<decltype(hc)::value + 1>{}); });
+                if (bad) {
+                    if (lane == 0) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *s_flag = 1;
+                    }
+                }
+                lds_barrier();
+                if (*s_flag) return;
+            } else if constexpr (LL) {
                 // the data is the flag: re-read this wave's share until no word of it holds the sentinel any more
-                unsigned spins = 0;
-                int bad = 0;
                 if (!(p.dbg & 4)) {
                     for (;;) {
                         load_h();
@@ -193,8 +234,15 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
                 if (!(p.dbg & 4)) load_h();
             }
             if (s + 1 < p.T) load_gx(s + 1, rvn);          // behind the h loads in the queue, lands during this step
-#pragma unroll
-            for (int half = 0; half < HALVES; ++half) {
+            emage_dev::static_for<HALVES>([&](auto halfc) {
+                constexpr int half = decltype(halfc)::value;
+                if constexpr (LL && HALVES > 1 && half > 0) {
+                    poll_part(halfc, false);                 // normally true at the first look: the phase arrived behind the previous phase's MFMAs
+                    if (bad && lane == 0) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *s_flag = 1;
+                    }
+                }
                 if (!(p.dbg & 4)) {
 #pragma unroll
                     for (int i2 = 0; i2 < KH; ++i2) {
@@ -208,6 +256,8 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
                     }
                 }
                 lds_barrier();
+                if constexpr (LL && HALVES > 1 && half > 0) { if (*s_flag) { gave_up = true; return; } }
+                if (gave_up) return;
                 if (!(p.dbg & 2)) {
 #pragma unroll
                     for (int k2 = 0; k2 < KH; ++k2) {
@@ -229,7 +279,8 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
                         for (int fb = 0; fb < 4; ++fb) acc[fb] = mma_f16(wh[kt], ah[fb], acc[fb]);
                     }
                 }
-            }
+            });
+            if (gave_up) return;
 #pragma unroll
             for (int fb = 0; fb < 4; ++fb) acc[fb] = acc[fb] * os;
         }
@@ -376,6 +427,8 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
     a.T = T;
     a.dbg = emage_dev::g_lstm_layer_dbg;
 #ifdef EMAGE_TOOLS
+    if (ll && (a.dbg & 128)) return H == 512 ? launch_seq<512, 2, true>(a, B, max_slices, sync, s) : launch_seq<256, 2, true>(a, B, max_slices, sync, s);   // tools A/B (round 5): two pipelined hand-over phases
+    if (ll && (a.dbg & 256) && H == 512) return launch_seq<512, 4, true>(a, B, max_slices, sync, s);                                                       // ... four
     if (!ll) {                                          // tools A/B: round 2's counter protocol (bit 16: two staging phases, measured equal)
         if (a.dbg & 16) return H == 512 ? launch_seq<512, 2, false>(a, B, max_slices, sync, s) : launch_seq<256, 2, false>(a, B, max_slices, sync, s);
         return H == 512 ? launch_seq<512, 1, false>(a, B, max_slices, sync, s) : launch_seq<256, 1, false>(a, B, max_slices, sync, s);

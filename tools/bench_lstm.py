@@ -70,9 +70,12 @@ def main():
             from pantomatrix_amd import _lib
             lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
             names = {0: "shipped (data-as-flag hand-over)", 32: "round 2's arrival-counter protocol", 2: "no MFMA phase", 4: "no h load / staging",
-                     8: "no wait for the group (one read)", 14: "skeleton: cell + h store only", 64: "shipped + s_sleep 1 between re-reads"}
+                     8: "no wait for the group (one read)", 14: "skeleton: cell + h store only", 64: "shipped + s_sleep 1 between re-reads",
+                     128: "round 5: two pipelined hand-over phases", 256: "round 5: four pipelined hand-over phases"}
             line["lstm_layer_us_per_step"] = {}
-            for dbg in (0, 32, 64, 2, 4, 8, 14):
+            line["same_bits_as_shipped"] = {}
+            base = None
+            for dbg in (0, 128, 256, 0, 128, 256, 32, 2, 4, 8, 14):
                 lib.emage_set_tuning(3, dbg)
                 ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
                 torch.cuda.synchronize()
@@ -83,7 +86,12 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 ops.lstm_layer_check(sync)
-                line["lstm_layer_us_per_step"][names[dbg]] = round(1e3 * e0.elapsed_time(e1) / 3 / tt, 2)
+                if dbg == 0 and base is None:
+                    base = hseq.clone()
+                elif dbg in (128, 256):
+                    line["same_bits_as_shipped"][names[dbg]] = bool(torch.equal(hseq, base))
+                key = names[dbg] if names[dbg] not in line["lstm_layer_us_per_step"] else names[dbg] + " (second run)"
+                line["lstm_layer_us_per_step"][key] = round(1e3 * e0.elapsed_time(e1) / 3 / tt, 2)
             lib.emage_set_tuning(3, 0)
         if not args.no_cpu:
             torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
