@@ -427,12 +427,15 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
     a.T = T;
     a.dbg = emage_dev::g_lstm_layer_dbg;
 #ifdef EMAGE_TOOLS
-    if (ll && (a.dbg & 128)) return H == 512 ? launch_seq<512, 2, true>(a, B, max_slices, sync, s) : launch_seq<256, 2, true>(a, B, max_slices, sync, s);   // tools A/B (round 5): two pipelined hand-over phases
-    if (ll && (a.dbg & 256) && H == 512) return launch_seq<512, 4, true>(a, B, max_slices, sync, s);                                                       // ... four
+    if (ll && (a.dbg & 128)) return H == 512 ? launch_seq<512, 1, true>(a, B, max_slices, sync, s) : launch_seq<256, 1, true>(a, B, max_slices, sync, s);   // tools A/B: round 3's single hand-over phase
+    if (ll && (a.dbg & 256) && H == 512) return launch_seq<512, 4, true>(a, B, max_slices, sync, s);                                                       // tools A/B: four phases (slower)
     if (!ll) {                                          // tools A/B: round 2's counter protocol (bit 16: two staging phases, measured equal)
         if (a.dbg & 16) return H == 512 ? launch_seq<512, 2, false>(a, B, max_slices, sync, s) : launch_seq<256, 2, false>(a, B, max_slices, sync, s);
         return H == 512 ? launch_seq<512, 1, false>(a, B, max_slices, sync, s) : launch_seq<256, 1, false>(a, B, max_slices, sync, s);
     }
 #endif
-    return H == 512 ? launch_seq<512, 1, true>(a, B, max_slices, sync, s) : launch_seq<256, 1, true>(a, B, max_slices, sync, s);
+    // round 5: TWO pipelined hand-over phases — only the first K half of h_{t-1} is waited for up front, the second half's loads land behind the
+    // first half's staging + MFMAs: 8.11-8.13 -> 7.48-7.64 us per time step at DisCo's size, 8.4-9.0 -> 8.4-8.5 at CaMN's, same bits
+    // (profiles/r05_lstm_layer_pipelined_handover.json); four phases are slower (8.7-8.8 / 9.4-9.5)
+    return H == 512 ? launch_seq<512, 2, true>(a, B, max_slices, sync, s) : launch_seq<256, 2, true>(a, B, max_slices, sync, s);
 }

@@ -69,9 +69,9 @@ def main():
             sync = ops.lstm_layer_sync(batch, hid, dev)
             from pantomatrix_amd import _lib
             lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
-            names = {0: "shipped (data-as-flag hand-over)", 32: "round 2's arrival-counter protocol", 2: "no MFMA phase", 4: "no h load / staging",
+            names = {0: "shipped (data-as-flag hand-over, two pipelined phases)", 32: "round 2's arrival-counter protocol", 2: "no MFMA phase", 4: "no h load / staging",
                      8: "no wait for the group (one read)", 14: "skeleton: cell + h store only", 64: "shipped + s_sleep 1 between re-reads",
-                     128: "round 5: two pipelined hand-over phases", 256: "round 5: four pipelined hand-over phases"}
+                     128: "round 3: one hand-over phase", 256: "four pipelined hand-over phases"}
             line["lstm_layer_us_per_step"] = {}
             line["same_bits_as_shipped"] = {}
             base = None
