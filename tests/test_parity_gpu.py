@@ -475,3 +475,32 @@ def test_grouped_launches_change_no_bit(golden_dir):
         if ca[k] is not None:
             assert torch.equal(ca[k], cb[k]), k
             assert torch.equal(ca[k], cc[k]), k
+
+
+def test_lockstep_chains_touch_no_recorded_output():
+    """inside a lock-step chain emage ops are deferred while torch ops run at once.  With `ops.LOCKSTEP_CHECK` a torch
+    operator that touches the storage of a recorded, not yet launched emage output raises: a forward window, a 2-window + tail clip with the
+    final decode (every chain of the model: VQ part decoders, refinement layers + heads, second MLP layers) and the face / body lock-step
+    walk run clean under it, and give the bits of the unchecked run."""
+    from pantomatrix_amd import ops
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    audio, spk, motion, mask = (x.to(DEV) for x in common.window_inputs(2))
+    clip = synthetic.synthetic_audio(2, synthetic.samples_for_frames(150)).to(DEV)
+    with torch.no_grad():
+        ref = model.forward(audio, spk, motion, mask)
+    (pr, er, tr), _ = common.product_infer_clip(model, vq, clip)
+    ops.LOCKSTEP_CHECK = True
+    try:
+        fresh, fvq = common.product_models(precision="f16x3", device=DEV)          # packing included: `_engine()` runs outside the chains
+        with torch.no_grad():
+            got = fresh.forward(audio, spk, motion, mask)
+        (pg, eg, tg), _ = common.product_infer_clip(fresh, fvq, clip)
+        fresh.group_face_body = True
+        with torch.no_grad():
+            paired = fresh.forward(audio, spk, motion, mask)
+    finally:
+        ops.LOCKSTEP_CHECK = False
+    for k in orc.OUT_KEYS:
+        assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], paired[k]), k
+    assert np.array_equal(pr, pg) and np.array_equal(er, eg) and np.array_equal(tr, tg)
+
