@@ -205,7 +205,9 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     constexpr bool LONE = (FN & 1) != 0;
     constexpr int GA = BM / RPI / NL, GB = BN / RPI / NL, G = GA + GB;
     static_assert((BM / RPI) % NL == 0 && (BN / RPI) % NL == 0, "every loading wave issues the same number of DMA instructions");
-    static_assert(WTM % 16 == 0 && WTN % 16 == 0 && NS >= 2 && NS <= 4, "tile shape");
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0 && NS >= 2 && NS <= 8, "tile shape");
+    static_assert(NS <= 4 || !PIPE, "rings deeper than 4: the plain K-loop");
+    static_assert((NS - 2) * (BM / 8 / (NLW ? NLW : WM * WN) + BN / 8 / (NLW ? NLW : WM * WN)) * KPB <= 63, "vmcnt is a 6-bit counter");
     static_assert(!PIPE || NS >= 3, "the register-pipelined K-loop reads one stage ahead: ring of >= 3");
     static_assert(KPB == 1 || (!PIPE && !DILV && KPB == 2), "several K-tiles per slot: the plain K-loop");
     constexpr int SUB = (BM + BN) * RB;               // one 32-k sub-tile of a slot
@@ -389,10 +391,17 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
         auto wait_landed = [&](const int st) {
             // the loading waves wait until stage st + AH has landed; stages issued after it may stay in flight
             const int last_issued = (st + NS - 2 < nk - 1) ? st + NS - 2 : nk - 1;
-            const int infl = last_issued - (st + AH);
-            if (NS >= 4 && infl >= 2) wait_vmcnt<2 * G * KPB>();
-            else if (NS >= 3 && infl >= 1) wait_vmcnt<G * KPB>();
-            else wait_vmcnt<0>();
+            const int infl = last_issued - (st + AH);      // 0 .. NS - 2 ring slots stay in flight behind the one needed now
+            if constexpr (NS <= 4) {
+                if (NS >= 4 && infl >= 2) wait_vmcnt<2 * G * KPB>();
+                else if (NS >= 3 && infl >= 1) wait_vmcnt<G * KPB>();
+                else wait_vmcnt<0>();
+            } else {                                       // deep rings (round 5: lone blocks on small grids): one counted wait per depth
+                static_for<NS - 1>([&](auto kc) {
+                    constexpr int KQ = decltype(kc)::value;
+                    if (infl == KQ) wait_vmcnt<KQ * G * KPB>();
+                });
+            }
         };
 
         // DILV: the DMA instructions of the stage issued in this iteration are spread between the MFMAs instead of in front of them
