@@ -59,6 +59,28 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+class native_stdout_to_stderr:
+    """Context: file descriptor 1 points at stderr while native libraries initialise — RCCL prints a version banner ("RCCL version : ...",
+    "Librccl path : ...") to the C-level stdout when its first communicator is created, which would put extra lines next to the ONE JSON line
+    the contract promises on stdout.  C stdio is flushed on both edges, so nothing written inside can surface later on the real stdout."""
+
+    def __enter__(self):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # multi-GPU launch: one process per GPU
 # ----------------------------------------------------------------------------------------------------------------------
@@ -573,7 +595,8 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw
     # captured graph (the form every rank of a multi-GPU run replays)
     try:
         if exchange:
-            line["exchange"] = bench_exchange_single_rank(dev, data, random_mask, steps)
+            with native_stdout_to_stderr():      # RCCL's version banner goes to stderr, not next to the JSON line
+                line["exchange"] = bench_exchange_single_rank(dev, data, random_mask, steps)
     except Exception as exc:                      # noqa: BLE001
         line["exchange"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
     torch.cuda.empty_cache()
@@ -784,7 +807,10 @@ def main():
     audio = audio_host.to(dev)
     # the process group (RCCL; barriers and the max-over-ranks of the timing only) is joined AFTER the graph capture, so
     # no communicator thread is alive while the stream capture is open; None without a launcher
-    pdist.init("nccl", dev)
+    with native_stdout_to_stderr():          # the backend's banner must not reach stdout (one JSON line there)
+        if pdist.init("nccl", dev) is not None:
+            pdist.barrier()                  # the communicator (and its banner) is created by the first collective
+            torch.cuda.synchronize()
 
     def barrier():
         pdist.barrier()
