@@ -254,7 +254,9 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
 #endif
         case 119: return launch_h2<128, 256, 4, 2, 2, 0, false>(a, s);             // 8 waves 32x128
         case 120: return launch_h2<64, 64, 2, 2, 3, 0, false, false, 2>(a, s);     // 768-wide / small outputs: 4 waves 32x32, three blocks per CU
-        case 188: return launch_h2<64, 64, 2, 2, 8, 0, false, false, 1>(a, s);     // round 5: at most one tile per CU (one clip, the N = 256 heads): a LONE block per CU, ring of 8
+#ifdef EMAGE_TOOLS
+        case 188: return launch_h2<64, 64, 2, 2, 8, 0, false, false, 1>(a, s);     // round 5 (negative): a LONE block per CU with a ring of 8 for grids of at most one tile per CU
+#endif
 #ifdef EMAGE_TOOLS
         case 121: return launch_h2<64, 64, 2, 2, 3, 0, true, false, 2>(a, s);
         case 122: return launch_h2<64, 128, 2, 2, 3, 0, true>(a, s);               // 4 waves 32x64
@@ -371,15 +373,17 @@ static int h2_config_for(const GemmArgs& a) {
 // called by emage_gemm (gemm.hip) for dtype EMAGE_H2 after the common argument checks
 int gemm_h2_dispatch(GemmArgs& a, hipStream_t s) {
     int cfg = h2_config_for(a);
-    // a grid of at most one 64 x 64 tile per CU (ONE clip: M = 64 rows; the N = 256 heads / conv3 of the 64-clip batch): every block is alone
-    // on its CU and its K-loop is one LDS-DMA round trip per ring slot — nothing else overlaps it.  With 128 KB of LDS to itself the block keeps 7
-    // ring slots in flight instead of 2 (config 188: same tile, same MFMA order, same bits).  Grouped launches keep 120 (several blocks per CU).
-    if (cfg == 120 && g_h2_force_config < 0 && !(g_h2_variant & 262144)) {
+#ifdef EMAGE_TOOLS
+    // round 5, measured NEGATIVE (profiles/r05_small_grids_ring_of_8_ab.txt): grids of at most one 64 x 64 tile per CU (ONE clip: M = 64 rows; the
+    // N = 256 heads / conv3 of the 64-clip batch) on config 188 — the same tile as a LONE block per CU with a ring of 8 K-tiles in flight instead
+    // of 3 — are SLOWER: one clip 4.38-4.45 vs 4.33-4.34 ms, 28 s 29.2-29.4 vs 28.6-28.7, the 64-clip step 13.25-13.31 vs 13.14-13.19 (same bits).
+    // Kept behind emage_set_tuning key 5 bit 524288 for A/B only
+    if (cfg == 120 && g_h2_force_config < 0 && (g_h2_variant & 524288)) {
         const long t64 = (long)((a.M + 63) / 64) * ((((a.n_store > a.N ? a.n_store : a.N)) + 63) / 64);
-        // (bare long-K contractions — the weight gradients — keep 120: their split-K fills the chip with K-slices instead)
         const bool bare = a.taps == 1 && !a.out && !a.out_t && !a.bias && !a.slope && a.out_f32 && a.K / 32 >= 64;
         if (t64 <= 256 && !bare) cfg = 188;
     }
+#endif
     return cfg < 0 ? cfg : run_config(cfg, a, s);
 }
 

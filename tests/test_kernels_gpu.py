@@ -501,7 +501,7 @@ def test_gemm_h2_every_tile_configuration(cfg):
 def test_gemm_h2_two_ktiles_per_slot_change_no_bit():
     """Round 5 (VERDICT next #1b, "BK = 64"): the KPB = 2 configurations — two 32-k sub-tiles per ring slot and s_barrier — issue the MFMAs
     of every accumulator in the order of their KPB = 1 twins: the same bits, on a residual GEMM, a ragged V^T GEMM and a convolution.
-    Likewise the ring-of-8 tile for grids of at most one tile per CU (188, shipped) against the three-blocks-per-CU tile (120)."""
+    Likewise the ring-of-8 tile for grids of at most one tile per CU (188: measured slower, tools only) against the three-blocks-per-CU tile (120)."""
     from pantomatrix_amd import _lib
     lib = _lib.use_tools(True)
     cases = [("kpb_res", (64, 64, 64), 768, 768, 1, 1, 0, dict(bias=True, res="h2")),
