@@ -59,10 +59,14 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int H, int HALVES, bool LL>
+// ROWS (round 5): clips per block — 64, or 32 so that a SMALL batch still fills the chip (DisCo's 128 clips are 2 slices of 64 = 128 blocks on 256
+// CUs; as 4 slices of 32 every CU has a block, and a block's staging, MFMA and cell work per time step halve).  Same arithmetic per clip: same bits.
+template <int H, int HALVES, bool LL, int ROWS = 64>
 __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
     constexpr int KT = H / 32, WPG = H / 16;           // K-tiles; blocks per group
-    constexpr unsigned PLANE = KT * 64 * 64;           // one fp16 plane of the 64 x H slice: [kt][row][4 chunks of 16 B]
+    constexpr int FB = ROWS / 16;                      // 16-clip fragments per block
+    constexpr unsigned PLANE = KT * ROWS * 64;         // one fp16 plane of the ROWS x H slice: [kt][row][4 chunks of 16 B]
+    static_assert(ROWS == 64 || ROWS == 32, "clips per block");
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     int* s_flag = (int*)(smem + 2 * PLANE);
 
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
     const int g = blockIdx.x % groups, j = blockIdx.x / groups;
     const int dir = g / p.slices, slice = g - dir * p.slices;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
-    const int b_base = slice * 64;
+    const int b_base = slice * ROWS;
     const int unit = j * 16 + wave * 4 + fg;           // the hidden unit whose 4 gates this lane ends up with
     unsigned* const cnt = p.sync + 32 * g;
     unsigned* const err = p.sync + 32 * MAX_GROUPS;
@@ -86,22 +90,24 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
         }
     }
     const float os = p.os[dir], as = p.a_scale;
-    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    float c[FB];
+#pragma unroll
+    for (int fb = 0; fb < FB; ++fb) c[fb] = 0.f;
 
     const int st_row = lane >> 2, st_g = lane & 3;
 
     // the input projection of a step is fetched one step ahead (it does not depend on the recurrence): its HBM latency hides
     // behind the previous step instead of sitting on the serial path
-    auto load_gx = [&](int step, float4 (&dst)[4]) {
+    auto load_gx = [&](int step, float4 (&dst)[FB]) {
         const int tt = dir ? p.T - 1 - step : step;
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
+        for (int fb = 0; fb < FB; ++fb) {
             const int b = b_base + fb * 16 + fr;
             dst[fb] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (b < p.B) dst[fb] = *(const float4*)(p.gx + (long)b * p.ld_gx_b + (long)tt * p.ld_gx_t + dir * 4 * H + 4 * unit);
         }
     };
-    float4 rv[4];
+    float4 rv[FB];
     load_gx(0, rv);
     if constexpr (LL) {
         if (tid == 0) *s_flag = 0;
@@ -110,13 +116,13 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
 
     for (int s = 0; s < p.T; ++s) {
         const int t = dir ? p.T - 1 - s : s;
-        float4 rvn[4];
+        float4 rvn[FB];
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) rvn[fb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int fb = 0; fb < FB; ++fb) rvn[fb] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s == 0 && p.T > 1) load_gx(1, rvn);
-        f32x4 acc[4];
+        f32x4 acc[FB];
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) acc[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int fb = 0; fb < FB; ++fb) acc[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         if (s > 0) {
             if constexpr (!LL) {
@@ -144,20 +150,24 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
             const int tp = dir ? t + 1 : t - 1;
             const float* hp = p.hseq + (long)b_base * p.ld_h_b + (long)tp * p.ld_h_t + dir * H;      // row 0 of the block's slice at step tp
             // rows past the batch end lie beyond num_records: the buffer load returns zeros for them, no branch per load
-            const int rows_in = p.B - b_base < 64 ? p.B - b_base : 64;
+            const int rows_in = p.B - b_base < ROWS ? p.B - b_base : ROWS;
             const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)hp, 0, (int)((long)(rows_in - 1) * p.ld_h_b * 4) + H * 4, 0x00020000);
             // staging role: iteration `it` of this wave moves rows 16 * (it & 3) + (lane >> 2), chunk lane & 3 of K-tile
             // kt_of(it); with HALVES = 2 (A/B only: measured equal, 9.5 vs 9.4 us per step) iterations [0, KT/2) cover the first K half, the rest the
             // second, and the MFMAs of the first half run while the second half is still arriving
             constexpr int KH = KT / HALVES;                 // K-tiles per staging phase
-            auto kt_of = [&](int it) { return (it / KH) * KH + wave * (KH / 4) + ((it % KH) >> 2); };
-            u32x4 c0[KT], c1[KT];
+            constexpr int IPP = KH / 4 * FB;                // staging iterations of a wave per phase: its KH / 4 K-tiles x FB row groups
+            constexpr int NI = IPP * HALVES;
+            static_assert(KH % 4 == 0, "a phase gives every wave whole K-tiles");
+            auto kt_of = [&](int it) { return (it / IPP) * KH + wave * (KH / 4) + (it % IPP) / FB; };
+            auto row_of = [&](int it) { return 16 * (it % FB) + st_row; };
+            u32x4 c0[NI], c1[NI];
             auto load_part = [&](auto hc) {             // the loads of staging phase `hc` (iterations [hc * KH, (hc + 1) * KH))
                 constexpr int HF = decltype(hc)::value;
 #pragma unroll
-                for (int i2 = 0; i2 < KH; ++i2) {
-                    const int it = HF * KH + i2;
-                    const int row = 16 * (it & 3) + st_row, kt = kt_of(it);
+                for (int i2 = 0; i2 < IPP; ++i2) {
+                    const int it = HF * IPP + i2;
+                    const int row = row_of(it), kt = kt_of(it);
                     const int off = (int)((long)row * p.ld_h_b * 4) + (kt * 32 + st_g * 4) * 4;         // < 2^31: checked by the host entry
                     c0[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off, 0, 16));      // aux 16 = sc1: agent-coherent reads
                     c1[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, off + 64, 0, 16));
@@ -167,8 +177,8 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
                 constexpr int HF = decltype(hc)::value;
                 unsigned mx = 0u;
 #pragma unroll
-                for (int i2 = 0; i2 < KH; ++i2) {
-                    const int it = HF * KH + i2;
+                for (int i2 = 0; i2 < IPP; ++i2) {
+                    const int it = HF * IPP + i2;
                     const unsigned a = max(max(c0[it].x, c0[it].y), max(c0[it].z, c0[it].w));
                     const unsigned b2 = max(max(c1[it].x, c1[it].y), max(c1[it].z, c1[it].w));
                     mx = max(mx, max(a, b2));
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
                         load_h();
                         unsigned mx = 0u;
 #pragma unroll
-                        for (int it = 0; it < KT; ++it) {
+                        for (int it = 0; it < NI; ++it) {
                             const unsigned a = max(max(c0[it].x, c0[it].y), max(c0[it].z, c0[it].w));
                             const unsigned b2 = max(max(c1[it].x, c1[it].y), max(c1[it].z, c1[it].w));
                             mx = max(mx, max(a, b2));
@@ -245,12 +255,12 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
                 }
                 if (!(p.dbg & 4)) {
 #pragma unroll
-                    for (int i2 = 0; i2 < KH; ++i2) {
-                        const int it = half * KH + i2;
-                        const int row = 16 * (it & 3) + st_row, kt = kt_of(it);
+                    for (int i2 = 0; i2 < IPP; ++i2) {
+                        const int it = half * IPP + i2;
+                        const int row = row_of(it), kt = kt_of(it);
                         f16x8 hi, lo;
                         split_f16(c0[it], c1[it], as, hi, lo);
-                        const unsigned off = kt * 4096 + row * 64 + ((st_g ^ swz4(row)) << 4);
+                        const unsigned off = kt * (ROWS * 64) + row * 64 + ((st_g ^ swz4(row)) << 4);
                         *(f16x8*)(smem + off) = hi;
                         *(f16x8*)(smem + PLANE + off) = lo;
                     }
@@ -262,32 +272,32 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
 #pragma unroll
                     for (int k2 = 0; k2 < KH; ++k2) {
                         const int kt = half * KH + k2;
-                        f16x8 ah[4], al[4];
+                        f16x8 ah[FB], al[FB];
 #pragma unroll
-                        for (int fb = 0; fb < 4; ++fb) {
+                        for (int fb = 0; fb < FB; ++fb) {
                             const int row = fb * 16 + fr;
-                            const unsigned off = kt * 4096 + row * 64 + ((fg ^ swz4(row)) << 4);
+                            const unsigned off = kt * (ROWS * 64) + row * 64 + ((fg ^ swz4(row)) << 4);
                             ah[fb] = *(const f16x8*)(smem + off);
                             al[fb] = *(const f16x8*)(smem + PLANE + off);
                         }
                         // small terms first, the order of emage_gemm's X3 K-loop; consecutive MFMAs never share an accumulator
 #pragma unroll
-                        for (int fb = 0; fb < 4; ++fb) acc[fb] = mma_f16(wl[kt], ah[fb], acc[fb]);
+                        for (int fb = 0; fb < FB; ++fb) acc[fb] = mma_f16(wl[kt], ah[fb], acc[fb]);
 #pragma unroll
-                        for (int fb = 0; fb < 4; ++fb) acc[fb] = mma_f16(wh[kt], al[fb], acc[fb]);
+                        for (int fb = 0; fb < FB; ++fb) acc[fb] = mma_f16(wh[kt], al[fb], acc[fb]);
 #pragma unroll
-                        for (int fb = 0; fb < 4; ++fb) acc[fb] = mma_f16(wh[kt], ah[fb], acc[fb]);
+                        for (int fb = 0; fb < FB; ++fb) acc[fb] = mma_f16(wh[kt], ah[fb], acc[fb]);
                     }
                 }
             });
             if (gave_up) return;
 #pragma unroll
-            for (int fb = 0; fb < 4; ++fb) acc[fb] = acc[fb] * os;
+            for (int fb = 0; fb < FB; ++fb) acc[fb] = acc[fb] * os;
         }
 
         // the LSTM cell (gate order i, f, g, o), arithmetic of gemm_tile.h's EPI_LSTM
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
+        for (int fb = 0; fb < FB; ++fb) {
             const int b = b_base + fb * 16 + fr;
             const float gi = lstm_sigmoid<true>(acc[fb][0] + rv[fb].x), gf = lstm_sigmoid<true>(acc[fb][1] + rv[fb].y);
             const float gg = lstm_tanh<true>(acc[fb][2] + rv[fb].z), go = lstm_sigmoid<true>(acc[fb][3] + rv[fb].w);
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
         }
 
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) rv[fb] = rvn[fb];
+        for (int fb = 0; fb < FB; ++fb) rv[fb] = rvn[fb];
 
         if constexpr (!LL) {
         if (s + 1 < p.T) {                              // publish h_t to the group
@@ -336,31 +346,38 @@ int max_slices_for(int H) {                            // co-resident blocks: on
     return m > MAX_GROUPS / 2 ? MAX_GROUPS / 2 : m;
 }
 
-template <int H, int HALVES, bool LL>
+// clips per block for a batch of B: 32 when the whole batch then still fits ONE launch (B <= 32 x max_slices: every CU gets a block where 64-clip
+// slices would leave half the chip idle — DisCo's 128 clips), else 64
+int rows_for(int B, int H) {
+    if (emage_dev::g_lstm_layer_dbg & 512) return 64;          // tools A/B: always 64 clips per block (round 4's geometry)
+    return B <= 32 * max_slices_for(H) ? 32 : 64;
+}
+
+template <int H, int HALVES, bool LL, int ROWS = 64>
 int launch_seq(SeqArgs a, int B, int max_slices, unsigned* sync, hipStream_t s) {
     constexpr int KT = H / 32, WPG = H / 16;
-    constexpr size_t LDS = 2 * (size_t)KT * 64 * 64 + 128;
-    static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    constexpr size_t LDS = 2 * (size_t)KT * ROWS * 64 + 128;
+    static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES, LL, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (configured != hipSuccess) return (int)configured;
-    // the group barrier needs every block of a launch resident at once: one block per CU (LDS), so the occupancy query must admit >= 1
+    // the group barrier needs every block of a launch resident at once: one block per CU (registers), so the occupancy query must admit >= 1
     // block per CU for this kernel's register / LDS footprint (a plain launch has the residency of a cooperative one, without its check)
     static const int blocks_per_cu = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)lstm_seq_kernel<H, HALVES, LL>, 256, LDS) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)lstm_seq_kernel<H, HALVES, LL, ROWS>, 256, LDS) != hipSuccess) return 0;
         return n;
     }();
     if (blocks_per_cu < 1 || 2 * max_slices * WPG > blocks_per_cu * device_cus()) return EMAGE_EINVAL;
     const float* gx = a.gx;
     float* hseq = a.hseq;
     int chunk = 0;
-    for (int b0 = 0; b0 < B; b0 += 64 * max_slices, ++chunk) {
-        const int nb = B - b0 < 64 * max_slices ? B - b0 : 64 * max_slices;
+    for (int b0 = 0; b0 < B; b0 += ROWS * max_slices, ++chunk) {
+        const int nb = B - b0 < ROWS * max_slices ? B - b0 : ROWS * max_slices;
         a.gx = gx + (long)b0 * a.ld_gx_b;
         a.hseq = hseq + (long)b0 * a.ld_h_b;
         a.B = nb;
-        a.slices = (nb + 63) / 64;
+        a.slices = (nb + ROWS - 1) / ROWS;
         a.sync = sync + chunk * EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH;
-        hipLaunchKernelGGL((lstm_seq_kernel<H, HALVES, LL>), dim3(2 * a.slices * WPG), dim3(256), LDS, s, a);
+        hipLaunchKernelGGL((lstm_seq_kernel<H, HALVES, LL, ROWS>), dim3(2 * a.slices * WPG), dim3(256), LDS, s, a);
         const int rc = launch_status();
         if (rc) return rc;
     }
@@ -389,7 +406,8 @@ extern "C" int emage_lstm_layer_sync_words(int B, int H) {
     if (B <= 0 || (H != 256 && H != 512)) return EMAGE_EINVAL;
     const int max_slices = max_slices_for(H);
     if (max_slices < 1) return EMAGE_EINVAL;
-    const int launches = (B + 64 * max_slices - 1) / (64 * max_slices);
+    const int rows = rows_for(B, H);
+    const int launches = (B + rows * max_slices - 1) / (rows * max_slices);
     return launches * EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH;
 }
 
@@ -437,5 +455,7 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
     // round 5: TWO pipelined hand-over phases — only the first K half of h_{t-1} is waited for up front, the second half's loads land behind the
     // first half's staging + MFMAs: 8.11-8.13 -> 7.48-7.64 us per time step at DisCo's size, 8.4-9.0 -> 8.4-8.5 at CaMN's, same bits
     // (profiles/r05_lstm_layer_pipelined_handover.json); four phases are slower (8.7-8.8 / 9.4-9.5)
+    if (rows_for(B, H) == 32)          // round 5: a small batch as 32-clip slices — every CU gets a block (profiles/r05_lstm_layer_32_clip_slices.json)
+        return H == 512 ? launch_seq<512, 2, true, 32>(a, B, max_slices, sync, s) : launch_seq<256, 2, true, 32>(a, B, max_slices, sync, s);
     return H == 512 ? launch_seq<512, 2, true>(a, B, max_slices, sync, s) : launch_seq<256, 2, true>(a, B, max_slices, sync, s);
 }
