@@ -61,8 +61,10 @@ __device__ __forceinline__ void lds_barrier() {
 
 // ROWS (round 5): clips per block — 64, or 32 so that a SMALL batch still fills the chip (DisCo's 128 clips are 2 slices of 64 = 128 blocks on 256
 // CUs; as 4 slices of 32 every CU has a block, and a block's staging, MFMA and cell work per time step halve).  Same arithmetic per clip: same bits.
-template <int H, int HALVES, bool LL, int ROWS = 64>
-__global__ __launch_bounds__(256, 1) void lstm_seq_kernel(SeqArgs p) {
+// OCC = 2 (ROWS = 32 only): the register budget of TWO resident blocks per CU (<= 256 VGPRs) — a batch of up to 256 clips then runs as 8 slices of 32
+// clips, two independent blocks per CU whose waiting, staging and MFMA phases interleave.
+template <int H, int HALVES, bool LL, int ROWS = 64, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void lstm_seq_kernel(SeqArgs p) {
     constexpr int KT = H / 32, WPG = H / 16;           // K-tiles; blocks per group
     constexpr int FB = ROWS / 16;                      // 16-clip fragments per block
     constexpr unsigned PLANE = KT * ROWS * 64;         // one fp16 plane of the ROWS x H slice: [kt][row][4 chunks of 16 B]
@@ -346,24 +348,34 @@ int max_slices_for(int H) {                            // co-resident blocks: on
     return m > MAX_GROUPS / 2 ? MAX_GROUPS / 2 : m;
 }
 
-// clips per block for a batch of B: 32 when the whole batch then still fits ONE launch (B <= 32 x max_slices: every CU gets a block where 64-clip
-// slices would leave half the chip idle — DisCo's 128 clips), else 64
-int rows_for(int B, int H) {
-    if (emage_dev::g_lstm_layer_dbg & 512) return 64;          // tools A/B: always 64 clips per block (round 4's geometry)
-    return B <= 32 * max_slices_for(H) ? 32 : 64;
+// The launch geometry for a batch of B clips (round 5).  64 clips per block, one block per CU, is round 4's: a launch holds max_slices_for(H) slices.
+//   * B <= 32 x max_slices: 32 clips per block, one block per CU — the whole batch in ONE launch with every CU busy (DisCo: 128 clips);
+//   * B <= 32 x 2 x max_slices (capped by the sync record: 8 slices): 32 clips per block, TWO blocks per CU (the OCC = 2 build: <= 256 VGPRs, 2 x 64 KB of
+//     LDS) — still one launch, and the two resident blocks of a CU (different slices: independent recurrences) fill each other's waits (CaMN: 256 clips);
+//   * else 64 clips per block, the batch walked in launches of 64 x max_slices clips.
+struct SeqGeometry { int rows, occ, max_slices; };
+SeqGeometry geometry_for(int B, int H) {
+    const int one = max_slices_for(H);
+    if (one < 1) return SeqGeometry{64, 1, one};
+    const int dbg = emage_dev::g_lstm_layer_dbg;
+    if (!(dbg & 512) && B <= 32 * one) return SeqGeometry{32, 1, one};
+    int two = 2 * device_cus() / (2 * (H / 16));
+    if (two > MAX_GROUPS / 2) two = MAX_GROUPS / 2;
+    if (!(dbg & 512) && !(dbg & 1024) && B <= 32 * two) return SeqGeometry{32, 2, two};     // tools A/B: 512 = always 64 clips per block, 1024 = no two-blocks-per-CU form
+    return SeqGeometry{64, 1, one};
 }
 
-template <int H, int HALVES, bool LL, int ROWS = 64>
+template <int H, int HALVES, bool LL, int ROWS = 64, int OCC = 1>
 int launch_seq(SeqArgs a, int B, int max_slices, unsigned* sync, hipStream_t s) {
     constexpr int KT = H / 32, WPG = H / 16;
     constexpr size_t LDS = 2 * (size_t)KT * ROWS * 64 + 128;
-    static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES, LL, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t configured = hipFuncSetAttribute((const void*)lstm_seq_kernel<H, HALVES, LL, ROWS, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (configured != hipSuccess) return (int)configured;
     // the group barrier needs every block of a launch resident at once: one block per CU (registers), so the occupancy query must admit >= 1
     // block per CU for this kernel's register / LDS footprint (a plain launch has the residency of a cooperative one, without its check)
     static const int blocks_per_cu = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)lstm_seq_kernel<H, HALVES, LL, ROWS>, 256, LDS) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)lstm_seq_kernel<H, HALVES, LL, ROWS, OCC>, 256, LDS) != hipSuccess) return 0;
         return n;
     }();
     if (blocks_per_cu < 1 || 2 * max_slices * WPG > blocks_per_cu * device_cus()) return EMAGE_EINVAL;
@@ -377,7 +389,7 @@ int launch_seq(SeqArgs a, int B, int max_slices, unsigned* sync, hipStream_t s) 
         a.B = nb;
         a.slices = (nb + ROWS - 1) / ROWS;
         a.sync = sync + chunk * EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH;
-        hipLaunchKernelGGL((lstm_seq_kernel<H, HALVES, LL, ROWS>), dim3(2 * a.slices * WPG), dim3(256), LDS, s, a);
+        hipLaunchKernelGGL((lstm_seq_kernel<H, HALVES, LL, ROWS, OCC>), dim3(2 * a.slices * WPG), dim3(256), LDS, s, a);
         const int rc = launch_status();
         if (rc) return rc;
     }
@@ -406,8 +418,8 @@ extern "C" int emage_lstm_layer_sync_words(int B, int H) {
     if (B <= 0 || (H != 256 && H != 512)) return EMAGE_EINVAL;
     const int max_slices = max_slices_for(H);
     if (max_slices < 1) return EMAGE_EINVAL;
-    const int rows = rows_for(B, H);
-    const int launches = (B + rows * max_slices - 1) / (rows * max_slices);
+    const SeqGeometry geo = geometry_for(B, H);
+    const int launches = (B + geo.rows * geo.max_slices - 1) / (geo.rows * geo.max_slices);
     return launches * EMAGE_LSTM_SYNC_WORDS_PER_LAUNCH;
 }
 
@@ -455,7 +467,10 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
     // round 5: TWO pipelined hand-over phases — only the first K half of h_{t-1} is waited for up front, the second half's loads land behind the
     // first half's staging + MFMAs: 8.11-8.13 -> 7.48-7.64 us per time step at DisCo's size, 8.4-9.0 -> 8.4-8.5 at CaMN's, same bits
     // (profiles/r05_lstm_layer_pipelined_handover.json); four phases are slower (8.7-8.8 / 9.4-9.5)
-    if (rows_for(B, H) == 32)          // round 5: a small batch as 32-clip slices — every CU gets a block (profiles/r05_lstm_layer_32_clip_slices.json)
-        return H == 512 ? launch_seq<512, 2, true, 32>(a, B, max_slices, sync, s) : launch_seq<256, 2, true, 32>(a, B, max_slices, sync, s);
+    const SeqGeometry geo = geometry_for(B, H);      // round 5 (profiles/r05_lstm_layer_32_clip_slices.json, r05_lstm_layer_two_blocks_per_cu.json)
+    if (geo.rows == 32 && geo.occ == 2)
+        return H == 512 ? launch_seq<512, 2, true, 32, 2>(a, B, geo.max_slices, sync, s) : launch_seq<256, 2, true, 32, 2>(a, B, geo.max_slices, sync, s);
+    if (geo.rows == 32)
+        return H == 512 ? launch_seq<512, 2, true, 32>(a, B, geo.max_slices, sync, s) : launch_seq<256, 2, true, 32>(a, B, geo.max_slices, sync, s);
     return H == 512 ? launch_seq<512, 2, true>(a, B, max_slices, sync, s) : launch_seq<256, 2, true>(a, B, max_slices, sync, s);
 }

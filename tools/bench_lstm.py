@@ -71,11 +71,12 @@ def main():
             lib = _lib.use_tools(True)      # tools build of the library: every tile configuration + emage_set_tuning
             names = {0: "shipped (data-as-flag hand-over, two pipelined phases)", 32: "round 2's arrival-counter protocol", 2: "no MFMA phase", 4: "no h load / staging",
                      8: "no wait for the group (one read)", 14: "skeleton: cell + h store only", 64: "shipped + s_sleep 1 between re-reads",
-                     128: "round 3: one hand-over phase", 256: "four pipelined hand-over phases", 512: "64 clips per block for every batch (round 4's geometry)"}
+                     128: "round 3: one hand-over phase", 256: "four pipelined hand-over phases", 512: "64 clips per block for every batch (round 4's geometry)",
+                     1024: "no two-blocks-per-CU geometry (32 clips per block only when one block per CU suffices)"}
             line["lstm_layer_us_per_step"] = {}
             line["same_bits_as_shipped"] = {}
             base = None
-            for dbg in (0, 512, 128, 0, 512, 128, 2, 4, 8, 14):
+            for dbg in (0, 1024, 512, 0, 1024, 512, 2, 4, 8, 14):
                 lib.emage_set_tuning(3, dbg)
                 ops.lstm_layer(F16X3, gx, wp, ws, hseq, sync)
                 torch.cuda.synchronize()
@@ -88,7 +89,7 @@ def main():
                 ops.lstm_layer_check(sync)
                 if dbg == 0 and base is None:
                     base = hseq.clone()
-                elif dbg in (128, 256, 512):
+                elif dbg in (128, 256, 512, 1024):
                     line["same_bits_as_shipped"][names[dbg]] = bool(torch.equal(hseq, base))
                 key = names[dbg] if names[dbg] not in line["lstm_layer_us_per_step"] else names[dbg] + " (second run)"
                 line["lstm_layer_us_per_step"][key] = round(1e3 * e0.elapsed_time(e1) / 3 / tt, 2)
