@@ -349,19 +349,23 @@ int max_slices_for(int H) {                            // co-resident blocks: on
 }
 
 // The launch geometry for a batch of B clips (round 5).  64 clips per block, one block per CU, is round 4's: a launch holds max_slices_for(H) slices.
-//   * B <= 32 x max_slices: 32 clips per block, one block per CU — the whole batch in ONE launch with every CU busy (DisCo: 128 clips);
-//   * B <= 32 x 2 x max_slices (capped by the sync record: 8 slices): 32 clips per block, TWO blocks per CU (the OCC = 2 build: <= 256 VGPRs, 2 x 64 KB of
-//     LDS) — still one launch, and the two resident blocks of a CU (different slices: independent recurrences) fill each other's waits (CaMN: 256 clips);
-//   * else 64 clips per block, the batch walked in launches of 64 x max_slices clips.
+//   * B <= 32 x max_slices: 32 clips per block, one block per CU — the whole batch in ONE launch with every CU busy (DisCo's 128 clips: 7.4-7.8 ->
+//     6.2-6.4 us per time step, profiles/r05_lstm_layer_32_clip_slices.json);
+//   * else 64 clips per block, the batch walked in launches of 64 x max_slices clips (CaMN's 256 clips: one launch, every CU busy).
+//   Measured NEGATIVE, tools only (emage_set_tuning key 3 bit 1024): 32 clips per block with TWO blocks per CU (the OCC = 2 build: 256 VGPRs, no spills,
+//   2 x 64 KB of LDS) for batches up to 256 clips — CaMN's time step 8.5 -> 11.1-11.3 us, the forward 72 -> 80 ms (profiles/r05_lstm_layer_two_blocks_per_cu.json):
+//   two resident blocks double the hand-over traffic and polling on every CU and slow each other more than they fill each other's waits.
 struct SeqGeometry { int rows, occ, max_slices; };
 SeqGeometry geometry_for(int B, int H) {
     const int one = max_slices_for(H);
     if (one < 1) return SeqGeometry{64, 1, one};
     const int dbg = emage_dev::g_lstm_layer_dbg;
-    if (!(dbg & 512) && B <= 32 * one) return SeqGeometry{32, 1, one};
+    if (!(dbg & 512) && B <= 32 * one) return SeqGeometry{32, 1, one};                      // tools A/B: 512 = always 64 clips per block
+#ifdef EMAGE_TOOLS
     int two = 2 * device_cus() / (2 * (H / 16));
     if (two > MAX_GROUPS / 2) two = MAX_GROUPS / 2;
-    if (!(dbg & 512) && !(dbg & 1024) && B <= 32 * two) return SeqGeometry{32, 2, two};     // tools A/B: 512 = always 64 clips per block, 1024 = no two-blocks-per-CU form
+    if (!(dbg & 512) && (dbg & 1024) && B <= 32 * two) return SeqGeometry{32, 2, two};
+#endif
     return SeqGeometry{64, 1, one};
 }
 
@@ -468,8 +472,10 @@ extern "C" int emage_lstm_layer(int dtype, const float* gates_x, long ld_gx_b, i
     // first half's staging + MFMAs: 8.11-8.13 -> 7.48-7.64 us per time step at DisCo's size, 8.4-9.0 -> 8.4-8.5 at CaMN's, same bits
     // (profiles/r05_lstm_layer_pipelined_handover.json); four phases are slower (8.7-8.8 / 9.4-9.5)
     const SeqGeometry geo = geometry_for(B, H);      // round 5 (profiles/r05_lstm_layer_32_clip_slices.json, r05_lstm_layer_two_blocks_per_cu.json)
+#ifdef EMAGE_TOOLS
     if (geo.rows == 32 && geo.occ == 2)
         return H == 512 ? launch_seq<512, 2, true, 32, 2>(a, B, geo.max_slices, sync, s) : launch_seq<256, 2, true, 32, 2>(a, B, geo.max_slices, sync, s);
+#endif
     if (geo.rows == 32)
         return H == 512 ? launch_seq<512, 2, true, 32>(a, B, geo.max_slices, sync, s) : launch_seq<256, 2, true, 32>(a, B, geo.max_slices, sync, s);
     return H == 512 ? launch_seq<512, 2, true>(a, B, max_slices, sync, s) : launch_seq<256, 2, true>(a, B, max_slices, sync, s);

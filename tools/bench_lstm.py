@@ -72,7 +72,7 @@ def main():
             names = {0: "shipped (data-as-flag hand-over, two pipelined phases)", 32: "round 2's arrival-counter protocol", 2: "no MFMA phase", 4: "no h load / staging",
                      8: "no wait for the group (one read)", 14: "skeleton: cell + h store only", 64: "shipped + s_sleep 1 between re-reads",
                      128: "round 3: one hand-over phase", 256: "four pipelined hand-over phases", 512: "64 clips per block for every batch (round 4's geometry)",
-                     1024: "no two-blocks-per-CU geometry (32 clips per block only when one block per CU suffices)"}
+                     1024: "two 32-clip blocks per CU for batches up to 256 clips (measured slower: tools only)"}
             line["lstm_layer_us_per_step"] = {}
             line["same_bits_as_shipped"] = {}
             base = None
