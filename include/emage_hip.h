@@ -311,7 +311,9 @@ int emage_lstm_step_pair(int dtype, const float* h_prev0, const float* h_prev1, 
 /*
  * emage_lstm_layer — the whole recurrence of one bidirectional nn.LSTM layer in ONE launch per <= n_CU / (2 * H/16) * 64 clips
  * (D:190-195,252; C:204-218,261-268): persistent blocks keep their W_hh slice (both split-fp16 planes) and their cell state in
- * registers for all T steps and exchange h_t through the layer output with agent-scope release / acquire (csrc/lstmseq.hip).
+ * registers for all T steps and exchange h_t through the layer output as write-through stores the consumers poll (the data is the flag;
+ * csrc/lstmseq.hip).  A block owns 64 clips — or 32 when the whole batch then still fits one launch (B <= n_CU / (2 * H/16) * 32), so that
+ * every CU has a block; the result does not depend on that choice.
  * Bit-identical to T emage_lstm_step_pair launches with zero initial state.  dtype: EMAGE_F16X3 only; H = 256 or 512.
  *   gates_x  (B, T, >= 8H) fp32: the input projection of every step incl. both biases, columns dir * 4H + 4u + g
  *            (row strides ld_gx_b per clip, ld_gx_t per step, in floats)
