@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 
 from . import ops, spec
-from ._lib import F16X3
+from ._lib import F16X3, H2
 from .configuration_emage_audio import _AttrConfig
 from .modeling_emage_audio import _EmageModule, _WavEncoderMixin, _Ctx, _rup
 
@@ -42,6 +42,9 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         self.pose_rep = getattr(config, "pose_rep", "smplx")
         self.pair_convs = True                 # WavEncoder: 32-channel blocks through the 64-channel kernels on position pairs (A/B switch)
         self.persistent_lstm = True            # one launch per LSTM layer (csrc/lstmseq.hip) instead of one per time step; same bits
+        self.h2_input_projection = True        # f16x3: the per-layer input projection x W_ih^T (the models' largest contractions: 106 k rows x 4096
+                                               # columns at CaMN's batch) runs on PRE-SPLIT operands (EMAGE_H2: one cast of x, no VALU in the K-loop)
+                                               # instead of splitting every A fragment in every wave at every K-tile (A/B switch; round 5)
         self._sync = {}                        # scratch of the persistent recurrences, see _lstm_sync
 
     def set_precision(self, precision: str):
@@ -66,8 +69,13 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
                 b_all.append((pk.p[f"{name}.bias_ih_l{k}{suffix}"].float() + pk.p[f"{name}.bias_hh_l{k}{suffix}"].float())[perm])
                 w, kp, ws = pk._pack_mat(pk.p[f"{name}.weight_hh_l{k}{suffix}"].float()[perm])
                 pk.w[f"{name}.hh.{k}.{d}"] = dict(w=w, ws=ws)
-            w, kp, ws = pk._pack_mat(torch.cat(w_ih, 0))
+            wcat = torch.cat(w_ih, 0)
+            w, kp, ws = pk._pack_mat(wcat)
             pk.w[f"{name}.ih.{k}"] = dict(w=w, b=torch.cat(b_all).contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=w_ih[0].shape[1], ws=ws)
+            if pk.dt == F16X3:                     # the same weights as an EMAGE_H2 operand (`h2_input_projection`)
+                wpad = torch.nn.functional.pad(wcat, (0, kp - wcat.shape[1])) if kp != wcat.shape[1] else wcat
+                w2, ws2 = pk._operand(wpad, dt=H2)
+                pk.w[f"{name}.ih.{k}.h2"] = dict(pk.w[f"{name}.ih.{k}"], w=w2, ws=ws2, dt=H2)
 
     def _pack_common(self, pk):
         self._pack_wav_encoders(pk, ("audio_encoder",))
@@ -130,7 +138,11 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         persistent = self.persistent_lstm and ops.lstm_layer_supported(cx.gdt, hid)
         zeros = None if persistent else torch.zeros(b, hid, dtype=torch.float32, device=cx.dev)
         for k in range(n_layer):
-            gx, _ = cx.gemm(x, f"{name}.ih.{k}")                                     # (B*T, 8H): all steps, both directions
+            e_h2 = cx.pk.w.get(f"{name}.ih.{k}.h2") if self.h2_input_projection else None
+            if e_h2 is not None and x.shape[1] == e_h2["cp"]:
+                _, gx = cx.gemm(ops.cast_pad(H2, x, x.shape[1]), f"{name}.ih.{k}.h2", want="f32")       # (B*T, 8H) fp32: all steps, both directions
+            else:
+                gx, _ = cx.gemm(x, f"{name}.ih.{k}")
             hseq = torch.empty(b * t, 2 * hid, dtype=torch.float32, device=cx.dev)
             g3, h3 = gx.view(b, t, -1), hseq.view(b, t, 2 * hid)
             w0, w1 = cx.pk.w[f"{name}.hh.{k}.0"], cx.pk.w[f"{name}.hh.{k}.1"]
