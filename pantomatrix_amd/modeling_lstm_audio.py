@@ -42,9 +42,9 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
         self.pose_rep = getattr(config, "pose_rep", "smplx")
         self.pair_convs = True                 # WavEncoder: 32-channel blocks through the 64-channel kernels on position pairs (A/B switch)
         self.persistent_lstm = True            # one launch per LSTM layer (csrc/lstmseq.hip) instead of one per time step; same bits
-        self.h2_input_projection = True        # f16x3: the per-layer input projection x W_ih^T (the models' largest contractions: 106 k rows x 4096
-                                               # columns at CaMN's batch) runs on PRE-SPLIT operands (EMAGE_H2: one cast of x, no VALU in the K-loop)
-                                               # instead of splitting every A fragment in every wave at every K-tile (A/B switch; round 5)
+        self.h2_input_projection = False       # A/B switch (round 5, measured: no gain — profiles/r05_lstm_input_projection_h2_ab.txt: CaMN 70.7 / 72.2 vs 72.1 / 72.1 ms,
+                                               # DisCo 8.05 / 8.23 vs 7.98 / 8.03): True runs the per-layer input projection x W_ih^T on pre-split
+                                               # EMAGE_H2 operands (one cast of x per layer) instead of splitting A inside the GEMM
         self._sync = {}                        # scratch of the persistent recurrences, see _lstm_sync
 
     def set_precision(self, precision: str):
