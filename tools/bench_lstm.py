@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--per-step", action="store_true", help="one launch per time step instead of the persistent recurrence (A/B; same bits)")
     ap.add_argument("--no-pair-convs", action="store_true", help="WavEncoder: zero-padded 64-channel route for the 32-channel blocks (A/B)")
-    ap.add_argument("--no-h2-proj", action="store_true", help="A/B: the per-layer input projections on float32 activations (EMAGE_F16X3: split in the GEMM) instead of pre-split EMAGE_H2 operands")
+    ap.add_argument("--h2-proj", action="store_true", help="A/B (measured: no gain, off in the product): the per-layer input projections on pre-split EMAGE_H2 operands instead of float32 activations split in the GEMM")
     ap.add_argument("--layer-only", action="store_true", help="also time one bare lstm_layer launch at the model's size")
     args = ap.parse_args()
     from pantomatrix_amd import synthetic
@@ -38,7 +38,7 @@ def main():
         model = product(kind, "f16x3", dev)
         model.persistent_lstm = not args.per_step
         model.pair_convs = not args.no_pair_convs
-        model.h2_input_projection = not args.no_h2_proj
+        model.h2_input_projection = bool(args.h2_proj)
         audio = synthetic.synthetic_audio(batch, n, seed=5).to(dev)
         t0 = time.time()
         runner = LstmClipRunner(model, batch, n)
@@ -54,7 +54,7 @@ def main():
         line = {"model": kind, "batch": batch, "frames_per_clip": int(motion.shape[1]), "ms_per_step": ms, "value": frames / (ms * 1e-3),
                 "unit": "motion-frames/s (15 fps)", "dtype": "f16x3", "launch": "hipGraph replay", "graph_capture_s": t_capture,
                 "recurrence": "one launch per step" if args.per_step else "persistent (one launch per layer)",
-                "input_projections": "float32 activations, split in the GEMM" if args.no_h2_proj else "pre-split EMAGE_H2 operands",
+                "input_projections": "pre-split EMAGE_H2 operands" if args.h2_proj else "float32 activations, split in the GEMM",
                 "wav_encoder_narrow_blocks": "zero-padded to 64 channels" if args.no_pair_convs else "position pairs",
                 "lstm_layers": (1 if kind == "disco" else 2) * 4, "steps_per_layer": int(motion.shape[1])}
         if args.layer_only and not args.per_step:
