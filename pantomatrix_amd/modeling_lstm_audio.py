@@ -72,7 +72,7 @@ class _LstmAudioModel(_WavEncoderMixin, _EmageModule):
             wcat = torch.cat(w_ih, 0)
             w, kp, ws = pk._pack_mat(wcat)
             pk.w[f"{name}.ih.{k}"] = dict(w=w, b=torch.cat(b_all).contiguous(), n=w.shape[0], cp=kp, taps=1, k_real=w_ih[0].shape[1], ws=ws)
-            if pk.dt == F16X3:                     # the same weights as an EMAGE_H2 operand (`h2_input_projection`)
+            if pk.dt == F16X3 and self.h2_input_projection:      # the same weights as an EMAGE_H2 operand (set the switch before the first forward)
                 wpad = torch.nn.functional.pad(wcat, (0, kp - wcat.shape[1])) if kp != wcat.shape[1] else wcat
                 w2, ws2 = pk._operand(wpad, dt=H2)
                 pk.w[f"{name}.ih.{k}.h2"] = dict(pk.w[f"{name}.ih.{k}"], w=w2, ws=ws2, dt=H2)
