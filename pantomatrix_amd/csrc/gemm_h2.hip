@@ -256,6 +256,7 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
         case 120: return launch_h2<64, 64, 2, 2, 3, 0, false, false, 2>(a, s);     // 768-wide / small outputs: 4 waves 32x32, three blocks per CU
 #ifdef EMAGE_TOOLS
         case 188: return launch_h2<64, 64, 2, 2, 8, 0, false, false, 1>(a, s);     // round 5 (negative): a LONE block per CU with a ring of 8 for grids of at most one tile per CU
+        case 189: return launch_h2<64, 64, 2, 4, 3, 0, false, false, 1>(a, s);     // round 5: the same tile on 8 waves of 32 x 16 (2 DMA instructions per wave and K-tile instead of 4)
 #endif
 #ifdef EMAGE_TOOLS
         case 121: return launch_h2<64, 64, 2, 2, 3, 0, true, false, 2>(a, s);
@@ -382,6 +383,11 @@ int gemm_h2_dispatch(GemmArgs& a, hipStream_t s) {
         const long t64 = (long)((a.M + 63) / 64) * ((((a.n_store > a.N ? a.n_store : a.N)) + 63) / 64);
         const bool bare = a.taps == 1 && !a.out && !a.out_t && !a.bias && !a.slope && a.out_f32 && a.K / 32 >= 64;
         if (t64 <= 256 && !bare) cfg = 188;
+    }
+    if (cfg == 120 && g_h2_force_config < 0 && (g_h2_variant & 1048576)) {       // tools A/B: lone-block grids on 8 waves
+        const long t64 = (long)((a.M + 63) / 64) * ((((a.n_store > a.N ? a.n_store : a.N)) + 63) / 64);
+        const bool bare = a.taps == 1 && !a.out && !a.out_t && !a.bias && !a.slope && a.out_f32 && a.K / 32 >= 64;
+        if (t64 <= 256 && !bare) cfg = 189;
     }
 #endif
     return cfg < 0 ? cfg : run_config(cfg, a, s);

@@ -470,7 +470,7 @@ def test_gemm_h2(case):
 
 
 @pytest.mark.parametrize("cfg", [100, 101, 102, 103, 105, 107, 108, 110, 111, 113, 115, 116, 119, 120, 121, 122, 123, 124, 125, 127, 130, 131, 141, 144, 148, 150, 160, 164, 166, 170, 171,
-                                 180, 181, 183, 184, 185, 186, 188])
+                                 180, 181, 183, 184, 185, 186, 188, 189])
 def test_gemm_h2_every_tile_configuration(cfg):
     """Every EMAGE_H2 tile configuration (wave grids, loader waves, register-pipelined / interleaved K-loops, odd fragment
     counts) on a ragged shape with a transposed tail and on a convolution with a zero-filled channel tail."""
@@ -508,7 +508,7 @@ def test_gemm_h2_two_ktiles_per_slot_change_no_bit():
              ("kpb_vt", (3, 70, 70), 768, 2304, 1, 1, 0, dict(bias=True, vt=1536)),
              ("kpb_conv", (3, 37, 37), 337, 106, 3, 1, 1, dict(bias=True, slope=0.2, n_store=128, res=None, want="both"))]
     try:
-        for one, two in ((100, 180), (170, 181), (120, 183), (113, 184), (120, 186), (120, 188)):
+        for one, two in ((100, 180), (170, 181), (120, 183), (113, 184), (120, 186), (120, 188), (120, 189)):
             for case in cases:
                 outs = []
                 for cfg in (one, two):

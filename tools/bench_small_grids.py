@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of the EMAGE_H2 dispatch for grids of at most one tile per CU (config 188: a lone 64 x 64 block per CU with a ring of 8 K-tiles; round 5):
 ONE clip (128 frames, 28 s), 8 clips and the 64-clip BASELINE batch through `runtime.ClipRunner` graph replays, tools library,
-`emage_set_tuning` key 5 = 524288 (config 188 for such grids) against 131072 (neutral: the shipped dispatch, every such launch on the three-blocks-per-CU tile).
+`emage_set_tuning` key 5 = 1048576 (config 189: the tile on 8 waves) / 524288 (config 188 for such grids) against 131072 (neutral: the shipped dispatch, every such launch on the three-blocks-per-CU tile).
 Measured in round 5 (profiles/r05_small_grids_ring_of_8_ab.txt, where the tree still SHIPPED 188 and 262144 switched it off): slower — not shipped.
 Prints one JSON line per arm; the results of the two arms are compared bit for bit (same tile, same MFMA order)."""
 import json
@@ -26,10 +26,10 @@ def main():
              ("b64_128f", 64, synthetic.samples_for_frames(128), 20))
     outs = {}
     for rep in range(2):
-        for variant in (524288, 131072):
+        for variant in (1048576, 524288, 131072):
             lib.emage_set_tuning(5, variant)
             model, vq = common.product_models(precision="f16x3", device=dev)
-            line = {"h2_variant": variant, "ring_of_8_for_small_grids": variant == 524288, "rep": rep}
+            line = {"h2_variant": variant, "small_grid_tile": {1048576: "64 x 64 on 8 waves (config 189)", 524288: "64 x 64, ring of 8 (config 188)"}.get(variant, "shipped: 64 x 64, 4 waves, ring of 3 (config 120)"), "rep": rep}
             for key, b, n, steps in cases:
                 runner = ClipRunner(model, vq, b, n)
                 audio = synthetic.synthetic_audio(b, n, seed=1234).to(dev)
