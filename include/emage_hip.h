@@ -53,7 +53,8 @@ const char* emage_target_arch(void);
  *   key 1: diagnostic ablation mask for tools/bench_gemm.py --ablate (1 no operand DMA, 2 no MFMA, 4 no epilogue;
  *          8 / 16: write-through / non-temporal result stores, a recorded negative experiment);
  *   key 2: tile-heuristic variant for A/B runs;   key 3: timing ablations of emage_lstm_layer;
- *   key 4: force the EMAGE_H2 tile configuration id;   key 5: EMAGE_H2 tile-heuristic variant.
+ *   key 4: force the EMAGE_H2 tile configuration id;   key 5: EMAGE_H2 tile-heuristic variant;   key 6: attention variant;
+ *   key 7: EMAGE_H2 tile configuration for grids of at most one 64 x 64 tile per CU (0 = the shipped one).
  * Returns EMAGE_EINVAL for unknown keys.  emage_h2_set_trace: device buffer (waves x 512 uint64) for the phase tracer of the
  * instrumented EMAGE_H2 configurations (tools/trace_gemm_h2.py).
  */

@@ -9,9 +9,10 @@ namespace emage_dev {
 #ifdef EMAGE_TOOLS
 int g_h2_force_config = -1;      // tools build (emage_set_tuning key 4): fixed tile configuration for sweeps
 int g_h2_variant = 0;            // tools build: dispatch-heuristic variant for A/B runs (emage_set_tuning key 5)
+int g_h2_small_cfg = 0;          // tools build: tile configuration for grids of at most one 64 x 64 tile per CU (emage_set_tuning key 7; 0 = the shipped 120)
 unsigned long long* g_h2_trace = nullptr;   // tools build: device buffer of (waves x 512) s_memtime stamps (emage_h2_set_trace)
 #else
-constexpr int g_h2_force_config = -1, g_h2_variant = 0;
+constexpr int g_h2_force_config = -1, g_h2_variant = 0, g_h2_small_cfg = 0;
 constexpr unsigned long long* g_h2_trace = nullptr;
 #endif
 }
@@ -384,10 +385,10 @@ int gemm_h2_dispatch(GemmArgs& a, hipStream_t s) {
         const bool bare = a.taps == 1 && !a.out && !a.out_t && !a.bias && !a.slope && a.out_f32 && a.K / 32 >= 64;
         if (t64 <= 256 && !bare) cfg = 188;
     }
-    if (cfg == 120 && g_h2_force_config < 0 && (g_h2_variant & 1048576)) {       // tools A/B: lone-block grids on 8 waves
+    if (cfg == 120 && g_h2_force_config < 0 && ((g_h2_variant & 1048576) || g_h2_small_cfg > 0)) {       // tools A/B: lone-block grids on 8 waves / on any 64 x 64 configuration
         const long t64 = (long)((a.M + 63) / 64) * ((((a.n_store > a.N ? a.n_store : a.N)) + 63) / 64);
         const bool bare = a.taps == 1 && !a.out && !a.out_t && !a.bias && !a.slope && a.out_f32 && a.K / 32 >= 64;
-        if (t64 <= 256 && !bare) cfg = 189;
+        if (t64 <= 256 && !bare) cfg = g_h2_small_cfg > 0 ? g_h2_small_cfg : 189;
     }
 #endif
     return cfg < 0 ? cfg : run_config(cfg, a, s);

@@ -25,11 +25,14 @@ def main():
     cases = (("b1_128f", 1, synthetic.samples_for_frames(128), 30), ("b1_28s", 1, 448000, 8), ("b8_128f", 8, synthetic.samples_for_frames(128), 20),
              ("b64_128f", 64, synthetic.samples_for_frames(128), 20))
     outs = {}
+    arms = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [189, 188, 0]      # EMAGE_H2 configuration ids for the lone-block grids; 0 = shipped (120)
     for rep in range(2):
-        for variant in (1048576, 524288, 131072):
-            lib.emage_set_tuning(5, variant)
+        for small_cfg in arms:
+            lib.emage_set_tuning(5, 131072)
+            lib.emage_set_tuning(7, small_cfg)
+            variant = small_cfg
             model, vq = common.product_models(precision="f16x3", device=dev)
-            line = {"h2_variant": variant, "small_grid_tile": {1048576: "64 x 64 on 8 waves (config 189)", 524288: "64 x 64, ring of 8 (config 188)"}.get(variant, "shipped: 64 x 64, 4 waves, ring of 3 (config 120)"), "rep": rep}
+            line = {"small_grid_config": variant or 120, "rep": rep}
             for key, b, n, steps in cases:
                 runner = ClipRunner(model, vq, b, n)
                 audio = synthetic.synthetic_audio(b, n, seed=1234).to(dev)
