@@ -344,7 +344,7 @@ int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, con
     a.t_col0 = out_t ? t_col0 : N; a.t_rows = t_rows > 0 ? t_rows : 1; a.t_ld = t_ld;
     a.tiles_m = a.tiles_n = 0;
     a.dbg = g_debug_skip;
-    a.trace = nullptr; a.cstate = nullptr; a.ldc = 0; a.ksplit = 1; a.nk_split = 0; a.ws = nullptr; a.ws_plane = 0; a.ldws = 0;
+    a.trace = nullptr; a.cstate = nullptr; a.ldc = 0; a.ksplit = 1; a.nk_split = 0; a.ws = nullptr; a.ws_plane = 0; a.ldws = 0; a.tile_order = 0;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
     const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2;
     a.a_scale = split ? a_scale : 1.f;

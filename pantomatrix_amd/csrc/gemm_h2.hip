@@ -28,7 +28,7 @@ __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) vo
     const int nblk = p.tiles_m * p.tiles_n;
     const int split = p.ksplit > 1 ? (int)blockIdx.x / nblk : 0;
     int bid = (int)blockIdx.x - split * nblk;
-    if (!EMAGE_DBG(p, 32)) {     // tools (emage_set_tuning key 1 bit 32, tools/prof_traffic_calib.py): dispatch order = tile order, no XCD remap
+    if (p.tile_order == 0 && !EMAGE_DBG(p, 32)) {     // (tools: emage_set_tuning key 1 bit 32, tools/prof_traffic_calib.py: dispatch order for every launch)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
@@ -90,6 +90,13 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     a.tiles_n = (ncols + BN - 1) / BN;
     a.trace = TRACE ? g_h2_trace : nullptr;
+    // Tile order (round 5, profiles/r05_traffic_calibration.txt, r05_gemm_h2_tile_order_ab.txt).  XCD-aware runs keep an XCD's W panels in ITS L2 — as long
+    // as W fits the eight 4 MB L2s next to the A panels.  The K / V projection of all cross-attention layers (W = 12 288 x 768 x 4 B = 37.7 MB) does not:
+    // a strip-shaped run shares an A panel among its 64 concurrent blocks and a W panel among none (1 233 MB over the fabric, 3.9x the model); in
+    // dispatch order consecutive tiles sit on different XCDs and every XCD works on the same few W panels at a time: 390 MB, 227 vs 242 us.  Smaller W
+    // (qkv 7 MB: no difference; out_proj 2.4 MB: 4 % slower) keeps the runs.  Tools: emage_set_tuning key 5 bit 4194304 keeps the runs everywhere
+    // Only the measured kind of launch takes it: a biased projection (no gradient contraction — those were never timed in dispatch order)
+    a.tile_order = (!(g_h2_variant & 4194304) && a.bias && a.taps == 1 && (long)a.N * a.K * 4 >= (32L << 20)) ? 1 : 0;
     // split-K: a bare contraction (only out_f32, no bias / activation / residual — the weight gradients of a training step: few output
     // tiles, a very long K) with too few tiles to fill the chip is cut into K-slices whose partial tiles are atomically added in memory.
     a.ksplit = 1;

@@ -26,6 +26,7 @@ struct GemmArgs {
     int ksplit, nk_split;        // EMAGE_H2 split-K (gemm_h2.hip): > 1 K-slices of nk_split K-tiles each; partial tiles atomically added into out_f32,
     float* ws; long ws_plane; int ldws;   // ... or (ws != NULL, emage_gemm_ws) stored as plane `slice` of the workspace — (M, ldws) fp32 each, ws_plane
                                  // elements apart — and summed in slice order by a second launch (deterministic)
+    int tile_order;              // EMAGE_H2 single launches: 0 = XCD-aware runs (each XCD walks a contiguous run of tiles), 1 = dispatch order (gemm_h2.hip)
     unsigned long long* trace;   // tools builds: per-wave s_memtime stamps of one block (h2_tile.h TRACE), else NULL
 };
 

@@ -414,6 +414,8 @@ from pantomatrix_amd._lib import H2  # noqa: E402
 H2_GEMM_CASES = [c for c in GEMM_CASES if c[0] not in ("conv15_s6", "conv15_s1_resfirst", "conv15_s3")] + [
     ("h2_kv_all", (4, 64, 64), 768, 3072, 1, 1, 0, dict(bias=True, vt=1536)),
     ("h2_ragged_tail", (2, 65, 65), 512, 1536, 1, 1, 0, dict(bias=True, vt=768)),
+    # the K / V projection of all eight cross-attention layers: weights past the eight L2s -> tiles in dispatch order (round 5)
+    ("h2_kv_all_8_layers_dispatch_order", (3, 70, 70), 768, 12288, 1, 1, 0, dict(bias=True)),
     ("h2_out106_f32", (2, 29, 29), 106, 106, 3, 1, 1, dict(bias=True, want="f32")),
     ("h2_res_h2", (3, 64, 64), 256, 256, 3, 1, 1, dict(bias=True, res="h2", n_store=256)),
     ("h2_small_m", (1, 17, 17), 256, 256, 3, 1, 1, dict(bias=True, slope=0.2)),
@@ -495,6 +497,27 @@ def test_gemm_h2_every_tile_configuration(cfg):
                     _cmp(f"cfg{cfg}.{case[0]}.{nm}", gt[..., :width], rf[..., :width], atol=2e-5, rtol=1e-5)
     finally:
         lib.emage_set_tuning(4, -1)
+        _lib.use_tools(False)
+
+
+def test_gemm_h2_dispatch_order_tiles_change_no_bit():
+    """Round 5: a biased projection whose weights exceed the eight L2s (the K / V projection of all cross-attention layers, 12 288 x 768) walks
+    its tiles in dispatch order instead of XCD-aware runs (gemm_h2.hip `tile_order`).  Tile order only: the same bits as the runs
+    (tools library, emage_set_tuning key 5 bit 4194304 = runs everywhere), and a narrower projection is untouched by the bit."""
+    from pantomatrix_amd import _lib
+    lib = _lib.use_tools(True)
+    try:
+        for case in (("kv_all", (5, 50, 50), 768, 12288, 1, 1, 0, dict(bias=True)), ("narrow", (5, 50, 50), 768, 768, 1, 1, 0, dict(bias=True))):
+            outs = []
+            for variant in (0, 4194304):
+                lib.emage_set_tuning(5, variant)
+                outs.append(_run_h2_gemm(case, ops, DEV))
+            torch.cuda.synchronize()
+            for nm, a, b in zip(("out", "out_f32", "out_t"), outs[0][:3], outs[1][:3]):
+                if a is not None:
+                    assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (case[0], nm)
+    finally:
+        lib.emage_set_tuning(5, 0)
         _lib.use_tools(False)
 
 
