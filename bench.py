@@ -320,6 +320,11 @@ def roofline_report(records, precision, ms_per_step, serial_ms=None):
         with open(tfile) as f:
             tj = json.load(f)
         traffic = tj.get(f"{name}:{precision}")
+        roof["traffic_collected_on"] = {"commit": tj.get("_commit"), "kernel_sources_sha": tj.get("_kernel_sources_sha"), "gpu_call": tj.get("_gpu_call")}
+        roof["kernel_sources_sha_now"] = kernel_sources_sha()
+        roof["traffic_is_stale"] = (tj.get("_kernel_sources_sha") != roof["kernel_sources_sha_now"])
+        if roof["traffic_is_stale"]:
+            log("WARNING: profiles/hbm_traffic.json was collected on other kernel sources than this tree's (roofline.traffic_is_stale)")
         if traffic is not None:
             traffic_source = ("STATIC — not measured in this run: bytes per launch read from profiles/hbm_traffic.json ("
                               + str(tj.get("_source", "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over bench.py, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per the microarch guide"))
@@ -377,6 +382,44 @@ def vq_argmin_large(device, n=1 << 20, iters=5):
             "fp32_mfma_tflops": 2.0 * n * 256 * 256 / (ms * 1e-3) / 1e12}
 
 
+def code_agreement(model, vq, audio, batch):
+    """VQ code indices of THIS run against the REFERENCE's run of the same 64-clip batch (tests/golden/infer_128f_b64.npz, generated from the real
+    reference by tests/golden/make_golden.py; rank 0's synthetic batch is that batch): the fraction of equal codes per part and of frames whose
+    three body codes all agree.  1.0 everywhere = north_star's "bit-exact on VQ code indices"."""
+    from tools import workloads as common
+    path = os.path.join(ROOT, "tests", "golden", "infer_128f_b64.npz")
+    if batch != 64 or not os.path.exists(path):
+        return {"skipped": "needs the 64-clip BASELINE batch and tests/golden/infer_128f_b64.npz"}
+    g = np.load(path)
+    _res, lat = common.product_infer_clip(model, vq, audio)
+    sel = model._select_codes(lat)
+    out, frames_ok = {}, None
+    for part in ("upper", "hands", "lower"):
+        eq = sel[f"{part}_index"].cpu().numpy() == g[f"index_{part}"].astype(np.int64)
+        out[part] = float(eq.mean())
+        frames_ok = eq if frames_ok is None else (frames_ok & eq)
+    from pantomatrix_amd.modeling_emage_audio import _Ctx
+    face = vq.vq_model_face._nearest(_Ctx(vq.vq_model_face._engine()), lat["rec_face"].reshape(-1, 256).contiguous())
+    out["face"] = float((face.view(batch, -1).cpu().numpy() == g["index_face"].astype(np.int64)).mean())
+    out["frames_with_all_body_codes_equal"] = float(frames_ok.mean())
+    out["codes_compared"] = int(4 * frames_ok.size)
+    out["against"] = "tests/golden/infer_128f_b64.npz (the real reference's fp32 CPU run of the same batch)"
+    return out
+
+
+def kernel_sources_sha():
+    """sha256 (16 hex digits) over the kernel sources the traffic figures depend on: pantomatrix_amd/csrc/*.{hip,h} in name order."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "pantomatrix_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(frames, seconds_budget=15.0):
     """The CPU oracle (a port of the reference path, oracle/emage_oracle.py) on a bounded sample of the same
     workload: `bs` 128-frame clips per call, repeated until ~seconds_budget of CPU work."""
@@ -402,7 +445,15 @@ def cpu_baseline(frames, seconds_budget=15.0):
         if time.time() - t_start > seconds_budget or len(times) >= 200:
             break
     med = float(np.median(times))
-    return {"value": out_frames / med, "unit": "motion-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    b64 = None
+    if t_one < 2.0:                       # the headline batch itself, ONCE (the same inputs; the survey measured ~7 s on 8 cores)
+        a64 = synthetic.synthetic_audio(64, synthetic.samples_for_frames(frames))
+        t0 = time.time()
+        p64, _, _ = orc.infer_clip(omodel, ovq, a64)
+        dt = time.time() - t0
+        b64 = {"value": p64.shape[0] * p64.shape[1] / dt, "unit": "motion-frames/s", "seconds": dt, "sample": f"64 clips x {frames} frames, one call: the batch `value` is quoted on"}
+        log(f"cpu_baseline: the 64-clip batch took {dt:.1f}s")
+    return {"value": out_frames / med, "unit": "motion-frames/s", "cores": torch.get_num_threads(), "kind": "port", "b64": b64,
             "sample": f"{bs} clips x {frames} frames per call (the survey measured B = 64 slower per frame than B = 8 on CPU), "
                       f"median of {len(times)} calls ({sum(times):.1f} s CPU), fp32 torch CPU oracle = a port of the reference "
                       f"(the reference itself cannot travel to this box)"}
@@ -622,6 +673,72 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw
     return line
 
 
+def bench_train_step_ranks(dev, world, rank, barrier, reduce_max, steps=3, warmup=1, batch=56, t=64, captured=None, models=None, prepare=None):
+    """BASELINE configs[2] at N ranks (train_emage_audio.py:214, 248-251, 275-276: DistributedDataParallel + SyncBatchNorm): EVERY rank calls
+    this behind an initialised process group.  Two arms on the same model and per-rank data (`batch` clips x `t` frames per rank: weak scaling),
+    each timed like the headline figure — barrier, `steps` steps, barrier, max over ranks:
+
+      with_exchange     Trainer(sync_bn=True, exchange=True): the four backward-ordered bucket all-reduces (started mid-backward), SyncBatchNorm's
+                        all-gathers / small all-reduces; on the `nccl` (= RCCL) backend the step is ONE hipGraph per rank whose nodes include
+                        the collectives (Trainer.capture), on any other backend (gloo: the CPU tests) the eager Trainer.step;
+      without_exchange  Trainer(sync_bn=False, exchange=False): the same step with no collective at all (each rank on its own).
+
+    exposed_exchange_ms = with - without: what the collectives cost BEHIND the overlap with the third backward.  `value` = clip-windows/s summed
+    over ranks.  `captured` None: by backend; `models` / `prepare`: test hooks (the CPU stand-ins)."""
+    import torch.distributed as tdist
+    from tools import workloads as common
+    from pantomatrix_amd import dist as pdist
+    from pantomatrix_amd import training
+    backend = str(tdist.get_backend())
+    if captured is None:
+        captured = backend == "nccl"
+    model, vq = models if models is not None else common.product_models(precision="f16x3", device=dev)
+    data = {k: v.to(dev) for k, v in common.train_batch(bs=batch, t=t, seed=5 + rank).items()}      # every rank its own clips
+    random_mask = (torch.rand(batch, t, 337, generator=torch.Generator().manual_seed(6 + rank)) < 0.5).float().to(dev)
+    out = {"workload": f"EMAGE training step f16x3, {batch} x {t}-frame synthetic clips PER RANK on {world} rank(s) (BASELINE configs[2]: DDP + SyncBatchNorm), "
+                       + ("one hipGraph replay per step and rank, collectives inside the graph" if captured else "eager Trainer.step"),
+           "backend": backend, "world": world, "steps": steps, "dtype": "f16x3", "launch": "hipGraph replay" if captured else "eager"}
+    arms = {}
+    for arm, kw in (("with_exchange", dict(sync_bn=True, exchange=True)), ("without_exchange", dict(sync_bn=False, exchange=False))):
+        trainer = training.Trainer(model, vq, seed=1, **kw)
+        if prepare is not None:
+            prepare(trainer)
+        counts = None
+        if captured:
+            trainer.capture(data, random_mask)
+            step = trainer.replay
+        else:
+            step = lambda trainer=trainer: trainer.step(data, random_mask=random_mask)
+        with pdist.CollectiveCounter() as cc:                 # the first step: eager = the collectives of a step; captured = none (they are graph nodes)
+            losses = step()
+        counts = {k: v for k, v in cc.counts.items()}
+        elapsed, losses = timed_steps(step, steps, max(0, warmup - 1), barrier, reduce_max)      # the counted step above was the first warm-up
+        ms = 1e3 * elapsed / steps
+        arms[arm] = {"ms_per_step": ms, "value": batch * world / (ms * 1e-3), "unit": "clip-windows/s", "loss_all_rank0": losses["all"],
+                     "skipped_steps": trainer.skipped_steps}
+        if arm == "with_exchange":
+            arms[arm]["bucket_bytes"] = trainer.buckets.nbytes()
+            arms[arm]["bytes_all_reduced_per_step_and_rank"] = int(sum(trainer.buckets.nbytes()))
+            if not captured:
+                arms[arm]["collectives_per_step"] = {k: v for k, v in counts.items() if k != "bucket_bytes"}
+            else:
+                arms[arm]["collectives_per_step"] = "4 bucket all-reduces + 12 SyncBatchNorm all-gathers + 13 small all-reduces, nodes of the graph (counts pinned by tests/test_rccl_gpu.py)"
+        del trainer
+        if dev is not None and getattr(dev, "type", "cpu") == "cuda":
+            torch.cuda.empty_cache()
+    out.update(arms)
+    w, wo = arms["with_exchange"]["ms_per_step"], arms["without_exchange"]["ms_per_step"]
+    out["ms_per_step"], out["value"], out["unit"] = w, arms["with_exchange"]["value"], "clip-windows/s"
+    out["exposed_exchange_ms"] = w - wo
+    flops = batch * (9 * 20.5e9 + 1.16e9) * world
+    out["roofline"] = {"bound": "mfma", "achieved": flops / (w * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                       "frac": flops / (w * 1e-3) / 1e12 / (F16_MFMA_PEAK_TFLOPS * world), "traffic": None,
+                       "note": "whole-job algorithmic flops of the step / step time against world x the dense fp16 MFMA peak"}
+    out["xgmi_arithmetic"] = ("ring all-reduce: 2 x (N-1)/N x bytes per GPU and step over ~150 GB/s per xGMI link pair; three of the four buckets "
+                              "overlap the third backward (DESIGN.md section 8)")
+    return out
+
+
 CLIP_GFLOP_128 = 44.0          # algorithmic GFLOP of one 128-frame clip end to end (SURVEY 8d: 2 x (20.50 + 0.574) + (0.574 + 0.41) x 120 / 64)
 
 
@@ -768,8 +885,11 @@ def main():
     ap.add_argument("--no-group-gemms", action="store_true", help="A/B: one stream lane per part-wise chain and one launch per contraction instead of lock-step chains with grouped launches")
     ap.add_argument("--attn-variant", type=int, default=0, help="experiments: emage_set_tuning key 6 (1 = split-f16 attention without the LDS-staged K / V^T)")
     ap.add_argument("--h2-variant", type=int, default=0, help="experiments: emage_set_tuning key 5 (EMAGE_H2 tile-heuristic variant)")
+    ap.add_argument("--tools-lib", action="store_true", help="experiments: run on libemage_hip_tools.so even with every tuning key at its default (the fair A arm of a tools-library A/B)")
+    ap.add_argument("--h2-pp", type=int, default=0, help="experiments: emage_set_tuning key 8 (antiphase tile configuration, gemm_h2_pp.hip, for the 768-wide launches; tools library)")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--train-batch", type=int, default=56, help="clips per GPU of the training-step leg at N > 1 ranks (BASELINE configs[2]: 56)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -792,12 +912,13 @@ def main():
     from pantomatrix_amd import dist as pdist
     from pantomatrix_amd import synthetic
 
-    if args.gemm_dbg or args.gemm_variant >= 0 or args.h2_variant or args.attn_variant:
+    if args.gemm_dbg or args.gemm_variant >= 0 or args.h2_variant or args.attn_variant or args.h2_pp or args.tools_lib:
         from pantomatrix_amd import _lib
         _lib.use_tools(True)         # experiments only: the tuning hooks live in the tools build of the library
         _lib.load().emage_set_tuning(1, args.gemm_dbg)
         _lib.load().emage_set_tuning(5, args.h2_variant)
         _lib.load().emage_set_tuning(6, args.attn_variant)
+        _lib.load().emage_set_tuning(8, args.h2_pp)
         if args.gemm_variant >= 0:
             _lib.load().emage_set_tuning(2, args.gemm_variant)
     log(f"rank {rank}/{world}: building the {args.precision} models on {dev} and capturing the clip graph")
@@ -863,6 +984,8 @@ def main():
                 rep.setdefault("vq_argmin", {})["n_1m"] = vq_argmin_large(dev)
             return rep
         guarded("roofline", roofline)
+    if rank == 0 and world == 1 and not args.no_roofline:
+        guarded("code_agreement", lambda: code_agreement(model, vq, audio, args.batch))
     if world == 1 and args.also:
         del runner, model, vq
         torch.cuda.empty_cache()
@@ -873,10 +996,28 @@ def main():
                 m2, v2, r2, _ = build(p, dev, args)
                 el2, _ = timed_steps(lambda: r2(audio), args.steps, args.warmup, barrier, reduce_max)
                 others[p] = {"value": frames_per_step * args.steps / el2, "ms_per_step": 1e3 * el2 / args.steps, "precision": PRECISION_NOTE[p]}
+                if not args.no_roofline:
+                    # the same measurement as the headline `roofline`, for THIS precision (north_star quotes its 0.40 against bf16 MFMA)
+                    try:
+                        recs, _mk = profile_kernels(r2, m2, v2)
+                        ser = None if args.no_graph else serialized_graph_ms(m2, v2, args, n_samples, audio, args.steps)
+                        rep = roofline_report(recs, p, others[p]["ms_per_step"], ser)
+                        others[p]["roofline"] = {k: rep.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "avg_launch_us",
+                                                                          "algorithmic_gflop_per_launch", "serialized_kernel_ms", "kernel_time_ms_by_family", "transformer_blocks")}
+                    except Exception as e:  # noqa: BLE001
+                        others[p]["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                try:
+                    others[p]["code_agreement"] = code_agreement(m2, v2, audio, args.batch)
+                except Exception as e:  # noqa: BLE001
+                    others[p]["code_agreement"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 del m2, v2, r2
                 torch.cuda.empty_cache()
             return others
         guarded("other_precisions", other_precisions)
+    if world > 1 and not args.no_other_configs:
+        # BASELINE configs[2] at N ranks: EVERY rank runs the captured 56-clip step with its RCCL collectives (and the same step without them)
+        log(f"rank {rank}/{world}: the training step at {world} ranks (DDP bucket all-reduces + SyncBatchNorm inside the captured graph)")
+        guarded("train_step", lambda: bench_train_step_ranks(dev, world, rank, barrier, reduce_max, steps=max(3, min(10, args.steps // 2)), batch=args.train_batch))
     if rank == 0:
         result["host"] = host_info()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

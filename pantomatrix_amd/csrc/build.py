@@ -13,8 +13,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm_h2.hip", "attention.hip", "vq.hip", "elementwise.hip", "motion.hip", "wavconv.hip", "convslab.hip", "lstm.hip", "lstmseq.hip", "train.hip", "version.hip"]
-HEADERS = ["common.h", "gemm_tile.h", "h2_tile.h", "h2.h", "attn_tile.h", "ln_row.h", "rot_math.h"]
+SOURCES = ["gemm.hip", "gemm_h2.hip", "gemm_h2_pp.hip", "attention.hip", "vq.hip", "elementwise.hip", "motion.hip", "wavconv.hip", "convslab.hip", "lstm.hip", "lstmseq.hip", "train.hip", "version.hip"]
+HEADERS = ["common.h", "gemm_tile.h", "h2_tile.h", "h2_pp_tile.h", "h2.h", "attn_tile.h", "ln_row.h", "rot_math.h"]
 LIB = os.path.join(HERE, "libemage_hip.so")
 TOOLS_LIB = os.path.join(HERE, "libemage_hip_tools.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
@@ -39,12 +39,38 @@ def needs_build(lib: str = None) -> bool:
     return False
 
 
-def _build_one(lib, objdir, extra, verbose):
+def _includes(path, seen=None):
+    """The in-tree headers a source pulls in (quoted #include lines, followed recursively)."""
+    import re
+    seen = set() if seen is None else seen
+    try:
+        text = open(path).read()
+    except OSError:
+        return seen
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, re.M):
+        q = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if q not in seen and os.path.exists(q):
+            seen.add(q)
+            _includes(q, seen)
+    return seen
+
+
+def _stale(src, obj):
+    """An object is rebuilt when its source, one of the headers it includes, or this script is newer (or `force`)."""
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src, os.path.abspath(__file__), *_includes(src)])
+
+
+def _build_one(lib, objdir, extra, verbose, force=False):
     objs, procs = [], []
     os.makedirs(objdir, exist_ok=True)
     for s in SOURCES:
         o = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(o)
+        if not force and not _stale(os.path.join(HERE, s), o):
+            continue
         procs.append((s, subprocess.Popen([_hipcc(), *FLAGS, *extra, "-c", os.path.join(HERE, s), "-o", o],
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
@@ -61,13 +87,14 @@ def _build_one(lib, objdir, extra, verbose):
         print("built", lib)
 
 
-def build(force: bool = False, verbose: bool = True, tools: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, tools: bool = True, all_objects: bool = False) -> str:
+    # `force` (a missing or out-of-date library): objects whose own dependencies did not change are kept — `python build.py --force --all` rebuilds everything
     if force or needs_build(LIB):
-        _build_one(LIB, os.path.join(HERE, "build"), [], verbose)
+        _build_one(LIB, os.path.join(HERE, "build"), [], verbose, force=all_objects)
     if tools and (force or needs_build(TOOLS_LIB)):
-        _build_one(TOOLS_LIB, os.path.join(HERE, "build_tools"), ["-DEMAGE_TOOLS"], verbose)
+        _build_one(TOOLS_LIB, os.path.join(HERE, "build_tools"), ["-DEMAGE_TOOLS"], verbose, force=all_objects)
     return LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, all_objects="--all" in sys.argv)

@@ -46,6 +46,17 @@ template <> struct Elem<bf16_t> {
 
 __device__ __forceinline__ float leaky(float v, float s) { return v > 0.f ? v : v * s; }
 
+// CU count of the CURRENT device (cached per device id; 256 on MI355X).  Steers tile / split-K heuristics and residency checks only
+static inline int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64 && cached[dev] > 0) return cached[dev];
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) cached[dev] = v;
+    return v;
+}
+
 static inline int launch_status() {
     hipError_t e = hipGetLastError();
     return (int)e;

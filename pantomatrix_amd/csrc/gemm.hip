@@ -12,7 +12,7 @@
 namespace emage_dev {
 #ifdef EMAGE_TOOLS
 extern int g_lstm_layer_dbg;                        // csrc/lstmseq.hip
-extern int g_h2_force_config, g_h2_variant, g_h2_small_cfg;         // csrc/gemm_h2.hip
+extern int g_h2_force_config, g_h2_variant, g_h2_small_cfg, g_h2_pp_cfg;         // csrc/gemm_h2.hip
 extern int g_attn_variant;                          // csrc/attention.hip
 #endif
 int gemm_h2_dispatch(GemmArgs& a, hipStream_t s);   // csrc/gemm_h2.hip: the EMAGE_H2 (pre-split operands) tile kernels
@@ -430,8 +430,9 @@ extern "C" int emage_set_tuning(int key, int value) {
     if (key == 3) { emage_dev::g_lstm_layer_dbg = value; return 0; }     // csrc/lstmseq.hip: A/B and timing ablations
     if (key == 4) { emage_dev::g_h2_force_config = value; return 0; }    // csrc/gemm_h2.hip: fixed EMAGE_H2 tile configuration
     if (key == 5) { emage_dev::g_h2_variant = value; return 0; }         // csrc/gemm_h2.hip: dispatch-heuristic variant (A/B runs)
-    if (key == 6) { emage_dev::g_attn_variant = value; return 0; }
-    if (key == 7) { emage_dev::g_h2_small_cfg = value; return 0; }       // csrc/gemm_h2.hip: EMAGE_H2 configuration for lone-block grids (A/B)       // csrc/attention.hip: 1 = split-f16 attention without the LDS-staged K / V^T (A/B, bitwise test)
+    if (key == 6) { emage_dev::g_attn_variant = value; return 0; }       // csrc/attention.hip: 1 = split-f16 attention without the LDS-staged K / V^T (A/B, bitwise test)
+    if (key == 7) { emage_dev::g_h2_small_cfg = value; return 0; }       // csrc/gemm_h2.hip: EMAGE_H2 configuration for lone-block grids (A/B)
+    if (key == 8) { emage_dev::g_h2_pp_cfg = value; return 0; }          // csrc/gemm_h2.hip: antiphase configuration (gemm_h2_pp.hip) for the 768-wide launches (A/B)
     return EMAGE_EINVAL;
 }
 #endif

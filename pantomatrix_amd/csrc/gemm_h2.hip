@@ -10,9 +10,10 @@ namespace emage_dev {
 int g_h2_force_config = -1;      // tools build (emage_set_tuning key 4): fixed tile configuration for sweeps
 int g_h2_variant = 0;            // tools build: dispatch-heuristic variant for A/B runs (emage_set_tuning key 5)
 int g_h2_small_cfg = 0;          // tools build: tile configuration for grids of at most one 64 x 64 tile per CU (emage_set_tuning key 7; 0 = the shipped 120)
+int g_h2_pp_cfg = 0;             // tools build: antiphase configuration for the 768-wide launches (emage_set_tuning key 8; 0 = the shipped 120)
 unsigned long long* g_h2_trace = nullptr;   // tools build: device buffer of (waves x 512) s_memtime stamps (emage_h2_set_trace)
 #else
-constexpr int g_h2_force_config = -1, g_h2_variant = 0, g_h2_small_cfg = 0;
+constexpr int g_h2_force_config = -1, g_h2_variant = 0, g_h2_small_cfg = 0, g_h2_pp_cfg = 0;
 constexpr unsigned long long* g_h2_trace = nullptr;
 #endif
 }
@@ -74,18 +75,22 @@ __global__ __launch_bounds__(256) void h2_splitk_reduce_kernel(const float* __re
     else { for (int e = 0; e < 4; ++e) if (n + e < N) dst[e] = v[e]; }
 }
 
-// block slots of the chip for a tile configuration (LDS-bound residency x CUs): what a split-K launch should fill.  256 CUs (MI355X); the
-// count only steers how many K-slices are cut, never correctness
+// CU count the heuristics plan for: the current device's (256 on MI355X; the fallback when the query fails)
+static inline int h2_cus() { const int c = device_cus(); return c > 0 ? c : 256; }
+
+// block slots of the chip for a tile configuration (LDS-bound residency x CUs of the current device): what a split-K launch should fill.
+// The count only steers how many K-slices are cut, never correctness
 template <int BM, int BN, int NS, int THREADS, int KPB = 1>
-constexpr int h2_block_slots() {
+int h2_block_slots() {
     constexpr int by_lds = (160 * 1024) / h2_smem_bytes<BM, BN, NS, KPB>();
     constexpr int by_waves = 32 / (THREADS / 64);
-    return 256 * (by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves);
+    return h2_cus() * (by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves);
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false, bool TRACE = false, int KPB = 1>
 int launch_h2(GemmArgs& a, hipStream_t s) {
     if (a.out_t && a.t_col0 % BN != 0) return EMAGE_EINVAL;      // a tile is either row-major or transposed
+    if (KPB > 1 && (a.K / 32) % KPB != 0) return EMAGE_EINVAL;   // a ring slot holds KPB whole K-tiles: an odd count would drop the last one
     a.tiles_m = (a.M + BM - 1) / BM;
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     a.tiles_n = (ncols + BN - 1) / BN;
@@ -113,7 +118,7 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
     if (bare && ws && !(g_h2_variant & 16384)) {      // tools A/B: bit 16384 = ignore the workspace (the atomic form)
         // two-pass split-K (emage_gemm_ws): as many K-slices as fill the chip's block slots ONCE, each slice >= 16 K-tiles, partial tiles as
         // planes of the workspace.  Cheap enough (plain stores + one streaming pass) to use up to twice the tile count of the atomic form
-        constexpr int SLOTS = h2_block_slots<BM, BN, NS, (WM * WN + NLW) * 64, KPB>();
+        const int SLOTS = h2_block_slots<BM, BN, NS, (WM * WN + NLW) * 64, KPB>();
         const int ldws = (a.N + 3) & ~3;
         const long plane = ((long)a.M * ldws + 3) & ~3L;
         int want = (int)(SLOTS / tiles);
@@ -171,12 +176,6 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
 // The argument block carries the problems by value (kernarg segment: no device table to allocate); a block finds its problem by
 // comparing its (XCD-remapped) id with the running tile counts — scalar work — and then runs the unchanged tile routine on that
 // problem's arguments: the result is bit for bit that of the single-problem launch.
-constexpr int MAXG = 8;
-struct GroupArgs {
-    GemmArgs p[MAXG];
-    int tile_end[MAXG];          // running sum of tiles_m * tiles_n
-    int n, total;
-};
 
 template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV>
 __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) void gemm_h2_group_kernel(GroupArgs g) {
@@ -342,6 +341,9 @@ extern "C" int emage_h2_set_trace(void* buf) { emage_dev::g_h2_trace = (unsigned
 
 namespace emage_dev {
 
+int run_pp_config(int cfg, GemmArgs& a, hipStream_t s);       // gemm_h2_pp.hip
+int run_pp_group(int cfg, GemmArgs** a, int n, hipStream_t s);
+
 // the tile configuration of one problem.  Measured on MI355X (tools/bench_gemm_h2.py, profiles/r03_h2_sweep*.txt).  Wide outputs: 8-wave
 // 64x192 / 128x256 tiles; everything else: 64x64 tiles, three resident blocks per CU (their barriers de-synchronise, which hides each
 // block's DMA / LDS phases behind the others' MFMAs better than one fat block per CU does at M = 4096).  < 0: unsupported argument
@@ -361,8 +363,9 @@ static int h2_config_for(const GemmArgs& a) {
         // many tiles per CU (the K/V projections of all cross-attention layers, N = 12288): 64x48 wave tiles read 14 KB of fragments per 36
         // MFMAs (the 32x128 ones of 119: 20 KB per 48) and two 80 KB blocks fit a CU: 239 vs 270 us (profiles/r04_gemm_h2_sweep_fewer_waves_wide.txt)
         const long t128x192 = (long)((a.M + 127) / 128) * ((ncols + 191) / 192);
-        if (!(v & 512) && t128x192 >= 1024 && ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return 170;
-        if (!(v & 2) && t128x256 >= 512 && ncols % 256 == 0 && (!a.out_t || a.t_col0 % 256 == 0)) return 119;
+        const long cus = h2_cus();                     // the thresholds were measured on 256 CUs: 4 / 2 tiles per CU
+        if (!(v & 512) && t128x192 >= 4 * cus && ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return 170;
+        if (!(v & 2) && t128x256 >= 2 * cus && ncols % 256 == 0 && (!a.out_t || a.t_col0 % 256 == 0)) return 119;
         if (ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return 100;
         if (!a.out_t || a.t_col0 % 128 == 0) return 113;
     }
@@ -371,11 +374,15 @@ static int h2_config_for(const GemmArgs& a) {
     // its operands — the 8-wave tiles move half the bytes per MFMA (profiles/r05_gemm_h2_sweep_backward_two_pass.txt: 187-197 vs 234-266 us,
     // 104-116 vs 133-134 us).  Below ~20 M (rows x k) the 64 x 64 tile wins (the window shapes of inference: M = 4096, K <= 1536)
     if (!(v & 65536) && !a.out_t && ncols % 192 == 0 && ncols >= 768 && a.taps == 1) {
-        const long mk = (long)a.M * a.K;
-        if (mk >= 40L * 1000 * 1000) return 170;
-        if (mk >= 20L * 1000 * 1000) return 100;
+        const long mk = (long)a.M * a.K, per_cu = 1000L * 1000 * h2_cus() / 256;     // measured on 256 CUs: 40 M / 20 M (rows x k)
+        if (mk >= 40L * per_cu) return 170;
+        if (mk >= 20L * per_cu) return 100;
     }
     if (a.out_t && a.t_col0 % 64 != 0) return EMAGE_EINVAL;
+#ifdef EMAGE_TOOLS
+    // round 6 A/B (emage_set_tuning key 8 = g_h2_pp_cfg): 768-wide launches over many rows on an ANTIPHASE configuration (gemm_h2_pp.hip)
+    if (g_h2_pp_cfg > 0 && !a.out_t && ncols % 96 == 0 && ncols >= 768 && a.M >= 2048) return g_h2_pp_cfg;
+#endif
     return (v & 8) ? 130 : 120;
 }
 
@@ -398,6 +405,7 @@ int gemm_h2_dispatch(GemmArgs& a, hipStream_t s) {
         if (t64 <= 256 && !bare) cfg = g_h2_small_cfg > 0 ? g_h2_small_cfg : 189;
     }
 #endif
+    if (cfg >= 300 && cfg < 400) return run_pp_config(cfg, a, s);       // antiphase tiles: gemm_h2_pp.hip
     return cfg < 0 ? cfg : run_config(cfg, a, s);
 }
 
@@ -421,6 +429,7 @@ int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only) {
             case 120: return !h2_wants_split_k<64, 64>(a[i]);
             case 170: return !h2_wants_split_k<128, 192>(a[i]);
 #ifdef EMAGE_TOOLS
+            case 300: case 301: case 302: case 303: return true;
             case 160: case 161: return !h2_wants_split_k<64, 96>(a[i]);
             case 162: case 163: case 164: return !h2_wants_split_k<64, 64>(a[i]);
 #endif
@@ -440,7 +449,9 @@ int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only) {
             done[i] = true;
             continue;
         }
-        if (m >= 2) {
+        if (m >= 2 && cfg[i] >= 300 && cfg[i] < 400) {
+            rc = run_pp_group(cfg[i], grp, m, s);
+        } else if (m >= 2) {
             switch (cfg[i]) {
                 case 100: rc = launch_h2_group<64, 192, 4, 2, 2, 0, false>(grp, m, s); break;
                 case 113: rc = launch_h2_group<128, 128, 4, 2, 3, 0, false>(grp, m, s); break;

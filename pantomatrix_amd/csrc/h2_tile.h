@@ -24,6 +24,14 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     [&]<int... I>(std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }(std::make_integer_sequence<int, N>{});
 }
 
+// grouped launches (emage_gemm_grouped): several independent problems of ONE tile configuration in one grid, the argument block by value
+constexpr int MAXG = 8;
+struct GroupArgs {
+    GemmArgs p[MAXG];
+    int tile_end[MAXG];          // running sum of tiles_m * tiles_n
+    int n, total;
+};
+
 template <int BM, int BN, int NS, int KPB = 1> constexpr int h2_smem_bytes() { return NS * KPB * (BM + BN) * 128; }
 
 // ---- the epilogue of an EMAGE_H2 tile (gemm_h2_tile; kept separate for fused kernels that end in the same stores) ----
@@ -279,6 +287,7 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     // DMA instruction J of a stage (J < GA: A rows, else W rows) and the bookkeeping that follows the last one
     auto issue_piece = [&](auto jc) {
         constexpr int J = decltype(jc)::value;
+        if (EMAGE_DBG(p, 1)) return;                   // tools, timing only (emage_set_tuning key 1): no operand DMA
         unsigned char* base = smem + is_slot * STAGE + (KPB > 1 ? is_sub * SUB : 0);
         if constexpr (J < GA) {
             unsigned vo = a_voff[J];
@@ -423,7 +432,9 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
                   static_for<KPB>([&](auto subc) {
                     constexpr int SB2 = decltype(subc)::value * SUB;
                     Frag f;
-                    static_for<NR>([&](auto rc) { read_one(rc, f, sb + SB2); });
+                    if (!EMAGE_DBG(p, 2)) static_for<NR>([&](auto rc) { read_one(rc, f, sb + SB2); });        // (tools, timing only: bit 2 = no fragment reads)
+                    else { static_for<FM>([&](auto ic) { f.ah[decltype(ic)::value] = f.al[decltype(ic)::value] = u32x4{0u, 0u, 0u, 0u}; });
+                           static_for<FN>([&](auto jc) { f.wh[decltype(jc)::value] = f.wl[decltype(jc)::value] = u32x4{0u, 0u, 0u, 0u}; }); }
                     tr();
                     wait_lgkmcnt<FN + FM>();              // A hi and W lo are there: first sweep
                     __builtin_amdgcn_sched_barrier(0);
@@ -435,7 +446,7 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
                             wait_lgkmcnt<0>();
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        mma_one(qc, f);
+                        if (!EMAGE_DBG(p, 4)) mma_one(qc, f);                                                 // (bit 4 = no MFMAs)
                         if constexpr (DILV && NLW == 0 && Q % DSTEP == DSTEP - 1 && Q / DSTEP < G) {
                             __builtin_amdgcn_sched_barrier(0);
                             if (do_issue) issue_piece(IC<Q / DSTEP>{});

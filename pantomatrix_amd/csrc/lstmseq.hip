@@ -205,8 +205,10 @@ __global__ __launch_bounds__(256, OCC) void lstm_seq_kernel(SeqArgs p) {
             if constexpr (LL && HALVES > 1) {
                 // PIPELINED hand-over (round 5, VERDICT next #7): only phase 0 of h_{t-1} is waited for here; the loads of the later phases
                 // are issued once and checked just before their staging — they land while phase 0 is staged and multiplied
-                poll_part(emage_dev::IC<0>{}, true);
-                emage_dev::static_for<HALVES - 1>([&](auto hc) { load_part(emage_dev::IC<decltype(hc)::value + 1>{}); });
+                if (!(p.dbg & 4)) {                         // (tools ablation bit 4: no h loads / no staging — honoured here as in the single-phase branch)
+                    poll_part(emage_dev::IC<0>{}, true);
+                    emage_dev::static_for<HALVES - 1>([&](auto hc) { load_part(emage_dev::IC<decltype(hc)::value + 1>{}); });
+                }
                 if (bad) {
                     if (lane == 0) {
                         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, OCC) void lstm_seq_kernel(SeqArgs p) {
             emage_dev::static_for<HALVES>([&](auto halfc) {
                 constexpr int half = decltype(halfc)::value;
                 if constexpr (LL && HALVES > 1 && half > 0) {
-                    poll_part(halfc, false);                 // normally true at the first look: the phase arrived behind the previous phase's MFMAs
+                    if (!(p.dbg & 4)) poll_part(halfc, false);                 // normally true at the first look: the phase arrived behind the previous phase's MFMAs
                     if (bad && lane == 0) {
                         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         *s_flag = 1;
@@ -333,15 +335,6 @@ namespace emage_dev { constexpr int g_lstm_layer_dbg = 0; }
 #endif
 namespace {
 
-int device_cus() {                                     // CU count of the CURRENT device (cached per device id)
-    static int cached[64] = {0};
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (dev >= 0 && dev < 64 && cached[dev] > 0) return cached[dev];
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (dev >= 0 && dev < 64) cached[dev] = v;
-    return v;
-}
 
 int max_slices_for(int H) {                            // co-resident blocks: one per CU, 2 * H/16 per slice of 64 clips
     int m = device_cus() / (2 * (H / 16));

@@ -135,6 +135,7 @@ class _EmageModule(torch.nn.Module):
         step re-packs without a host read-back) — for weights REPLACED other than through this module's `load_state_dict`."""
         self._packed = None
         self._templates = {}
+        self.__dict__.pop("_version_slots", None)       # parameters / buffers / submodules registered since the last stamp are tracked from the next one on
         if reset_scales:
             self.__dict__["_scale_caches"] = {}
         return self
@@ -164,8 +165,18 @@ class _EmageModule(torch.nn.Module):
         """Advance the version counters of tensors that were updated through raw device pointers (`emage_adam_multi`, a graph replay): the
         staleness check of `_engine()` then sees the update without anyone having to call `invalidate_packed()`."""
         ts = [t for t in tensors if torch.is_tensor(t)]
-        if ts:
+        if not ts:
+            return
+        try:
             torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
+        except (TypeError, AttributeError, RuntimeError):       # a torch whose private setter takes one tensor at a time, or has none
+            setter = getattr(torch._C._autograd, "_unsafe_set_version_counter", None)
+            for t in ts:
+                try:
+                    setter(t, t._version + 1)
+                except Exception:                               # noqa: BLE001 — last resort: an in-place no-op advances the counter
+                    with torch.no_grad():
+                        t.add_(0)
 
     _trainable = False       # EmageAudioModel: train() switches forward() to the differentiable train-mode forward
 

@@ -1341,6 +1341,9 @@ class Trainer:
             return self._device_step_body(batch, dropout_masks, random_mask, grad_hook, step_counter, index, latent, masked_motion, speaker_id, seed_mask)
         except BaseException:
             fwd._pg_dst, fwd._pg_src, fwd._pg_spans, fwd._pg_bytes = [], [], {}, 0       # a step that died mid-backward: its queued contributions die with it
+            fwd._fin.entries = []                         # ... and its queued finalize launches (their float64 partials would land in the NEXT step's buckets)
+            for flat in self.buckets.flat:                # Adam's zero_grad never ran for the dead step
+                flat.zero_()
             raise
         finally:
             fwd._wt_cache, fwd._wt_keep = {}, False
@@ -1380,6 +1383,12 @@ class Trainer:
             if f == 2:                                    # the shared WavEncoder pass: the tail of the third backward
                 fwd.finish_shared(share, progress, base=fwd.last_run_nodes)
             log.append(("backward_done", f))
+        # non-finite LOSS words of this rank — in an exchanging run the MAXIMUM over ranks (one more small all-reduce; a graph node in a captured
+        # step): a loss is rank-local, so without it `on_nonfinite="raise"` would raise on ONE rank and leave the others in their next collective
+        self.loss_health = (~torch.isfinite(torch.stack([v.reshape(()) for v in out.values()]))).sum().to(torch.int32).reshape(1)
+        if exchanging and world > 1:
+            import torch.distributed as tdist
+            tdist.all_reduce(self.loss_health, op=tdist.ReduceOp.MAX, group=self.group)
         if learning:
             last = {}
             for name, pos in fwd.touch.items():
@@ -1462,6 +1471,9 @@ class Trainer:
             self.fwd.reset_scales()
             recapture = self._recapture_pending = True
         finite = all(v == v and abs(v) != float("inf") for v in res.values())
+        lh = getattr(self, "loss_health", None)
+        if lh is not None and int(lh[0]) != 0:            # some rank's loss was non-finite: every rank takes the branch below together
+            finite = False
         if bad:                                           # the DEVICE skipped the update (Adam's skip word, the same on every rank: it is counted
             self.steps_done -= 1                          # behind the gradient exchange) — the host only follows that decision
             for st in self.state.values():
@@ -1494,6 +1506,8 @@ class Trainer:
             res, _ = self._finish(out, ws)
         finally:
             self._parameters_moved()                      # the MFMA operand copies are rebuilt from the updated parameters
+            if self._graph is not None:                   # hand-over from the captured step (a ragged last batch runs eagerly): the graph's
+                self._step_counter.fill_(self.steps_done) # device-side step counter follows, so a later replay() continues the same count
         return res
 
     def _parameters_moved(self):

@@ -96,6 +96,30 @@ def main():
         res["captured"] = dict(ok=True, worst=worst, loss_all=losses["all"], steps_done=trainer.steps_done, replay_ms=round(e0.elapsed_time(e1) / 3, 2))
     except Exception as e:  # noqa: BLE001
         res["captured"] = dict(error=f"{type(e).__name__}: {e}", trace=traceback.format_exc()[-1500:])
+    # ---- 3. hand-over: captured steps, a RAGGED last batch through the eager step, the graph again ----
+    try:
+        ragged = {k: v[:1].contiguous() for k, v in batch.items()}
+        ragged_mask = random_mask[:1].contiguous()
+        model, vq = common.product_models(precision="f16x3", device=dev)
+        trainer = training.Trainer(model, vq, sync_bn=True, exchange=True, seed=3)
+        trainer.capture(batch, random_mask)                      # dropout masks drawn on the device from (seed, step)
+        la = [trainer.replay()["all"], trainer.step(ragged, random_mask=ragged_mask)["all"], trainer.replay()["all"]]
+        counter = int(trainer._step_counter)
+        model2, vq2 = common.product_models(precision="f16x3", device=dev)
+        twin = training.Trainer(model2, vq2, sync_bn=True, exchange=True, seed=3)
+        lb = [twin.step(batch, random_mask=random_mask)["all"], twin.step(ragged, random_mask=ragged_mask)["all"], twin.step(batch, random_mask=random_mask)["all"]]
+        pa, pb = model._flat_params(), model2._flat_params()
+        worst, equal = 0.0, True
+        for k, v in pa.items():
+            if not v.dtype.is_floating_point:
+                continue
+            d = float((v - pb[k]).abs().max())
+            worst = max(worst, d / (float(pb[k].abs().max()) + 1e-12))
+            equal = equal and bool(torch.equal(v, pb[k]))
+        res["handover"] = dict(ok=True, losses_graph_eager_graph=la, losses_twin_eager=lb, steps_done=[trainer.steps_done, twin.steps_done],
+                               device_step_counter=counter, worst_rel_param_diff=worst, bit_equal=equal)
+    except Exception as e:  # noqa: BLE001
+        res["handover"] = dict(error=f"{type(e).__name__}: {e}", trace=traceback.format_exc()[-1500:])
     print("RCCL_WORKER " + json.dumps(res, default=float), flush=True)
     try:
         tdist.destroy_process_group()

@@ -71,6 +71,52 @@ def test_timed_region_on_two_gloo_ranks():
     assert l0["config"]["frames_out_per_clip"] == 120 and "replicas x2" in l0["config"]["parallelism"]
 
 
+def _train_leg_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import bench
+    import common
+    import fake_ops
+    from pantomatrix_amd import dist as pd
+    assert pd.init("gloo") is not None
+    torch.set_num_threads(2)
+    models = common.product_models(precision="fp32")
+    with fake_ops.installed(), torch.no_grad():
+        out = bench.bench_train_step_ranks(torch.device("cpu"), world, rank, pd.barrier, pd.max_over_ranks, steps=1, warmup=1, batch=1, models=models)
+    q.put((rank, out))
+    pd.finalize()
+
+
+def test_train_step_leg_on_two_gloo_ranks():
+    """bench.py's training leg at N > 1 ranks (BASELINE configs[2]): both arms run on two gloo ranks with the CPU
+    stand-ins of the kernels (eager — a captured graph needs the device and the nccl backend): the exchanging arm issues the step's
+    collectives (4 bucket all-reduces, SyncBatchNorm's 12 all-gathers and 12 + 1 + 1 small all-reduces), the other arm none; both ranks
+    report the same max-over-ranks time, the whole-job rate and the exposed exchange time."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_leg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=1500) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, o0), (_, o1) = res
+    for o in (o0, o1):
+        assert o["backend"] == "gloo" and o["world"] == 2 and o["launch"] == "eager"
+        w, wo = o["with_exchange"], o["without_exchange"]
+        assert w["collectives_per_step"] == {"all_gather": 12, "all_reduce_small": 14, "all_reduce_bucket": 4}, w
+        assert 500e6 < w["bytes_all_reduced_per_step_and_rank"] < 600e6 and len(w["bucket_bytes"]) == 4
+        assert abs(o["exposed_exchange_ms"] - (w["ms_per_step"] - wo["ms_per_step"])) < 1e-9
+        assert abs(o["value"] - 1 * 2 / (w["ms_per_step"] * 1e-3)) < 1e-6 and o["unit"] == "clip-windows/s"
+        assert o["roofline"]["peak"] == 2 * 2500.0
+    assert o0["ms_per_step"] == o1["ms_per_step"]                      # max over ranks: every rank reports the slowest
+
+
 def test_main_prints_one_json_line_and_reports_a_failing_extra(monkeypatch, capsys):
     """bench.main() end to end with the device work stubbed out (a stand-in runner, stand-in profiling): ONE JSON line with the
     contract's keys and every additional object; an exception inside an additional object (here: the training-step line) is reported

@@ -221,7 +221,8 @@ def _sync_worker(rank, world, port, q):
     # ONE WavEncoder pass, whose blocks run the two encoders in lock step — per block one exchange for the bn1 pair and one for the bn2 +
     # shortcut BatchNorms: 12 all-gathers forward, 12 all-reduces backward (the BatchNorms of consecutive stages depend on each other: no
     # further merging keeps nn.SyncBatchNorm's arithmetic), plus ONE integer all-reduce (the clips of all ranks) per step
-    assert calls == {"all_gather": 12, "all_reduce_small": 12 + 1, "all_reduce_bucket": 4}, calls
+    # round 6: + ONE integer all-reduce (MAX) of the non-finite-LOSS flag, so `on_nonfinite="raise"` raises on every rank together
+    assert calls == {"all_gather": 12, "all_reduce_small": 12 + 1 + 1, "all_reduce_bucket": 4}, calls
     keep = ("audio_encoder_face.feat_extractor.0.bn1.weight", "audio_encoder_body.feat_extractor.4.conv2.weight", "face_out_proj.weight",
             "audio_motion_cross_attn.layers.3.linear1.bias", "mask_embedding", "motion_encoder.main.0.weight", "speaker_embedding_body.weight")
     rv = model._flat_params()["audio_encoder_body.feat_extractor.2.bn2.running_var"].clone().numpy()

@@ -43,3 +43,17 @@ def test_captured_step_holds_its_collectives_and_matches_the_reference(rccl_resu
     assert "error" not in c, c
     assert c["steps_done"] == 1
     print("captured step with RCCL collectives:", json.dumps(c))
+
+
+@pytest.mark.gpu
+def test_ragged_last_batch_hands_over_from_the_graph_to_the_eager_step_and_back(rccl_result):
+    """A captured multi-rank step replays the batch size it captured (SyncBatchNorm's clip total is a launch-time constant); the ragged LAST
+    batch of an epoch therefore takes `Trainer.step` — which exchanges the count itself — and the graph continues behind it: replay, eager
+    step on ONE clip, replay equals three eager steps of a twin trainer (losses, parameters, step counts on host and device)."""
+    h = rccl_result["handover"]
+    assert "error" not in h, h
+    assert h["steps_done"] == [3, 3] and h["device_step_counter"] == 3
+    for a, b in zip(h["losses_graph_eager_graph"], h["losses_twin_eager"]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), h
+    assert h["worst_rel_param_diff"] <= 1e-6, h
+    print("hand-over graph -> eager -> graph:", json.dumps(h))

@@ -114,6 +114,8 @@ def main():
         w_x3, ws_x3 = ops.split_f16_weights(w)
         ldo = ops.round_up(max(ncol, n_store), 8)
 
+        ref_bits = {}
+
         def run(cfg):
             h2 = cfg is not None
             lib.emage_set_tuning(4, cfg if h2 else -1)
@@ -160,6 +162,13 @@ def main():
                 vt_ref = ref[:, vt0:].reshape(nb, lout, n - vt0).permute(0, 2, 1)
                 errs.append(float((out_t[:, :, :lout].double() - vt_ref).abs().max()))
             ok &= all(e <= tol for e in errs)
+            # bit identity against the first EMAGE_H2 configuration of the row (the K order per output is the same in every configuration)
+            if h2:
+                bits = [t.clone() for t in (out, out_f, out_t) if t is not None]
+                if "h2" not in ref_bits:
+                    ref_bits["h2"] = bits
+                same = all(torch.equal(x, y) for x, y in zip(bits, ref_bits["h2"]))
+                run.same = same
             return us, ok
 
         cells, best = [], (1e9, None)
@@ -176,7 +185,7 @@ def main():
                 continue
             if args.loop:
                 return
-            cells.append(f"{us:6.1f}{' ' if ok else '!'}")
+            cells.append(f"{us:6.1f}{('=' if getattr(run, 'same', False) else '~') if ok else '!'}")        # '=': the first configuration's bits
             if ok and us < best[0]:
                 best = (us, cfg)
         lib.emage_set_tuning(4, -1)
