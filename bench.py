@@ -849,6 +849,7 @@ def build(precision, device, args):
     for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.split_acts = not args.no_split_acts
     model.h2_residual = not args.f32_residual
+    model.fold_layernorm = not args.no_fold_ln
     for part in (model, vq.vq_model_face, vq.vq_model_upper, vq.vq_model_hands, vq.vq_model_lower, vq.global_motion):
         part.concurrent = not args.no_concurrent
         part.group_gemms = not args.no_group_gemms
@@ -887,6 +888,7 @@ def main():
     ap.add_argument("--h2-variant", type=int, default=0, help="experiments: emage_set_tuning key 5 (EMAGE_H2 tile-heuristic variant)")
     ap.add_argument("--tools-lib", action="store_true", help="experiments: run on libemage_hip_tools.so even with every tuning key at its default (the fair A arm of a tools-library A/B)")
     ap.add_argument("--h2-pp", type=int, default=0, help="experiments: emage_set_tuning key 8 (antiphase tile configuration, gemm_h2_pp.hip, for the 768-wide launches; tools library)")
+    ap.add_argument("--no-fold-ln", action="store_true", help="A/B: every LayerNorm is a launch (round 5's form) instead of folded into the contractions around it")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--train-batch", type=int, default=56, help="clips per GPU of the training-step leg at N > 1 ranks (BASELINE configs[2]: 56)")

@@ -163,6 +163,21 @@ typedef struct emage_gemm_problem {
     int lda, ldr, res_is_f32, res_first, ldo, n_store, ldf, t_col0, t_rows, t_ld;
     int M, N, Cp, taps, stride, pad, Lin, Lout;
     float a_scale, w_scale;
+    /* LayerNorm FOLDED into the contractions around it (EMAGE_H2, taps = 1; every pointer NULL = off; emage_gemm itself never folds).
+     * A post-norm transformer layer (nn.TransformerDecoderLayer, modeling_emage_audio.py:238-250) computes y = LN(s) W^T + b on the
+     * pre-norm sum s of the previous sub-layer.  With W' = W gamma, c[n] = sum_k W'[n][k], b' = W beta + b (packed by the host):
+     *     y[m][n] = rstd[m] ( (s W'^T)[m][n] - mu[m] c[n] ) + b'[n]
+     * so the contraction runs on the RAW sum (A = the EMAGE_H2 image of s, W = W', bias = b') and no LayerNorm launch / normalised
+     * tensor exists.  Row statistics travel as PARTIALS {mean, M2} (float pairs) over 32 columns each, written by the epilogue of the
+     * launch that produced s (st_out) and merged (Chan) by every consumer:
+     *   ln_stats (M, ln_np) pairs, ln_np * 32 == Cp, ln_np == 24 (the 768-wide residual stream; other widths are refused: EMAGE_EINVAL): statistics of A's rows;  ln_c (N): c;  ln_eps: the LayerNorm's eps;
+     *   rs_stats (M, rs_np) pairs, rs_np * 32 == N: `res` (an EMAGE_H2 image, res_is_f32 = 0) is the raw sum s' of a folded LayerNorm,
+     *       the residual added is (s' - mu) rstd rs_gamma[n] + rs_beta[n];
+     *   st_out (M, N / 32) pairs: partial statistics of THIS launch's output rows (values as stored to out / out_f32); N % 64 == 0, no
+     *       out_t, launches that take the 64 x 64 tile (N < 1024) only. */
+    const float* ln_stats; const float* ln_c; const float* rs_stats; const float* rs_gamma; const float* rs_beta; float* st_out;
+    int ln_np, rs_np;
+    float ln_eps;
 } emage_gemm_problem;
 int emage_gemm_grouped(int dtype, const emage_gemm_problem* problems, int n_problems, void* stream);
 /* Launches nothing: the number of kernel launches emage_gemm_grouped would make of these problems (> 0), or a negative EMAGE_E* code. */
@@ -360,6 +375,9 @@ int emage_rot6d_scatter(const float* rot6d, int ld, const int* slot_of_joint, fl
 
 /* counter[0] += number of non-finite values in the contiguous fp32 array x[0 .. n): the runners' end-of-batch health check. */
 int emage_count_nonfinite(const float* x, long n, int* counter, void* stream);
+/* The same over `count` <= 16 tensors in ONE launch (contiguous fp32, ns[i] elements each; the pointer table is read on the host at call time
+ * and travels by value): the end-of-batch health check of the clip runners. */
+int emage_count_nonfinite_multi(const float* const* xs, const long* ns, int count, int* counter, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Train-mode forward (train_emage_audio.py:130-204): what differs from the inference path.

@@ -19,7 +19,9 @@ class GemmProblem(C.Structure):
     _fields_ = ([(n, _p) for n in ("A", "W", "bias", "slope", "res", "out", "out_f32", "out_t")]
                 + [(n, _i) for n in ("lda", "ldr", "res_is_f32", "res_first", "ldo", "n_store", "ldf", "t_col0", "t_rows", "t_ld",
                                      "M", "N", "Cp", "taps", "stride", "pad", "Lin", "Lout")]
-                + [("a_scale", _f), ("w_scale", _f)])
+                + [("a_scale", _f), ("w_scale", _f)]
+                + [(n, _p) for n in ("ln_stats", "ln_c", "rs_stats", "rs_gamma", "rs_beta", "st_out")]       # the LayerNorm fold (round 6; all NULL = off)
+                + [("ln_np", _i), ("rs_np", _i), ("ln_eps", _f)])
 
 
 class FinalizeEntry(C.Structure):
@@ -70,6 +72,7 @@ SIGNATURES = {
     "emage_wav_conv_in_backward_workspace_bytes": [_i, _i, _i],
     "emage_wav_conv_in_backward": [_p, _i, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p],
     "emage_count_nonfinite": [_p, _l, _p, _p],
+    "emage_count_nonfinite_multi": [C.POINTER(_p), C.POINTER(_l), _i, _p, _p],
     "emage_adam_step_dev": [_p, _p, _p, _p, _l, _p, _f, _f, _f, _f, _f, _p],
     "emage_adam_step": [_p, _p, _p, _p, _l, _i, _f, _f, _f, _f, _f, _p],
     "emage_adam_multi_chunk": [],

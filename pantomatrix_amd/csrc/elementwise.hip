@@ -282,6 +282,44 @@ __global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __res
 }
 }  // namespace
 
+// several tensors in ONE launch (round 6: the 11 health-check launches of a clip batch become one): the table of (pointer, count) travels by
+// value in the kernel arguments; blocks are dealt round-robin over the tensors' 64 K-element chunks
+namespace {
+constexpr int CNF_MAX = 16;
+struct CountTable { const float* x[CNF_MAX]; long n[CNF_MAX]; int chunk_end[CNF_MAX]; int count; };
+constexpr long CNF_CHUNK = 1L << 16;
+__global__ __launch_bounds__(256) void count_nonfinite_multi_kernel(CountTable t, int* __restrict__ counter) {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < CNF_MAX - 1; ++i) k += (i + 1 < t.count && (int)blockIdx.x >= t.chunk_end[i]) ? 1 : 0;
+    const long c0 = ((long)blockIdx.x - (k ? t.chunk_end[k - 1] : 0)) * CNF_CHUNK;
+    const long c1 = c0 + CNF_CHUNK < t.n[k] ? c0 + CNF_CHUNK : t.n[k];
+    const float* __restrict__ x = t.x[k];
+    int bad = 0;
+    for (long i = c0 + threadIdx.x; i < c1; i += 256) {
+        const unsigned u = __builtin_bit_cast(unsigned, x[i]);
+        bad += (u & 0x7f800000u) == 0x7f800000u;
+    }
+    if (bad) atomicAdd(counter, bad);
+}
+}  // namespace
+
+extern "C" int emage_count_nonfinite_multi(const float* const* xs, const long* ns, int count, int* counter, void* stream) {
+    if (!xs || !ns || !counter || count <= 0 || count > CNF_MAX) return EMAGE_EINVAL;
+    CountTable t;
+    int chunks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!xs[i] || ns[i] <= 0) return EMAGE_EINVAL;
+        t.x[i] = xs[i]; t.n[i] = ns[i];
+        chunks += (int)((ns[i] + CNF_CHUNK - 1) / CNF_CHUNK);
+        t.chunk_end[i] = chunks;
+    }
+    for (int i = count; i < CNF_MAX; ++i) { t.x[i] = xs[0]; t.n[i] = 0; t.chunk_end[i] = chunks; }
+    t.count = count;
+    hipLaunchKernelGGL(count_nonfinite_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, t, counter);
+    return launch_status();
+}
+
 extern "C" int emage_count_nonfinite(const float* x, long n, int* counter, void* stream) {
     if (!x || !counter || n <= 0) return EMAGE_EINVAL;
     long g = (n + 255) / 256;

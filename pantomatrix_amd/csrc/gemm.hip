@@ -345,10 +345,31 @@ int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, con
     a.tiles_m = a.tiles_n = 0;
     a.dbg = g_debug_skip;
     a.trace = nullptr; a.cstate = nullptr; a.ldc = 0; a.ksplit = 1; a.nk_split = 0; a.ws = nullptr; a.ws_plane = 0; a.ldws = 0; a.tile_order = 0;
+    a.ln_stats = nullptr; a.ln_np = 0; a.ln_c = nullptr; a.rs_stats = nullptr; a.rs_np = 0; a.rs_gamma = nullptr; a.rs_beta = nullptr; a.st_out = nullptr; a.ln_eps = 0.f;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
     const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2;
     a.a_scale = split ? a_scale : 1.f;
     a.o_scale = split ? 1.f / (a_scale * w_scale) : 1.f;
+    return 0;
+}
+
+// the LayerNorm-fold fields of an emage_gemm_problem (include/emage_hip.h) -> GemmArgs; EMAGE_H2 only
+int apply_fold(int dtype, GemmArgs& a, const emage_gemm_problem& q) {
+    if (!q.ln_stats && !q.rs_stats && !q.st_out) return 0;
+    if (dtype != EMAGE_H2 || a.taps != 1) return EMAGE_EINVAL;
+    if (q.ln_stats) {
+        if (!q.ln_c || q.ln_np != 24 || q.ln_np * 32 != a.Cp || !(q.ln_eps > 0.f)) return EMAGE_EINVAL;     // the operand's rows ARE the normalised rows
+        if (((uintptr_t)q.ln_stats & 15) || ((uintptr_t)q.ln_c & 15)) return EMAGE_EINVAL;
+    }
+    if (q.rs_stats) {
+        if (!a.res || a.res_is_f32 || !q.rs_gamma || !q.rs_beta || q.rs_np != 24 || q.rs_np * 32 != a.N || !(q.ln_eps > 0.f)) return EMAGE_EINVAL;
+        if (((uintptr_t)q.rs_stats & 15) || ((uintptr_t)q.rs_gamma & 15) || ((uintptr_t)q.rs_beta & 15)) return EMAGE_EINVAL;
+    }
+    if (q.st_out) {
+        if (a.out_t || a.N % 64 != 0 || a.n_store > a.N || ((uintptr_t)q.st_out & 7)) return EMAGE_EINVAL;                    // whole 64 x 64 tiles of 32 x 32 wave tiles
+    }
+    a.ln_stats = q.ln_stats; a.ln_np = q.ln_np; a.ln_c = q.ln_c; a.rs_stats = q.rs_stats; a.rs_np = q.rs_np; a.rs_gamma = q.rs_gamma; a.rs_beta = q.rs_beta;
+    a.st_out = q.st_out; a.ln_eps = q.ln_eps;
     return 0;
 }
 
@@ -403,6 +424,8 @@ int grouped(int dtype, const emage_gemm_problem* problems, int n_problems, hipSt
                                  q.out_f32, q.ldf, q.out_t, q.t_col0, q.t_rows, q.t_ld, q.M, q.N, q.Cp, q.taps, q.stride, q.pad, q.Lin, q.Lout,
                                  q.a_scale, q.w_scale);
         if (rc) return rc;
+        const int rf = apply_fold(dtype, args[i], q);
+        if (rf) return rf;
     }
     if (dtype == EMAGE_H2) return gemm_h2_dispatch_group(args, n_problems, s, count_only);
     if (count_only) return n_problems;

@@ -22,7 +22,7 @@ namespace {
 
 using namespace emage_dev;
 
-template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV, bool TRACE, int KPB = 1>
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV, bool TRACE, int KPB = 1, bool LNF = false>
 __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) void gemm_h2_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[h2_smem_bytes<BM, BN, NS, KPB>()];
     // XCD-aware tile order (gemm.hip): each XCD walks a contiguous run of tiles; split-K: slice s = blockIdx / tiles
@@ -35,7 +35,7 @@ __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) vo
     }
     int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     if (EMAGE_DBG(p, 64)) { tile_m = bid % p.tiles_m; tile_n = bid / p.tiles_m; }      // tools: an XCD's run walks M first (it owns a slice of N: A re-fetched per XCD, W once)
-    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE, KPB>(p, tile_m * BM, tile_n * BN, smem, split);
+    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE, KPB, LNF>(p, tile_m * BM, tile_n * BN, smem, split);
 }
 
 // most tiles a split-K launch may have: 100.  Measured on the captured training step (A/Bs on one box each, tools library variants):
@@ -87,8 +87,9 @@ int h2_block_slots() {
     return h2_cus() * (by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false, bool TRACE = false, int KPB = 1>
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false, bool TRACE = false, int KPB = 1, bool LNF = false>
 int launch_h2(GemmArgs& a, hipStream_t s) {
+    if (!LNF && (a.ln_stats || a.rs_stats || a.st_out)) return EMAGE_EINVAL;      // only the LNF instantiations know the LayerNorm-fold fields
     if (a.out_t && a.t_col0 % BN != 0) return EMAGE_EINVAL;      // a tile is either row-major or transposed
     if (KPB > 1 && (a.K / 32) % KPB != 0) return EMAGE_EINVAL;   // a ring slot holds KPB whole K-tiles: an odd count would drop the last one
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -160,7 +161,7 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
         }
     }
     if (reduce) {
-        hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE, KPB>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
+        hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE, KPB, LNF>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
         const int rc = launch_status();
         if (rc) return rc;
         const long quads = (long)a.M * ((a.N + 3) >> 2);
@@ -168,7 +169,7 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
                            a.out_f32, a.ldf, a.M, a.N, accumulate ? 1 : 0);
         return launch_status();
     }
-    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE, KPB>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE, KPB, LNF>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
     return launch_status();
 }
 
@@ -177,7 +178,7 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
 // comparing its (XCD-remapped) id with the running tile counts — scalar work — and then runs the unchanged tile routine on that
 // problem's arguments: the result is bit for bit that of the single-problem launch.
 
-template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV>
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV, bool LNF = false>
 __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) void gemm_h2_group_kernel(GroupArgs g) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[h2_smem_bytes<BM, BN, NS>()];
     // XCD-aware order over the WHOLE grid: each XCD walks a contiguous run of the concatenated tile list, i.e. mostly one problem
@@ -195,7 +196,7 @@ __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) vo
     const int t = bid - (pi ? g.tile_end[pi - 1] : 0);
     const GemmArgs& p = g.p[pi];
     const int tile_n = t % p.tiles_n, tile_m = t / p.tiles_n;
-    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, false>(p, tile_m * BM, tile_n * BN, smem, 0);
+    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, false, 1, LNF>(p, tile_m * BM, tile_n * BN, smem, 0);
 }
 
 template <int BM, int BN>
@@ -212,7 +213,7 @@ bool h2_wants_split_k(const GemmArgs& a) {
     return a.taps == 1 && !a.out && !a.out_t && (!a.res || h2_accumulates_in_place(a)) && !a.bias && !a.slope && a.out_f32 && tiles <= h2_split_k_tiles() && a.K / 32 >= 64;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false>
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE = false, int OCC = 1, bool DILV = false, bool LNF = false>
 int launch_h2_group(GemmArgs** a, int n, hipStream_t s) {
     GroupArgs g;
     int total = 0;
@@ -229,7 +230,7 @@ int launch_h2_group(GemmArgs** a, int n, hipStream_t s) {
     for (int i = n; i < MAXG; ++i) { g.p[i] = *a[0]; g.tile_end[i] = total; }
     g.n = n;
     g.total = total;
-    hipLaunchKernelGGL((gemm_h2_group_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV>), dim3(total), dim3((WM * WN + NLW) * 64), 0, s, g);
+    hipLaunchKernelGGL((gemm_h2_group_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, LNF>), dim3(total), dim3((WM * WN + NLW) * 64), 0, s, g);
     return launch_status();
 }
 
@@ -261,6 +262,9 @@ int run_config(int cfg, GemmArgs& a, hipStream_t s) {
 #endif
         case 119: return launch_h2<128, 256, 4, 2, 2, 0, false>(a, s);             // 8 waves 32x128
         case 120: return launch_h2<64, 64, 2, 2, 3, 0, false, false, 2>(a, s);     // 768-wide / small outputs: 4 waves 32x32, three blocks per CU
+        // the same two tiles WITH the LayerNorm-fold paths (GemmArgs::ln_stats / rs_stats / st_out; round 6): taken only by launches that fold
+        case 1100: return launch_h2<64, 192, 4, 2, 2, 0, false, false, 1, false, false, 1, true>(a, s);
+        case 1120: return launch_h2<64, 64, 2, 2, 3, 0, false, false, 2, false, false, 1, true>(a, s);
 #ifdef EMAGE_TOOLS
         case 188: return launch_h2<64, 64, 2, 2, 8, 0, false, false, 1>(a, s);     // round 5 (negative): a LONE block per CU with a ring of 8 for grids of at most one tile per CU
         case 189: return launch_h2<64, 64, 2, 4, 3, 0, false, false, 1>(a, s);     // round 5: the same tile on 8 waves of 32 x 16 (2 DMA instructions per wave and K-tile instead of 4)
@@ -386,9 +390,20 @@ static int h2_config_for(const GemmArgs& a) {
     return (v & 8) ? 130 : 120;
 }
 
+// a launch that folds a LayerNorm (operand statistics, a folded residual, statistics out) takes the LNF twin of its configuration — 100 / 120 only
+static int h2_fold_config(const GemmArgs& a, int cfg) {
+    if (!(a.ln_stats || a.rs_stats || a.st_out) || cfg < 0) return cfg;
+    const int ncols = a.n_store > a.N ? a.n_store : a.N;
+    if (a.st_out) return (a.out_t || ncols >= 1024) ? EMAGE_EINVAL : 1120;      // row statistics come out of the 64 x 64 tile's 32 x 32 wave tiles only
+    if (cfg == 120 || cfg == 100) return cfg + 1000;
+    // batches whose plain launch would take another tile (119 / 170 / 113 beyond ~7 000 rows): the fold exists in two tiles only
+    if (ncols >= 1024 && ncols % 192 == 0 && (!a.out_t || a.t_col0 % 192 == 0)) return 1100;
+    return (a.out_t && a.t_col0 % 64 != 0) ? EMAGE_EINVAL : 1120;
+}
+
 // called by emage_gemm (gemm.hip) for dtype EMAGE_H2 after the common argument checks
 int gemm_h2_dispatch(GemmArgs& a, hipStream_t s) {
-    int cfg = h2_config_for(a);
+    int cfg = h2_fold_config(a, h2_config_for(a));
 #ifdef EMAGE_TOOLS
     // round 5, measured NEGATIVE (profiles/r05_small_grids_ring_of_8_ab.txt): grids of at most one 64 x 64 tile per CU (ONE clip: M = 64 rows; the
     // N = 256 heads / conv3 of the 64-clip batch) on config 188 — the same tile as a LONE block per CU with a ring of 8 K-tiles in flight instead
@@ -417,13 +432,14 @@ int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only) {
     int cfg[64];
     bool done[64];
     for (int i = 0; i < n; ++i) {
-        cfg[i] = h2_config_for(a[i]);
+        cfg[i] = h2_fold_config(a[i], h2_config_for(a[i]));
         if (cfg[i] < 0) return cfg[i];
         done[i] = false;
     }
     auto groupable = [&](int i) {
         switch (cfg[i]) {
-            case 100: return !h2_wants_split_k<64, 192>(a[i]);
+            case 100: case 1100: return !h2_wants_split_k<64, 192>(a[i]);
+            case 1120: return !h2_wants_split_k<64, 64>(a[i]);
             case 113: return !h2_wants_split_k<128, 128>(a[i]);
             case 119: return !h2_wants_split_k<128, 256>(a[i]);
             case 120: return !h2_wants_split_k<64, 64>(a[i]);
@@ -454,6 +470,8 @@ int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only) {
         } else if (m >= 2) {
             switch (cfg[i]) {
                 case 100: rc = launch_h2_group<64, 192, 4, 2, 2, 0, false>(grp, m, s); break;
+                case 1100: rc = launch_h2_group<64, 192, 4, 2, 2, 0, false, false, 1, false, true>(grp, m, s); break;
+                case 1120: rc = launch_h2_group<64, 64, 2, 2, 3, 0, false, false, 2, false, true>(grp, m, s); break;
                 case 113: rc = launch_h2_group<128, 128, 4, 2, 3, 0, false>(grp, m, s); break;
                 case 119: rc = launch_h2_group<128, 256, 4, 2, 2, 0, false>(grp, m, s); break;
                 case 170: rc = launch_h2_group<128, 192, 2, 4, 2, 0, false>(grp, m, s); break;

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_pp_kernel(GemmArgs p) {
 template <int BM, int BN, int WM, int WN, int NS, bool PRIO = true, bool TRACE = false, int MODE = 0>
 int launch_h2_pp(GemmArgs& a, hipStream_t s) {
     if (a.out_t && a.t_col0 % BN != 0) return EMAGE_EINVAL;      // a tile is either row-major or transposed
+    if (a.ln_stats || a.rs_stats || a.st_out) return EMAGE_EINVAL; // no LayerNorm fold in these tiles
     a.tiles_m = (a.M + BM - 1) / BM;
     const int ncols = a.n_store > a.N ? a.n_store : a.N;
     a.tiles_n = (ncols + BN - 1) / BN;

@@ -27,6 +27,15 @@ struct GemmArgs {
     float* ws; long ws_plane; int ldws;   // ... or (ws != NULL, emage_gemm_ws) stored as plane `slice` of the workspace — (M, ldws) fp32 each, ws_plane
                                  // elements apart — and summed in slice order by a second launch (deterministic)
     int tile_order;              // EMAGE_H2 single launches: 0 = XCD-aware runs (each XCD walks a contiguous run of tiles), 1 = dispatch order (gemm_h2.hip)
+    // LayerNorm FOLDED into the contractions around it (round 6, EMAGE_H2 only; every pointer NULL = off).  A post-norm layer's
+    // y = LN(s) W^T + b is computed on the RAW pre-norm sum s:  y = rstd (s W'^T - mu c) + b'  with W' = W gamma, c[n] = sum_k W'[n][k],
+    // b' = W beta + b (packed by the host; b' arrives as `bias`), and the residual LN(s) of the next sub-layer is recomputed from s:
+    const float* ln_stats; int ln_np;     // operand A = s: (M, ln_np) partial row statistics {mean, M2} over 32 columns each (ln_np * 32 = the normalised width)
+    const float* ln_c;                    // c (N)
+    const float* rs_stats; int rs_np;     // `res` = the raw sum s' of a folded LayerNorm: its partial row statistics, and ...
+    const float* rs_gamma; const float* rs_beta;      // ... its affine parameters: res'[m][n] = (s'[m][n] - mu) rstd gamma[n] + beta[n]
+    float* st_out;                        // (M, N / 32) {mean, M2}: partial row statistics of THIS launch's output rows, one per 32 columns (64 x 64 tiles of 32 x 32 wave tiles only)
+    float ln_eps;
     unsigned long long* trace;   // tools builds: per-wave s_memtime stamps of one block (h2_tile.h TRACE), else NULL
 };
 

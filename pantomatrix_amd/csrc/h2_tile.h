@@ -34,14 +34,85 @@ struct GroupArgs {
 
 template <int BM, int BN, int NS, int KPB = 1> constexpr int h2_smem_bytes() { return NS * KPB * (BM + BN) * 128; }
 
+// ---- LayerNorm fold (GemmArgs::ln_stats / rs_stats / st_out): per-row statistics travel as partials {mean, M2} over 32 columns each ----
+// Chan's merge of partial b (32 values) into the running (n, mean, M2)
+__device__ __forceinline__ void ln_merge32(float& n, float& mean, float& m2, const float mb, const float m2b) {
+    const float nn = n + 32.f, d = mb - mean, w = 32.f / nn;
+    mean += d * w;
+    m2 += m2b + d * d * n * w;
+    n = nn;
+}
+// (mu, rstd) of the R = WTM rows of a wave tile from their `np` partials each (np % 8 == 0; 24 = the 768-wide residual stream), loaded
+// COALESCED: the R rows' partials are one contiguous block of R np 8 bytes, lane L takes bytes [L, L + 1) R np / 8 of it — 64 / R lanes per
+// row, np R / 64 partials per lane (np = 24: 6 x 16 bytes per lane at R = 32, all in flight before the first merge) — merges its share (Chan),
+// meets the other lanes of its row through lane exchanges (equal counts), and the lane (fr, fg) of the MFMA accumulator layout fetches the
+// statistics of its rows 16 i + fr from the lanes that hold them.  (The first version had each lane read 16-byte pieces of ITS row: 64
+// scattered pieces per load instruction, ~3 us per launch on the texture path: profiles/r06_ln_fold_per_launch_v1.txt.)
+// Split in two so that the loads go out IN FRONT of the operand DMA of the first K-tiles (they return first; the merge then runs while the DMA is
+// still landing) — `ln_wave_load` / `ln_wave_finish`.  np == 24 (the 768-wide residual stream; gemm.hip refuses anything else): every trip count
+// is a compile-time constant, rows beyond M read the last row's partials (in bounds, never used).
+constexpr int LN_NP = 24;
+template <int R> struct LnPart { float4 q[LN_NP * R / 128]; };
+template <int R>
+__device__ __forceinline__ void ln_wave_load(const float* __restrict__ st, const int m_base, const int M, const int lane, LnPart<R>& w) {
+    static_assert(R == 16 || R == 32 || R == 64, "rows of a wave tile");
+    constexpr int LPR = 64 / R, PER = LN_NP / LPR, NV = PER / 2;    // lanes per row (4, 2, 1), partials / float4s per lane (6 / 3, 12 / 6, 24 / 12)
+    const int row = lane / LPR, part = lane % LPR;
+    const int m = m_base + row < M ? m_base + row : M - 1;
+    const float4* s = (const float4*)(st + ((long)m * LN_NP + part * PER) * 2);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) w.q[j] = s[j];
+}
+template <int R, int FM>
+__device__ __forceinline__ void ln_wave_finish(const int fr, const float eps, const LnPart<R>& w, float (&mu)[FM], float (&rstd)[FM]) {
+    constexpr int LPR = 64 / R, PER = LN_NP / LPR, NV = PER / 2;
+    // PER partials of EQUAL count (32): mean = the mean of the means, M2 = sum M2_j + 32 sum (mean_j - mean)^2 — pairwise sums, a dependent
+    // chain of ~10 operations (Chan's running merge was 6 per partial: ~0.4 us in front of the K-loop)
+    float sm[NV], sq[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { sm[j] = w.q[j].x + w.q[j].z; sq[j] = w.q[j].y + w.q[j].w; }
+#pragma unroll
+    for (int stp = 1; stp < NV; stp *= 2)
+#pragma unroll
+        for (int j = 0; j + stp < NV; j += 2 * stp) { sm[j] += sm[j + stp]; sq[j] += sq[j + stp]; }
+    float mean = sm[0] * (1.0f / (float)PER), m2 = sq[0];
+    float dv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { const float d0 = w.q[j].x - mean, d1 = w.q[j].z - mean; dv[j] = d0 * d0 + d1 * d1; }
+#pragma unroll
+    for (int stp = 1; stp < NV; stp *= 2)
+#pragma unroll
+        for (int j = 0; j + stp < NV; j += 2 * stp) dv[j] += dv[j + stp];
+    m2 += 32.f * dv[0];
+    float cnt = 32.f * (float)PER;                     // values behind each lane's (mean, m2)
+    if constexpr (LPR >= 2) {
+        const float mo = __shfl_xor(mean, 1), qo = __shfl_xor(m2, 1), d = mo - mean;
+        m2 = m2 + qo + d * d * (0.5f * cnt); mean = 0.5f * (mean + mo); cnt *= 2.f;
+    }
+    if constexpr (LPR >= 4) {
+        const float mo = __shfl_xor(mean, 2), qo = __shfl_xor(m2, 2), d = mo - mean;
+        m2 = m2 + qo + d * d * (0.5f * cnt); mean = 0.5f * (mean + mo); cnt *= 2.f;
+    }
+    const float rs = 1.0f / sqrtf(m2 / cnt + eps);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int src = (16 * i + fr) * LPR;
+        mu[i] = __shfl(mean, src);
+        rstd[i] = __shfl(rs, src);
+    }
+}
+
 // ---- the epilogue of an EMAGE_H2 tile (gemm_h2_tile; kept separate for fused kernels that end in the same stores) ----
 // acc: the wave's FM x FN accumulator fragments; (mw, nw): first row / column of the wave tile.  NAT = false: W rows were fed to the MFMAs in
 // the pair-permuted order (a lane ends with 8 consecutive columns per fragment pair; an odd last fragment in natural order); NAT = true:
 // every fragment in natural row order (a lane holds 4 consecutive columns per fragment).  Swapped MFMA operands (row-major tiles): lane
 // (fr, fg) holds row mw + 16 i + fr; V^T tiles (un-swapped): lane holds rows mw + 16 i + 4 fg + r of one column.
-template <int FM, int FN, bool NAT, bool PRE, int PM, int PP>
+// ln_mu / ln_rs / rs_mu / rs_rs: (mu, rstd) of the lane's FM rows for the folded LayerNorm of the operand / of the residual (row-major tiles;
+// V^T tiles fetch theirs here); ignored unless p.ln_stats / p.rs_stats
+template <int FM, int FN, bool NAT, bool PRE, int PM, int PP, bool LNF = false>
 __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)[FM][FN], const int mw, const int nw, const int fr, const int fg,
-                                                 const bool vt_tile, const float (&pre_r)[PM][PP][8], const int split = 0) {
+                                                 const bool vt_tile, const float (&pre_r)[PM][PP][8], const int split = 0,
+                                                 const float* ln_mu = nullptr, const float* ln_rs = nullptr, const float* rs_mu = nullptr, const float* rs_rs = nullptr) {
     constexpr int FP = NAT ? 0 : FN / 2;
     constexpr bool LONE = !NAT && (FN & 1) != 0;
     constexpr int NLONE = NAT ? FN : (LONE ? 1 : 0);          // trailing fragments handled 4 columns at a time
@@ -58,17 +129,35 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
         float* __restrict__ out_t = (float*)p.out_t;
         const int t_ncols = p.N - p.t_col0;
         const bool tvec = (p.t_rows % 4 == 0) && (p.t_ld % 4 == 0) && (((uintptr_t)out_t & 15) == 0);
+        // folded LayerNorm of the operand: ln_mu / ln_rs hold the statistics of row mw + 16 i + fr (the row-major layout's rows); this lane's
+        // rows mw + 16 i + 4 fg + r live in lanes 4 fg + r
+        float vmu[LNF ? FM : 1][4], vrs[LNF ? FM : 1][4];
+        if constexpr (LNF) {
+            if (p.ln_stats) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { vmu[i][r] = __shfl(ln_mu[i], 4 * fg + r); vrs[i][r] = __shfl(ln_rs[i], 4 * fg + r); }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int wrow = (NAT || (LONE && j == FN - 1)) ? j * 16 + fr : (j >> 1) * 32 + (j & 1) * 4 + 8 * (fr >> 2) + (fr & 3);
             const int n = nw + wrow;
             if (n >= p.N) continue;
             const float bv = p.bias ? p.bias[n] : 0.f, sv = p.slope ? p.slope[n] : 1.f;
+            const float cv = (LNF && p.ln_stats) ? p.ln_c[n] : 0.f;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int m = mw + i * 16 + fg * 4;
                 if (m >= p.M) continue;
                 float v[4];
+                if constexpr (LNF) {
+                    if (p.ln_stats) {                    // folded LayerNorm of the operand
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = vrs[i][r] * (acc[i][j][r] - vmu[i][r] * cv);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = leaky(acc[i][j][r] + bv, sv);
                 if (tvec && m + 3 < p.M) {
@@ -97,13 +186,24 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
     float* __restrict__ of32 = to_plane ? p.ws + (long)split * p.ws_plane : p.out_f32;
     const int ldf = to_plane ? p.ldws : p.ldf;
     const bool f32_vec = of32 && (ldf % 4 == 0) && (((uintptr_t)of32 & 15) == 0);
-    auto finish = [&](auto wc, const int m, const int n, float (&x)[decltype(wc)::value], const float (&rpre)[decltype(wc)::value], const bool have_pre) {
-        // x: accumulators (already scaled) of W consecutive columns n.. of row m -> bias, residual, activation, stores
+    auto finish = [&](auto wc, const int m, const int n, float (&x)[decltype(wc)::value], const float (&rpre)[decltype(wc)::value], const bool have_pre, const int i) {
+        // x: accumulators (already scaled) of W consecutive columns n.. of row m (fragment row i of the lane) -> bias, residual, activation, stores
         constexpr int W = decltype(wc)::value;
         const bool full = n + W <= ncol_n;
         float bv[W], sv[W], rv[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) { bv[e] = 0.f; sv[e] = 1.f; rv[e] = 0.f; }
+        if (LNF && p.ln_stats) {                        // folded LayerNorm of the operand: x <- rstd (x - mu c)
+            const float mu = ln_mu[i], rs = ln_rs[i];
+            float cv[W];
+            if (full) { if constexpr (W == 8) load8<float>(p.ln_c + n, cv); else { const float4 q = *(const float4*)(p.ln_c + n); cv[0] = q.x; cv[1] = q.y; cv[2] = q.z; cv[3] = q.w; } }
+            else {
+#pragma unroll
+                for (int e = 0; e < W; ++e) cv[e] = n + e < ncol_n ? p.ln_c[n + e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) x[e] = rs * (x[e] - mu * cv[e]);
+        }
         if (full) {
             if (p.bias) { if constexpr (W == 8) load8<float>(p.bias + n, bv); else { const float4 t = *(const float4*)(p.bias + n); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; } }
             if (p.slope) { if constexpr (W == 8) load8<float>(p.slope + n, sv); else { const float4 t = *(const float4*)(p.slope + n); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; } }
@@ -140,6 +240,20 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
                 for (int e = 0; e < W; ++e) rv[e] = n + e < ncol_n ? t[e] : 0.f;
             }
         }
+        if (LNF && p.rs_stats && p.res) {               // the residual is a folded LayerNorm of the raw sum just read
+            const float mu = rs_mu[i], rs = rs_rs[i];
+            float gv[W], bt[W];
+            if (full) {
+                if constexpr (W == 8) { load8<float>(p.rs_gamma + n, gv); load8<float>(p.rs_beta + n, bt); }
+                else { const float4 q = *(const float4*)(p.rs_gamma + n), r4 = *(const float4*)(p.rs_beta + n);
+                       gv[0] = q.x; gv[1] = q.y; gv[2] = q.z; gv[3] = q.w; bt[0] = r4.x; bt[1] = r4.y; bt[2] = r4.z; bt[3] = r4.w; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < W; ++e) { gv[e] = n + e < ncol_n ? p.rs_gamma[n + e] : 0.f; bt[e] = n + e < ncol_n ? p.rs_beta[n + e] : 0.f; }
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) rv[e] = n + e < ncol_n ? (rv[e] - mu) * rs * gv[e] + bt[e] : 0.f;
+        }
         float v[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) {
@@ -153,6 +267,20 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
             // out rows are padded to a multiple of 8 columns (host contract): the whole group is always addressable
             if constexpr (W == 8) h2_store8(out + (long)m * p.ldo + n, v);
             else h2_store4(out + (long)m * p.ldo + n, n, v);
+        }
+        if constexpr (LNF && W == 8 && FN == 2 && !NAT) {
+            if (p.st_out) {                             // partial row statistics of the 32 columns this wave holds of row m: 8 per lane, 4 lanes (fg) per row
+                float sm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += v[e];
+                float mean = sm * 0.125f, m2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; m2 += d * d; }
+                // Chan's merge of equal counts, 8 -> 16 -> 32 (lanes fr + 16 fg: the same row)
+                { const float mo = __shfl_xor(mean, 16), qo = __shfl_xor(m2, 16), d = mo - mean; m2 = m2 + qo + d * d * 4.f; mean = 0.5f * (mean + mo); }
+                { const float mo = __shfl_xor(mean, 32), qo = __shfl_xor(m2, 32), d = mo - mean; m2 = m2 + qo + d * d * 8.f; mean = 0.5f * (mean + mo); }
+                if (fg == 0) *(float2*)(p.st_out + ((long)m * (p.N >> 5) + (n >> 5)) * 2) = make_float2(mean, m2);
+            }
         }
         if (of32 && n < ncol_n) {
             float* dst = of32 + (long)m * ldf + n;
@@ -181,7 +309,7 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = e < 4 ? acc[i][2 * jp][e] : acc[i][2 * jp + 1][e - 4];
-            finish(IC<8>{}, m, n, x, pre_r[i % PM][jp % PP], PRE && p.res && n + 8 <= ncol_n);
+            finish(IC<8>{}, m, n, x, pre_r[i % PM][jp % PP], PRE && p.res && n + 8 <= ncol_n, i);
         }
     }
 #pragma unroll
@@ -196,7 +324,7 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = acc[i][jl][e];
                 const float none[4] = {0.f, 0.f, 0.f, 0.f};
-                finish(IC<4>{}, m, n, x, none, false);
+                finish(IC<4>{}, m, n, x, none, false, i);
             }
         }
     }
@@ -205,7 +333,8 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
 // KPB (round 5, VERDICT next #1b "BK = 64"): K-tiles per ring slot and per s_barrier — a slot holds KPB consecutive 32-k sub-tiles (each in the
 // unchanged [4 hi | 4 lo] row image), one rendezvous and one counted wait serve KPB x (3 FM FN) MFMAs per wave; the MFMA order per
 // accumulator is that of KPB = 1, so the result is the same bits.  Plain K-loop only (not PIPE / DILV).
-template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, bool DILV = false, bool TRACE = false, int KPB = 1>
+// LNF: the instantiation carries the LayerNorm-fold paths (GemmArgs::ln_stats / rs_stats / st_out); the plain one ignores those fields
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, bool DILV = false, bool TRACE = false, int KPB = 1, bool LNF = false>
 __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem, const int split = 0) {
     constexpr int ES = 4, BK = 32, RB = 128, RPI = 8;
     constexpr int NCW = WM * WN, NL = NLW ? NLW : NCW;
@@ -352,6 +481,18 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
         for (int s = 0; s < NS - 1; ++s)
             if (s < nk) issue();
     }
+    // folded LayerNorms (GemmArgs::ln_stats / rs_stats): the wave tile's partial row statistics are requested here, behind the first K-tiles'
+    // DMA (in front of it, a register-reuse wait of the compiler stalled the DMA issue), ...
+    LnPart<LNF ? WTM : 16> lnp, rsp;
+    if constexpr (LNF) {
+        if (is_compute && p.ln_stats) ln_wave_load<WTM>(p.ln_stats, m0 + wm * WTM, p.M, lane, lnp);
+        if (is_compute && p.rs_stats) ln_wave_load<WTM>(p.rs_stats, m0 + wm * WTM, p.M, lane, rsp);
+    }
+
+    // ---- folded LayerNorms (GemmArgs::ln_stats / rs_stats): (mu, rstd) of the lane's FM rows ----
+    float ln_mu[FM], ln_rs[FM], rs_mu[FM], rs_rs[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) { ln_mu[i] = 0.f; ln_rs[i] = 1.f; rs_mu[i] = 0.f; rs_rs[i] = 1.f; }
 
     // ---- fragment read addresses ----
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -540,7 +681,13 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     if (!is_compute) { if constexpr (TRACE) { if (p.trace && blockIdx.x == 0 && lane == 0) p.trace[wave * 512] = (unsigned long long)tr_n; } __syncthreads(); return; }
     if constexpr (PRE && NLW > 0) wait_vmcnt<0>();
 
-    h2_tile_epilogue<FM, FN, false, PRE, PM, PP>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r, split);
+    if constexpr (LNF) {
+        // ... and merged HERE, behind the K-loop: the partials arrived long ago, and no wait for them sits in front of the loop (merged in the
+        // prologue, the compiler's vmcnt(0) for these loads also drained the first K-tiles' DMA: +1 us per launch, profiles/r06_ln_fold_per_launch_v3.txt)
+        if (p.ln_stats) ln_wave_finish<WTM, FM>(fr, p.ln_eps, lnp, ln_mu, ln_rs);     // (wave-uniform conditions: the lane exchanges inside need every lane)
+        if (p.rs_stats) ln_wave_finish<WTM, FM>(fr, p.ln_eps, rsp, rs_mu, rs_rs);
+    }
+    h2_tile_epilogue<FM, FN, false, PRE, PM, PP, LNF>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r, split, ln_mu, ln_rs, rs_mu, rs_rs);
     if (vt_tile) { __syncthreads(); return; }
     tr();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -72,10 +72,15 @@ class _EmageModule(torch.nn.Module):
         self.hoist_audio = True                # inference(): waveform-only features of all full windows in one pass
         self.seed_only_decode = True           # inference(): per-window decode covers only the frames that feed the seed
         self.health_counter = None             # optional int32 device counter of non-finite logits / latents met by infer_codes (runtime.ClipRunner)
+        self.health_pending = None             # ... or a list that collects those tensors instead: the runner counts them in one launch at the end
         self.slab_convs = True                 # WavEncoder: LDS-resident-slab convolutions + fused block 0 (A/B switch; same bits)
         self.h2_residual = True                # EMAGE_H2 mode: LayerNorm writes ONE output, the H2 image, and the sub-layers read their residual from
                                                # it ((hi + lo) / 16: 2^-22 relative); False = a float32 twin beside every H2 image (round 3's default:
                                                # 25 instead of 12.6 MB per LayerNorm at 64 clips).  Parity-green on every golden in both forms
+        self.fold_layernorm = True             # EMAGE_H2 mode with H2 residuals: the interior LayerNorms of the post-norm transformer layers are
+                                               # FOLDED into the contractions around them (LN(s) W^T + b = rstd (s W'^T - mu c) + b': 41 of the 47
+                                               # LayerNorm launches of a window disappear; include/emage_hip.h: emage_gemm_problem); False = every
+                                               # LayerNorm is a launch (round 5's form).  Parity-green on every golden in both forms
         self.split_acts = True                 # f16x3 precision: activations that feed a contraction are stored PRE-SPLIT (EMAGE_H2,
                                                # csrc/h2.h) by their producers; False = float32 activations split inside every GEMM
         self.group_gemms = True                # part-wise stacks (VQ part decoders, refinement layers + heads, ...) walk in lock step and
@@ -337,8 +342,16 @@ class _Packed:
         w, ws = self._operand(w2d)
         return w, kp, ws
 
-    def linear(self, key, names, rows=None):
-        """Stack nn.Linear weights along N (optionally row-slices `rows[i]` of each) -> entry `key`."""
+    def _fold_norm(self, wcat, bcat, norm):
+        """A LayerNorm folded into the Linear that consumes it (include/emage_hip.h: emage_gemm_problem): LN(s) W^T + b =
+        rstd (s W'^T - mu c) + b' with W' = W gamma, c[n] = sum_k W'[n][k], b' = W beta + b -> (W', b', c)."""
+        g, be = self.p[norm + ".weight"].float(), self.p[norm + ".bias"].float()
+        w2 = wcat * g[None, :]
+        return w2, (bcat.double() + wcat.double() @ be.double()).float(), w2.double().sum(dim=1).float().contiguous()
+
+    def linear(self, key, names, rows=None, fold=None):
+        """Stack nn.Linear weights along N (optionally row-slices `rows[i]` of each) -> entry `key`.  fold: the name of the LayerNorm
+        whose output is this Linear's operand — the entry then holds the FOLDED operands (`_fold_norm`) and `c`; eval only."""
         ws, bs = [], []
         for i, nm in enumerate(names):
             w, b = self.p[nm + ".weight"], self.p[nm + ".bias"]
@@ -348,27 +361,40 @@ class _Packed:
             bs.append(b)
         k_real = ws[0].shape[1]
         wcat = (torch.cat(ws, 0) if len(ws) > 1 else ws[0]).float()       # one source: the operand packing reads the parameter itself
+        bcat = torch.cat(bs).float().contiguous()
+        extra = {}
+        if fold is not None:
+            wcat, bcat, c = self._fold_norm(wcat, bcat, fold)
+            extra = dict(c=c, norm=fold)
         w, kp, wsc = self._pack_mat(wcat)
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt)
-        self.origin[key] = [(nm + ".weight", nm + ".bias", rows[i] if rows is not None else slice(0, self.p[nm + ".weight"].shape[0]))
-                            for i, nm in enumerate(names)]
+        self.w[key] = dict(w=w, b=bcat, n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt, **extra)
+        if fold is None:
+            self.origin[key] = [(nm + ".weight", nm + ".bias", rows[i] if rows is not None else slice(0, self.p[nm + ".weight"].shape[0]))
+                                for i, nm in enumerate(names)]
 
-    def in_proj(self, key, names, parts):
+    def in_proj(self, key, names, parts, fold=None):
         """Row blocks of packed in_proj weights: parts e.g. "qkv", "q", "kv"; several layers stack as
-        [K_0..K_n | V_0..V_n] so that one GEMM emits every layer's K and V^T (V columns last)."""
+        [K_0..K_n | V_0..V_n] so that one GEMM emits every layer's K and V^T (V columns last).  fold: see `linear`."""
         d = self.p[names[0] + ".in_proj_weight"].shape[1]
         sl = {"q": slice(0, d), "k": slice(d, 2 * d), "v": slice(2 * d, 3 * d)}
         ws, bs = [], []
-        self.origin[key] = []
+        origin = []
         for part in parts:
             for nm in names:
                 ws.append(self.p[nm + ".in_proj_weight"][sl[part]])
                 bs.append(self.p[nm + ".in_proj_bias"][sl[part]])
-                self.origin[key].append((nm + ".in_proj_weight", nm + ".in_proj_bias", sl[part]))
+                origin.append((nm + ".in_proj_weight", nm + ".in_proj_bias", sl[part]))
         k_real = ws[0].shape[1]
         wcat = (torch.cat(ws, 0) if len(ws) > 1 else ws[0]).float()
+        bcat = torch.cat(bs).float().contiguous()
+        extra = {}
+        if fold is not None:
+            wcat, bcat, c = self._fold_norm(wcat, bcat, fold)
+            extra = dict(c=c, norm=fold)
+        else:
+            self.origin[key] = origin
         w, kp, wsc = self._pack_mat(wcat)
-        self.w[key] = dict(w=w, b=torch.cat(bs).float().contiguous(), n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt)
+        self.w[key] = dict(w=w, b=bcat, n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt, **extra)
 
     def folded(self, cname, bn=None):
         """Raw Conv1d (weight (Cout,Cin,k), bias) with an eval-mode BatchNorm1d folded in:
@@ -440,7 +466,7 @@ class _Packed:
 class _Ctx:
     """One forward's launch context: packed weights + dtype + allocation helpers."""
 
-    def __init__(self, pk: _Packed, h2_residual=False):
+    def __init__(self, pk: _Packed, h2_residual=False, fold_ln=False):
         # h2_residual (EMAGE_H2 mode): LayerNorm writes ONLY the H2 image and the sub-layer epilogues read the residual from it
         # ((hi + lo) / 16: 2^-22 relative to the float32 value) instead of from a float32 twin: one 12.6 MB store less per norm
         self.h2res = bool(h2_residual) and pk.dt == H2
@@ -452,6 +478,9 @@ class _Ctx:
         # WavEncoder: float32 activations in both split-f16 forms (its slab kernels split once per block in LDS)
         self.wgdt = pk.wav_dt
         self.wdt = F32 if pk.wav_dt == F16X3 else pk.wav_dt
+        # fold_ln (EMAGE_H2 with H2 residuals; `model.fold_layernorm`): interior LayerNorms of the post-norm layers are FOLDED into the
+        # contractions around them (include/emage_hip.h: emage_gemm_problem) — no LayerNorm launch, no normalised tensor
+        self.fold_ln = bool(fold_ln) and self.h2res
 
     def lo(self, m, n):
         return torch.empty(m, n, dtype=self.tdt, device=self.dev)
@@ -460,7 +489,7 @@ class _Ctx:
         return torch.empty(m, n, dtype=torch.float32, device=self.dev)
 
     def gemm(self, a, key, *, slope=None, res=None, res_first=False, out=None, out_f32=None, want="lo", n_store=0,
-             out_t=None, t_col0=0, t_rows=0, conv=None, m=None, dt=None, w=None, res_h2=False):
+             out_t=None, t_col0=0, t_rows=0, conv=None, m=None, dt=None, w=None, res_h2=False, ln=None, res_ln=None, stats_out=None):
         """Run one contraction.  want: "lo", "f32", "both" allocate the outputs when not passed in.
         conv = (stride, pad, lin, lout) turns it into the implicit-GEMM Conv1d with the entry's tap count.
         The operand mode is the weight entry's packing (EMAGE_H2 entries take an H2 image `a` and write H2 `lo` outputs;
@@ -480,8 +509,36 @@ class _Ctx:
             kw = dict(taps=e["taps"], stride=stride, pad=pad, lin=lin, lout=lout)
         ops.gemm(dt, a, e["w"], e["b"], sl, res, out, out_f32, out_t, n=n, cp=e["cp"], n_store=n_store,
                  t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, k_real=e.get("k_real"), w_scale=e.get("ws", 1.0),
-                 res_h2=bool(res_h2 and dt == H2), **kw)
+                 res_h2=bool(res_h2 and dt == H2), **kw, **({} if (ln is None and res_ln is None and stats_out is None)
+                                                            else dict(ln=ln, res_ln=res_ln, stats_out=stats_out)))
         return out, out_f32
+
+    # ---- folded LayerNorms (`fold_ln`): an `_X` whose `.ln` is set stands for LayerNorm(x.a) without that tensor existing ----
+    def gemm_ln(self, x, key, **kw):
+        """Contraction whose operand is the `_X` x: a folded LayerNorm's consumer runs on the raw sum with the folded operands of `key`."""
+        if x.ln is None:
+            return self.gemm(x.a, key, **kw)
+        stats, nkey = x.ln
+        e = self.pk.w[key + "@" + nkey]
+        return self.gemm(x.a, key, w=e, ln=(stats, e["c"]), **kw)
+
+    def res_of(self, x):
+        """The residual keywords of a sub-layer's output contraction for the `_X` x."""
+        if x.ln is None:
+            return dict(res=x.r, res_h2=x.h2r)
+        stats, nkey = x.ln
+        n = self.pk.w[nkey]
+        return dict(res=x.a, res_h2=True, res_ln=(stats, n["g"], n["b"]))
+
+    def gemm_s(self, a, key, x, stats=False):
+        """The pre-norm sum x + a W^T + b of a sub-layer.  stats (the LayerNorm behind it is folded): -> `_S` (the sum as an EMAGE_H2 image
+        + its partial row statistics, written by the contraction's epilogue); else the tensor `gemm_r` returns."""
+        if not stats:
+            return self.gemm_r(a, key, **self.res_of(x))
+        e = self.pk.w[key]
+        st = torch.empty(a.shape[0], e["n"] // 32, 2, dtype=torch.float32, device=self.dev)
+        out, _ = self.gemm(a, key, want="lo", stats_out=st, **self.res_of(x))
+        return _S(out, st)
 
     # ---- the two forms of an activation: `.a` feeds contractions (storage type of the mode), `.r` carries the residual stream
     # (the same tensor, except in EMAGE_H2 mode where it is the float32 twin) ----
@@ -505,11 +562,21 @@ class _Ctx:
 
 
 class _X:
-    """An activation in its two forms (see _Ctx.gemm_x); h2r: `.r` is an EMAGE_H2 image too (then it IS `.a`)."""
-    __slots__ = ("a", "r", "h2r")
+    """An activation in its two forms (see _Ctx.gemm_x); h2r: `.r` is an EMAGE_H2 image too (then it IS `.a`).
+    ln = (partial row statistics, norm key): the activation is LayerNorm_key(.a) and has NOT been computed — `.a` is the raw pre-norm
+    sum (an EMAGE_H2 image); its consumers fold the norm (`_Ctx.gemm_ln` / `res_of`)."""
+    __slots__ = ("a", "r", "h2r", "ln")
 
-    def __init__(self, a, r, h2r=False):
-        self.a, self.r, self.h2r = a, r, h2r
+    def __init__(self, a, r, h2r=False, ln=None):
+        self.a, self.r, self.h2r, self.ln = a, r, h2r, ln
+
+
+class _S:
+    """A pre-norm sum whose LayerNorm will be folded: the EMAGE_H2 image and its (M, C / 32, 2) partial row statistics."""
+    __slots__ = ("img", "stats")
+
+    def __init__(self, img, stats):
+        self.img, self.stats = img, stats
 
 
 def _conv_encoder(cx: _Ctx, prefix, x_lo, t, n_layer, length, want_f32):
@@ -1006,12 +1073,34 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             self._pack_layer(pk, nm, cross=True)
         pk.in_proj("cross.kv_all", [n + ".multihead_attn" for n in cross], "kv")
         pk.in_proj("face.kv_all", [n + ".multihead_attn" for n in face], "kv")
+        # LayerNorm folds (behind every plain entry, so that the packing order of those — the scale cache's key — does not depend on them)
+        self._pack_folds(pk, "motion_self_encoder.layers.0", cross=False)
+        for stack in (cross, face):
+            for i, nm in enumerate(stack):
+                self._pack_folds(pk, nm, cross=True, prev=stack[i - 1] if i else None)
+        for p in parts:
+            self._pack_folds(pk, f"body_motion_decoder_{p}.layers.0", cross=True)
         if not pk.train_only:        # eval-mode WavEncoders (BatchNorms folded into the convolutions); training packs the raw ones (`_train_pack`)
             self._pack_wav_encoders(pk, ("audio_encoder_face", "audio_encoder_body"))
         pk.w["pe"] = pk.f32("position_embeddings.pe")[0].contiguous()                 # (2*pose_length, d)
         pk.w["spk_body"] = pk.f32("speaker_embedding_body.weight")
         pk.w["spk_face"] = pk.f32("speaker_embedding_face.weight")
         pk.w["mask_emb"] = pk.f32("mask_embedding").reshape(-1).contiguous()
+
+    @staticmethod
+    def _pack_folds(pk, name, cross, prev=None):
+        """The folded twins of a layer's LayerNorm consumers (eval-mode EMAGE_H2 only; `fold_layernorm`): key "<consumer>@<norm>".
+        prev: the layer in front of it in the same stack — its last norm folds into this layer's Q / K / V projection."""
+        if pk.dt != H2 or pk.train_only:
+            return
+        last = ".norm3" if cross else ".norm2"
+        if prev is not None:
+            pk.in_proj(name + ".sa.qkv@" + prev + last, [name + ".self_attn"], "qkv", fold=prev + last)
+        if cross:
+            pk.in_proj(name + ".ca.q@" + name + ".norm1", [name + ".multihead_attn"], "q", fold=name + ".norm1")
+            pk.linear(name + ".ff1@" + name + ".norm2", [name + ".linear1"], fold=name + ".norm2")
+        else:
+            pk.linear(name + ".ff1@" + name + ".norm1", [name + ".linear1"], fold=name + ".norm1")
 
     @staticmethod
     def _pack_layer(pk, name, cross):
@@ -1030,24 +1119,27 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
     # ---- building blocks -----------------------------------------------------------------
     # The residual stream x is stored in the compute dtype (fp32 in parity mode, bf16 in bf16 mode): each
     # sub-layer's GEMM epilogue adds the residual and writes the pre-norm sum once, LayerNorm reads it once.
-    def _self_attn(self, cx, name, x, b, t):
-        """x: _X.  Returns the pre-norm sum x + out_proj(attention) at residual precision."""
+    def _self_attn(self, cx, name, x, b, t, stats=False):
+        """x: _X.  Returns the pre-norm sum x + out_proj(attention) at residual precision (stats: as an `_S`, for a folded LayerNorm)."""
         d, h = self.config.hidden_size, spec.N_HEAD
         m = b * t
         qk = cx.f32(m, 2 * d) if cx.h2 else cx.lo(m, 2 * d)          # the attention kernel reads float32 q / k / v^T in the split modes
         vt = cx.vt_buffer(b, d, t)
         if cx.h2:
-            cx.gemm(x.a, name + ".sa.qkv", out_f32=qk, out_t=vt, t_col0=2 * d, t_rows=t, want=None)
+            cx.gemm_ln(x, name + ".sa.qkv", out_f32=qk, out_t=vt, t_col0=2 * d, t_rows=t, want=None)
         else:
             cx.gemm(x.a, name + ".sa.qkv", out=qk, out_t=vt, t_col0=2 * d, t_rows=t)
         att = cx.lo(m, d)
         ops.attention(cx.gdt, qk[:, :d], qk[:, d:], vt, d, att, b, h, t, t, d // h)
-        return cx.gemm_r(att, name + ".sa.out", res=x.r, res_h2=x.h2r)
+        return cx.gemm_s(att, name + ".sa.out", x, stats)
 
     def _ln(self, cx, key, s, add=None, want_f32=False):
         """LayerNorm of a pre-norm sum (residual precision) -> _X; `add`: float32 / storage-type tensor folded in behind the norm.
         want_f32 (EMAGE_H2 mode with H2 residuals): keep a float32 twin anyway (the result is later an `add` operand)."""
         n = cx.pk.w[key]
+        if isinstance(s, _S):                        # folded: nothing is launched — the consumers work on the raw sum and its statistics
+            assert add is None and not want_f32
+            return _X(s.img, s.img, True, ln=(s.stats, key))
         y = cx.lo(*s.shape)
         if cx.h2 and cx.h2res and not want_f32:
             ops.layernorm(H2, s, n["g"], n["b"], 1e-5, add, None, y)
@@ -1059,26 +1151,28 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
         ops.layernorm(cx.dt, s, n["g"], n["b"], 1e-5, add, None, y)
         return _X(y, y)
 
-    def _ffn(self, cx, name, x):
-        f, _ = cx.gemm(x.a, name + ".ff1", slope=0.0)
-        return cx.gemm_r(f, name + ".ff2", res=x.r, res_h2=x.h2r)
+    def _ffn(self, cx, name, x, stats=False):
+        f, _ = cx.gemm_ln(x, name + ".ff1", slope=0.0)
+        return cx.gemm_s(f, name + ".ff2", x, stats)
 
     def _encoder_layer(self, cx, name, x, b, t, post_add=None, want_f32=False):
-        """nn.TransformerEncoderLayer, post-norm, ReLU, no masks."""
-        x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
+        """nn.TransformerEncoderLayer, post-norm, ReLU, no masks.  `fold_ln`: norm1 is folded into linear1 / the FFN's residual."""
+        x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t, stats=cx.fold_ln))
         return self._ln(cx, name + ".norm2", self._ffn(cx, name, x), add=post_add, want_f32=want_f32)
 
-    def _decoder_layer(self, cx, name, x, b, t, mem_k, mem_vt, vt_rows, tk, post_add=None):
+    def _decoder_layer(self, cx, name, x, b, t, mem_k, mem_vt, vt_rows, tk, post_add=None, fold_out=False):
         """nn.TransformerDecoderLayer, post-norm, ReLU, no masks.  x: _X; mem_k: (B*Tk, ld) view of this
-        layer's projected memory keys; mem_vt: view at this layer's first row of a (B, vt_rows, Tp) V^T buffer."""
+        layer's projected memory keys; mem_vt: view at this layer's first row of a (B, vt_rows, Tp) V^T buffer.
+        `fold_ln`: norm1 / norm2 are folded into the contractions around them; fold_out: norm3 too — the result is then an `_X` with
+        `.ln` set, which only the next layer of the same stack can take."""
         d, h = self.config.hidden_size, spec.N_HEAD
-        x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t))
-        q = cx.gemm_r(x.a, name + ".ca.q")
+        fold = cx.fold_ln
+        x = self._ln(cx, name + ".norm1", self._self_attn(cx, name, x, b, t, stats=fold))
+        q = cx.gemm_ln(x, name + ".ca.q", want="f32")[1] if cx.h2 else cx.gemm_r(x.a, name + ".ca.q")
         att = cx.lo(b * t, d)
         ops.attention(cx.gdt, q, mem_k, mem_vt, vt_rows, att, b, h, t, tk, d // h)
-        s = cx.gemm_r(att, name + ".ca.out", res=x.r, res_h2=x.h2r)
-        x = self._ln(cx, name + ".norm2", s)
-        return self._ln(cx, name + ".norm3", self._ffn(cx, name, x), add=post_add)
+        x = self._ln(cx, name + ".norm2", cx.gemm_s(att, name + ".ca.out", x, fold))
+        return self._ln(cx, name + ".norm3", self._ffn(cx, name, x, stats=fold and fold_out and post_add is None), add=post_add)
 
     def _memory_kv(self, cx, key, mem_lo, b, tk, n_layers):
         """Project a cross-attention memory for `n_layers` layers at once: K (B*Tk, n_layers*d) and
@@ -1166,7 +1260,7 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             from . import training
             return training.train_forward(self, audio, speaker_id, masked_motion, mask, use_audio)
         c = self.config
-        cx = _Ctx(self._engine(), self.h2_residual)
+        cx = _Ctx(self._engine(), self.h2_residual, self.fold_layernorm)
         pk = cx.pk
         dev = cx.dev
         b, t, cm = masked_motion.shape
@@ -1213,12 +1307,12 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             fk.after(1, 0)
             def face_layer(i, face):
                 return self._decoder_layer(cx, f"face_motion_decoder.layers.{i}", face, b, t,
-                                           fkk[:, i * d:(i + 1) * d], fvt[:, i * d:], nf * d, t)
+                                           fkk[:, i * d:(i + 1) * d], fvt[:, i * d:], nf * d, t, fold_out=i < nf - 1)
 
             def cross_layer(i, x, base):
                 return self._decoder_layer(cx, f"audio_motion_cross_attn.layers.{i}", x, b, t,
                                            bk[:, i * d:(i + 1) * d], bvt[:, i * d:], nc * d, ta,
-                                           post_add=base.r if i == nc - 1 else None)               # motion_fea + cross
+                                           post_add=base.r if i == nc - 1 else None, fold_out=i < nc - 1)     # motion_fea + cross
 
             # the two decoder stacks side by side: lock step (one lane, shared launches) or two lanes
             paired = self.group_face_body and self.group_gemms and use_audio and dev.type == "cuda" and nf < nc
@@ -1348,7 +1442,9 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                 continue
             dst = codes[p][:, col0:col0 + t]
             src = net[f"cls_{p}" if route == "cls" else f"rec_{p}"].reshape(bs * t, -1)
-            if self.health_counter is not None:      # the quantiser turns a NaN logit / latent into a valid-looking code: count them here
+            if self.health_pending is not None:      # the quantiser turns a NaN logit / latent into a valid-looking code: the caller counts
+                self.health_pending.append(src.contiguous())      # them with ONE launch at the end of the batch (runtime.ClipRunner)
+            elif self.health_counter is not None:
                 ops.count_nonfinite(src.contiguous(), self.health_counter)
             if route == "cls":
                 ops.argmax_logsoftmax(src, out=dst)

@@ -8,6 +8,8 @@ The public functions below (what the model classes call) allocate outputs, fill 
 PyTorch is plumbing here (device memory, streams, the dispatcher); every kernel is in libemage_hip.so."""
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -386,22 +388,31 @@ def gather_rows(table, idx, dtype, n_store=None):
 
 
 def _gemm_fields(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, res_first, taps, stride, pad, lin, lout, m,
-                 w_scale, a_scale, res_h2):
+                 w_scale, a_scale, res_h2, ln_stats=None, ln_c=None, rs_stats=None, rs_gamma=None, rs_beta=None, st_out=None, ln_eps=0.0):
     """The arguments of the `emage::gemm` operator -> the fields of one emage_gemm call (the order of `emage_gemm_problem`)."""
     res_f32 = 1 if (res is not None and res.dtype == torch.float32 and not res_h2) else 0
     t_ld = out_t.shape[-1] if out_t is not None else 0
+    for st in (ln_stats, rs_stats, st_out):             # (M, partials, 2) float32, contiguous: {mean, M2} over 32 columns each
+        assert st is None or (st.dtype == torch.float32 and st.is_contiguous() and st.dim() == 3 and st.shape[2] == 2 and st.shape[0] >= m)
     return dict(A=_ptr(a), W=_ptr(w), bias=_ptr(bias), slope=_ptr(slope), res=_ptr(res), out=_ptr(out), out_f32=_ptr(out_f32), out_t=_ptr(out_t),
                 lda=_ld(a), ldr=_ld(res) if res is not None else 0, res_is_f32=res_f32, res_first=1 if res_first else 0,
                 ldo=_ld(out) if out is not None else 0, n_store=n_store, ldf=_ld(out_f32) if out_f32 is not None else 0,
                 t_col0=t_col0, t_rows=t_rows, t_ld=t_ld, M=m, N=n, Cp=cp, taps=taps, stride=stride, pad=pad, Lin=lin, Lout=lout,
-                a_scale=a_scale, w_scale=w_scale)
+                a_scale=a_scale, w_scale=w_scale,
+                ln_stats=_ptr(ln_stats), ln_c=_ptr(ln_c), rs_stats=_ptr(rs_stats), rs_gamma=_ptr(rs_gamma), rs_beta=_ptr(rs_beta), st_out=_ptr(st_out),
+                ln_np=ln_stats.shape[1] if ln_stats is not None else 0, rs_np=rs_stats.shape[1] if rs_stats is not None else 0, ln_eps=float(ln_eps))
 
 
 @_op("gemm", "(int dtype, Tensor a, Tensor w, Tensor? bias, Tensor? slope, Tensor? res, Tensor(a!)? out, Tensor(b!)? out_f32, "
              "Tensor(c!)? out_t, int n, int cp, int n_store, int t_col0, int t_rows, bool res_first, int taps, int stride, int pad, "
-             "int lin, int lout, int m, float w_scale, float a_scale, bool res_h2) -> ()")
+             "int lin, int lout, int m, float w_scale, float a_scale, bool res_h2, Tensor? ln_stats=None, Tensor? ln_c=None, "
+             "Tensor? rs_stats=None, Tensor? rs_gamma=None, Tensor? rs_beta=None, Tensor(d!)? st_out=None, float ln_eps=0.0) -> ()")
 def _gemm(dtype, *args):
     f = _gemm_fields(dtype, *args)
+    if f["ln_stats"] or f["rs_stats"] or f["st_out"]:     # a LayerNorm-folding launch: the problem-struct entry point carries the fold fields
+        arr, n = _problem_array([int(f[k] or 0) for k in _GEMM_PROBLEM_INTS], [float(f["a_scale"]), float(f["w_scale"]), float(f["ln_eps"])])
+        check(_lib.load().emage_gemm_grouped(dtype, arr, n, _stream()), "gemm (LayerNorm fold)")
+        return
     check(_lib.load().emage_gemm(dtype, f["A"], f["lda"], f["W"], f["bias"], f["slope"], f["res"], f["ldr"], f["res_is_f32"], f["res_first"],
                                  f["out"], f["ldo"], f["n_store"], f["out_f32"], f["ldf"], f["out_t"], f["t_col0"], f["t_rows"], f["t_ld"],
                                  f["M"], f["N"], f["Cp"], f["taps"], f["stride"], f["pad"], f["Lin"], f["Lout"], f["a_scale"], f["w_scale"], _stream()), "gemm")
@@ -421,8 +432,11 @@ def _gemm_ws(dtype, *args):
 
 # Descriptor-table operator: `tensors` lists every tensor the problems touch (dispatch key, aliasing: they may be written), `desc` holds
 # per problem the 26 integer words of `emage_gemm_problem` in field order (device addresses first), `scales` its (a_scale, w_scale).
+_GEMM_PROBLEM_PTRS = ("A", "W", "bias", "slope", "res", "out", "out_f32", "out_t", "ln_stats", "ln_c", "rs_stats", "rs_gamma", "rs_beta", "st_out")
 _GEMM_PROBLEM_INTS = ("A", "W", "bias", "slope", "res", "out", "out_f32", "out_t", "lda", "ldr", "res_is_f32", "res_first", "ldo", "n_store", "ldf",
-                      "t_col0", "t_rows", "t_ld", "M", "N", "Cp", "taps", "stride", "pad", "Lin", "Lout")
+                      "t_col0", "t_rows", "t_ld", "M", "N", "Cp", "taps", "stride", "pad", "Lin", "Lout",
+                      "ln_stats", "ln_c", "rs_stats", "rs_gamma", "rs_beta", "st_out", "ln_np", "rs_np")
+_GEMM_PROBLEM_SCALES = 3                  # floats per problem: a_scale, w_scale, ln_eps
 
 
 def _problem_array(desc, scales):
@@ -432,8 +446,8 @@ def _problem_array(desc, scales):
     for i in range(n):
         for j, name in enumerate(_GEMM_PROBLEM_INTS):
             v = desc[i * k + j]
-            setattr(arr[i], name, (v or None) if j < 8 else v)
-        arr[i].a_scale, arr[i].w_scale = scales[2 * i], scales[2 * i + 1]
+            setattr(arr[i], name, (v or None) if name in _GEMM_PROBLEM_PTRS else v)
+        arr[i].a_scale, arr[i].w_scale, arr[i].ln_eps = scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]
     return arr, n
 
 
@@ -449,7 +463,7 @@ def grouped_launch_count(entries):
     for e in entries:
         f = _gemm_fields(*e[2])
         desc += [int(f[k] or 0) for k in _GEMM_PROBLEM_INTS]
-        scales += [float(f["a_scale"]), float(f["w_scale"])]
+        scales += [float(f["a_scale"]), float(f["w_scale"]), float(f["ln_eps"])]
     arr, n = _problem_array(desc, scales)
     rc = _lib.load().emage_gemm_grouped_launches(dtype, arr, n)
     if rc <= 0:
@@ -465,8 +479,8 @@ def _gemm_grouped_entries(entries):
         assert args[0] == dtype
         f = _gemm_fields(*args)
         desc += [int(f[k] or 0) for k in _GEMM_PROBLEM_INTS]
-        scales += [float(f["a_scale"]), float(f["w_scale"])]
-        tensors += [t for t in args[1:9] if t is not None]
+        scales += [float(f["a_scale"]), float(f["w_scale"]), float(f["ln_eps"])]
+        tensors += [t for t in list(args[1:9]) + list(args[24:30]) if torch.is_tensor(t)]
     _gemm_grouped.op(dtype, tensors, desc, scales)
 
 
@@ -484,7 +498,7 @@ def gemm_grouped(dtype, problems):
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None):
+         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None, ln=None, res_ln=None, stats_out=None, ln_eps=1e-5):
     """See include/emage_hip.h:emage_gemm.  `a` (rows, lda) and `w` (n, taps*cp) are in `dtype`.  `k_real` (the
     unpadded contraction length) is bookkeeping for bench.py's algorithmic-flop count; the kernel ignores it.
     dtype F16X3: `a` is float32, `w` / `w_scale` come from `split_f16_weights`.  dtype H2: `a` / `out` are H2 images
@@ -502,8 +516,19 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         _gemm_ws(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
                  lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2), workspace)
         return
+    if ln is None and res_ln is None and stats_out is None:
+        _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
+              lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2))
+        return
+    # LayerNorm fold (include/emage_hip.h: emage_gemm_problem): ln = (row statistics of `a`, c) — `a` is the RAW pre-norm sum, `w` / `bias` the
+    # folded W gamma / W beta + b; res_ln = (row statistics of `res`, gamma, beta) — `res` is the raw sum of a folded LayerNorm; stats_out: the
+    # (M, n / 32, 2) partial row statistics of this launch's output
+    assert dtype == H2 and workspace is None
+    ln_stats, ln_c = ln if ln is not None else (None, None)
+    rs_stats, rs_gamma, rs_beta = res_ln if res_ln is not None else (None, None, None)
     _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
-          lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2))
+          lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2),
+          ln_stats, ln_c, rs_stats, rs_gamma, rs_beta, stats_out, float(ln_eps))
 
 
 @_op("wav_conv_in", "(int dtype, Tensor wav, Tensor w, Tensor? bias, Tensor? slope, Tensor(a!) out, int lout, int stride, int pad, "
@@ -1061,6 +1086,26 @@ def wav_conv_in_backward(dy, wav, lout, taps, stride, pad):
 @_op("count_nonfinite", "(Tensor x, Tensor(a!) counter) -> ()")
 def _count_nonfinite(x, counter):
     check(_lib.load().emage_count_nonfinite(_ptr(x), x.numel(), _ptr(counter), _stream()), "count_nonfinite")
+
+
+@_op("count_nonfinite_multi", "(Tensor[] xs, Tensor(a!) counter) -> ()")
+def _count_nonfinite_multi(xs, counter):
+    n = len(xs)
+    ptrs, sizes = (C.c_void_p * n)(*[x.data_ptr() for x in xs]), (C.c_long * n)(*[x.numel() for x in xs])
+    check(_lib.load().emage_count_nonfinite_multi(ptrs, sizes, n, _ptr(counter), _stream()), "count_nonfinite_multi")
+
+
+COUNT_NONFINITE_MAX = 16
+
+
+def count_nonfinite_multi(xs, counter):
+    """counter[0] += the number of inf / NaN among the contiguous fp32 tensors `xs`, one launch per 16 of them."""
+    xs = [x for x in xs if x.numel()]
+    for x in xs:
+        _dev(x)
+        assert x.dtype == torch.float32 and x.is_contiguous()
+    for i in range(0, len(xs), COUNT_NONFINITE_MAX):
+        _count_nonfinite_multi(xs[i:i + COUNT_NONFINITE_MAX], counter)
 
 
 def count_nonfinite(x, counter):

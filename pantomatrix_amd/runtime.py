@@ -77,15 +77,14 @@ class ClipRunner:
         # health check: inf / NaN among the network outputs the codes are taken from (the quantiser would launder them into valid
         # codes) and among the results — e.g. an activation beyond the f16x3 range
         self.nonfinite.zero_()
-        self.model.health_counter = self.nonfinite
+        self.model.health_pending = pending = []
         try:
             codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
         finally:
-            self.model.health_counter = None
+            self.model.health_pending = None
         pred = self.vq.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
         out = pred["motion_axis_angle"], pred["expression"], pred["trans"]
-        for t in out:
-            ops.count_nonfinite(t, self.nonfinite)
+        ops.count_nonfinite_multi(pending + [t.contiguous() for t in out], self.nonfinite)      # ONE launch (round 5: 11)
         return out
 
     def run_device(self, audio=None, speaker_id=None):

@@ -50,10 +50,20 @@ def h2_store(dst2d, values):
     torch.as_strided(dst2d, (rows, cols), (dst2d.stride(0), 1))[:] = ops.h2_pack(values.float())
 
 
+def _merge_row_stats(st, eps):
+    """(M, P, 2) partials {mean, M2} over 32 columns each -> (mu, rstd) per row (what the consuming kernel's Chan merge computes)."""
+    mean_p, m2_p = st[:, :, 0].double(), st[:, :, 1].double()
+    mu = mean_p.mean(dim=1)
+    m2 = m2_p.sum(dim=1) + 32.0 * ((mean_p - mu[:, None]) ** 2).sum(dim=1)
+    return mu.float(), (1.0 / torch.sqrt(m2 / (32.0 * st.shape[1]) + eps)).float()
+
+
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None):
+         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None, ln=None, res_ln=None, stats_out=None, ln_eps=1e-5):
     CALLS.append("gemm")
+    if ln is not None or res_ln is not None or stats_out is not None:
+        assert dtype == H2 and taps == 1 and workspace is None, "the LayerNorm fold: EMAGE_H2 Linears only"
     m = a.shape[0] if m is None else m
     lin = m if lin is None else lin
     lout = m if lout is None else lout
@@ -102,6 +112,11 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         v = ((xh @ wh.t() + (xh @ wl.t() + xl @ wh.t())) / (sa * w_scale)).float()
     else:
         v = x @ w.float().t()
+    if ln is not None:                               # folded LayerNorm of the operand: v = rstd (x W'^T - mu c) (+ bias' below)
+        st, cvec = ln
+        assert st.shape[1] * 32 == cp and cvec.shape == (n,)
+        mu, rstd = _merge_row_stats(st[:m], ln_eps)
+        v = rstd[:, None] * (v - mu[:, None] * cvec[None, :])
     if bias is not None:
         v = v + bias
     rv = 0.0
@@ -113,6 +128,11 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
             rv = h2_values(torch.as_strided(res, (m, n8), (res.stride(0), 1)), n8)[:, :n]
         else:
             rv = torch.as_strided(res, (m, n), (res.stride(0), 1)).float()
+        if res_ln is not None:                       # the residual is a folded LayerNorm of the raw sum just read
+            st, gamma, beta = res_ln
+            assert res_h2 and st.shape[1] * 32 == n
+            mu, rstd = _merge_row_stats(st[:m], ln_eps)
+            rv = (rv - mu[:, None]) * rstd[:, None] * gamma[None, :] + beta[None, :]
     if res_first:
         v = v + rv
     if slope is not None:
@@ -121,6 +141,12 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
     if not res_first:
         v = v + rv
     ncol_n = n if out_t is None else t_col0
+    if stats_out is not None:                        # partial row statistics {mean, M2} over 32 columns each of the values stored
+        assert out_t is None and n % 64 == 0 and stats_out.shape[1:] == (n // 32, 2)
+        g = v[:, :n].reshape(m, n // 32, 32)
+        mean = g.mean(dim=2)
+        stats_out[:m, :, 0] = mean
+        stats_out[:m, :, 1] = ((g - mean[:, :, None]) ** 2).sum(dim=2)
     if out is not None and dtype == H2:
         width = (max(ncol_n, n_store) + 7) // 8 * 8
         assert out.stride(0) >= width and out.stride(0) % 8 == 0
@@ -310,6 +336,12 @@ def wav_conv_in_backward(dy, wav, lout, taps, stride, pad):
     b, l = wav.shape
     col = _im2col(wav.reshape(b * l, 1), 1, taps, stride, pad, l, lout, b).reshape(b * lout, taps)
     return (dy.double().t() @ col.double()).float()
+
+
+def count_nonfinite_multi(xs, counter):
+    CALLS.append("count_nonfinite_multi")
+    for x in xs:
+        counter[:1] += int((~torch.isfinite(x)).sum())
 
 
 def count_nonfinite(x, counter):
@@ -696,7 +728,7 @@ def rot6d_scatter(rot6d2d, slot_of_joint, n_joints=55):
     return out.reshape(m, n_joints * 3)
 
 
-_NAMES = ["im2col_t_h2", "grad_prep", "h2_cast", "adam_multi", "dropout_mask", "count_nonfinite", "loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
+_NAMES = ["im2col_t_h2", "grad_prep", "h2_cast", "adam_multi", "dropout_mask", "count_nonfinite", "count_nonfinite_multi", "loss_check", "bn_backward_sums", "bn_backward_apply", "im2col_t", "col2im", "bn_backward", "wav_conv_in_backward", "adam_step", "transpose", "col_sum", "act_backward", "layernorm_backward", "attention_backward", "mse_loss_grad", "nll_loss_grad", "loss_workspace", "mse_loss", "nll_loss", "attention_dropout", "bn_stats", "bn_apply", "mul_add", "conv_slab", "wav_block0", "lstm_step", "lstm_step_pair", "lstm_layer", "lstm_layer_supported", "lstm_layer_sync", "lstm_layer_check", "softmax2_mix", "lstm_inputs", "rot6d_scatter", "gemm", "attention", "layernorm", "add", "pack_motion", "cast_pad", "gather_rows", "vq_argmin",
           "argmax_logsoftmax", "wav_conv_in", "merge_parts", "velocity_to_position", "rot6d_to_axis_angle", "axis_angle_to_rot6d"]
 
 

@@ -78,6 +78,53 @@ def test_forward_window_f16x3_host_logic(golden_dir):
     assert float(((hi + lo) / scale - w).abs().max()) <= 2.0 ** -22 * float(w.abs().max())
 
 
+def test_layernorm_fold_host_logic(golden_dir):
+    """Round 6: the interior LayerNorms of the post-norm layers are FOLDED into the contractions around them (`fold_layernorm`, EMAGE_H2 mode:
+    LN(s) W^T + b = rstd (s W'^T - mu c) + b', residuals recomputed from the raw sum and its statistics).  On the CPU stand-ins: 41 of a window's
+    47 LayerNorm launches disappear — what stays are the norms whose result leaves the stack (the last layer of each stack, the encoder layer's
+    second norm with its post-add) —, the contraction count is unchanged, and the window stays at the reference (golden) and at the unfolded
+    result to fp32 rounding; `use_audio=False` (no cross-attention stack) folds the remaining layers."""
+    model, _ = common.product_models(precision="f16x3")
+    assert model.fold_layernorm
+    g = np.load(os.path.join(golden_dir, "forward_b1.npz"))
+    audio, spk, motion, mask = common.window_inputs(1)
+    outs, calls = {}, {}
+    with fake_ops.installed(), torch.no_grad():
+        for fold in (True, False):
+            model.fold_layernorm = fold
+            fake_ops.CALLS.clear()
+            outs[fold] = {k: v.clone() for k, v in model.forward(audio, spk, motion, mask).items()}
+            calls[fold] = (fake_ops.CALLS.count("layernorm"), fake_ops.CALLS.count("gemm"))
+        model.fold_layernorm = True
+        fake_ops.CALLS.clear()
+        out_na = model.forward(audio, spk, motion, mask, use_audio=False)
+        ln_na = fake_ops.CALLS.count("layernorm")
+        model.fold_layernorm = False
+        ref_na = model.forward(audio, spk, motion, mask, use_audio=False)
+    model.fold_layernorm = True
+    assert calls[False][0] == 47 and calls[True][0] == 6 and calls[True][1] == calls[False][1], calls
+    assert ln_na == 5                       # face 1 + the encoder layer's second norm + the three refinement layers
+    for k in orc.OUT_KEYS:
+        np.testing.assert_allclose(outs[True][k].numpy(), g[k], atol=3e-4, rtol=0)
+        assert float((outs[True][k] - outs[False][k]).abs().max()) < 2e-5, k
+        assert float((out_na[k] - ref_na[k]).abs().max()) < 2e-5, k
+    # the folded operand entries: W' = W gamma, b' = W beta + b, c = the row sums of W'
+    pk = model._packed if model._packed is not None else None
+    with fake_ops.installed(), torch.no_grad():
+        model.forward(audio, spk, motion, mask)
+        pk = model._packed
+    name, norm = "face_motion_decoder.layers.1", "face_motion_decoder.layers.1.norm2"
+    e = pk.w[name + ".ff1@" + norm]
+    p = pk.p
+    w, b = p[name + ".linear1.weight"].float(), p[name + ".linear1.bias"].float()
+    gm, bt = p[norm + ".weight"].float(), p[norm + ".bias"].float()
+    assert e["norm"] == norm and e["n"] == w.shape[0]
+    np.testing.assert_allclose(e["c"].numpy(), (w * gm).sum(1).numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(e["b"].numpy(), (b + w @ bt).numpy(), rtol=0, atol=1e-5)
+    hi, lo = fake_ops.h2_planes(e["w"], w.shape[1])
+    np.testing.assert_allclose(((hi + lo) / e["ws"]).numpy(), (w * gm).numpy(), rtol=0, atol=2.0 ** -21 * float((w * gm).abs().max()))
+
+
 @pytest.mark.parametrize("frames,batch,precision", [(128, 2, "fp32"), (70, 1, "fp32"), (129, 1, "fp32"), (129, 1, "f16x3"), (310, 1, "f16x3"), (40, 1, "f16x3"), (64, 1, "fp32")])
 def test_inference_and_decode_host_logic(golden_dir, frames, batch, precision):
     """Whole clip: window schedule, seed carry-over through the VQ decode, tail windows with T+1 audio

@@ -10,7 +10,7 @@ import torch
 import fake_ops as F
 from oracle import emage_oracle as orc
 from pantomatrix_amd import ops
-from pantomatrix_amd._lib import BF16, F32, F16X3
+from pantomatrix_amd._lib import BF16, F32, F16X3, H2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -740,6 +740,105 @@ def test_gemm_grouped_is_bit_identical_to_single_launches():
     operands, kw, outputs = probs[0]
     with pytest.raises(EmageKernelError):
         ops.gemm_grouped(H2, [dict(a=operands[0], w=operands[1], out=outputs()[0], **{**kw, "cp": kw["cp"] + 8})] * 2)
+
+
+@pytest.mark.parametrize("m", [4096, 200, 64])
+def test_gemm_layernorm_fold(m):
+    """The LayerNorm fold of emage_gemm_problem (round 6): a sub-layer chain of a post-norm transformer layer —
+        s1 = x + a W_o^T + b_o (st_out)  ->  q = LN(s1) W_q^T + b_q  and  [Q | K | V^T] = LN(s1) W_qkv^T + b  (ln fold, row-major AND V^T tiles)
+        ->  s2 = LN(s1) + a2 W_2^T + b_2 (folded residual, st_out again)
+    against float64 torch (nn.LayerNorm semantics) and against the CPU stand-in of the same arithmetic; single launches and, at M = 4096,
+    the grouped form (bit-identical to the single launches)."""
+    from pantomatrix_amd.modeling_emage_audio import _Packed
+    d, t = 768, 8
+    g = _g(300 + m)
+    x = torch.randn(m, d, generator=g) * 1.5 + 0.3
+    a = torch.randn(m, d, generator=g)
+    a2 = torch.randn(m, d, generator=g)
+    lin = lambda n: (torch.randn(n, d, generator=g) / math.sqrt(d), torch.randn(n, generator=g) * 0.1)
+    (wo, bo), (wq, bq), (wqkv, bqkv), (w2, b2) = lin(d), lin(d), lin(3 * d), lin(d)
+    gamma, beta = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    # float64 reference
+    s1 = x.double() + a.double() @ wo.double().t() + bo.double()
+    ln1 = torch.nn.functional.layer_norm(s1, (d,), gamma.double(), beta.double(), 1e-5)
+    q_ref = ln1 @ wq.double().t() + bq.double()
+    qkv_ref = ln1 @ wqkv.double().t() + bqkv.double()
+    s2_ref = ln1 + a2.double() @ w2.double().t() + b2.double()
+    fold = lambda w, b: _Packed._fold_norm(type("P", (), {"p": {"n.weight": gamma, "n.bias": beta}})(), w, b, "n")
+
+    def run(mod, dev, grouped=False):
+        mv = lambda v: v.to(dev)
+        pack = lambda w: tuple(mv(v) if torch.is_tensor(v) else v for v in ops.split_f16_weights_h2(w))
+        wo_p, wo_s = pack(wo)
+        (wq_f, bq_f, cq), (wqkv_f, bqkv_f, cqkv) = fold(wq, bq), fold(wqkv, bqkv)
+        wq_p, wq_s = pack(wq_f)
+        wqkv_p, wqkv_s = pack(wqkv_f)
+        w2_p, w2_s = pack(w2)
+        s1_img, st1 = torch.zeros(m, d, device=dev), torch.zeros(m, d // 32, 2, device=dev)
+        mod.gemm(H2, mv(ops.h2_pack(a)), wo_p, mv(bo), None, mv(ops.h2_pack(x)), s1_img, None, None, n=d, cp=d, w_scale=wo_s, res_h2=True, stats_out=st1)
+        q = torch.zeros(m, d, device=dev)
+        qk, vt = torch.zeros(m, 2 * d, device=dev), torch.zeros(m // t, d, 32, device=dev)
+        s2_img, st2 = torch.zeros(m, d, device=dev), torch.zeros(m, d // 32, 2, device=dev)
+        calls = [lambda: mod.gemm(H2, s1_img, wq_p, mv(bq_f), None, None, None, q, None, n=d, cp=d, w_scale=wq_s, ln=(st1, mv(cq))),
+                 lambda: mod.gemm(H2, s1_img, wqkv_p, mv(bqkv_f), None, None, None, qk, vt, n=3 * d, cp=d, w_scale=wqkv_s, t_col0=2 * d, t_rows=t, ln=(st1, mv(cqkv))),
+                 lambda: mod.gemm(H2, mv(ops.h2_pack(a2)), w2_p, mv(b2), None, s1_img, s2_img, None, None, n=d, cp=d, w_scale=w2_s, res_h2=True,
+                                  res_ln=(st1, mv(gamma), mv(beta)), stats_out=st2)]
+        if grouped:
+            with ops.lockstep() as ls:
+                for c in calls:
+                    with ls.chain():
+                        c()
+            assert ls.launches == [("group", 3)]
+        else:
+            for c in calls:
+                c()
+        return ops.h2_unpack(s1_img), st1, q, qk, vt[:, :, :t], ops.h2_unpack(s2_img), st2
+
+    got = run(ops, DEV)
+    torch.cuda.synchronize()
+    ref = run(F, "cpu")
+    names = ("s1", "st1", "q", "qk", "vt", "s2", "st2")
+    for nm, gt, rf in zip(names, got, ref):
+        if nm.startswith("st"):                     # {mean, M2} per 32 columns: M2 is a sum of 32 squares of O(1) values
+            _cmp(f"fold.{nm}.mean", gt[..., 0], rf[..., 0], atol=2e-6)
+            _cmp(f"fold.{nm}.m2", gt[..., 1], rf[..., 1], atol=1e-4, rtol=1e-5)
+        else:
+            _cmp(f"fold.{nm}", gt, rf, atol=3e-5, rtol=1e-5)
+    _cmp("fold.q vs float64", got[2], q_ref, atol=4e-5, rtol=1e-5)
+    _cmp("fold.qk vs float64", got[3], qkv_ref[:, :2 * d], atol=4e-5, rtol=1e-5)
+    _cmp("fold.vt vs float64", got[4], qkv_ref[:, 2 * d:].reshape(m // t, t, d).permute(0, 2, 1), atol=4e-5, rtol=1e-5)
+    _cmp("fold.s2 vs float64", got[5], s2_ref, atol=4e-5, rtol=1e-5)
+    # the statistics the consumers merge equal the rows' LayerNorm statistics
+    mu, rstd = F._merge_row_stats(got[1].cpu(), 1e-5)
+    _cmp("fold.mu", mu, s1.mean(dim=1), atol=2e-6)
+    _cmp("fold.rstd", rstd, 1.0 / torch.sqrt(s1.var(dim=1, unbiased=False) + 1e-5), atol=0.0, rtol=2e-6)
+    if m == 4096:
+        again = run(ops, DEV, grouped=True)
+        torch.cuda.synchronize()
+        for nm, a_, b_ in zip(names, got, again):
+            assert torch.equal(a_, b_), nm
+
+
+def test_count_nonfinite_multi_equals_the_single_launches():
+    """`emage_count_nonfinite_multi` (round 6: the clip runner's health check is ONE launch): the count over several tensors of very different
+    sizes (an empty chunk tail, one element, more than one 64 K chunk, more tensors than one launch takes) equals the sum of the single launches."""
+    g = _g(77)
+    sizes = [1, 7, 65536, 65537, 300000, 4096 * 256, 3, 120 * 165 * 64] + [100 + i for i in range(12)]
+    xs = []
+    for i, n in enumerate(sizes):
+        x = torch.randn(n, generator=g)
+        idx = torch.randint(0, n, (min(n, 1 + i),), generator=g)
+        x[idx] = float("inf") if i % 2 else float("nan")
+        xs.append(x.to(DEV))
+    want = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for x in xs:
+        ops.count_nonfinite(x, want)
+    got = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.count_nonfinite_multi(xs, got)
+    assert int(got) == int(want) == sum(int((~torch.isfinite(x)).sum()) for x in xs)
+    clean = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.count_nonfinite_multi([torch.randn(1000, generator=g).to(DEV), torch.zeros(70000, device=DEV)], clean)
+    assert int(clean) == 0
 
 
 def test_gemm_ws_split_k_is_deterministic_and_fp32_grade():

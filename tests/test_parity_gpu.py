@@ -234,6 +234,54 @@ def test_clip_runner_raises_on_overflow_of_the_split_fp16_range():
     assert auto.fallbacks == 2 and np.array_equal(got2[0], want[0])
 
 
+RANGE_CASES = {
+    # name -> (parameter, factor): synthetic weights rescaled so that activations leave the split-fp16 image's range (|x| < 4094) somewhere
+    # different each time (real checkpoints are what users load, test_emage_audio.py:82-97)
+    "layernorm_gain": ("audio_motion_cross_attn.layers.3.norm3.weight", 4000.0),       # a LayerNorm gain: the residual stream of the next layer
+    "ffn_out": ("face_motion_decoder.layers.1.linear2.weight", 3000.0),                 # an FFN output projection: a pre-norm sum
+    "wav_bn": ("audio_encoder_body.feat_extractor.5.bn2.weight", 20000.0),              # the WavEncoder's last BatchNorm: the audio features
+    "hint_mlp": ("bodyhints_body.fc2.weight", 5000.0),                                  # the body hint MLP: the operand of `moton_proj`
+}
+
+
+@pytest.mark.parametrize("case", sorted(RANGE_CASES), ids=sorted(RANGE_CASES))
+def test_out_of_range_activations_are_detected_and_rerun_in_fp32(case):
+    """Range robustness of the default (f16x3 / EMAGE_H2) path without real checkpoints: one weight of the synthetic model is rescaled so that
+    an activation exceeds what the x16 fp16 planes hold.  Required: (i) the device-side health check sees it — `on_overflow="raise"` raises
+    instead of returning laundered codes; (ii) `on_overflow="fp32"` re-runs exactly that batch through the exact-fp32 twin and returns BIT-equal
+    results to a model in fp32 mode (same codes, same motion); (iii) the f16x3 graph survives and the next batch behaves the same.
+    A perturbation the split-fp16 path absorbs (per-tensor weight scales, the LayerNorm fold multiplying the gain into the weights) must
+    then agree with fp32 mode to the parity tolerance instead — reported either way."""
+    from pantomatrix_amd.runtime import ClipRunner
+    name, factor = RANGE_CASES[case]
+    n = synthetic.samples_for_frames(128)
+    a = synthetic.synthetic_audio(2, n).to(DEV)
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    sd = model.state_dict()
+    sd[name] = sd[name] * factor
+    model.load_state_dict(sd)
+    auto = ClipRunner(model, vq, 2, n, use_graph=True, on_overflow="fp32")
+    got = [x.copy() for x in auto(a)]
+    fell_back = auto.fallbacks
+    assert model.precision == "f16x3" and vq.precision == "f16x3"
+    if fell_back:
+        with pytest.raises(FloatingPointError, match="non-finite"):
+            ClipRunner(model, vq, 2, n, use_graph=True)(a)
+    again = auto(a)
+    assert auto.fallbacks == 2 * fell_back and all(np.array_equal(x, y) for x, y in zip(got, again))
+    model.set_precision("fp32")
+    vq.set_precision("fp32")
+    want = ClipRunner(model, vq, 2, n, use_graph=False)(a)
+    assert all(np.isfinite(w).all() for w in want)
+    if fell_back:
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y)
+    else:
+        for x, y in zip(got, want):
+            assert float(np.abs(x - y).max()) < TOL
+    print(f"range case {case}: {name} x {factor:g} -> {'overflow detected on the device, fp32 re-run bit-equal to fp32 mode' if fell_back else 'absorbed by the split-fp16 path (within tolerance of fp32 mode)'}")
+
+
 def test_clip_runner_sub_batches_match():
     """Splitting the batch into stream-parallel groups changes scheduling only: results equal the single-group run."""
     from pantomatrix_amd.runtime import ClipRunner
