@@ -891,6 +891,9 @@ def main():
     ap.add_argument("--no-fold-ln", action="store_true", help="A/B: every LayerNorm is a launch (round 5's form) instead of folded into the contractions around it")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--train", action="store_true", help="run the N-rank training-step leg also at N = 1 (needs a launcher: a process group of one rank on RCCL) - "
+                                                         "what every rank of a multi-GPU run does, on the one GPU of a box")
+    ap.add_argument("--train-timeout", type=float, default=480.0, help="watchdog of the N-rank training-step leg (seconds)")
     ap.add_argument("--train-batch", type=int, default=56, help="clips per GPU of the training-step leg at N > 1 ranks (BASELINE configs[2]: 56)")
     args = ap.parse_args()
 
@@ -968,6 +971,8 @@ def main():
         result["pipelined"] = {"depth": args.pipeline, "value": frames_per_step * world * args.steps / el_p, "ms_per_step": 1e3 * el_p / args.steps}
         del pipe
 
+    hard_exit = False
+
     def guarded(key, fn):
         """The headline measurement above is done: a failure in one of the additional objects is reported in its place, not raised."""
         try:
@@ -1016,10 +1021,36 @@ def main():
                 torch.cuda.empty_cache()
             return others
         guarded("other_precisions", other_precisions)
-    if world > 1 and not args.no_other_configs:
+    if (world > 1 and not args.no_other_configs) or (args.train and pdist.is_initialized()):
         # BASELINE configs[2] at N ranks: EVERY rank runs the captured 56-clip step with its RCCL collectives (and the same step without them)
         log(f"rank {rank}/{world}: the training step at {world} ranks (DDP bucket all-reduces + SyncBatchNorm inside the captured graph)")
-        guarded("train_step", lambda: bench_train_step_ranks(dev, world, rank, barrier, reduce_max, steps=max(3, min(10, args.steps // 2)), batch=args.train_batch))
+        # Under a WATCHDOG: the leg holds collectives (eager warm-up steps, captured graphs); a rank that fails alone would leave the others in
+        # theirs for the backend's timeout and cost the driver the HEADLINE line, which is already measured at this point.  The leg runs in a
+        # worker thread; when it has not come back after --train-timeout seconds the line is printed with the error in its place and the
+        # process leaves through os._exit (a hung collective cannot be cancelled, `finalize` would wait for it).
+        import threading
+        box = {}
+
+        def train_leg():
+            try:
+                torch.cuda.set_device(local_rank)
+                box["out"] = bench_train_step_ranks(dev, world, rank, barrier, reduce_max, steps=max(3, min(10, args.steps // 2)), batch=args.train_batch)
+            except Exception as e:  # noqa: BLE001
+                box["err"] = f"{type(e).__name__}: {e}"[:500]
+
+        th = threading.Thread(target=train_leg, daemon=True)
+        th.start()
+        th.join(timeout=args.train_timeout)
+        if th.is_alive():
+            log(f"rank {rank}: the training-step leg did not finish within {args.train_timeout} s: reported as an error; leaving through os._exit after the line")
+            result["train_step"] = {"error": f"timeout: the N-rank training-step leg did not finish within {args.train_timeout} s on rank {rank}"}
+            hard_exit = True
+        elif "err" in box:
+            log(f"train_step failed: {box['err']}")
+            result["train_step"] = {"error": box["err"]}
+            hard_exit = world > 1             # the other ranks may be inside a collective this rank will never join
+        else:
+            result["train_step"] = box["out"]
     if rank == 0:
         result["host"] = host_info()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1037,6 +1068,10 @@ def main():
             guarded(key, lambda fn=fn: fn(dev, cpu=not args.no_cpu_baseline))
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if hard_exit:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     pdist.finalize()
 
 

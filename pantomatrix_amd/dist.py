@@ -25,6 +25,10 @@ def init(backend: str, device=None):
     return dist.group.WORLD
 
 
+def is_initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
 def shard_clips(n_clips: int, rank: int, world: int):
     """Indices of the clips rank `rank` owns: round-robin, i -> rank i % world."""
     return list(range(rank, n_clips, world))
