@@ -765,7 +765,7 @@ def bench_config1(precision, dev, args, cpu=True):
     out = {"workload": "EMAGE inference, ONE clip (BASELINE configs[0], test_emage_audio.py:16-56): graph replay, audio resident in HBM, results on the host",
            "dtype": precision}
     for key, n_samples in (("b1_128f", synthetic.samples_for_frames(128)), ("b1_28s", 448000)):
-        runner = ClipRunner(model, vq, 1, n_samples, use_graph=not args.no_graph)
+        runner = ClipRunner(model, vq, 1, n_samples, use_graph=not args.no_graph, split_k=args.split_k)
         audio = synthetic.synthetic_audio(1, n_samples, seed=1234).to(dev)
         ms, res = _time_runner(runner, audio, steps=max(5, args.steps))
         frames = int(res[0].shape[1])
@@ -806,7 +806,7 @@ def bench_batch_sweep(precision, dev, args, batches=(1, 8, 64, 256)):
     out = {"workload": "EMAGE inference, B x 128-frame clips per step (graph replay, audio resident in HBM)", "dtype": precision, "by_batch": {}}
     for b in batches:
         try:
-            runner = ClipRunner(model, vq, b, n_samples, use_graph=not args.no_graph)
+            runner = ClipRunner(model, vq, b, n_samples, use_graph=not args.no_graph, split_k=args.split_k)
             audio = synthetic.synthetic_audio(b, n_samples, seed=1234).to(dev)
             ms, res = _time_runner(runner, audio, steps=max(3, args.steps // 2))
             frames = int(res[0].shape[0] * res[0].shape[1])
@@ -888,6 +888,7 @@ def main():
     ap.add_argument("--h2-variant", type=int, default=0, help="experiments: emage_set_tuning key 5 (EMAGE_H2 tile-heuristic variant)")
     ap.add_argument("--tools-lib", action="store_true", help="experiments: run on libemage_hip_tools.so even with every tuning key at its default (the fair A arm of a tools-library A/B)")
     ap.add_argument("--h2-pp", type=int, default=0, help="experiments: emage_set_tuning key 8 (antiphase tile configuration, gemm_h2_pp.hip, for the 768-wide launches; tools library)")
+    ap.add_argument("--split-k", action="store_true", help="A/B (config1 / small batches): in-launch split-K for the few-row contractions (measured slower: off by default)")
     ap.add_argument("--no-fold-ln", action="store_true", help="A/B: every LayerNorm is a launch (round 5's form) instead of folded into the contractions around it")
     ap.add_argument("--no-concurrent", action="store_true", help="A/B / profiling: single stream, no fork/join lanes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")

@@ -178,6 +178,13 @@ typedef struct emage_gemm_problem {
     const float* ln_stats; const float* ln_c; const float* rs_stats; const float* rs_gamma; const float* rs_beta; float* st_out;
     int ln_np, rs_np;
     float ln_eps;
+    /* Split-K with an in-kernel fix-up (EMAGE_H2; optional, NULL = off): a launch of few rows (ONE clip: M = 64 — a dozen 64 x 64 tiles that
+     * would each walk the whole K range alone on one CU) may be cut into K-slices when the caller lends it scratch memory: sk_ws (16-byte
+     * aligned, sk_ws_bytes; 16 KiB per tile and slice) and sk_count (sk_tiles ints, ZERO on entry; the launch leaves them zero).  Every
+     * block stores its partial accumulators write-through, the last block of a tile to arrive adds the slices in slice order (the same bits on
+     * every run) and runs the ordinary epilogue.  The library decides per launch (<= 128 tiles, >= 8 K-tiles of 32, capacity); launches on
+     * ONE stream may share the scratch, concurrent streams need their own. */
+    void* sk_ws; long sk_ws_bytes; int* sk_count; int sk_tiles;
 } emage_gemm_problem;
 int emage_gemm_grouped(int dtype, const emage_gemm_problem* problems, int n_problems, void* stream);
 /* Launches nothing: the number of kernel launches emage_gemm_grouped would make of these problems (> 0), or a negative EMAGE_E* code. */

@@ -21,7 +21,8 @@ class GemmProblem(C.Structure):
                                      "M", "N", "Cp", "taps", "stride", "pad", "Lin", "Lout")]
                 + [("a_scale", _f), ("w_scale", _f)]
                 + [(n, _p) for n in ("ln_stats", "ln_c", "rs_stats", "rs_gamma", "rs_beta", "st_out")]       # the LayerNorm fold (round 6; all NULL = off)
-                + [("ln_np", _i), ("rs_np", _i), ("ln_eps", _f)])
+                + [("ln_np", _i), ("rs_np", _i), ("ln_eps", _f)]
+                + [("sk_ws", _p), ("sk_ws_bytes", _l), ("sk_count", _p), ("sk_tiles", _i)])             # split-K fix-up scratch (round 6; NULL = off)
 
 
 class FinalizeEntry(C.Structure):

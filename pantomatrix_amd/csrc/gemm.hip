@@ -345,6 +345,7 @@ int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, con
     a.tiles_m = a.tiles_n = 0;
     a.dbg = g_debug_skip;
     a.trace = nullptr; a.cstate = nullptr; a.ldc = 0; a.ksplit = 1; a.nk_split = 0; a.ws = nullptr; a.ws_plane = 0; a.ldws = 0; a.tile_order = 0;
+    a.sk_ws = nullptr; a.sk_count = nullptr; a.sk_ws_bytes = 0; a.sk_tiles = 0;
     a.ln_stats = nullptr; a.ln_np = 0; a.ln_c = nullptr; a.rs_stats = nullptr; a.rs_np = 0; a.rs_gamma = nullptr; a.rs_beta = nullptr; a.st_out = nullptr; a.ln_eps = 0.f;
     a.M = M; a.N = N; a.K = taps * Cp; a.Cp = Cp; a.taps = taps; a.stride = stride; a.pad = pad; a.Lin = Lin; a.Lout = Lout;
     const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2;
@@ -426,6 +427,10 @@ int grouped(int dtype, const emage_gemm_problem* problems, int n_problems, hipSt
         if (rc) return rc;
         const int rf = apply_fold(dtype, args[i], q);
         if (rf) return rf;
+        if (q.sk_ws && q.sk_count && dtype == EMAGE_H2) {      // split-K fix-up workspace (optional: the dispatch decides)
+            if (((uintptr_t)q.sk_ws & 15) || q.sk_ws_bytes <= 0 || q.sk_tiles <= 0) return EMAGE_EINVAL;
+            args[i].sk_ws = (float*)q.sk_ws; args[i].sk_count = q.sk_count; args[i].sk_ws_bytes = q.sk_ws_bytes; args[i].sk_tiles = q.sk_tiles;
+        }
     }
     if (dtype == EMAGE_H2) return gemm_h2_dispatch_group(args, n_problems, s, count_only);
     if (count_only) return n_problems;

@@ -22,7 +22,7 @@ namespace {
 
 using namespace emage_dev;
 
-template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV, bool TRACE, int KPB = 1, bool LNF = false>
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, int OCC, bool DILV, bool TRACE, int KPB = 1, bool LNF = false, bool SKF = false>
 __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) void gemm_h2_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(128))) unsigned char smem[h2_smem_bytes<BM, BN, NS, KPB>()];
     // XCD-aware tile order (gemm.hip): each XCD walks a contiguous run of tiles; split-K: slice s = blockIdx / tiles
@@ -35,7 +35,7 @@ __global__ __launch_bounds__((WM * WN + NLW) * 64, OCC * (WM * WN + NLW) / 4) vo
     }
     int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     if (EMAGE_DBG(p, 64)) { tile_m = bid % p.tiles_m; tile_n = bid / p.tiles_m; }      // tools: an XCD's run walks M first (it owns a slice of N: A re-fetched per XCD, W once)
-    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE, KPB, LNF>(p, tile_m * BM, tile_n * BN, smem, split);
+    gemm_h2_tile<BM, BN, WM, WN, NS, NLW, PIPE, PRE, DILV, TRACE, KPB, LNF, SKF>(p, tile_m * BM, tile_n * BN, smem, split);
 }
 
 // most tiles a split-K launch may have: 100.  Measured on the captured training step (A/Bs on one box each, tools library variants):
@@ -170,6 +170,41 @@ int launch_h2(GemmArgs& a, hipStream_t s) {
         return launch_status();
     }
     hipLaunchKernelGGL((gemm_h2_kernel<BM, BN, WM, WN, NS, NLW, PIPE, PRE, OCC, DILV, TRACE, KPB, LNF>), dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3((WM * WN + NLW) * 64), 0, s, a);
+    return launch_status();
+}
+
+// ---- split-K with the in-kernel fix-up (h2_tile.h SKF; round 6): few-row launches (ONE clip: M = 64 — 12 to 36 tiles of 64 x 64 that each
+// walk their 24-48 K-tiles ALONE on a CU, profiles/r05_bench_kernel_stats_one_clip_serialized.csv) are cut into K-slices so that a launch
+// occupies ~a block per CU; the last block of a tile to arrive sums the slices in slice order and runs the unchanged epilogue (every
+// output form, the LayerNorm fold).  The 64 x 64 tile only.  Returns < 0: not applicable (the caller launches the plain form).
+static int h2_skf_slices(const GemmArgs& a, int* per_out) {
+    if (!a.sk_ws || !a.sk_count) return -1;
+    const int ncols = a.n_store > a.N ? a.n_store : a.N;
+    const long tiles = (long)((a.M + 63) / 64) * ((ncols + 63) / 64);
+    const int nk_all = a.K / 32;
+    if (tiles > 128 || tiles > a.sk_tiles || nk_all < 8) return -1;
+    int want = (int)((h2_cus() + tiles - 1) / tiles);          // ~one block per CU
+    if (want > nk_all / 4) want = nk_all / 4;                  // >= 4 K-tiles per slice
+    if (want > 16) want = 16;
+    if (want < 2) return -1;
+    const int per = (nk_all + want - 1) / want;
+    const int ksplit = (nk_all + per - 1) / per;
+    if (ksplit < 2 || tiles * ksplit * (64L * 64 * 4) > a.sk_ws_bytes) return -1;
+    *per_out = per;
+    return ksplit;
+}
+
+template <bool LNF>
+int launch_h2_skf(GemmArgs& a, int ksplit, int per, hipStream_t s) {
+    if (a.out_t && a.t_col0 % 64 != 0) return EMAGE_EINVAL;
+    a.tiles_m = (a.M + 63) / 64;
+    const int ncols = a.n_store > a.N ? a.n_store : a.N;
+    a.tiles_n = (ncols + 63) / 64;
+    a.trace = nullptr;
+    a.tile_order = 0;
+    a.ws = nullptr; a.ws_plane = 0; a.ldws = 0;
+    a.ksplit = ksplit; a.nk_split = per;
+    hipLaunchKernelGGL((gemm_h2_kernel<64, 64, 2, 2, 3, 0, false, false, 2, false, false, 1, LNF, true>), dim3(a.tiles_m * a.tiles_n * ksplit), dim3(256), 0, s, a);
     return launch_status();
 }
 
@@ -420,6 +455,11 @@ int gemm_h2_dispatch(GemmArgs& a, hipStream_t s) {
         if (t64 <= 256 && !bare) cfg = g_h2_small_cfg > 0 ? g_h2_small_cfg : 189;
     }
 #endif
+    if (cfg == 120 || cfg == 1120) {                                    // few rows + a fix-up workspace: split-K inside the launch
+        int per = 0;
+        const int ksplit = h2_skf_slices(a, &per);
+        if (ksplit > 1) return cfg == 120 ? launch_h2_skf<false>(a, ksplit, per, s) : launch_h2_skf<true>(a, ksplit, per, s);
+    }
     if (cfg >= 300 && cfg < 400) return run_pp_config(cfg, a, s);       // antiphase tiles: gemm_h2_pp.hip
     return cfg < 0 ? cfg : run_config(cfg, a, s);
 }
@@ -439,10 +479,10 @@ int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only) {
     auto groupable = [&](int i) {
         switch (cfg[i]) {
             case 100: case 1100: return !h2_wants_split_k<64, 192>(a[i]);
-            case 1120: return !h2_wants_split_k<64, 64>(a[i]);
+            case 1120: { int per = 0; return !h2_wants_split_k<64, 64>(a[i]) && h2_skf_slices(a[i], &per) < 2; }
             case 113: return !h2_wants_split_k<128, 128>(a[i]);
             case 119: return !h2_wants_split_k<128, 256>(a[i]);
-            case 120: return !h2_wants_split_k<64, 64>(a[i]);
+            case 120: { int per = 0; return !h2_wants_split_k<64, 64>(a[i]) && h2_skf_slices(a[i], &per) < 2; }
             case 170: return !h2_wants_split_k<128, 192>(a[i]);
 #ifdef EMAGE_TOOLS
             case 300: case 301: case 302: case 303: return true;
@@ -486,7 +526,10 @@ int gemm_h2_dispatch_group(GemmArgs* a, int n, hipStream_t s, bool count_only) {
             }
         } else {
             done[i] = true;
-            rc = run_config(cfg[i], a[i], s);
+            int per = 0;
+            const int ksplit = (cfg[i] == 120 || cfg[i] == 1120) ? h2_skf_slices(a[i], &per) : -1;
+            if (ksplit > 1) rc = cfg[i] == 120 ? launch_h2_skf<false>(a[i], ksplit, per, s) : launch_h2_skf<true>(a[i], ksplit, per, s);
+            else rc = run_config(cfg[i], a[i], s);
         }
         if (rc) return rc;
     }

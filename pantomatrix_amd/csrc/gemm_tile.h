@@ -36,6 +36,11 @@ struct GemmArgs {
     const float* rs_gamma; const float* rs_beta;      // ... its affine parameters: res'[m][n] = (s'[m][n] - mu) rstd gamma[n] + beta[n]
     float* st_out;                        // (M, N / 32) {mean, M2}: partial row statistics of THIS launch's output rows, one per 32 columns (64 x 64 tiles of 32 x 32 wave tiles only)
     float ln_eps;
+    // split-K with an IN-KERNEL fix-up (round 6, EMAGE_H2; few-row launches: ONE clip has M = 64): the tile's K range is cut into `ksplit` slices
+    // (blockIdx = slice * tiles + tile, K-tiles [slice * nk_split, ...)); every block stores its accumulators write-through into sk_ws, counts
+    // itself on sk_count[tile], and the LAST block to arrive adds the slices in slice order and runs the whole epilogue (csrc/h2_tile.h)
+    float* sk_ws; int* sk_count;
+    long sk_ws_bytes; int sk_tiles;      // capacities the caller provides (bytes of sk_ws, counters behind sk_count): the dispatch splits only within them
     unsigned long long* trace;   // tools builds: per-wave s_memtime stamps of one block (h2_tile.h TRACE), else NULL
 };
 

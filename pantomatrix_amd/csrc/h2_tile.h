@@ -109,7 +109,7 @@ __device__ __forceinline__ void ln_wave_finish(const int fr, const float eps, co
 // (fr, fg) holds row mw + 16 i + fr; V^T tiles (un-swapped): lane holds rows mw + 16 i + 4 fg + r of one column.
 // ln_mu / ln_rs / rs_mu / rs_rs: (mu, rstd) of the lane's FM rows for the folded LayerNorm of the operand / of the residual (row-major tiles;
 // V^T tiles fetch theirs here); ignored unless p.ln_stats / p.rs_stats
-template <int FM, int FN, bool NAT, bool PRE, int PM, int PP, bool LNF = false>
+template <int FM, int FN, bool NAT, bool PRE, int PM, int PP, bool LNF = false, bool SKF = false>
 __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)[FM][FN], const int mw, const int nw, const int fr, const int fg,
                                                  const bool vt_tile, const float (&pre_r)[PM][PP][8], const int split = 0,
                                                  const float* ln_mu = nullptr, const float* ln_rs = nullptr, const float* rs_mu = nullptr, const float* rs_rs = nullptr) {
@@ -182,7 +182,8 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
     // n0 + wn*WTN + jp*32 + fg*8 + e (e < 4 from acc[i][2jp], e >= 4 from acc[i][2jp+1]); lone fragment -> 4 columns ----
     const int n_lim = ncol_n > p.n_store ? ncol_n : p.n_store;   // columns any store may touch (`out` zero-fills [N, n_store))
     // split-K with a workspace (emage_gemm_ws): this slice's partial tile goes to ITS plane with plain stores — block-uniform scalars
-    const bool to_plane = p.ksplit > 1 && p.ws != nullptr;
+    const int ksplit = (SKF && p.sk_count) ? 1 : p.ksplit;        // a fix-up launch ends in ONE ordinary epilogue per tile
+    const bool to_plane = ksplit > 1 && p.ws != nullptr;
     float* __restrict__ of32 = to_plane ? p.ws + (long)split * p.ws_plane : p.out_f32;
     const int ldf = to_plane ? p.ldws : p.ldf;
     const bool f32_vec = of32 && (ldf % 4 == 0) && (((uintptr_t)of32 & 15) == 0);
@@ -284,7 +285,7 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
         }
         if (of32 && n < ncol_n) {
             float* dst = of32 + (long)m * ldf + n;
-            if (p.ksplit > 1 && !to_plane) {          // partial sums of the K-slices meet in memory (the destination was cleared by the host call)
+            if (ksplit > 1 && !to_plane) {            // partial sums of the K-slices meet in memory (the destination was cleared by the host call)
 #pragma unroll
                 for (int e = 0; e < W; ++e)
                     if (n + e < ncol_n) __hip_atomic_fetch_add(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -334,7 +335,8 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
 // unchanged [4 hi | 4 lo] row image), one rendezvous and one counted wait serve KPB x (3 FM FN) MFMAs per wave; the MFMA order per
 // accumulator is that of KPB = 1, so the result is the same bits.  Plain K-loop only (not PIPE / DILV).
 // LNF: the instantiation carries the LayerNorm-fold paths (GemmArgs::ln_stats / rs_stats / st_out); the plain one ignores those fields
-template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, bool DILV = false, bool TRACE = false, int KPB = 1, bool LNF = false>
+// SKF: the instantiation carries the in-kernel split-K fix-up (GemmArgs::sk_ws / sk_count)
+template <int BM, int BN, int WM, int WN, int NS, int NLW, bool PIPE, bool PRE, bool DILV = false, bool TRACE = false, int KPB = 1, bool LNF = false, bool SKF = false>
 __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, const int n0, unsigned char* smem, const int split = 0) {
     constexpr int ES = 4, BK = 32, RB = 128, RPI = 8;
     constexpr int NCW = WM * WN, NL = NLW ? NLW : NCW;
@@ -410,8 +412,9 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     // split-K (p.ksplit > 1, Linear only): this block contracts K-tiles [kt0, kt0 + nk) and adds its partial tile into out_f32
     const int nk_all = p.K / BK;
     const int kt0 = p.ksplit > 1 ? split * p.nk_split : 0;
-    int is_tap = 0, is_c0 = kt0 * BK, is_slot = 0, is_sub = 0;
-    unsigned soff_a = (unsigned)(kt0 * BK * ES), soff_w = (unsigned)(kt0 * BK * ES);
+    // (a slice of a convolution starts inside tap (kt0 BK) / Cp: the scalar offset of A advances lda elements per tap)
+    int is_tap = (kt0 * BK) / p.Cp, is_c0 = kt0 * BK - is_tap * p.Cp, is_slot = 0, is_sub = 0;
+    unsigned soff_a = (unsigned)((is_tap * p.lda + is_c0) * ES), soff_w = (unsigned)(kt0 * BK * ES);
     const unsigned tap_step = (unsigned)(p.lda - p.Cp + BK) * ES;
     // DMA instruction J of a stage (J < GA: A rows, else W rows) and the bookkeeping that follows the last one
     auto issue_piece = [&](auto jc) {
@@ -681,13 +684,58 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     if (!is_compute) { if constexpr (TRACE) { if (p.trace && blockIdx.x == 0 && lane == 0) p.trace[wave * 512] = (unsigned long long)tr_n; } __syncthreads(); return; }
     if constexpr (PRE && NLW > 0) wait_vmcnt<0>();
 
+    if constexpr (SKF) {
+        if (p.sk_count) {
+            // ---- split-K fix-up: this block's accumulators go to its slot of the workspace (write-through: other XCDs' L2s are not coherent);
+            // the last block of the tile to arrive adds the slots in slice order (the same bits whoever is last) and goes on to the epilogue ----
+            static_assert(NLW == 0, "every wave computes");
+            constexpr int NF = FM * FN, NT = NCW * 64;
+            const int tile_id = (m0 / BM) * p.tiles_n + n0 / BN;
+            const unsigned slot_bytes = (unsigned)(NT * NF * 16);
+            const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.sk_ws, 0, (unsigned)(p.tiles_m * p.tiles_n * p.ksplit) * slot_bytes, 0x00020000);
+            const unsigned mine = (unsigned)(tile_id * p.ksplit + split) * slot_bytes + (unsigned)tid * 16;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), ws_rsrc, (int)(mine + (unsigned)((i * FN + j) * NT * 16)), 0, 16);     // aux 16 = sc1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* flag = (int*)smem;                    // the operand ring is idle behind the K-loop
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(p.sk_count + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == p.ksplit - 1;
+                if (last) __hip_atomic_store(p.sk_count + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag == 0) return;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < p.ksplit; ++sl) {
+                const unsigned at = (unsigned)(tile_id * p.ksplit + sl) * slot_bytes + (unsigned)tid * 16;
+                f32x4 part[FM][FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        part[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws_rsrc, (int)(at + (unsigned)((i * FN + j) * NT * 16)), 0, 16));
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = acc[i][j] + part[i][j];
+            }
+        }
+    }
     if constexpr (LNF) {
         // ... and merged HERE, behind the K-loop: the partials arrived long ago, and no wait for them sits in front of the loop (merged in the
         // prologue, the compiler's vmcnt(0) for these loads also drained the first K-tiles' DMA: +1 us per launch, profiles/r06_ln_fold_per_launch_v3.txt)
         if (p.ln_stats) ln_wave_finish<WTM, FM>(fr, p.ln_eps, lnp, ln_mu, ln_rs);     // (wave-uniform conditions: the lane exchanges inside need every lane)
         if (p.rs_stats) ln_wave_finish<WTM, FM>(fr, p.ln_eps, rsp, rs_mu, rs_rs);
     }
-    h2_tile_epilogue<FM, FN, false, PRE, PM, PP, LNF>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r, split, ln_mu, ln_rs, rs_mu, rs_rs);
+    h2_tile_epilogue<FM, FN, false, PRE, PM, PP, LNF, SKF>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r, split, ln_mu, ln_rs, rs_mu, rs_rs);
     if (vt_tile) { __syncthreads(); return; }
     tr();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -507,6 +507,9 @@ class _Ctx:
         if conv is not None:
             stride, pad, lin, lout = conv
             kw = dict(taps=e["taps"], stride=stride, pad=pad, lin=lin, lout=lout)
+        sk = ops._SPLITK[0]
+        if sk is not None and dt == H2 and m <= ops.SPLITK_MAX_ROWS and self.dev.type == "cuda":
+            kw["splitk"] = sk.get(self.dev)       # few rows (ONE clip: 64): the launch may split its K range (ops.SplitKScratch)
         ops.gemm(dt, a, e["w"], e["b"], sl, res, out, out_f32, out_t, n=n, cp=e["cp"], n_store=n_store,
                  t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, k_real=e.get("k_real"), w_scale=e.get("ws", 1.0),
                  res_h2=bool(res_h2 and dt == H2), **kw, **({} if (ln is None and res_ln is None and stats_out is None)

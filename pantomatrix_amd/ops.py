@@ -387,8 +387,45 @@ def gather_rows(table, idx, dtype, n_store=None):
     return out
 
 
+class SplitKScratch:
+    """Scratch memory a caller lends to `gemm` launches of few rows so that they may split their K range inside the launch (include/emage_hip.h:
+    emage_gemm_problem sk_ws / sk_count): one (workspace, zeroed tile counters) pair per (device, stream) — launches on one stream are ordered, so
+    they share a pair; concurrent lanes get their own.  Owned by whoever owns the launch sequence (runtime.ClipRunner: one per captured graph, so two
+    graphs in flight never share scratch); `with ops.splitk_scope(scratch):` makes it the one the model code hands to its contractions."""
+
+    def __init__(self, mbytes=8, tiles=256):
+        self.mbytes, self.tiles, self.pool = int(mbytes), int(tiles), {}
+
+    def get(self, device):
+        device = torch.device(device)
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        hit = self.pool.get(key)
+        if hit is None:
+            hit = self.pool[key] = (torch.empty(self.mbytes << 18, dtype=torch.float32, device=device), torch.zeros(self.tiles, dtype=torch.int32, device=device))
+        return hit
+
+
+_SPLITK = [None]
+SPLITK_MAX_ROWS = 512        # rows up to which the model code offers its contractions the scratch (the library still decides per launch)
+
+
+def splitk_scope(scratch):
+    """Context: contractions of at most SPLITK_MAX_ROWS rows issued inside are lent `scratch` (a `SplitKScratch`, or None = none)."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        prev, _SPLITK[0] = _SPLITK[0], scratch
+        try:
+            yield scratch
+        finally:
+            _SPLITK[0] = prev
+    return cm()
+
+
 def _gemm_fields(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, res_first, taps, stride, pad, lin, lout, m,
-                 w_scale, a_scale, res_h2, ln_stats=None, ln_c=None, rs_stats=None, rs_gamma=None, rs_beta=None, st_out=None, ln_eps=0.0):
+                 w_scale, a_scale, res_h2, ln_stats=None, ln_c=None, rs_stats=None, rs_gamma=None, rs_beta=None, st_out=None, ln_eps=0.0,
+                 sk_ws=None, sk_count=None):
     """The arguments of the `emage::gemm` operator -> the fields of one emage_gemm call (the order of `emage_gemm_problem`)."""
     res_f32 = 1 if (res is not None and res.dtype == torch.float32 and not res_h2) else 0
     t_ld = out_t.shape[-1] if out_t is not None else 0
@@ -400,16 +437,19 @@ def _gemm_fields(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_st
                 t_col0=t_col0, t_rows=t_rows, t_ld=t_ld, M=m, N=n, Cp=cp, taps=taps, stride=stride, pad=pad, Lin=lin, Lout=lout,
                 a_scale=a_scale, w_scale=w_scale,
                 ln_stats=_ptr(ln_stats), ln_c=_ptr(ln_c), rs_stats=_ptr(rs_stats), rs_gamma=_ptr(rs_gamma), rs_beta=_ptr(rs_beta), st_out=_ptr(st_out),
-                ln_np=ln_stats.shape[1] if ln_stats is not None else 0, rs_np=rs_stats.shape[1] if rs_stats is not None else 0, ln_eps=float(ln_eps))
+                ln_np=ln_stats.shape[1] if ln_stats is not None else 0, rs_np=rs_stats.shape[1] if rs_stats is not None else 0, ln_eps=float(ln_eps),
+                sk_ws=_ptr(sk_ws), sk_ws_bytes=sk_ws.numel() * sk_ws.element_size() if sk_ws is not None else 0,
+                sk_count=_ptr(sk_count), sk_tiles=sk_count.numel() if sk_count is not None else 0)
 
 
 @_op("gemm", "(int dtype, Tensor a, Tensor w, Tensor? bias, Tensor? slope, Tensor? res, Tensor(a!)? out, Tensor(b!)? out_f32, "
              "Tensor(c!)? out_t, int n, int cp, int n_store, int t_col0, int t_rows, bool res_first, int taps, int stride, int pad, "
              "int lin, int lout, int m, float w_scale, float a_scale, bool res_h2, Tensor? ln_stats=None, Tensor? ln_c=None, "
-             "Tensor? rs_stats=None, Tensor? rs_gamma=None, Tensor? rs_beta=None, Tensor(d!)? st_out=None, float ln_eps=0.0) -> ()")
+             "Tensor? rs_stats=None, Tensor? rs_gamma=None, Tensor? rs_beta=None, Tensor(d!)? st_out=None, float ln_eps=0.0, "
+             "Tensor(e!)? sk_ws=None, Tensor(f!)? sk_count=None) -> ()")
 def _gemm(dtype, *args):
     f = _gemm_fields(dtype, *args)
-    if f["ln_stats"] or f["rs_stats"] or f["st_out"]:     # a LayerNorm-folding launch: the problem-struct entry point carries the fold fields
+    if f["ln_stats"] or f["rs_stats"] or f["st_out"] or f["sk_ws"]:     # LayerNorm fold / split-K scratch: the problem-struct entry point carries those fields
         arr, n = _problem_array([int(f[k] or 0) for k in _GEMM_PROBLEM_INTS], [float(f["a_scale"]), float(f["w_scale"]), float(f["ln_eps"])])
         check(_lib.load().emage_gemm_grouped(dtype, arr, n, _stream()), "gemm (LayerNorm fold)")
         return
@@ -432,10 +472,10 @@ def _gemm_ws(dtype, *args):
 
 # Descriptor-table operator: `tensors` lists every tensor the problems touch (dispatch key, aliasing: they may be written), `desc` holds
 # per problem the 26 integer words of `emage_gemm_problem` in field order (device addresses first), `scales` its (a_scale, w_scale).
-_GEMM_PROBLEM_PTRS = ("A", "W", "bias", "slope", "res", "out", "out_f32", "out_t", "ln_stats", "ln_c", "rs_stats", "rs_gamma", "rs_beta", "st_out")
+_GEMM_PROBLEM_PTRS = ("A", "W", "bias", "slope", "res", "out", "out_f32", "out_t", "ln_stats", "ln_c", "rs_stats", "rs_gamma", "rs_beta", "st_out", "sk_ws", "sk_count")
 _GEMM_PROBLEM_INTS = ("A", "W", "bias", "slope", "res", "out", "out_f32", "out_t", "lda", "ldr", "res_is_f32", "res_first", "ldo", "n_store", "ldf",
                       "t_col0", "t_rows", "t_ld", "M", "N", "Cp", "taps", "stride", "pad", "Lin", "Lout",
-                      "ln_stats", "ln_c", "rs_stats", "rs_gamma", "rs_beta", "st_out", "ln_np", "rs_np")
+                      "ln_stats", "ln_c", "rs_stats", "rs_gamma", "rs_beta", "st_out", "ln_np", "rs_np", "sk_ws", "sk_ws_bytes", "sk_count", "sk_tiles")
 _GEMM_PROBLEM_SCALES = 3                  # floats per problem: a_scale, w_scale, ln_eps
 
 
@@ -480,7 +520,7 @@ def _gemm_grouped_entries(entries):
         f = _gemm_fields(*args)
         desc += [int(f[k] or 0) for k in _GEMM_PROBLEM_INTS]
         scales += [float(f["a_scale"]), float(f["w_scale"]), float(f["ln_eps"])]
-        tensors += [t for t in list(args[1:9]) + list(args[24:30]) if torch.is_tensor(t)]
+        tensors += [t for t in list(args[1:9]) + list(args[24:30]) + list(args[31:33]) if torch.is_tensor(t)]
     _gemm_grouped.op(dtype, tensors, desc, scales)
 
 
@@ -498,7 +538,7 @@ def gemm_grouped(dtype, problems):
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None, ln=None, res_ln=None, stats_out=None, ln_eps=1e-5):
+         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None, ln=None, res_ln=None, stats_out=None, ln_eps=1e-5, splitk=None):
     """See include/emage_hip.h:emage_gemm.  `a` (rows, lda) and `w` (n, taps*cp) are in `dtype`.  `k_real` (the
     unpadded contraction length) is bookkeeping for bench.py's algorithmic-flop count; the kernel ignores it.
     dtype F16X3: `a` is float32, `w` / `w_scale` come from `split_f16_weights`.  dtype H2: `a` / `out` are H2 images
@@ -516,19 +556,23 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         _gemm_ws(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
                  lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2), workspace)
         return
-    if ln is None and res_ln is None and stats_out is None:
+    if ln is None and res_ln is None and stats_out is None and splitk is None:
         _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
               lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2))
         return
     # LayerNorm fold (include/emage_hip.h: emage_gemm_problem): ln = (row statistics of `a`, c) — `a` is the RAW pre-norm sum, `w` / `bias` the
     # folded W gamma / W beta + b; res_ln = (row statistics of `res`, gamma, beta) — `res` is the raw sum of a folded LayerNorm; stats_out: the
     # (M, n / 32, 2) partial row statistics of this launch's output
+    # splitk = (scratch (float32, contiguous), counters (int32, ZERO, left zero)): lets a launch of few rows cut its K range into slices that meet
+    # inside the launch (emage_gemm_problem: sk_ws / sk_count); launches on one stream may share the pair
     assert dtype == H2 and workspace is None
     ln_stats, ln_c = ln if ln is not None else (None, None)
     rs_stats, rs_gamma, rs_beta = res_ln if res_ln is not None else (None, None, None)
+    sk_ws, sk_count = splitk if splitk is not None else (None, None)
+    assert sk_ws is None or (sk_ws.is_contiguous() and sk_count.is_contiguous() and sk_count.dtype == torch.int32)
     _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
           lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2),
-          ln_stats, ln_c, rs_stats, rs_gamma, rs_beta, stats_out, float(ln_eps))
+          ln_stats, ln_c, rs_stats, rs_gamma, rs_beta, stats_out, float(ln_eps), sk_ws, sk_count)
 
 
 @_op("wav_conv_in", "(int dtype, Tensor wav, Tensor w, Tensor? bias, Tensor? slope, Tensor(a!) out, int lout, int stride, int pad, "

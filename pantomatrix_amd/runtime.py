@@ -21,7 +21,7 @@ from . import ops
 
 class ClipRunner:
     def __init__(self, model, vq_model, batch: int, n_samples: int, use_graph: bool = True, warmup: int = 2,
-                 sub_batches: int = 1, main_priority: bool = False, on_overflow: str = "raise"):
+                 sub_batches: int = 1, main_priority: bool = False, on_overflow: str = "raise", split_k: bool = False):
         """main_priority (experiment): capture on a HIGH-priority stream, so the launch chain issued on lane 0 (the critical
         path: motion encoder -> body stack -> decode) outranks the side lanes (face decoder, WavEncoders) when both have
         ready kernels — if the runtime's graph kernel nodes inherit the capturing stream's priority.
@@ -33,7 +33,7 @@ class ClipRunner:
         self.model, self.vq = model, vq_model
         self.on_overflow, self.fallbacks, self._fp32_twin = on_overflow, 0, None
         self.precision = model.precision             # what THIS runner's launches compute in (the models may be re-packed later)
-        self._args = dict(batch=batch, n_samples=n_samples, use_graph=use_graph, warmup=warmup)
+        self._args = dict(batch=batch, n_samples=n_samples, use_graph=use_graph, warmup=warmup, split_k=split_k)
         dev = model.device
         if dev.type != "cuda":
             raise RuntimeError("ClipRunner needs the models on an MI355X device")
@@ -56,6 +56,12 @@ class ClipRunner:
         self.ref_trans = torch.zeros(1, 3, device=dev)
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nonfinite_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        # split_k (round 6; OFF by default — measured SLOWER: one clip 4.40 vs 4.18 ms, 28 s 28.9 vs 27.2, four clips 4.87 vs 4.32, eight 5.20 vs 4.72,
+        # profiles/r06_one_clip_split_k_ab.txt): few clips (<= 8: at most 512 rows per contraction) — the launches of a window occupy a few CUs
+        # each and walk their K range alone; lent scratch (ops.SplitKScratch; this runner's own, one pair per stream lane) they split K inside
+        # the launch.  The fix-up's own chain (write-through stores -> counter -> re-read of the slices: three trips to memory) costs what the
+        # shorter K-loop saves, and the lanes already run the few-block launches side by side
+        self.splitk = ops.SplitKScratch() if (split_k and batch * 64 <= ops.SPLITK_MAX_ROWS and model.precision == "f16x3" and getattr(model, "split_acts", False)) else None
         self.graph = None
         for _ in range(max(1, warmup)):            # packs weights, warms the allocator, validates shapes
             out = self._step()
@@ -78,11 +84,12 @@ class ClipRunner:
         # codes) and among the results — e.g. an activation beyond the f16x3 range
         self.nonfinite.zero_()
         self.model.health_pending = pending = []
-        try:
-            codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
-        finally:
-            self.model.health_pending = None
-        pred = self.vq.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
+        with ops.splitk_scope(self.splitk):
+            try:
+                codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
+            finally:
+                self.model.health_pending = None
+            pred = self.vq.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
         out = pred["motion_axis_angle"], pred["expression"], pred["trans"]
         ops.count_nonfinite_multi(pending + [t.contiguous() for t in out], self.nonfinite)      # ONE launch (round 5: 11)
         return out

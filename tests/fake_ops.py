@@ -60,8 +60,10 @@ def _merge_row_stats(st, eps):
 
 def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, out_t=None, *, n, cp,
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
-         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None, ln=None, res_ln=None, stats_out=None, ln_eps=1e-5):
+         k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None, ln=None, res_ln=None, stats_out=None, ln_eps=1e-5, splitk=None):
     CALLS.append("gemm")
+    if splitk is not None:                           # scratch the kernel may use for an in-launch split-K: the counters must come and stay zero
+        assert dtype == H2 and splitk[1].dtype == torch.int32 and int(splitk[1].abs().sum()) == 0
     if ln is not None or res_ln is not None or stats_out is not None:
         assert dtype == H2 and taps == 1 and workspace is None, "the LayerNorm fold: EMAGE_H2 Linears only"
     m = a.shape[0] if m is None else m

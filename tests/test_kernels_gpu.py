@@ -819,6 +819,50 @@ def test_gemm_layernorm_fold(m):
             assert torch.equal(a_, b_), nm
 
 
+SPLITK_CASES = [
+    # name, M-structure (nb, lin, lout), cin, n, taps, stride, pad, flags
+    ("sk_out_proj", (1, 64, 64), 768, 768, 1, 1, 0, dict(bias=True, res="h2", want="f32")),
+    ("sk_qkv_vt", (1, 64, 64), 768, 2304, 1, 1, 0, dict(bias=True, vt=1536, want="f32")),
+    ("sk_ffn2", (1, 64, 64), 1536, 768, 1, 1, 0, dict(bias=True, res="h2", want="both")),
+    ("sk_conv3", (1, 64, 64), 256, 256, 3, 1, 1, dict(bias=True, slope=0.2, n_store=256)),
+    ("sk_conv3_res_t17", (3, 17, 17), 256, 256, 3, 1, 1, dict(bias=True, res="lo", n_store=256)),
+    ("sk_head", (2, 100, 100), 768, 256, 1, 1, 0, dict(bias=True, want="both")),
+    ("sk_ragged_n", (1, 70, 70), 512, 106, 1, 1, 0, dict(bias=True, slope=0.1, n_store=128)),
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
+def test_gemm_split_k_fixup(case):
+    """Round 6: launches of few rows (ONE clip: M = 64) lent scratch memory (`splitk=`) cut their K range into slices that meet INSIDE the launch —
+    the last block of a tile adds the slices in slice order and runs the ordinary epilogue (emage_gemm_problem: sk_ws / sk_count).  Every
+    output form against the CPU restatement and the unsplit launch (fp32 summation order differs: 2e-5), the same bits on every run, the
+    counters left at zero."""
+    name, (nb, lin, lout), cin, n, taps, stride, pad, fl = case
+    scratch = torch.empty(8 << 20, dtype=torch.float32, device=DEV)
+    counters = torch.zeros(256, dtype=torch.int32, device=DEV)
+
+    class WithScratch:
+        @staticmethod
+        def gemm(*a, **k):
+            return ops.gemm(*a, splitk=(scratch, counters), **k)
+
+    got = _run_h2_gemm(case, WithScratch, DEV)
+    again = _run_h2_gemm(case, WithScratch, DEV)
+    plain = _run_h2_gemm(case, ops, DEV)
+    torch.cuda.synchronize()
+    assert int(counters.abs().sum()) == 0
+    ref = _run_h2_gemm(case, F, "cpu")
+    for nm, gt, ag, pl, rf in zip(("out", "out_f32", "out_t"), got[:3], again[:3], plain[:3], ref[:3]):
+        if gt is not None:
+            width = got[3] if nm == "out" else gt.shape[-1]
+            _cmp(f"{name}.{nm}", gt[..., :width], rf[..., :width], atol=2e-5, rtol=1e-5)
+            _cmp(f"{name}.{nm} vs unsplit", gt[..., :width], pl[..., :width], atol=2e-5, rtol=1e-5)
+            assert torch.equal(gt, ag), (name, nm)
+    # the launch really was split: with the K range in one piece the bits are those of the plain launch, with slices they (almost surely) are not
+    differs = any(gt is not None and not torch.equal(gt, pl) for gt, pl in zip(got[:3], plain[:3]))
+    assert differs, "the launch was not split"
+
+
 def test_count_nonfinite_multi_equals_the_single_launches():
     """`emage_count_nonfinite_multi` (round 6: the clip runner's health check is ONE launch): the count over several tensors of very different
     sizes (an empty chunk tail, one element, more than one 64 K chunk, more tensors than one launch takes) equals the sum of the single launches."""

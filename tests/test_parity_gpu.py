@@ -208,6 +208,34 @@ def test_clip_runner_graph_equals_eager(precision):
     assert e[0].shape == (4, 120, 165)
 
 
+@pytest.mark.parametrize("frames", [70, 310])
+def test_one_clip_runner_with_split_k_matches_the_reference(golden_dir, frames):
+    """BASELINE configs[0] (test_emage_audio.py:16-56: ONE clip) through `ClipRunner`: at M = 64 rows the contractions split their K range
+    inside the launch (round 6, `split_k`: ops.SplitKScratch / emage_gemm_problem sk_ws) — another fp32 summation order than the 64-clip
+    batch's, so: poses / expressions / trans against the REAL reference's golden within the parity tolerance, against the unsplit runner
+    within 5e-4 (identical codes: a flipped code would move rotations by O(1)), the graph bit-equal to itself and to the eager launches."""
+    from pantomatrix_amd.runtime import ClipRunner
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    g = np.load(os.path.join(golden_dir, f"infer_{frames}f_b1.npz"))
+    n = synthetic.samples_for_frames(frames)
+    a = synthetic.synthetic_audio(1, n).to(DEV)
+    split = ClipRunner(model, vq, 1, n, use_graph=True, split_k=True)
+    assert split.splitk is not None
+    plain = ClipRunner(model, vq, 1, n, use_graph=True, split_k=False)
+    eager = ClipRunner(model, vq, 1, n, use_graph=False)
+    got = [x.copy() for x in split(a)]
+    again = [x.copy() for x in split(a)]
+    ref = [x.copy() for x in plain(a)]
+    eag = [x.copy() for x in eager(a)]
+    for nm, x, y, z, e, gold in zip(("poses", "expressions", "trans"), got, again, ref, eag, (g["poses"], g["expressions"], g["trans"])):
+        assert np.array_equal(x, y) and np.array_equal(x, e), nm
+        assert float(np.abs(x - z).max()) < 5e-4, (nm, float(np.abs(x - z).max()))
+        err = float(np.abs(x - gold).max())
+        print(f"one clip, {frames} frames, split-K: {nm} max|err| vs reference {err:.2e}")
+        assert err < TOL, (nm, err)
+    assert all(int(c.abs().sum()) == 0 for _w, c in split.splitk.pool.values())
+
+
 def test_clip_runner_raises_on_overflow_of_the_split_fp16_range():
     """An activation beyond the fp16 planes' range (|x| >= 4094 in f16x3) becomes inf / NaN; the runner's end-of-batch health
     check turns that into an error instead of handing back poisoned motion — and the same checkpoint runs in fp32 mode."""
