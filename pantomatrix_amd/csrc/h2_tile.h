@@ -197,7 +197,10 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
         if (LNF && p.ln_stats) {                        // folded LayerNorm of the operand: x <- rstd (x - mu c)
             const float mu = ln_mu[i], rs = ln_rs[i];
             float cv[W];
-            if (full) { if constexpr (W == 8) load8<float>(p.ln_c + n, cv); else { const float4 q = *(const float4*)(p.ln_c + n); cv[0] = q.x; cv[1] = q.y; cv[2] = q.z; cv[3] = q.w; } }
+            if (EMAGE_DBG(p, 1024)) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) cv[e] = 0.5f;
+            } else if (full) { if constexpr (W == 8) load8<float>(p.ln_c + n, cv); else { const float4 q = *(const float4*)(p.ln_c + n); cv[0] = q.x; cv[1] = q.y; cv[2] = q.z; cv[3] = q.w; } }
             else {
 #pragma unroll
                 for (int e = 0; e < W; ++e) cv[e] = n + e < ncol_n ? p.ln_c[n + e] : 0.f;
@@ -244,7 +247,10 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
         if (LNF && p.rs_stats && p.res) {               // the residual is a folded LayerNorm of the raw sum just read
             const float mu = rs_mu[i], rs = rs_rs[i];
             float gv[W], bt[W];
-            if (full) {
+            if (EMAGE_DBG(p, 1024)) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) { gv[e] = 1.f; bt[e] = 0.f; }
+            } else if (full) {
                 if constexpr (W == 8) { load8<float>(p.rs_gamma + n, gv); load8<float>(p.rs_beta + n, bt); }
                 else { const float4 q = *(const float4*)(p.rs_gamma + n), r4 = *(const float4*)(p.rs_beta + n);
                        gv[0] = q.x; gv[1] = q.y; gv[2] = q.z; gv[3] = q.w; bt[0] = r4.x; bt[1] = r4.y; bt[2] = r4.z; bt[3] = r4.w; }
@@ -488,8 +494,8 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     // DMA (in front of it, a register-reuse wait of the compiler stalled the DMA issue), ...
     LnPart<LNF ? WTM : 16> lnp, rsp;
     if constexpr (LNF) {
-        if (is_compute && p.ln_stats) ln_wave_load<WTM>(p.ln_stats, m0 + wm * WTM, p.M, lane, lnp);
-        if (is_compute && p.rs_stats) ln_wave_load<WTM>(p.rs_stats, m0 + wm * WTM, p.M, lane, rsp);
+        if (is_compute && p.ln_stats && !EMAGE_DBG(p, 256)) ln_wave_load<WTM>(p.ln_stats, m0 + wm * WTM, p.M, lane, lnp);       // (tools, timing only: bit 256 = no statistics loads,
+        if (is_compute && p.rs_stats && !EMAGE_DBG(p, 256)) ln_wave_load<WTM>(p.rs_stats, m0 + wm * WTM, p.M, lane, rsp);       //  512 = no merge, 1024 = no c / gamma / beta loads)
     }
 
     // ---- folded LayerNorms (GemmArgs::ln_stats / rs_stats): (mu, rstd) of the lane's FM rows ----
@@ -732,8 +738,8 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
     if constexpr (LNF) {
         // ... and merged HERE, behind the K-loop: the partials arrived long ago, and no wait for them sits in front of the loop (merged in the
         // prologue, the compiler's vmcnt(0) for these loads also drained the first K-tiles' DMA: +1 us per launch, profiles/r06_ln_fold_per_launch_v3.txt)
-        if (p.ln_stats) ln_wave_finish<WTM, FM>(fr, p.ln_eps, lnp, ln_mu, ln_rs);     // (wave-uniform conditions: the lane exchanges inside need every lane)
-        if (p.rs_stats) ln_wave_finish<WTM, FM>(fr, p.ln_eps, rsp, rs_mu, rs_rs);
+        if (p.ln_stats && !EMAGE_DBG(p, 256 | 512)) ln_wave_finish<WTM, FM>(fr, p.ln_eps, lnp, ln_mu, ln_rs);     // (wave-uniform conditions: the lane exchanges inside need every lane)
+        if (p.rs_stats && !EMAGE_DBG(p, 256 | 512)) ln_wave_finish<WTM, FM>(fr, p.ln_eps, rsp, rs_mu, rs_rs);
     }
     h2_tile_epilogue<FM, FN, false, PRE, PM, PP, LNF, SKF>(p, acc, m0 + wm * WTM, n0 + wn * WTN, fr, fg, vt_tile, pre_r, split, ln_mu, ln_rs, rs_mu, rs_rs);
     if (vt_tile) { __syncthreads(); return; }

@@ -74,5 +74,10 @@ rows = [
     ("qkv + V^T: ln fold", lambda: ops.gemm(H2, x_img, wqkv, bqkv, None, None, None, wide_f, vt, n=3 * d, cp=d, w_scale=wqkvs, t_col0=2 * d, t_rows=t, ln=(st, cvec))),
     ("layernorm f32 -> H2 (round 5)", lambda: ops.layernorm(H2, out_f, gamma, beta, 1e-5, None, None, out_h)),
 ]
+dbg = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+if dbg:                                  # timing ablations of the fold (tools library, emage_set_tuning key 1: 256 = no statistics loads, 512 = no merge, 1024 = no vector loads)
+    from pantomatrix_amd import _lib
+    _lib.use_tools(True).emage_set_tuning(1, dbg)
+    print(f"== tools library, dbg {dbg}")
 for name, call in rows:
     print(f"{name:45s} {timed(call):7.2f} us", flush=True)
