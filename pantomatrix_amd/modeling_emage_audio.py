@@ -1383,9 +1383,8 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                 ops.add(cx.dt, lat[others[p][0]], lat[others[p][1]], out=mem_lo)
                 name = f"body_motion_decoder_{p}.layers.0"
                 k1, vt1 = self._memory_kv(cx, name + ".ca.kv", mem_lo, b, t, 1)
-                ref = self._decoder_layer(cx, name, tgt, b, t, k1, vt1, d, t)
-                sum_lo = cx.lo(m, d)
-                ops.add(cx.dt, lat[p], ref.r, out=sum_lo, h2_operands=(1,) if ref.h2r else ())
+                # motion_refined + latent (M:326-328): the latent rides as the post-add of the layer's last LayerNorm (one launch less per part)
+                sum_lo = self._decoder_layer(cx, name, tgt, b, t, k1, vt1, d, t, post_add=lat[p]).a
                 lean_cls = _lean and c_of[p] > 0         # decode takes the arg-max code: rec_* fp32 copy unused
                 rec_lo, out[f"rec_{p}"] = cx.gemm(sum_lo, f"motion_out_proj_{p}", want="lo" if lean_cls else "both")
                 if not (_lean and c_of[p] == 0):
