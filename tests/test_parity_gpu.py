@@ -222,7 +222,7 @@ def test_one_clip_runner_with_split_k_matches_the_reference(golden_dir, frames):
     split = ClipRunner(model, vq, 1, n, use_graph=True, split_k=True)
     assert split.splitk is not None
     plain = ClipRunner(model, vq, 1, n, use_graph=True, split_k=False)
-    eager = ClipRunner(model, vq, 1, n, use_graph=False)
+    eager = ClipRunner(model, vq, 1, n, use_graph=False, split_k=True)
     got = [x.copy() for x in split(a)]
     again = [x.copy() for x in split(a)]
     ref = [x.copy() for x in plain(a)]
