@@ -38,6 +38,9 @@ _WAV_TAPS = spec.WAV_KERNEL
 _NARROW = 32          # WavEncoder width of DisCo / CaMN's first blocks: half a 64-channel operand row (see _Packed.conv_pairs)
 
 
+_FOLD_WIDTH = 768        # the LayerNorm fold's row statistics are 24 partials of 32 columns (include/emage_hip.h: ln_np == 24): hidden_size 768 only
+
+
 def _rup(x, m=64):
     return (x + m - 1) // m * m
 
@@ -1094,7 +1097,7 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
     def _pack_folds(pk, name, cross, prev=None):
         """The folded twins of a layer's LayerNorm consumers (eval-mode EMAGE_H2 only; `fold_layernorm`): key "<consumer>@<norm>".
         prev: the layer in front of it in the same stack — its last norm folds into this layer's Q / K / V projection."""
-        if pk.dt != H2 or pk.train_only:
+        if pk.dt != H2 or pk.train_only or pk.p[name + ".norm1.weight"].shape[0] != _FOLD_WIDTH:
             return
         last = ".norm3" if cross else ".norm2"
         if prev is not None:
@@ -1263,7 +1266,7 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             from . import training
             return training.train_forward(self, audio, speaker_id, masked_motion, mask, use_audio)
         c = self.config
-        cx = _Ctx(self._engine(), self.h2_residual, self.fold_layernorm)
+        cx = _Ctx(self._engine(), self.h2_residual, self.fold_layernorm and c.hidden_size == _FOLD_WIDTH)
         pk = cx.pk
         dev = cx.dev
         b, t, cm = masked_motion.shape
