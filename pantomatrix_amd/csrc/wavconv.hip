@@ -6,7 +6,11 @@
 
 namespace {
 
-constexpr int ROWS = 64;      // output positions per block
+// Output positions per block: 16 per thread — a thread keeps 4 channels x 16 taps of filters in registers, loaded once per block, so narrow
+// encoders (DisCo / CaMN: C = 32 -> 8 channel groups, 32 row lanes) need MANY rows per block to amortise those 64 loads: with a fixed 64 rows
+// (2 per thread) the kernel ran at 0.4-0.8 TB/s of its output stream (CaMN: 7.3 ms for 2.9 GB, profiles/r05_lstm_kernel_stats_camn.csv).
+// C = 256 (EMAGE's two stacked encoders) keeps its 64 rows.  Per output the arithmetic is unchanged: the same bits.
+static inline int rows_per_block(int C) { const int r = 16384 / C; return r < 64 ? 64 : (r > 1024 ? 1024 : r); }
 constexpr int MAXTAPS = 16;
 
 __device__ __forceinline__ void store4(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
@@ -20,7 +24,7 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
 template <typename T>
 __global__ __launch_bounds__(256) void wav_conv_in_kernel(const float* __restrict__ wav, long ldw, int L, int nclip, long hop, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const float* __restrict__ slope,
-                                                          T* __restrict__ out, int ldo, int Lout, int C, int taps, int stride, int pad) {
+                                                          T* __restrict__ out, int ldo, int Lout, int C, int taps, int stride, int pad, int ROWS) {
     extern __shared__ float s_x[];                       // ROWS*stride + taps samples
     const int b = blockIdx.y;                            // output sequence b = window*nclip + clip
     const float* __restrict__ src = wav + (long)(b % nclip) * ldw + (long)(b / nclip) * hop;
@@ -74,10 +78,12 @@ extern "C" int emage_wav_conv_in(int dtype, const float* wav, long ldw, int L, i
     if (256 % (C / 4) != 0 || C / 4 > 256 || ldo % 4 != 0 || ((uintptr_t)out & 15)) return EMAGE_EINVAL;
     if (nwin <= 0 || hop < 0 || L <= 0 || ldw < (long)(nwin - 1) * hop + L || (long)nwin * B > 65535) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    int ROWS = rows_per_block(C);
+    while (ROWS > 64 && ((size_t)(ROWS - 1) * stride + taps) * sizeof(float) > 60 * 1024) ROWS >>= 1;       // the sample span stays inside 60 KB of LDS
     const dim3 grid((Lout + ROWS - 1) / ROWS, nwin * B), block(256);
-    const size_t lds = ((ROWS - 1) * stride + taps) * sizeof(float);
-    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((wav_conv_in_kernel<bf16_t>), grid, block, lds, s, wav, ldw, L, B, hop, w, bias, slope, (bf16_t*)out, ldo, Lout, C, taps, stride, pad);
-    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((wav_conv_in_kernel<float>), grid, block, lds, s, wav, ldw, L, B, hop, w, bias, slope, (float*)out, ldo, Lout, C, taps, stride, pad);
+    const size_t lds = ((size_t)(ROWS - 1) * stride + taps) * sizeof(float);
+    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((wav_conv_in_kernel<bf16_t>), grid, block, lds, s, wav, ldw, L, B, hop, w, bias, slope, (bf16_t*)out, ldo, Lout, C, taps, stride, pad, ROWS);
+    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((wav_conv_in_kernel<float>), grid, block, lds, s, wav, ldw, L, B, hop, w, bias, slope, (float*)out, ldo, Lout, C, taps, stride, pad, ROWS);
     else return EMAGE_EINVAL;
     return launch_status();
 }

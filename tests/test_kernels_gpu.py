@@ -284,6 +284,23 @@ def test_wav_conv_in():
         _cmp("wav_conv_in.windows", out, out_c, atol=1e-5 if dtype == F32 else 1e-2)
 
 
+@pytest.mark.parametrize("c,lw", [(32, 136000), (64, 34112), (128, 21003), (8, 9000)])
+def test_wav_conv_in_narrow_encoders(c, lw):
+    """The first layer at the widths of DisCo / CaMN (32 .. 128 channels; round 6: rows per block grow as the channels shrink — 512 at C = 32 —
+    so that a thread's register-resident filters are loaded once per 16 rows, not per 2): ragged lengths, the last block partly empty, against
+    the CPU restatement; per output the same fmaf chain as before."""
+    g = _g(40 + c)
+    wav = 0.1 * torch.randn(2, lw, generator=g)
+    w, bias = torch.randn(c, 15, generator=g) / 4, torch.randn(c, generator=g) * 0.1
+    slope = torch.full((c,), 0.01)
+    lout = (lw + 2 * 1600 - 15) // 5 + 1
+    out_c = torch.zeros(2 * lout, c)
+    F.wav_conv_in(F32, wav, w, bias, slope, out_c, lout, 5, 1600)
+    out = torch.full((2 * lout, c), 7.0, device=DEV)
+    ops.wav_conv_in(F32, wav.to(DEV), w.to(DEV), bias.to(DEV), slope.to(DEV), out, lout, 5, 1600)
+    _cmp(f"wav_conv_in.c{c}", out, out_c, atol=1e-5)
+
+
 def test_rotations_merge_scan(golden_dir):
     import os
     g = _g(5)
