@@ -134,9 +134,26 @@ __global__ __launch_bounds__(256) void cast_pad_h2_kernel(const float* src, int 
 __global__ __launch_bounds__(256) void h2_cast_t_kernel(const float* __restrict__ src, int lds_, h2_t* __restrict__ out, int ldo, int m_store, int M, int C, float scale) {
     __shared__ float tile[64][65];
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        tile[r][c] = (m0 + r < M && c0 + c < C) ? src[(long)(m0 + r) * lds_ + c0 + c] * scale : 0.f;
+    if ((lds_ & 3) == 0 && (((uintptr_t)src & 15) == 0) && c0 + 64 <= C) {
+        // whole tile columns, 16-byte aligned rows: four 16-byte loads per thread, all in flight before the first LDS write (round 6: the scalar
+        // form ran at 1.9 TB/s on the training step's 11 MB layer inputs — 522 launches, 6 ms per step)
+        const int r0 = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + 16 * k;
+            v[k] = m0 + r < M ? *(const float4*)(src + (long)(m0 + r) * lds_ + c0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + 16 * k;
+            tile[r][c4] = v[k].x * scale; tile[r][c4 + 1] = v[k].y * scale; tile[r][c4 + 2] = v[k].z * scale; tile[r][c4 + 3] = v[k].w * scale;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            tile[r][c] = (m0 + r < M && c0 + c < C) ? src[(long)(m0 + r) * lds_ + c0 + c] * scale : 0.f;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 8; i += 256) {
