@@ -39,6 +39,12 @@ extern "C" {
 #define EMAGE_BF16 1
 #define EMAGE_F16X3 2
 #define EMAGE_H2 3
+/* EMAGE_H2 with the activation scale of a MODEL: activation images (what emage_gemm / emage_layernorm / emage_attention / emage_add / emage_cast_pad /
+ * emage_pack_motion / emage_gather_rows WRITE as `out`, and what emage_gemm / emage_add read as an H2 residual / operand) hold x * 2^(4 - k)
+ * instead of 16 x: |x| < 4094 * 2^k stays finite in the fp16 hi plane, at the price of k bits of the smallest values' lo plane.  k = 0..12;
+ * EMAGE_H2_SHIFT(0) == EMAGE_H2 (the default: bit-identical to the plain code).  emage_gemm's operand A is described by `a_scale` as before
+ * (pass 2^(4 - k) for an activation image written under shift k); weight / gradient images (emage_h2_cast: explicit scale) are not affected. */
+#define EMAGE_H2_SHIFT(k) (EMAGE_H2 | ((k) << 8))
 
 #define EMAGE_EINVAL (-1)   /* unsupported size / alignment / null pointer */
 

@@ -80,6 +80,8 @@ int dispatch(AttnArgs& a, int hd, hipStream_t s) {
 static int attention_impl(int dtype, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int vt_rows,
                           void* out, int ldo, int B, int H, int Tq, int Tk, int hd, const float* pmask, void* stream) {
     if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0 || Tk > 128 || vt_rows < H * hd) return EMAGE_EINVAL;
+    emage_dev::H2Scale hs;
+    if (emage_dev::h2_dtype(dtype, hs)) return EMAGE_EINVAL;
     if (dtype != EMAGE_BF16 && dtype != EMAGE_F32 && dtype != EMAGE_F16X3 && dtype != EMAGE_H2) return EMAGE_EINVAL;
     if (pmask && (dtype == EMAGE_BF16 || dtype == EMAGE_H2)) return EMAGE_EINVAL;
     if (dtype == EMAGE_H2 && ldo % 8) return EMAGE_EINVAL;                  // out is an EMAGE_H2 image; q / k / vt are float32                 // the training forward runs in the fp32-storage modes
@@ -87,7 +89,7 @@ static int attention_impl(int dtype, const void* q, int ldq, const void* k, int 
     if (ldq % epc || ldk % epc || ldo % 4 || ldvt % 32 || ldvt < ((Tk + 31) / 32) * 32) return EMAGE_EINVAL;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) return EMAGE_EINVAL;
     if ((long)B * Tq * ldq * 4 >= (1L << 31) || (long)B * Tk * ldk * 4 >= (1L << 31) || (long)B * vt_rows * ldvt * 4 >= (1L << 31)) return EMAGE_EINVAL;
-    AttnArgs a{q, k, vt, out, ldq, ldk, ldvt, vt_rows, ldo, B, H, Tq, Tk, 1.0f / sqrtf((float)hd), pmask};
+    AttnArgs a{q, k, vt, out, ldq, ldk, ldvt, vt_rows, ldo, B, H, Tq, Tk, 1.0f / sqrtf((float)hd), pmask, hs.s, hs.inv};
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EMAGE_F16X3) return dispatch<float, true>(a, hd, s);     // float32 tensors, split-f16 MFMA
     if (dtype == EMAGE_H2) return dispatch<float, true, true>(a, hd, s);  // the same arithmetic, output as an EMAGE_H2 image

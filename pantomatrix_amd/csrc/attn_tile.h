@@ -12,6 +12,8 @@ struct AttnArgs {
     int ldq, ldk, ldvt, vt_rows, ldo, B, H, Tq, Tk;
     float scale;
     const float* pmask;       // optional (B, H, Tq, Tk) fp32 factor on the probabilities: the attention dropout of a training forward
+    float h2s, h2i;           // split-f16 forms: the power of two Q / K / V are scaled by before their fp16 split — and the scale of the EMAGE_H2 output image —
+                              // and its inverse (csrc/h2.h: 16 unless the dtype code carries the model's activation shift)
 };
 
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
@@ -56,7 +58,8 @@ __device__ __forceinline__ f32x4 mma_split(const SplitF16& a, const SplitF16& b,
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, acc, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, acc, 0, 0, 0);
 }
-constexpr float ATT_QKV_SCALE = 16.0f;     // Q, K, V planes: |x| < 4094 stays finite in fp16
+// Q, K, V planes: scaled by AttnArgs::h2s before the split — 16 (|x| < 4094 stays finite in fp16) unless the dtype code carries the model's
+// activation shift (include/emage_hip.h EMAGE_H2_SHIFT: 2^(4 - k)); powers of two, undone exactly behind the MFMAs
 constexpr float ATT_P_SCALE = 1024.0f;     // probabilities are <= 1
 
 constexpr int QW = 4;    // query tiles per workgroup: the waves of one (batch, head) share K / V^T through the CU's L1
@@ -129,7 +132,7 @@ __device__ __forceinline__ void attn_stage_kv(const AttnArgs& p, const int b, co
     for (int i = 0; i < KU; ++i) {
         const int u = i * NTHR + tid;
         const int key = u / (L::KS * 4), cell = u - key * (L::KS * 4);
-        const SplitF16 f = split_chunks(k0[i], k1[i], ATT_QKV_SCALE);
+        const SplitF16 f = split_chunks(k0[i], k1[i], p.h2s);
         unsigned char* dst = smem + key * L::KROW + cell * 32;
         *(h16x8*)dst = f.hi;
         *(h16x8*)(dst + 16) = f.lo;
@@ -138,7 +141,7 @@ __device__ __forceinline__ void attn_stage_kv(const AttnArgs& p, const int b, co
     for (int i = 0; i < VU; ++i) {
         const int u = i * NTHR + tid;
         const int j = u / (L::VS * 4), cell = u - j * (L::VS * 4);
-        const SplitF16 f = split_chunks(v0[i], v1[i], ATT_QKV_SCALE);
+        const SplitF16 f = split_chunks(v0[i], v1[i], p.h2s);
         unsigned char* dst = smem + L::K_BYTES + j * L::VROW + cell * 32;
         *(h16x8*)dst = f.hi;
         *(h16x8*)(dst + 16) = f.lo;
@@ -237,7 +240,7 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
     if constexpr (X3) {
         SplitF16 qs[NSTEP / 2];                // Q is re-used by every key tile: split once
 #pragma unroll
-        for (int s = 0; s < NSTEP / 2; ++s) qs[s] = split_chunks(qf[2 * s], qf[2 * s + 1], ATT_QKV_SCALE);
+        for (int s = 0; s < NSTEP / 2; ++s) qs[s] = split_chunks(qf[2 * s], qf[2 * s + 1], p.h2s);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -248,9 +251,9 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
                 if constexpr (!PRE) load_k(nt, kf[0]);
 #pragma unroll
                 for (int s = 0; s < NSTEP / 2; ++s)
-                    acc = mma_split(split_chunks(kf[PRE ? nt : 0][2 * s], kf[PRE ? nt : 0][2 * s + 1], ATT_QKV_SCALE), qs[s], acc);
+                    acc = mma_split(split_chunks(kf[PRE ? nt : 0][2 * s], kf[PRE ? nt : 0][2 * s + 1], p.h2s), qs[s], acc);
             }
-            sc[nt] = acc * (1.0f / (ATT_QKV_SCALE * ATT_QKV_SCALE));
+            sc[nt] = acc * (p.h2i * p.h2i);
         }
     } else {
 #pragma unroll
@@ -340,12 +343,12 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
 #pragma unroll
             for (int c = 0; c < NPC / 2; ++c)
                 acc = mma_split(lds_frag(smem + AttnLds<HD, NT>::K_BYTES, AttnLds<HD, NT>::VROW, dt * 16 + fr, c), ps[c], acc);
-            acc = acc * (1.0f / (ATT_QKV_SCALE * ATT_P_SCALE));
+            acc = acc * (p.h2i * (1.0f / ATT_P_SCALE));
         } else if constexpr (X3) {
 #pragma unroll
             for (int c = 0; c < NPC / 2; ++c)
-                acc = mma_split(split_chunks(vf[PRE ? dw : 0][2 * c], vf[PRE ? dw : 0][2 * c + 1], ATT_QKV_SCALE), ps[c], acc);
-            acc = acc * (1.0f / (ATT_QKV_SCALE * ATT_P_SCALE));
+                acc = mma_split(split_chunks(vf[PRE ? dw : 0][2 * c], vf[PRE ? dw : 0][2 * c + 1], p.h2s), ps[c], acc);
+            acc = acc * (p.h2i * (1.0f / ATT_P_SCALE));
         } else {
 #pragma unroll
             for (int c = 0; c < NPC; ++c) acc = Elem<T>::mma(vf[PRE ? dw : 0][c], pc[c], acc);
@@ -354,7 +357,7 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& p, const int b, const 
             if ((dw & 1) == 0) { held = acc; continue; }
             if (qq < p.Tq) {
                 const float v8[8] = {held[0], held[1], held[2], held[3], acc[0], acc[1], acc[2], acc[3]};
-                h2_store8((h2_t*)p.out + ((long)b * p.Tq + qq) * p.ldo + h * HD + 32 * (dt >> 1) + 8 * fg, v8);
+                h2_store8((h2_t*)p.out + ((long)b * p.Tq + qq) * p.ldo + h * HD + 32 * (dt >> 1) + 8 * fg, v8, p.h2s);
             }
             continue;
         }

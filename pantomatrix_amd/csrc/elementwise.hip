@@ -14,47 +14,48 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         const T* __restrict__ add, int ldadd,
                                                         float* __restrict__ yf, T* __restrict__ y, int ldy, int M, int C,
-                                                        h2_t* __restrict__ yh = nullptr) {
+                                                        h2_t* __restrict__ yh = nullptr, float h2s = H2_SCALE) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
     layernorm_row<T, MAXV>(x + (long)row * ldx, gamma, beta, eps, add ? add + (long)row * ldadd : nullptr,
                            yf ? yf + (long)row * ldy : nullptr, y ? y + (long)row * ldy : nullptr, C, lane,
-                           yh ? yh + (long)row * ldy : nullptr);
+                           yh ? yh + (long)row * ldy : nullptr, h2s);
 }
 
 // ---- EMAGE_H2 storage (csrc/h2.h): 4 logical columns at a 4-aligned column n of a row ----
-template <typename T> __device__ __forceinline__ float4 ldv4(const T* p, int n) { return Vec4<T>::load(p); }
-template <> __device__ __forceinline__ float4 ldv4<h2_t>(const h2_t* p, int n) {
+// hs: the activation-image scale of the call (csrc/h2.h; the other storage types ignore it)
+template <typename T> __device__ __forceinline__ float4 ldv4(const T* p, int n, const H2Scale& hs) { return Vec4<T>::load(p); }
+template <> __device__ __forceinline__ float4 ldv4<h2_t>(const h2_t* p, int n, const H2Scale& hs) {
     float v[4];
-    h2_load4(p, n, v);
+    h2_load4(p, n, v, hs.inv);
     return make_float4(v[0], v[1], v[2], v[3]);
 }
-template <typename T> __device__ __forceinline__ void stv4(T* p, int n, float4 v) { Vec4<T>::store(p, v); }
-template <> __device__ __forceinline__ void stv4<h2_t>(h2_t* p, int n, float4 v) {
+template <typename T> __device__ __forceinline__ void stv4(T* p, int n, float4 v, const H2Scale& hs) { Vec4<T>::store(p, v); }
+template <> __device__ __forceinline__ void stv4<h2_t>(h2_t* p, int n, float4 v, const H2Scale& hs) {
     const float t[4] = {v.x, v.y, v.z, v.w};
-    h2_store4(p, n, t);
+    h2_store4(p, n, t, hs.s);
 }
 
 // out[m] = a[m] + b[m % mod_b] (+ c[m % mod_c]); operand k is fp32 when bit k of f32_mask is set, else T
 template <typename T>
 __global__ __launch_bounds__(256) void add_kernel(const void* __restrict__ a, int lda, const void* __restrict__ b, int ldb, int mod_b,
                                                   const void* __restrict__ c, int ldc, int mod_c, int f32_mask,
-                                                  float* __restrict__ of, T* __restrict__ o, int ldo, int M, int C) {
+                                                  float* __restrict__ of, T* __restrict__ o, int ldo, int M, int C, H2Scale hs) {
     const int nv = C >> 2;
     const long total = (long)M * nv;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / nv), n = 4 * (int)(i - (long)m * nv);
         auto ld = [&](const void* p, int ldp, int mod, int bit) {
             const long r = mod ? m % mod : m;
-            return (f32_mask >> bit) & 1 ? Vec4<float>::load((const float*)p + r * ldp + n) : ldv4<T>((const T*)p + r * ldp + n, n);
+            return (f32_mask >> bit) & 1 ? Vec4<float>::load((const float*)p + r * ldp + n) : ldv4<T>((const T*)p + r * ldp + n, n, hs);
         };
         float4 v = ld(a, lda, 0, 0);
         const float4 w = ld(b, ldb, mod_b, 1);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         if (c) { const float4 u = ld(c, ldc, mod_c, 2); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
         if (of) Vec4<float>::store(of + (long)m * ldo + n, v);
-        if (o) stv4<T>(o + (long)m * ldo + n, n, v);
+        if (o) stv4<T>(o + (long)m * ldo + n, n, v, hs);
     }
 }
 
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
 // EMAGE_H2 forms: one thread per group of 8 logical columns (32 bytes)
 __global__ __launch_bounds__(256) void pack_motion_h2_kernel(const float* __restrict__ motion, const float* __restrict__ mask, long ldb,
                                                              const float* __restrict__ emb, const float* __restrict__ seed, long ld_seed, int pre,
-                                                             h2_t* __restrict__ out, int ldo, int n_store, int B, int Tn, int C) {
+                                                             h2_t* __restrict__ out, int ldo, int n_store, int B, int Tn, int C, float h2s) {
     const int ng = n_store >> 3;
     const long total = (long)B * Tn * ng;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -112,12 +113,12 @@ __global__ __launch_bounds__(256) void pack_motion_h2_kernel(const float* __rest
                 else v[e] = mk == 1.0f ? emb[n] : mv;
             }
         }
-        h2_store8(out + (long)m * ldo + n0, v);
+        h2_store8(out + (long)m * ldo + n0, v, h2s);
     }
 }
 
 // src may alias out (same row stride): each thread reads its 8 values before it writes their 32 bytes
-__global__ __launch_bounds__(256) void cast_pad_h2_kernel(const float* src, int lds, h2_t* out, int ldo, int n_store, int M, int C) {
+__global__ __launch_bounds__(256) void cast_pad_h2_kernel(const float* src, int lds, h2_t* out, int ldo, int n_store, int M, int C, float h2s) {
     const int ng = n_store >> 3;
     const long total = (long)M * ng;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void cast_pad_h2_kernel(const float* src, int 
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = n0 + e < C ? src[(long)m * lds + n0 + e] : 0.f;
-        h2_store8(out + (long)m * ldo + n0, v);
+        h2_store8(out + (long)m * ldo + n0, v, h2s);
     }
 }
 
@@ -208,6 +209,8 @@ inline int grid_for(long total) {
 
 extern "C" int emage_layernorm(int dtype, const void* x, int ldx, const float* gamma, const float* beta, float eps,
                                const void* add, int ldadd, float* y_f32, void* y, int ldy, int M, int C, void* stream) {
+    H2Scale hs;
+    if (h2_dtype(dtype, hs)) return EMAGE_EINVAL;
     if (!x || !gamma || !beta || (!y_f32 && !y) || M <= 0 || C <= 0 || C % 64 || C > 1024) return EMAGE_EINVAL;
     if (ldx % 4 || ldy % 4 || (add && ldadd % 4)) return EMAGE_EINVAL;
     if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)add | (uintptr_t)y_f32 | (uintptr_t)y) & 15) return EMAGE_EINVAL;
@@ -217,22 +220,24 @@ extern "C" int emage_layernorm(int dtype, const void* x, int ldx, const float* g
     else if (dtype == EMAGE_F32) hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, eps, (const float*)add, ldadd, y_f32, (float*)y, ldy, M, C, (h2_t*)nullptr);
     else if (dtype == EMAGE_H2) {      // x / add / y_f32 float32 (the fp32 residual stream), y the EMAGE_H2 copy for the next contraction
         if (ldy % 8) return EMAGE_EINVAL;
-        hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, eps, (const float*)add, ldadd, y_f32, (float*)nullptr, ldy, M, C, (h2_t*)y);
+        hipLaunchKernelGGL((layernorm_kernel<float, 4>), grid, block, 0, s, (const float*)x, ldx, gamma, beta, eps, (const float*)add, ldadd, y_f32, (float*)nullptr, ldy, M, C, (h2_t*)y, hs.s);
     } else return EMAGE_EINVAL;
     return launch_status();
 }
 
 extern "C" int emage_add(int dtype, const void* a, int lda, const void* b, int ldb, int mod_b, const void* c, int ldc, int mod_c,
                          int f32_mask, float* out_f32, void* out, int ldo, int M, int C, void* stream) {
+    H2Scale hs;
+    if (h2_dtype(dtype, hs)) return EMAGE_EINVAL;
     if (!a || !b || (!out_f32 && !out) || M <= 0 || C <= 0 || C % 4 || lda % 4 || ldb % 4 || ldo % 4 || (c && ldc % 4)) return EMAGE_EINVAL;
     if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out_f32 | (uintptr_t)out) & 7) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(grid_for((long)M * C / 4)), block(256);
-    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((add_kernel<bf16_t>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask, out_f32, (bf16_t*)out, ldo, M, C);
-    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((add_kernel<float>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask | 7, out_f32, (float*)out, ldo, M, C);
+    if (dtype == EMAGE_BF16) hipLaunchKernelGGL((add_kernel<bf16_t>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask, out_f32, (bf16_t*)out, ldo, M, C, hs);
+    else if (dtype == EMAGE_F32) hipLaunchKernelGGL((add_kernel<float>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask | 7, out_f32, (float*)out, ldo, M, C, hs);
     else if (dtype == EMAGE_H2) {      // operands with a clear f32_mask bit and `out` are EMAGE_H2 images: rows start on a 32-byte group
         if (lda % 8 || ldb % 8 || ldo % 8 || (c && ldc % 8)) return EMAGE_EINVAL;
-        hipLaunchKernelGGL((add_kernel<h2_t>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask, out_f32, (h2_t*)out, ldo, M, C);
+        hipLaunchKernelGGL((add_kernel<h2_t>), grid, block, 0, s, a, lda, b, ldb, mod_b, c, ldc, mod_c, f32_mask, out_f32, (h2_t*)out, ldo, M, C, hs);
     } else return EMAGE_EINVAL;
     return launch_status();
 }
@@ -240,6 +245,8 @@ extern "C" int emage_add(int dtype, const void* a, int lda, const void* b, int l
 extern "C" int emage_pack_motion(int dtype, const float* motion, const float* mask, long ldb, const float* mask_embedding,
                                  const float* seed, long ld_seed, int pre,
                                  void* out, int ldo, int n_store, int B, int T, int C, void* stream) {
+    H2Scale hs;
+    if (h2_dtype(dtype, hs)) return EMAGE_EINVAL;
     if (!motion || !mask || !mask_embedding || !out || B <= 0 || T <= 0 || C <= 0 || n_store < C || ldo < n_store) return EMAGE_EINVAL;
     if (ldb < (long)T * C || (seed && (pre <= 0 || pre > T || ld_seed < (long)pre * C))) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -248,12 +255,14 @@ extern "C" int emage_pack_motion(int dtype, const float* motion, const float* ma
     else if (dtype == EMAGE_F32) hipLaunchKernelGGL((pack_motion_kernel<float>), grid, block, 0, s, motion, mask, ldb, mask_embedding, seed, ld_seed, pre, (float*)out, ldo, n_store, B, T, C);
     else if (dtype == EMAGE_H2) {
         if (n_store % 8 || ldo % 8 || ((uintptr_t)out & 15)) return EMAGE_EINVAL;
-        hipLaunchKernelGGL(pack_motion_h2_kernel, dim3(grid_for((long)B * T * n_store / 8)), block, 0, s, motion, mask, ldb, mask_embedding, seed, ld_seed, pre, (h2_t*)out, ldo, n_store, B, T, C);
+        hipLaunchKernelGGL(pack_motion_h2_kernel, dim3(grid_for((long)B * T * n_store / 8)), block, 0, s, motion, mask, ldb, mask_embedding, seed, ld_seed, pre, (h2_t*)out, ldo, n_store, B, T, C, hs.s);
     } else return EMAGE_EINVAL;
     return launch_status();
 }
 
 extern "C" int emage_cast_pad(int dtype, const float* src, int lds, void* out, int ldo, int n_store, int M, int C, void* stream) {
+    H2Scale hs;
+    if (h2_dtype(dtype, hs)) return EMAGE_EINVAL;
     if (!src || !out || M <= 0 || C <= 0 || n_store < C || ldo < n_store || lds < C) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(grid_for((long)M * n_store)), block(256);
@@ -261,7 +270,7 @@ extern "C" int emage_cast_pad(int dtype, const float* src, int lds, void* out, i
     else if (dtype == EMAGE_F32) hipLaunchKernelGGL((cast_pad_kernel<float>), grid, block, 0, s, src, lds, (float*)out, ldo, n_store, M, C);
     else if (dtype == EMAGE_H2) {      // fp32 -> EMAGE_H2; in place when src == out and lds == ldo
         if (n_store % 8 || ldo % 8 || ((uintptr_t)out & 15) || ((const void*)src == out && lds != ldo)) return EMAGE_EINVAL;
-        hipLaunchKernelGGL(cast_pad_h2_kernel, dim3(grid_for((long)M * n_store / 8)), block, 0, s, src, lds, (h2_t*)out, ldo, n_store, M, C);
+        hipLaunchKernelGGL(cast_pad_h2_kernel, dim3(grid_for((long)M * n_store / 8)), block, 0, s, src, lds, (h2_t*)out, ldo, n_store, M, C, hs.s);
     } else return EMAGE_EINVAL;
     return launch_status();
 }

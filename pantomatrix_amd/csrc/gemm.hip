@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "gemm_tile.h"
+#include "h2.h"
 
 namespace emage_dev {
 #ifdef EMAGE_TOOLS
@@ -351,6 +352,7 @@ int make_args(GemmArgs& a, int dtype, const void* A, int lda, const void* W, con
     const bool split = dtype == EMAGE_F16X3 || dtype == EMAGE_H2;
     a.a_scale = split ? a_scale : 1.f;
     a.o_scale = split ? 1.f / (a_scale * w_scale) : 1.f;
+    a.h2s = emage_dev::H2_SCALE; a.h2i = emage_dev::H2_INV;
     return 0;
 }
 
@@ -388,9 +390,12 @@ extern "C" int emage_gemm(int dtype, const void* A, int lda, const void* W, cons
                           int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
                           float a_scale, float w_scale, void* stream) {
     GemmArgs a;
+    emage_dev::H2Scale hs;
+    if (emage_dev::h2_dtype(dtype, hs)) return EMAGE_EINVAL;
     const int rc = make_args(a, dtype, A, lda, W, bias, slope, res, ldr, res_is_f32, res_first, out, ldo, n_store, out_f32, ldf, out_t, t_col0, t_rows, t_ld,
                              M, N, Cp, taps, stride, pad, Lin, Lout, a_scale, w_scale);
     if (rc) return rc;
+    a.h2s = hs.s; a.h2i = hs.inv;
     return dispatch_one(dtype, a, (hipStream_t)stream);
 }
 
@@ -403,9 +408,12 @@ extern "C" int emage_gemm_ws(int dtype, const void* A, int lda, const void* W, c
                              int M, int N, int Cp, int taps, int stride, int pad, int Lin, int Lout,
                              float a_scale, float w_scale, void* workspace, size_t workspace_bytes, void* stream) {
     GemmArgs a;
+    emage_dev::H2Scale hs;
+    if (emage_dev::h2_dtype(dtype, hs)) return EMAGE_EINVAL;
     const int rc = make_args(a, dtype, A, lda, W, bias, slope, res, ldr, res_is_f32, res_first, out, ldo, n_store, out_f32, ldf, out_t, t_col0, t_rows, t_ld,
                              M, N, Cp, taps, stride, pad, Lin, Lout, a_scale, w_scale);
     if (rc) return rc;
+    a.h2s = hs.s; a.h2i = hs.inv;
     if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 16)) return EMAGE_EINVAL;
     if (workspace && dtype == EMAGE_H2) {
         a.ws = (float*)workspace;
@@ -418,6 +426,8 @@ namespace {
 int grouped(int dtype, const emage_gemm_problem* problems, int n_problems, hipStream_t s, bool count_only) {
     constexpr int MAX_PROBLEMS = 64;
     if (!problems || n_problems <= 0 || n_problems > MAX_PROBLEMS) return EMAGE_EINVAL;
+    emage_dev::H2Scale hs;
+    if (emage_dev::h2_dtype(dtype, hs)) return EMAGE_EINVAL;
     GemmArgs args[MAX_PROBLEMS];
     for (int i = 0; i < n_problems; ++i) {         // every problem is checked before the first launch
         const emage_gemm_problem& q = problems[i];
@@ -425,6 +435,7 @@ int grouped(int dtype, const emage_gemm_problem* problems, int n_problems, hipSt
                                  q.out_f32, q.ldf, q.out_t, q.t_col0, q.t_rows, q.t_ld, q.M, q.N, q.Cp, q.taps, q.stride, q.pad, q.Lin, q.Lout,
                                  q.a_scale, q.w_scale);
         if (rc) return rc;
+        args[i].h2s = hs.s; args[i].h2i = hs.inv;
         const int rf = apply_fold(dtype, args[i], q);
         if (rf) return rf;
         if (q.sk_ws && q.sk_count && dtype == EMAGE_H2) {      // split-K fix-up workspace (optional: the dispatch decides)

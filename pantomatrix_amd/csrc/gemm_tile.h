@@ -22,6 +22,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int dbg;
     float a_scale, o_scale;   // split-f16 mode: A is multiplied by a_scale before the hi/lo split, accumulators by o_scale after the K-loop
+    float h2s, h2i;           // EMAGE_H2: the scale of the activation IMAGES this launch writes (`out`) and reads as its residual, and its inverse (csrc/h2.h: 16 unless the dtype code carries a shift)
     float* cstate; int ldc;   // EPI_LSTM: the (M, N/4) cell state, updated in place
     int ksplit, nk_split;        // EMAGE_H2 split-K (gemm_h2.hip): > 1 K-slices of nk_split K-tiles each; partial tiles atomically added into out_f32,
     float* ws; long ws_plane; int ldws;   // ... or (ws != NULL, emage_gemm_ws) stored as plane `slice` of the workspace — (M, ldws) fp32 each, ws_plane

@@ -219,8 +219,8 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
                     if constexpr (W == 8) load8<float>((const float*)p.res + (long)m * p.ldr + n, rv);
                     else { const float4 t = *(const float4*)((const float*)p.res + (long)m * p.ldr + n); rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w; }
                 } else {
-                    if constexpr (W == 8) h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, rv);
-                    else h2_load4((const h2_t*)p.res + (long)m * p.ldr + n, n, rv);
+                    if constexpr (W == 8) h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, rv, p.h2i);
+                    else h2_load4((const h2_t*)p.res + (long)m * p.ldr + n, n, rv, p.h2i);
                 }
             }
         } else {
@@ -237,8 +237,8 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
 #pragma unroll
                     for (int e = 0; e < W; ++e) t[e] = n + e < ncol_n ? ((const float*)p.res)[(long)m * p.ldr + n + e] : 0.f;
                 } else {
-                    if constexpr (W == 8) h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, t);
-                    else h2_load4((const h2_t*)p.res + (long)m * p.ldr + n, n, t);
+                    if constexpr (W == 8) h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, t, p.h2i);
+                    else h2_load4((const h2_t*)p.res + (long)m * p.ldr + n, n, t, p.h2i);
                 }
 #pragma unroll
                 for (int e = 0; e < W; ++e) rv[e] = n + e < ncol_n ? t[e] : 0.f;
@@ -272,8 +272,8 @@ __device__ __forceinline__ void h2_tile_epilogue(const GemmArgs& p, f32x4 (&acc)
         }
         if (out && n < n_lim) {
             // out rows are padded to a multiple of 8 columns (host contract): the whole group is always addressable
-            if constexpr (W == 8) h2_store8(out + (long)m * p.ldo + n, v);
-            else h2_store4(out + (long)m * p.ldo + n, n, v);
+            if constexpr (W == 8) h2_store8(out + (long)m * p.ldo + n, v, p.h2s);
+            else h2_store4(out + (long)m * p.ldo + n, n, v, p.h2s);
         }
         if constexpr (LNF && W == 8 && FN == 2 && !NAT) {
             if (p.st_out) {                             // partial row statistics of the 32 columns this wave holds of row m: 8 per lane, 4 lanes (fg) per row
@@ -472,7 +472,7 @@ __device__ __forceinline__ void gemm_h2_tile(const GemmArgs& p, const int m0, co
                 for (int e = 0; e < 8; ++e) pre_r[i][jp][e] = 0.f;
                 if (is_compute && !vt_tile && p.res && m < p.M && n + 8 <= ncol_n) {
                     if (p.res_is_f32) load8<float>((const float*)p.res + (long)m * p.ldr + n, pre_r[i][jp]);
-                    else h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, pre_r[i][jp]);
+                    else h2_load8((const h2_t*)p.res + (long)m * p.ldr + n, pre_r[i][jp], p.h2i);
                 }
             }
         }

@@ -42,7 +42,7 @@ __device__ __forceinline__ void layernorm_row_load(const T* __restrict__ xp, int
 template <typename T, int MAXV>
 __device__ __forceinline__ void layernorm_row_finish(const float4 (&v)[MAXV], const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, const T* __restrict__ addp, float* __restrict__ yfp, T* __restrict__ yp,
-                                                     int C, int lane, h2_t* __restrict__ yhp = nullptr) {
+                                                     int C, int lane, h2_t* __restrict__ yhp = nullptr, float h2s = H2_SCALE) {
     const int nv = C >> 2;
     float s = 0.f;
 #pragma unroll
@@ -75,7 +75,7 @@ __device__ __forceinline__ void layernorm_row_finish(const float4 (&v)[MAXV], co
             if (addp) { const float4 a = Vec4<T>::load(addp + 4 * j); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
             if (yfp) ((float4*)yfp)[j] = o;
             if (yp) Vec4<T>::store(yp + 4 * j, o);
-            if (yhp) { const float o4[4] = {o.x, o.y, o.z, o.w}; h2_store4(yhp + 4 * j, 4 * j, o4); }   // EMAGE_H2 copy (csrc/h2.h): half a group per lane
+            if (yhp) { const float o4[4] = {o.x, o.y, o.z, o.w}; h2_store4(yhp + 4 * j, 4 * j, o4, h2s); }   // EMAGE_H2 copy (csrc/h2.h): half a group per lane
         }
     }
 }
@@ -83,10 +83,10 @@ __device__ __forceinline__ void layernorm_row_finish(const float4 (&v)[MAXV], co
 template <typename T, int MAXV>
 __device__ __forceinline__ void layernorm_row(const T* __restrict__ xp, const float* __restrict__ gamma, const float* __restrict__ beta,
                                               float eps, const T* __restrict__ addp, float* __restrict__ yfp, T* __restrict__ yp,
-                                              int C, int lane, h2_t* __restrict__ yhp = nullptr) {
+                                              int C, int lane, h2_t* __restrict__ yhp = nullptr, float h2s = H2_SCALE) {
     float4 v[MAXV];
     layernorm_row_load<T, MAXV>(xp, C, lane, v);
-    layernorm_row_finish<T, MAXV>(v, gamma, beta, eps, addp, yfp, yp, C, lane, yhp);
+    layernorm_row_finish<T, MAXV>(v, gamma, beta, eps, addp, yfp, yp, C, lane, yhp, h2s);
 }
 
 }  // namespace emage_dev

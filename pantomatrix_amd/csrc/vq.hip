@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void gather_rows(const float* __restrict__ tab
 
 // EMAGE_H2 output (csrc/h2.h): one thread per group of 8 columns
 __global__ __launch_bounds__(128) void gather_rows_h2(const float* __restrict__ table, const int64_t* __restrict__ idx, IdxView iv,
-                                                      emage_dev::h2_t* __restrict__ out, int ldo, int n_store, int N, int K, int D) {
+                                                      emage_dev::h2_t* __restrict__ out, int ldo, int n_store, int N, int K, int D, float h2s) {
     const int row = blockIdx.x;
     long k = idx[idx_at(iv, row)];
     k = k < 0 ? 0 : (k >= K ? K - 1 : k);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(128) void gather_rows_h2(const float* __restrict__ 
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 8 * g + e < D ? table[k * D + 8 * g + e] : 0.f;
-        emage_dev::h2_store8(out + (long)row * ldo + 8 * g, v);
+        emage_dev::h2_store8(out + (long)row * ldo + 8 * g, v, h2s);
     }
 }
 
@@ -294,13 +294,15 @@ extern "C" int emage_gather_rows(const float* table, const int64_t* idx, int idx
                                  void* out, int ldo, int n_store, int N, int K, int D, int dtype, void* stream) {
     if (!table || !idx || !out || N <= 0 || K <= 0 || D <= 0 || n_store < D || ldo < n_store) return EMAGE_EINVAL;
     if (idx_rows > 0 && (N % idx_rows != 0 || idx_tstride < 0 || idx_tstride > 1)) return EMAGE_EINVAL;
+    emage_dev::H2Scale hs;
+    if (emage_dev::h2_dtype(dtype, hs)) return EMAGE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const IdxView iv{idx_rows, idx_ld, idx_tstride};
     if (dtype == EMAGE_BF16) hipLaunchKernelGGL((gather_rows<bf16_t>), dim3(N), dim3(128), 0, s, table, idx, iv, (bf16_t*)out, ldo, n_store, N, K, D);
     else if (dtype == EMAGE_F32) hipLaunchKernelGGL((gather_rows<float>), dim3(N), dim3(128), 0, s, table, idx, iv, (float*)out, ldo, n_store, N, K, D);
     else if (dtype == EMAGE_H2) {
         if (n_store % 8 || ldo % 8 || ((uintptr_t)out & 15)) return EMAGE_EINVAL;
-        hipLaunchKernelGGL(gather_rows_h2, dim3(N), dim3(128), 0, s, table, idx, iv, (emage_dev::h2_t*)out, ldo, n_store, N, K, D);
+        hipLaunchKernelGGL(gather_rows_h2, dim3(N), dim3(128), 0, s, table, idx, iv, (emage_dev::h2_t*)out, ldo, n_store, N, K, D, hs.s);
     } else return EMAGE_EINVAL;
     return launch_status();
 }

@@ -86,6 +86,10 @@ class _EmageModule(torch.nn.Module):
                                                # LayerNorm is a launch (round 5's form).  Parity-green on every golden in both forms
         self.split_acts = True                 # f16x3 precision: activations that feed a contraction are stored PRE-SPLIT (EMAGE_H2,
                                                # csrc/h2.h) by their producers; False = float32 activations split inside every GEMM
+        self.activation_shift = 0              # EMAGE_H2 mode: activation images hold x * 2^(4 - shift) (include/emage_hip.h EMAGE_H2_SHIFT): 0 = the
+                                               # parity-green default (|x| < 4094); a checkpoint with larger activations runs with shift k
+                                               # (|x| < 4094 * 2^k) instead of leaving the split-fp16 path — `set_activation_shift`,
+                                               # `runtime.ClipRunner(on_overflow="rescale")`, `runtime.calibrate_activation_shift`
         self.group_gemms = True                # part-wise stacks (VQ part decoders, refinement layers + heads, ...) walk in lock step and
                                                # their contractions share launches (ops.lockstep / emage_gemm_grouped); False = one stream
                                                # lane per chain, one launch per contraction (the round-3 form; same bits)
@@ -194,6 +198,13 @@ class _EmageModule(torch.nn.Module):
                                       "train_emage_audio.py:233-245); the trainable class is EmageAudioModel")
         return super().train(mode)
 
+    def set_activation_shift(self, shift: int):
+        """See `activation_shift`.  Takes effect at the next forward (the packed weights do not change: their scales are per tensor already);
+        a captured graph keeps the shift it was captured with."""
+        ops.h2_shifted(shift)                  # validates the range
+        self.activation_shift = int(shift)
+        return self
+
     def set_precision(self, precision: str):
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
@@ -245,23 +256,26 @@ class _EmageModule(torch.nn.Module):
             raise RuntimeError("the EMAGE model classes run only on an MI355X device: call .to('cuda') first "
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests only)")
 
-    def _engine(self, h2=None, train_only=False):
+    def _engine(self, h2=None, train_only=False, lin_h2=False):
         """The packed operand set of the current precision.  h2 (f16x3 only): pre-split EMAGE_H2 operands (default: `split_acts`);
         the training forward asks for h2=False (float32 activations, weights in the EMAGE_F16X3 packing) and train_only=True: `_pack` may
         then leave out operands only the eval-mode forward reads (a training step re-packs behind every update); such a set is never
-        handed to an eval-mode caller."""
+        handed to an eval-mode caller.  lin_h2 (f16x3, h2=False, train_only): the Linear / in_proj entries alone are EMAGE_H2 images —
+        the training forward hands those contractions pre-split operands (`training.TrainForward.h2_forward`) and keeps float32 storage."""
         dev = self.device
         self._require_device(dev)
         want_h2 = self._dt == F16X3 and self._supports_h2 and (self.split_acts if h2 is None else h2)
         dt = H2 if want_h2 else self._dt
+        lin_dt = H2 if (lin_h2 and train_only and dt == F16X3 and self._supports_h2) else dt
         stamp = self._version_stamp()
         if (self._packed is None or self._packed.device != dev or self._packed.dt != dt or self._packed.stamp != stamp
-                or (self._packed.train_only and not train_only)):
+                or self._packed.lin_dt != lin_dt or (self._packed.train_only and not train_only)):
             capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
             for attempt in (0, 1):
                 # the scale cache is keyed by packing ORDER: a train-only set (fewer operands) keeps its own
-                cache = self.__dict__.setdefault("_scale_caches", {}).setdefault((str(dev), dt, bool(train_only)), {})
-                pk = _Packed(self._flat_params(), dev, dt, cache)
+                ckey = (str(dev), dt, bool(train_only)) + ((lin_dt,) if lin_dt != dt else ())
+                cache = self.__dict__.setdefault("_scale_caches", {}).setdefault(ckey, {})
+                pk = _Packed(self._flat_params(), dev, dt, cache, lin_dt=lin_dt)
                 pk.stamp, pk.train_only = stamp, bool(train_only)
                 self._pack(pk)
                 pk.finish_range_check()
@@ -269,10 +283,11 @@ class _EmageModule(torch.nn.Module):
                 # was replaced): choose the scales afresh.  Outside a stream capture only (the flag is read on the host); a training step
                 # (`training.Trainer`, eager or captured) leaves the flag unread here and reads it with its losses
                 if attempt == 0 and not capturing and not self.__dict__.get("_defer_range_check") and pk.range_flag is not None and int(pk.range_flag) != 0:
-                    self.__dict__["_scale_caches"].pop((str(dev), dt, bool(train_only)), None)
+                    self.__dict__["_scale_caches"].pop(ckey, None)
                     continue
                 break
             self._packed = pk
+        self._packed.act_shift = int(self.activation_shift)
         return self._packed
 
     def _flat_params(self):
@@ -287,8 +302,10 @@ class _EmageModule(torch.nn.Module):
 # packed weights: MFMA-operand dtype, K-contiguous rows, taps flattened, BatchNorm folded
 # ======================================================================================
 class _Packed:
-    def __init__(self, params, device, dt, scale_cache=None):
+    def __init__(self, params, device, dt, scale_cache=None, lin_dt=None):
         self.p, self.device, self.dt = params, device, dt
+        self.act_shift = 0           # the owning module's `activation_shift` at the time the set was handed out (`_engine`): read by `_Ctx`
+        self.lin_dt = dt if lin_dt is None else lin_dt       # operand packing of the Linear / in_proj entries (`_engine(lin_h2=True)`: EMAGE_H2 beside F16X3)
         # split-fp16 operand scales by packing order: chosen (one read-back of max|w|) at the FIRST packing of a model's weights and kept for
         # every re-packing (after an optimiser step: a pure sequence of launches, capturable); cleared when a state dict is loaded
         self.scale_cache = {} if scale_cache is None else scale_cache
@@ -342,7 +359,7 @@ class _Packed:
         kp = _rup(k)
         if kp != k:
             w2d = torch.nn.functional.pad(w2d, (0, kp - k))
-        w, ws = self._operand(w2d)
+        w, ws = self._operand(w2d, self.lin_dt)
         return w, kp, ws
 
     def _fold_norm(self, wcat, bcat, norm):
@@ -370,7 +387,7 @@ class _Packed:
             wcat, bcat, c = self._fold_norm(wcat, bcat, fold)
             extra = dict(c=c, norm=fold)
         w, kp, wsc = self._pack_mat(wcat)
-        self.w[key] = dict(w=w, b=bcat, n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt, **extra)
+        self.w[key] = dict(w=w, b=bcat, n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.lin_dt, **extra)
         if fold is None:
             self.origin[key] = [(nm + ".weight", nm + ".bias", rows[i] if rows is not None else slice(0, self.p[nm + ".weight"].shape[0]))
                                 for i, nm in enumerate(names)]
@@ -397,7 +414,7 @@ class _Packed:
         else:
             self.origin[key] = origin
         w, kp, wsc = self._pack_mat(wcat)
-        self.w[key] = dict(w=w, b=bcat, n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.dt, **extra)
+        self.w[key] = dict(w=w, b=bcat, n=wcat.shape[0], cp=kp, taps=1, k_real=k_real, ws=wsc, dt=self.lin_dt, **extra)
 
     def folded(self, cname, bn=None):
         """Raw Conv1d (weight (Cout,Cin,k), bias) with an eval-mode BatchNorm1d folded in:
@@ -478,6 +495,11 @@ class _Ctx:
         self.pk, self.gdt, self.tdt, self.dev = pk, pk.dt, pk.tdt, pk.device
         self.h2 = pk.dt == H2                   # activations that feed a contraction are EMAGE_H2 images (float32-sized elements)
         self.dt = F32 if pk.dt == F16X3 else pk.dt
+        # h2dt: the dtype code of ACTIVATION images — EMAGE_H2 carrying the model's activation shift (`_EmageModule.activation_shift`,
+        # include/emage_hip.h EMAGE_H2_SHIFT): every launch that writes or reads one takes it; 0 (the default) is plain EMAGE_H2
+        self.h2dt = ops.h2_shifted(pk.act_shift if self.h2 else 0)
+        if self.h2:
+            self.gdt = self.dt = self.h2dt
         # WavEncoder: float32 activations in both split-f16 forms (its slab kernels split once per block in LDS)
         self.wgdt = pk.wav_dt
         self.wdt = F32 if pk.wav_dt == F16X3 else pk.wav_dt
@@ -499,6 +521,9 @@ class _Ctx:
         res_h2: the residual is an H2 image too, else float32)."""
         e = w if w is not None else self.pk.w[key]
         dt = e.get("dt", self.gdt) if dt is None else dt
+        if dt == H2:
+            dt = self.h2dt
+        h2 = dt & 0xff == H2
         m = a.shape[0] if m is None else m
         n = e["n"]
         if out is None and out_t is None and want in ("lo", "both"):
@@ -511,11 +536,11 @@ class _Ctx:
             stride, pad, lin, lout = conv
             kw = dict(taps=e["taps"], stride=stride, pad=pad, lin=lin, lout=lout)
         sk = ops._SPLITK[0]
-        if sk is not None and dt == H2 and m <= ops.SPLITK_MAX_ROWS and self.dev.type == "cuda":
+        if sk is not None and h2 and m <= ops.SPLITK_MAX_ROWS and self.dev.type == "cuda":
             kw["splitk"] = sk.get(self.dev)       # few rows (ONE clip: 64): the launch may split its K range (ops.SplitKScratch)
         ops.gemm(dt, a, e["w"], e["b"], sl, res, out, out_f32, out_t, n=n, cp=e["cp"], n_store=n_store,
                  t_col0=t_col0, t_rows=t_rows, res_first=res_first, m=m, k_real=e.get("k_real"), w_scale=e.get("ws", 1.0),
-                 res_h2=bool(res_h2 and dt == H2), **kw, **({} if (ln is None and res_ln is None and stats_out is None)
+                 res_h2=bool(res_h2 and h2), **kw, **({} if (ln is None and res_ln is None and stats_out is None)
                                                             else dict(ln=ln, res_ln=res_ln, stats_out=stats_out)))
         return out, out_f32
 
@@ -738,6 +763,15 @@ class EmageVQModel(torch.nn.Module):
         for m in self._models():
             m.set_precision(precision)
         return self
+
+    def set_activation_shift(self, shift):
+        for m in self._models():
+            m.set_activation_shift(shift)
+        return self
+
+    @property
+    def activation_shift(self):
+        return max(m.activation_shift for m in self._models())
 
     @property
     def precision(self):
@@ -1148,11 +1182,11 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             return _X(s.img, s.img, True, ln=(s.stats, key))
         y = cx.lo(*s.shape)
         if cx.h2 and cx.h2res and not want_f32:
-            ops.layernorm(H2, s, n["g"], n["b"], 1e-5, add, None, y)
+            ops.layernorm(cx.h2dt, s, n["g"], n["b"], 1e-5, add, None, y)
             return _X(y, y, True)
         if cx.h2:
             yf = cx.f32(*s.shape)
-            ops.layernorm(H2, s, n["g"], n["b"], 1e-5, add, yf, y)
+            ops.layernorm(cx.h2dt, s, n["g"], n["b"], 1e-5, add, yf, y)
             return _X(y, yf)
         ops.layernorm(cx.dt, s, n["g"], n["b"], 1e-5, add, None, y)
         return _X(y, y)
@@ -1220,12 +1254,12 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
             if ta > t:  # tail windows: face features trimmed to T, body features keep T' = T+1 (M:278-281, sic)
                 feats["memcat"][:, :af] = a_face.view(b, ta, af)[:, :t].reshape(m, af)
             if cx.h2:   # the WavEncoder writes float32: convert the face-feature columns of the concatenation in place
-                ops.cast_pad(H2, feats["memcat"][:, :af], af, out=feats["memcat"][:, :af])
+                ops.cast_pad(cx.h2dt, feats["memcat"][:, :af], af, out=feats["memcat"][:, :af])
         with fk.lane(lane_body):
             a_body = self._wav_encoder_chain(cx, "audio_encoder_body", 1, y0, b, lens, **wkw)
             if use_audio:
                 if cx.h2:
-                    a_body = ops.cast_pad(H2, a_body, a_body.shape[1])
+                    a_body = ops.cast_pad(cx.h2dt, a_body, a_body.shape[1])
                 mem_body, _ = cx.gemm(a_body, "audio_body_motion_proj")                 # M:303
                 feats["bk"], feats["bvt"] = self._memory_kv(cx, "cross.kv_all", mem_body, b, ta, nc)
         feats["_keep"] = (y0, a_face, a_body)       # cross-lane operands stay alive until the caller's join
@@ -1243,7 +1277,7 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
         face0, pos_spk = cx.lo(m, d), (cx.f32(m, d) if cx.h2 else cx.lo(m, d))
         if cx.h2:       # face0 enters the face decoder as operand AND residual; pos_spk is only ever added (residual precision)
             face0_r = cx.f32(m, d)
-            ops.add(H2, spk_face, pe, out_f32=face0_r, out=face0, mod_b=t)
+            ops.add(cx.h2dt, spk_face, pe, out_f32=face0_r, out=face0, mod_b=t)
             ops.add(F32, spk_body, pe, out=pos_spk, mod_b=t)
             face0 = _X(face0, face0_r)
         else:
@@ -1378,7 +1412,7 @@ class EmageAudioModel(_WavEncoderMixin, _EmageModule):
                 tgt, mem_lo = cx.lo(m, d), cx.lo(m, d)
                 if cx.h2:
                     tgt_r = cx.f32(m, d)
-                    ops.add(H2, lat[p], spk_body, out_f32=tgt_r, out=tgt)
+                    ops.add(cx.h2dt, lat[p], spk_body, out_f32=tgt_r, out=tgt)
                     tgt = _X(tgt, tgt_r)
                 else:
                     ops.add(cx.dt, lat[p], spk_body, out=tgt)

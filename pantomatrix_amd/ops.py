@@ -139,7 +139,7 @@ class Lockstep:
 
     @staticmethod
     def _groupable(entry):
-        return entry[0] == "gemm" and entry[2][0] == H2
+        return entry[0] == "gemm" and entry[2][0] & 0xff == H2
 
     def _issue(self, entry):
         _fire(entry[0], [entry], lambda: entry[1](*entry[2]))
@@ -206,8 +206,28 @@ def lockstep(enabled=True):
 
 # storage type of activations per precision code; F16X3 is a GEMM-only operand mode over float32 storage
 # H2: the pre-split storage of the split-fp16 mode (csrc/h2.h) — float32-sized elements, 32-byte groups of 8 columns = [8 fp16 hi | 8 fp16 lo]
-TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32, H2: torch.float32}
+class _TorchDtypes(dict):
+    def __missing__(self, code):             # EMAGE_H2 with an activation shift (`h2_shifted`): the storage type of the plain code
+        return self[code & 0xff]
+
+
+TORCH_DTYPE = _TorchDtypes({F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32, H2: torch.float32})
 A_SCALE_F16X3 = 16.0    # activations are multiplied by this power of two before the fp16 hi/lo split (|x| < 4094 stays finite)
+MAX_ACT_SHIFT = 12
+
+
+def h2_shifted(shift):
+    """The dtype code EMAGE_H2_SHIFT(k) (include/emage_hip.h): activation images hold x * 2^(4 - k) — a model whose activations pass 4094
+    runs its split-fp16 path with k > 0 (|x| < 4094 * 2^k) instead of overflowing the fp16 hi plane; k = 0 is plain EMAGE_H2."""
+    shift = int(shift)
+    if not 0 <= shift <= MAX_ACT_SHIFT:
+        raise ValueError(f"activation shift {shift}: 0..{MAX_ACT_SHIFT}")
+    return H2 | (shift << 8)
+
+
+def act_scale(dtype):
+    """The scale of the activation images of a dtype code (16 for plain EMAGE_H2 / EMAGE_F16X3)."""
+    return A_SCALE_F16X3 * 2.0 ** -(dtype >> 8)
 
 
 def split_f16_weights(w2d, scale=None):
@@ -554,24 +574,24 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
     if workspace is not None:
         assert workspace.is_contiguous() and workspace.device == a.device
         _gemm_ws(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
-                 lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2), workspace)
+                 lin, lout, m, float(w_scale), float(act_scale(dtype) if a_scale is None else a_scale), bool(res_h2), workspace)
         return
     if ln is None and res_ln is None and stats_out is None and splitk is None:
         _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
-              lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2))
+              lin, lout, m, float(w_scale), float(act_scale(dtype) if a_scale is None else a_scale), bool(res_h2))
         return
     # LayerNorm fold (include/emage_hip.h: emage_gemm_problem): ln = (row statistics of `a`, c) — `a` is the RAW pre-norm sum, `w` / `bias` the
     # folded W gamma / W beta + b; res_ln = (row statistics of `res`, gamma, beta) — `res` is the raw sum of a folded LayerNorm; stats_out: the
     # (M, n / 32, 2) partial row statistics of this launch's output
     # splitk = (scratch (float32, contiguous), counters (int32, ZERO, left zero)): lets a launch of few rows cut its K range into slices that meet
     # inside the launch (emage_gemm_problem: sk_ws / sk_count); launches on one stream may share the pair
-    assert dtype == H2 and workspace is None
+    assert dtype & 0xff == H2 and workspace is None
     ln_stats, ln_c = ln if ln is not None else (None, None)
     rs_stats, rs_gamma, rs_beta = res_ln if res_ln is not None else (None, None, None)
     sk_ws, sk_count = splitk if splitk is not None else (None, None)
     assert sk_ws is None or (sk_ws.is_contiguous() and sk_count.is_contiguous() and sk_count.dtype == torch.int32)
     _gemm(dtype, a, w, bias, slope, res, out, out_f32, out_t, n, cp, n_store, t_col0, t_rows, bool(res_first), taps, stride, pad,
-          lin, lout, m, float(w_scale), float(A_SCALE_F16X3 if a_scale is None else a_scale), bool(res_h2),
+          lin, lout, m, float(w_scale), float(act_scale(dtype) if a_scale is None else a_scale), bool(res_h2),
           ln_stats, ln_c, rs_stats, rs_gamma, rs_beta, stats_out, float(ln_eps), sk_ws, sk_count)
 
 
@@ -1305,7 +1325,7 @@ def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0, h2_operan
     for bit, t in enumerate((a, b, c)):
         if t is not None:
             assert t.dtype in (torch.float32, TORCH_DTYPE[dtype])
-            if dtype == H2:
+            if dtype & 0xff == H2:
                 mask |= 0 if bit in h2_operands else (1 << bit)
             else:
                 mask |= (1 << bit) if t.dtype == torch.float32 else 0

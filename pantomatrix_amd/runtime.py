@@ -19,19 +19,51 @@ import torch
 from . import ops
 
 
+RESCALE_STEP = 4          # on_overflow="rescale": the twin's activation images hold x instead of 16 x (16x the range, 4 bits off the smallest values' lo plane)
+
+
+def calibrate_activation_shift(model, vq_model, audio, speaker_id=None, margin: int = 1, max_shift: int = 8):
+    """Choose the EMAGE_H2 activation shift of a checkpoint from a calibration batch: the smallest k at which `audio` (B, samples) runs the
+    split-fp16 path without a non-finite value (the on-device health check of `ClipRunner`), plus `margin` bits of headroom when k > 0;
+    k = 0 — the parity-green default — is kept whenever it suffices.  Sets the shift on both models and returns it; raises if even
+    `max_shift` overflows (run such a checkpoint in fp32)."""
+    audio = torch.as_tensor(audio, dtype=torch.float32)
+    if audio.dim() == 1:
+        audio = audio[None]
+    for k in range(0, max_shift + 1):
+        runner = ClipRunner(model, vq_model, audio.shape[0], audio.shape[1], use_graph=False, warmup=1, activation_shift=k)
+        try:
+            runner(audio.to(model.device), speaker_id)
+        except FloatingPointError:
+            continue
+        k = min(k + (margin if k else 0), ops.MAX_ACT_SHIFT)
+        model.set_activation_shift(k)
+        vq_model.set_activation_shift(k)
+        return k
+    raise FloatingPointError(f"calibrate_activation_shift: non-finite values up to shift {max_shift} — run this checkpoint with set_precision('fp32')")
+
+
 class ClipRunner:
     def __init__(self, model, vq_model, batch: int, n_samples: int, use_graph: bool = True, warmup: int = 2,
-                 sub_batches: int = 1, main_priority: bool = False, on_overflow: str = "raise", split_k: bool = False):
+                 sub_batches: int = 1, main_priority: bool = False, on_overflow: str = "raise", split_k: bool = False,
+                 activation_shift: int | None = None):
         """main_priority (experiment): capture on a HIGH-priority stream, so the launch chain issued on lane 0 (the critical
         path: motion encoder -> body stack -> decode) outranks the side lanes (face decoder, WavEncoders) when both have
         ready kernels — if the runtime's graph kernel nodes inherit the capturing stream's priority.
         on_overflow: what `__call__` does with a batch whose health counter is non-zero (in f16x3: an activation beyond the split-fp16
         range) — "raise" (FloatingPointError) or "fp32": run THAT batch again through an exact-fp32 twin of this runner (built on
-        first use: +26 ms per affected batch instead of an error; `fallbacks` counts them); a batch that is non-finite in fp32 too raises."""
-        if on_overflow not in ("raise", "fp32"):
-            raise ValueError("on_overflow must be 'raise' or 'fp32'")
+        first use: +26 ms per affected batch instead of an error; `fallbacks` counts them); a batch that is non-finite in fp32 too raises;
+        or "rescale" (f16x3): run that batch again on the SAME split-fp16 path with the activation images scaled down by 2^RESCALE_STEP
+        (`activation_shift` + 4: |x| < 65 504 instead of 4 094; a twin runner built on first use, `rescales` counts them) and only a batch
+        that overflows there too goes to the fp32 twin — a checkpoint with large pre-norm sums stays on the fast path.
+        activation_shift: the EMAGE_H2 activation shift THIS runner's launches use (None: the model's current `activation_shift`)."""
+        if on_overflow not in ("raise", "fp32", "rescale"):
+            raise ValueError("on_overflow must be 'raise', 'fp32' or 'rescale'")
         self.model, self.vq = model, vq_model
         self.on_overflow, self.fallbacks, self._fp32_twin = on_overflow, 0, None
+        self.rescales, self._rescaled_twin = 0, None
+        self.shift = int(model.activation_shift if activation_shift is None else activation_shift)
+        ops.h2_shifted(self.shift)
         self.precision = model.precision             # what THIS runner's launches compute in (the models may be re-packed later)
         self._args = dict(batch=batch, n_samples=n_samples, use_graph=use_graph, warmup=warmup, split_k=split_k)
         dev = model.device
@@ -44,7 +76,7 @@ class ClipRunner:
         self.device, self.batch, self.sub = dev, batch, sub_batches
         self.children, self.streams = [], []
         if sub_batches > 1:
-            self.children = [ClipRunner(model, vq_model, batch // sub_batches, n_samples, use_graph, warmup, 1)
+            self.children = [ClipRunner(model, vq_model, batch // sub_batches, n_samples, use_graph, warmup, 1, activation_shift=self.shift)
                              for _ in range(sub_batches)]
             self.streams = [torch.cuda.Stream(device=dev) for _ in range(sub_batches)]
             self.frames_out = self.children[0].frames_out
@@ -84,12 +116,19 @@ class ClipRunner:
         # codes) and among the results — e.g. an activation beyond the f16x3 range
         self.nonfinite.zero_()
         self.model.health_pending = pending = []
-        with ops.splitk_scope(self.splitk):
-            try:
-                codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
-            finally:
-                self.model.health_pending = None
-            pred = self.vq.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
+        was = (self.model.activation_shift, self.vq.activation_shift)
+        self.model.set_activation_shift(self.shift)          # this runner's own (a rescaled twin differs from the models' setting)
+        self.vq.set_activation_shift(self.shift)
+        try:
+            with ops.splitk_scope(self.splitk):
+                try:
+                    codes = self.model.infer_codes(self.audio, self.speaker_id, self.vq)
+                finally:
+                    self.model.health_pending = None
+                pred = self.vq.decode(**codes, get_global_motion=True, ref_trans=self.ref_trans)
+        finally:
+            self.model.set_activation_shift(was[0])
+            self.vq.set_activation_shift(was[1])
         out = pred["motion_axis_angle"], pred["expression"], pred["trans"]
         ops.count_nonfinite_multi(pending + [t.contiguous() for t in out], self.nonfinite)      # ONE launch (round 5: 11)
         return out
@@ -119,7 +158,9 @@ class ClipRunner:
             self._to_host(self.host)
             self.nonfinite_host.copy_(self.nonfinite, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
-            if int(self.nonfinite_host[0]) and self.on_overflow == "fp32" and self.precision != "fp32":
+            if int(self.nonfinite_host[0]) and self.on_overflow == "rescale" and self.precision == "f16x3" and self.shift + RESCALE_STEP <= ops.MAX_ACT_SHIFT:
+                return self._run_rescaled()
+            if int(self.nonfinite_host[0]) and self.on_overflow in ("fp32", "rescale") and self.precision != "fp32":
                 return self._run_in_fp32()
             self._raise_if_nonfinite()
             return tuple(h.numpy() for h in self.host)
@@ -139,6 +180,18 @@ class ClipRunner:
         for child in self.children:
             child._raise_if_nonfinite()
         return tuple(h.numpy() for h in self.host)
+
+    def _run_rescaled(self):
+        """The batch in `self.audio` / `self.speaker_id` again through a twin of this runner whose activation images are scaled down by
+        2^RESCALE_STEP (same packed weights, its own graph, built at the first overflow); a batch that overflows there too leaves the
+        split-fp16 path through the twin's own fp32 re-run."""
+        self.rescales += 1
+        if self._rescaled_twin is None:
+            self._rescaled_twin = ClipRunner(self.model, self.vq, on_overflow="fp32", activation_shift=self.shift + RESCALE_STEP, **self._args)
+        out = self._rescaled_twin(self.audio, self.speaker_id)
+        self.fallbacks += self._rescaled_twin.fallbacks - getattr(self, "_twin_fallbacks_seen", 0)
+        self._twin_fallbacks_seen = self._rescaled_twin.fallbacks
+        return out
 
     def _run_in_fp32(self):
         """The batch in `self.audio` / `self.speaker_id` again through an exact-fp32 twin runner (same weights; its own packed operands and

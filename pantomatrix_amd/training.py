@@ -229,6 +229,12 @@ class TrainForward:
         # a power of two so that their fp16 planes stay normal (the loss-scaling of mixed-precision training, undone exactly in the
         # GEMM epilogue); fp32 precision keeps the exact-fp32 MFMA contractions
         self.h2_backward = model.precision == "f16x3"
+        # h2_forward (round 6, A/B switch, OFF: measured 89.7-90.1 vs 87.5-89.3 ms per step): the forward's Linear contractions on EMAGE_H2 operands too —
+        # weights packed as H2 images (`_engine(lin_h2=True)`), a LayerNorm writes the image of its result beside the float32 tensor, every other
+        # operand is split by one `h2_cast` launch in front of its contraction; the float32 tensors the backward reads are unchanged.  The H2
+        # contractions save 2.5 ms per step against the in-kernel split of EMAGE_F16X3, the 237 cast launches cost 3.5 (profiles/r06_train_h2_forward_ab.txt)
+        self.h2_forward = False
+        self._h2img = {}                # id(float32 operand) -> (operand, its EMAGE_H2 image), filled by the producers that write one
         self.grad_scale = 1024.0
         self.conv_backward_rows = 1 << 17                 # output rows per piece of a long convolution's backward (_conv_backward_h2)
         self._w_scale, self._wt_cache = {}, {}
@@ -632,9 +638,27 @@ class TrainForward:
         return h
 
     # ---- differentiable pieces: each wrapper launches the forward op and, when a tape is attached, records its backward -----------
+    def _image(self, x, e):
+        """The EMAGE_H2 image of the float32 operand x for the packed Linear entry e: the one its producer wrote (`_layernorm`), else one cast launch."""
+        hit = self._h2img.pop(id(x), None)
+        if hit is not None and hit[0] is x and hit[1].shape[1] >= e["cp"]:
+            return hit[1]
+        k = e["k_real"]
+        return ops.h2_cast(x if x.shape[1] == k else x[:, :k], e["cp"])
+
+    def _gemm_fwd(self, cx, x, key, slope=None, out=None, **kw):
+        """One forward Linear: float32 in, float32 out; on pre-split operands when the entry is an EMAGE_H2 packing (`h2_forward`)."""
+        e = cx.pk.w[key]
+        if e.get("dt") != H2:
+            return cx.gemm(x, key, slope=slope, out=out, **kw)[0]
+        if out is None and kw.get("out_t") is None:
+            out = cx.f32(x.shape[0], e["n"])
+        cx.gemm(self._image(x, e), key, slope=slope, out_f32=out, want=None, **kw)
+        return out
+
     def _lin(self, cx, x, key, slope=None, out=None, need_dx=True):
         """y = act(x W^T + b) through emage_gemm (one fp32 output used both as the next operand and as the result)."""
-        y, _ = cx.gemm(x, key, slope=slope, out=out)
+        y = self._gemm_fwd(cx, x, key, slope=slope, out=out)
         if self.tape is not None:
             self.tape.node(lambda: self._lin_backward(cx, x, key, slope, y, y, need_dx))
         return y
@@ -645,7 +669,7 @@ class TrainForward:
         n = cx.pk.w[key]["n"]
         first = cx.lo(x.shape[0], n_first)
         vt = cx.vt_buffer(b, n - n_first, t_rows)
-        cx.gemm(x, key, out=first, out_t=vt, t_col0=n_first, t_rows=t_rows)
+        self._gemm_fwd(cx, x, key, out=first, out_t=vt, t_col0=n_first, t_rows=t_rows)
         token = _Token((x.shape[0], n))
         if self.tape is not None:
             self.tape.node(lambda: self._lin_backward(cx, x, key, None, token, None, True))
@@ -876,7 +900,12 @@ class TrainForward:
     def _layernorm(self, cx, key, s_in):
         n = cx.pk.w[key]
         y = cx.lo(*s_in.shape)
-        ops.layernorm(cx.dt, s_in, n["g"], n["b"], 1e-5, None, None, y)
+        if self.h2_forward and s_in.shape[1] % 64 == 0:      # the result feeds a Linear: its EMAGE_H2 image leaves the same launch
+            img = cx.f32(*s_in.shape)
+            ops.layernorm(H2, s_in, n["g"], n["b"], 1e-5, None, y, img)
+            self._h2img[id(y)] = (y, img)
+        else:
+            ops.layernorm(cx.dt, s_in, n["g"], n["b"], 1e-5, None, None, y)
         if self.tape is not None:
             def bw():
                 g = self.tape.get(y)
@@ -983,8 +1012,9 @@ class TrainForward:
         c = model.config
         # the training forward keeps float32 activations (split inside the GEMMs in f16x3); train_only: the operand set leaves out what
         # only the eval-mode forward reads (the WavEncoder convolutions with their BatchNorms folded in)
-        cx = _Ctx(model._engine(h2=False, train_only=True))
+        cx = _Ctx(model._engine(h2=False, train_only=True, lin_h2=self.h2_forward))
         pk, dev = cx.pk, cx.dev
+        self._h2img = {}
         self._train_pack(pk)
         self.tape = _Tape(dev) if tape else None
         self._cx = cx

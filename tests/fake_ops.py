@@ -39,15 +39,22 @@ def h2_planes(img2d, cols, scale=None):
     return g[:, :, 0, :].reshape(rows, cols), g[:, :, 1, :].reshape(rows, cols)
 
 
-def h2_values(img2d, cols):
+def h2_values(img2d, cols, scale=ops.A_SCALE_F16X3):
     hi, lo = h2_planes(img2d, cols)
-    return (hi + lo) / ops.A_SCALE_F16X3
+    return (hi + lo) / scale
 
 
-def h2_store(dst2d, values):
+def h2_store(dst2d, values, scale=ops.A_SCALE_F16X3):
     """Write fp32 `values` (rows, cols), cols % 8 == 0, into the first cols logical columns of the H2 image dst2d."""
     rows, cols = values.shape
-    torch.as_strided(dst2d, (rows, cols), (dst2d.stride(0), 1))[:] = ops.h2_pack(values.float())
+    torch.as_strided(dst2d, (rows, cols), (dst2d.stride(0), 1))[:] = ops.h2_pack(values.float(), scale)
+
+
+def _h2s(dtype):
+    """A dtype code as the kernels take it -> (plain code, activation-image scale): include/emage_hip.h EMAGE_H2_SHIFT(k) = x * 2^(4 - k)."""
+    k = dtype >> 8
+    assert k == 0 or ((dtype & 0xff) == H2 and 0 < k <= 12), dtype
+    return dtype & 0xff, ops.A_SCALE_F16X3 * 2.0 ** -k
 
 
 def _merge_row_stats(st, eps):
@@ -62,6 +69,7 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
          n_store=0, t_col0=0, t_rows=0, res_first=False, taps=1, stride=1, pad=0, lin=None, lout=None, m=None,
          k_real=None, w_scale=1.0, a_scale=None, res_h2=False, workspace=None, ln=None, res_ln=None, stats_out=None, ln_eps=1e-5, splitk=None):
     CALLS.append("gemm")
+    dtype, h2sc = _h2s(dtype)                        # activation images written / read as a residual: x * h2sc; the operand A: a_scale (default: the same)
     if splitk is not None:                           # scratch the kernel may use for an in-launch split-K: the counters must come and stay zero
         assert dtype == H2 and splitk[1].dtype == torch.int32 and int(splitk[1].abs().sum()) == 0
     if ln is not None or res_ln is not None or stats_out is not None:
@@ -95,7 +103,7 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         x = torch.cat(cols, dim=1)                               # (M, taps*cp)
     if dtype == H2:
         # both operands arrive pre-split: A planes hold x * 16, W planes w * w_scale (natural k order)
-        sa = ops.A_SCALE_F16X3 if a_scale is None else a_scale
+        sa = h2sc if a_scale is None else a_scale
         xt = x.view(m, taps, 2, cp)
         xh, xl = xt[:, :, 0].reshape(m, taps * cp).double(), xt[:, :, 1].reshape(m, taps * cp).double()
         wh, wl = h2_planes(w, taps * cp)
@@ -127,7 +135,7 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         if res_h2:
             assert dtype == H2
             n8 = (n + 7) // 8 * 8
-            rv = h2_values(torch.as_strided(res, (m, n8), (res.stride(0), 1)), n8)[:, :n]
+            rv = h2_values(torch.as_strided(res, (m, n8), (res.stride(0), 1)), n8, h2sc)[:, :n]
         else:
             rv = torch.as_strided(res, (m, n), (res.stride(0), 1)).float()
         if res_ln is not None:                       # the residual is a folded LayerNorm of the raw sum just read
@@ -154,7 +162,7 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
         assert out.stride(0) >= width and out.stride(0) % 8 == 0
         full = torch.zeros(m, width)
         full[:, :ncol_n] = v[:, :ncol_n]
-        h2_store(out, full)
+        h2_store(out, full, h2sc)
     elif out is not None:
         assert out.dtype == TD[dtype]
         o = torch.as_strided(out, (m, max(ncol_n, n_store)), (out.stride(0), 1))
@@ -173,10 +181,11 @@ def gemm(dtype, a, w, bias=None, slope=None, res=None, out=None, out_f32=None, o
 
 
 def attention(dtype, q, k, vt, vt_rows, out, b, h, tq, tk, hd):
+    dtype, h2sc = _h2s(dtype)
     if dtype == H2:          # float32 q / k / v^T, the output as an H2 image
         o = torch.empty(b * tq, h * hd)
         attention(F16X3, q, k, vt, vt_rows, o, b, h, tq, tk, hd)
-        h2_store(out, o)
+        h2_store(out, o, h2sc)
         return
     CALLS.append("attention")
     tp = vt.shape[-1]
@@ -462,6 +471,7 @@ def mul_add(a, mask, b=None, out=None, *, mask_t_rows=0):
 
 def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
     CALLS.append("layernorm")
+    dtype, h2sc = _h2s(dtype)
     assert x.dtype == TD[dtype] and (add is None or add.dtype == TD[dtype])
     v = torch.nn.functional.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps)
     if add is not None:
@@ -470,16 +480,17 @@ def layernorm(dtype, x, gamma, beta, eps=1e-5, add=None, y_f32=None, y=None):
         y_f32[:] = v
     if y is not None:
         if dtype == H2:      # x / add / y_f32 are float32, y the H2 copy
-            h2_store(y, v)
+            h2_store(y, v, h2sc)
         else:
             y[:] = v.to(TD[dtype])
 
 
 def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0, h2_operands=()):
     CALLS.append("add")
+    dtype, h2sc = _h2s(dtype)
     m, n = a.shape
     r = torch.arange(m)
-    val = lambda t, bit: h2_values(t, n) if (dtype == H2 and bit in h2_operands) else t.float()
+    val = lambda t, bit: h2_values(t, n, h2sc) if (dtype == H2 and bit in h2_operands) else t.float()
     v = val(a, 0) + val(b, 1)[r % mod_b if mod_b else r]
     if c is not None:
         v = v + val(c, 2)[r % mod_c if mod_c else r]
@@ -487,13 +498,14 @@ def add(dtype, a, b, c=None, out_f32=None, out=None, mod_b=0, mod_c=0, h2_operan
         out_f32[:] = v
     if out is not None:
         if dtype == H2:
-            h2_store(out, v)
+            h2_store(out, v, h2sc)
         else:
             out[:] = v.to(TD[dtype])
 
 
 def pack_motion(dtype, motion, mask, emb, n_store, seed=None):
     CALLS.append("pack_motion")
+    dtype, h2sc = _h2s(dtype)
     b, t, c = motion.shape
     assert mask.shape == motion.shape and motion.stride(2) == 1 and mask.stride(2) == 1
     assert (motion.stride(1) == c and mask.stride(1) == c) or t == 1
@@ -506,16 +518,17 @@ def pack_motion(dtype, motion, mask, emb, n_store, seed=None):
         mask[:, :pre] = 0
     out = torch.zeros(b * t, n_store, dtype=TD[dtype])
     out[:, :c] = torch.where(mask == 1, emb.expand_as(motion), motion).reshape(b * t, c).to(TD[dtype])
-    return ops.h2_pack(out) if dtype == H2 else out
+    return ops.h2_pack(out, h2sc) if dtype == H2 else out
 
 
 def cast_pad(dtype, src2d, n_store, out=None):
     CALLS.append("cast_pad")
+    dtype, h2sc = _h2s(dtype)
     m, c = src2d.shape
     full = torch.zeros(m, n_store, dtype=TD[dtype])
     full[:, :c] = src2d.to(TD[dtype])
     if dtype == H2:
-        full = ops.h2_pack(full)
+        full = ops.h2_pack(full, h2sc)
     if out is None:
         return full
     assert out.shape == (m, n_store)
@@ -534,13 +547,14 @@ def h2_cast(src2d, n_store, scale=1.0, transpose=False):
 
 def gather_rows(table, idx, dtype, n_store=None):
     CALLS.append("gather_rows")
+    dtype, h2sc = _h2s(dtype)
     k, d = table.shape
     n_store = d if n_store is None else n_store
     if idx.dim() == 2:
         ops.index_view(idx)                       # the strides the kernel would be handed must be supported
     out = torch.zeros(idx.numel(), n_store, dtype=TD[dtype])
     out[:, :d] = table[idx.reshape(-1)].to(TD[dtype])
-    return ops.h2_pack(out) if dtype == H2 else out
+    return ops.h2_pack(out, h2sc) if dtype == H2 else out
 
 
 def _store_idx(res, out):

@@ -125,6 +125,42 @@ def test_layernorm_fold_host_logic(golden_dir):
     np.testing.assert_allclose(((hi + lo) / e["ws"]).numpy(), (w * gm).numpy(), rtol=0, atol=2.0 ** -21 * float((w * gm).abs().max()))
 
 
+def test_activation_shift_host_logic(golden_dir):
+    """Round 6: the activation images of the EMAGE_H2 mode carry a per-model power-of-two scale 2^(4 - k) in the dtype code of every launch that
+    writes or reads one (include/emage_hip.h EMAGE_H2_SHIFT; `model.activation_shift`, default 0 = 16 x: the parity-green form).  On the CPU
+    stand-ins: at k = 4 (images hold x: |x| < 65 504 instead of 4 094) the window stays at the golden; the packed weights are the same objects
+    (their scales are per tensor); every H2 launch of the forward saw the shifted code; an activation of 10^4 — beyond the default range — comes
+    through a k = 4 image and overflows the k = 0 one."""
+    from pantomatrix_amd import ops
+    from pantomatrix_amd._lib import H2
+    model, _ = common.product_models(precision="f16x3")
+    g = np.load(os.path.join(golden_dir, "forward_b1.npz"))
+    audio, spk, motion, mask = common.window_inputs(1)
+    seen = []
+    with fake_ops.installed(), torch.no_grad():
+        out0 = {k: v.clone() for k, v in model.forward(audio, spk, motion, mask).items()}
+        pk0 = model._packed
+        model.set_activation_shift(4)
+        real = fake_ops._h2s
+        try:
+            fake_ops._h2s = lambda dtype: (seen.append(dtype), real(dtype))[1]
+            out4 = {k: v.clone() for k, v in model.forward(audio, spk, motion, mask).items()}
+        finally:
+            fake_ops._h2s = real
+        assert model._packed is pk0 and pk0.act_shift == 4                  # no re-pack: only the launches' dtype code changes
+        model.set_activation_shift(0)
+    codes = {c for c in seen if c & 0xff == H2}
+    assert codes == {ops.h2_shifted(4)} and ops.h2_shifted(4) == H2 | (4 << 8) and ops.h2_shifted(0) == H2, codes
+    for k in orc.OUT_KEYS:
+        np.testing.assert_allclose(out4[k].numpy(), g[k], atol=3e-4, rtol=0)
+        assert float((out4[k] - out0[k]).abs().max()) < 5e-5, k
+    big = torch.full((1, 8), 1.0e4)
+    assert not torch.isfinite(ops.h2_unpack(ops.h2_pack(big))).all()                                  # 16 x 10^4 > 65 504: the hi plane overflows
+    assert torch.allclose(ops.h2_unpack(ops.h2_pack(big, ops.act_scale(ops.h2_shifted(4))), ops.act_scale(ops.h2_shifted(4))), big)
+    with pytest.raises(ValueError):
+        model.set_activation_shift(13)
+
+
 @pytest.mark.parametrize("frames,batch,precision", [(128, 2, "fp32"), (70, 1, "fp32"), (129, 1, "fp32"), (129, 1, "f16x3"), (310, 1, "f16x3"), (40, 1, "f16x3"), (64, 1, "fp32")])
 def test_inference_and_decode_host_logic(golden_dir, frames, batch, precision):
     """Whole clip: window schedule, seed carry-over through the VQ decode, tail windows with T+1 audio

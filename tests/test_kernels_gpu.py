@@ -25,7 +25,7 @@ def _cmp(name, got, ref, atol, rtol=0.0):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     err = (got - ref).abs()
     tol = atol + rtol * ref.abs()
-    bad = int((err > tol).sum())
+    bad = int((~(err <= tol)).sum())           # a NaN on either side counts
     assert bad == 0, f"{name}: {bad}/{err.numel()} outside tol, max err {float(err.max()):.3e}, ref max {float(ref.abs().max()):.3e}"
 
 
@@ -1009,3 +1009,72 @@ def test_grad_prep_equals_the_separate_launches():
         only_h = ops.grad_prep(dy, None, 0.0, scale, n_store=n_store, want_bias=False)
         assert only_h[1] is None and only_h[2] is None
         assert same(only_h[0], ops.h2_cast(dy, n_store, scale=scale))
+
+
+@pytest.mark.parametrize("k", [0, 4, 7])
+def test_activation_shift_kernels(k):
+    """Round 6: EMAGE_H2_SHIFT(k) (include/emage_hip.h) — every entry point that writes or reads an ACTIVATION image takes the model's scale
+    2^(4 - k) from its dtype code.  Values up to 3000 x 2^k (beyond the k = 0 range for k > 0) through cast_pad / pack_motion / gather_rows /
+    layernorm / add / attention / gemm (operand, H2 residual, H2 output, the LayerNorm fold's raw-sum residual): images bit-equal to the host
+    packing at that scale where the kernel only stores, values against the CPU stand-ins elsewhere; k = 0 is the plain code."""
+    dt, sc = ops.h2_shifted(k), ops.act_scale(ops.h2_shifted(k))
+    assert sc == 16.0 * 2.0 ** -k and (k != 0 or dt == H2)
+    g = _g(900 + k)
+    amp = 3000.0 * 2.0 ** k
+    m, d, t = 128, 768, 8
+    x = torch.randn(m, d, generator=g)
+    x[::7, ::5] *= amp / 8                                   # a heavy tail: most values O(1), some near the top of the range
+    x = x.clamp(-amp, amp)
+    xd = x.to(DEV)
+    # pure stores: the image IS the host packing at that scale
+    img = ops.cast_pad(dt, xd, d)
+    assert torch.equal(img.cpu(), ops.h2_pack(x, sc)), "cast_pad"
+    assert bool(torch.isfinite(ops.h2_unpack(img, sc)).all())
+    table = torch.randn(50, 256, generator=g) * amp / 8
+    idx = torch.randint(0, 50, (m,), generator=g)
+    assert torch.equal(ops.gather_rows(table.to(DEV), idx.to(DEV), dt, 256).cpu(), ops.h2_pack(table[idx], sc)), "gather_rows"
+    motion, mask = torch.randn(2, 16, 337, generator=g) * amp / 16, (torch.rand(2, 16, 337, generator=g) < 0.3).float()
+    emb = torch.randn(1, 337, generator=g)
+    got = ops.pack_motion(dt, motion.to(DEV), mask.to(DEV), emb.to(DEV), 384)
+    assert torch.equal(got.cpu(), F.pack_motion(dt, motion, mask, emb, 384)), "pack_motion"
+    # layernorm: float32 in, image (+ float32 twin) out
+    gamma, beta = (1.0 + 0.2 * torch.randn(d, generator=g)) * amp / 64, 0.1 * torch.randn(d, generator=g)
+    y, yf = torch.zeros(m, d, device=DEV), torch.zeros(m, d, device=DEV)
+    ops.layernorm(dt, xd, gamma.to(DEV), beta.to(DEV), 1e-5, None, yf, y)
+    assert torch.equal(y.cpu(), ops.h2_pack(yf.cpu(), sc)), "layernorm image vs its float32 twin"
+    _cmp("shift.layernorm", yf, torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5), atol=amp * 2e-6, rtol=2e-6)
+    # add: image + float32 -> image + float32
+    o, of = torch.zeros(m, d, device=DEV), torch.zeros(m, d, device=DEV)
+    ops.add(dt, img, 0.25 * xd, out_f32=of, out=o, h2_operands=(0,))
+    assert torch.equal(o.cpu(), ops.h2_pack(of.cpu(), sc)), "add image vs its float32 twin"
+    _cmp("shift.add", of, ops.h2_unpack(img.cpu(), sc) + 0.25 * x, atol=0.0, rtol=1e-6)
+    # attention: float32 q / k / v^T, image out
+    b, h, hd = m // t, 4, d // 4
+    q, kk = torch.randn(m, d, generator=g), torch.randn(m, d, generator=g)
+    vt = torch.zeros(b, d, 32)
+    vt[:, :, :t] = torch.randn(b, d, t, generator=g) * amp / 4
+    att, att_ref = torch.zeros(m, d, device=DEV), torch.zeros(m, d)
+    ops.attention(dt, q.to(DEV), kk.to(DEV), vt.to(DEV), d, att, b, h, t, t, hd)
+    F.attention(dt, q, kk, vt, d, att_ref, b, h, t, t, hd)
+    _cmp("shift.attention", ops.h2_unpack(att.cpu(), sc), ops.h2_unpack(att_ref, sc), atol=amp * 3e-6, rtol=1e-5)
+    # gemm: image operand (a_scale defaults to the image scale), H2 residual, image + float32 outputs, statistics; then the folded forms on the raw sum
+    w, bias = torch.randn(d, d, generator=g) / math.sqrt(d), torch.randn(d, generator=g)
+    w_p, w_s = ops.split_f16_weights_h2(w)
+
+    def chain(mod, dev):
+        mv = lambda v: v.to(dev)
+        s_img, s_f, st = torch.zeros(m, d, device=dev), torch.zeros(m, d, device=dev), torch.zeros(m, d // 32, 2, device=dev)
+        mod.gemm(dt, mv(ops.h2_pack(x, sc)), mv(w_p), mv(bias), None, mv(ops.h2_pack(x, sc)), s_img, s_f, None, n=d, cp=d, w_scale=w_s, res_h2=True, stats_out=st)
+        s2_img = torch.zeros(m, d, device=dev)
+        g1, b1 = mv(1.0 + 0.1 * torch.randn(d, generator=_g(5))), mv(0.1 * torch.randn(d, generator=_g(6)))
+        mod.gemm(dt, mv(ops.h2_pack(q, sc)), mv(w_p), mv(bias), None, s_img, s2_img, None, None, n=d, cp=d, w_scale=w_s, res_h2=True, res_ln=(st, g1, b1))
+        return s_img, s_f, st, s2_img
+
+    got, ref = chain(ops, DEV), chain(F, "cpu")
+    torch.cuda.synchronize()
+    assert torch.equal(got[0].cpu(), ops.h2_pack(got[1].cpu(), sc)), "gemm image vs its float32 twin"
+    _cmp("shift.gemm.sum", got[1], ref[1], atol=amp * 4e-6, rtol=1e-5)
+    _cmp("shift.gemm.mean", got[2][..., 0], ref[2][..., 0], atol=amp * 4e-6, rtol=1e-5)
+    _cmp("shift.gemm.res_ln", ops.h2_unpack(got[3].cpu(), sc), ops.h2_unpack(ref[3], sc), atol=2e-4 + amp * 1e-7, rtol=2e-5)
+    with pytest.raises(Exception):
+        ops.cast_pad(F32 | (3 << 8), xd, d)                  # a shift on any other storage type is an invalid code

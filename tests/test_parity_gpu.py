@@ -580,3 +580,53 @@ def test_lockstep_chains_touch_no_recorded_output():
         assert torch.equal(ref[k], got[k]) and torch.equal(ref[k], paired[k]), k
     assert np.array_equal(pr, pg) and np.array_equal(er, eg) and np.array_equal(tr, tg)
 
+
+
+@pytest.mark.parametrize("case", sorted(RANGE_CASES), ids=sorted(RANGE_CASES))
+def test_out_of_range_activations_stay_on_the_split_fp16_path_when_rescaled(case):
+    """VERDICT round 5, next #5 (second half): the activation images' scale is a power of two per MODEL (`activation_shift`, carried in the dtype
+    code of every launch: include/emage_hip.h EMAGE_H2_SHIFT), so a checkpoint whose activations pass 4094 keeps the split-fp16 path:
+    `ClipRunner(on_overflow="rescale")` answers a batch that overflows at the default scale with a twin whose images hold x instead of 16 x
+    (|x| < 65 504), `calibrate_activation_shift` chooses the shift up front from a calibration batch.  Required per range case: the batch comes
+    back finite; when the default scale overflowed, the re-run happened on the rescaled twin (`rescales`) and only a batch beyond 65 504 went on
+    to fp32 (`fallbacks`); the result agrees with fp32 mode — frames whose codes all agree are within the parity tolerance, and the share of such
+    frames is reported (the weights of these cases are rescaled by 3 000 - 20 000: logits that far from the trained regime sit closer to ties)."""
+    from pantomatrix_amd.runtime import ClipRunner, calibrate_activation_shift
+    name, factor = RANGE_CASES[case]
+    n = synthetic.samples_for_frames(128)
+    a = synthetic.synthetic_audio(2, n).to(DEV)
+    model, vq = common.product_models(precision="f16x3", device=DEV)
+    sd = model.state_dict()
+    sd[name] = sd[name] * factor
+    model.load_state_dict(sd)
+    probe = ClipRunner(model, vq, 2, n, use_graph=True, on_overflow="fp32")
+    probe(a)
+    overflowed = bool(probe.fallbacks)
+    auto = ClipRunner(model, vq, 2, n, use_graph=True, on_overflow="rescale")
+    got = [x.copy() for x in auto(a)]
+    assert all(np.isfinite(x).all() for x in got)
+    assert auto.rescales == int(overflowed) and model.activation_shift == 0 and vq.activation_shift == 0
+    again = auto(a)
+    assert auto.rescales == 2 * int(overflowed) and all(np.array_equal(x, y) for x, y in zip(got, again))
+    try:
+        k = calibrate_activation_shift(model, vq, a)
+    except FloatingPointError:                      # no shift holds this batch: the rescaled twin must have gone on to fp32
+        k = None
+        assert auto.fallbacks == auto.rescales > 0
+    else:
+        assert (k > 0) == overflowed and model.activation_shift == k and vq.activation_shift == k
+    cal = got if k is None else [x.copy() for x in ClipRunner(model, vq, 2, n, use_graph=True)(a)]        # on_overflow="raise": the calibrated shift holds the batch
+    model.set_activation_shift(0)
+    vq.set_activation_shift(0)
+    model.set_precision("fp32")
+    vq.set_precision("fp32")
+    want = ClipRunner(model, vq, 2, n, use_graph=False)(a)
+    report = []
+    for tag, res in (("rescale twin", got), ("calibrated", cal)):
+        same = np.ones(want[0].shape[:2], dtype=bool)
+        for x, y in zip(res, want):
+            same &= np.abs(x - y).reshape(x.shape[0], x.shape[1], -1).max(axis=2) < TOL
+        report.append(f"{tag}: {same.mean():.3f} of frames within {TOL:g} of fp32 mode")
+        assert same.mean() >= (0.99 if not auto.fallbacks else 0.0), report
+    print(f"range case {case}: {name} x {factor:g} -> overflow at the default scale: {overflowed}; rescales {auto.rescales}, fp32 fallbacks {auto.fallbacks}, "
+          f"calibrated shift {k}; " + "; ".join(report))

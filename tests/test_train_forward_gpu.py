@@ -64,11 +64,13 @@ def test_mul_add_and_attention_dropout():
         assert float((out.cpu() - ref).abs().max()) < 5e-5
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp32", "f16x3+h2_forward"])
 def test_train_forward_matches_oracle(precision):
+    precision, _, h2f = precision.partition("+")            # +h2_forward: round 6's A/B switch (the forward's Linears on EMAGE_H2 operands)
     (audio, spk, motion, mask), ref, masks, ref_stats = tc.oracle_forward(seed=7)
     model, _ = common.product_models(precision=precision, device=DEV)
     fwd = training.TrainForward(model)
+    fwd.h2_forward = bool(h2f)
     out, stats = fwd(audio, spk, motion, mask, masks)
     for k in ref:
         err = float((out[k].cpu() - ref[k]).abs().max())

@@ -26,14 +26,20 @@ def test_recorder_is_transparent():
         assert torch.equal(out[k], ref[k]), k
 
 
-@pytest.mark.parametrize("precision,use_audio", [("fp32", True), ("f16x3", True), ("fp32", False)])
+@pytest.mark.parametrize("precision,use_audio", [("fp32", True), ("f16x3", True), ("fp32", False), ("f16x3+h2_forward", True)])
 def test_train_forward_host_logic(precision, use_audio):
+    """+h2_forward: the A/B switch of round 6 — the forward's Linear contractions on EMAGE_H2 operands (LayerNorm writes the image of its result,
+    the other operands go through `h2_cast`); the float32 tensors and the results stay at the oracle."""
+    precision, _, h2f = precision.partition("+")
     (audio, spk, motion, mask), ref, masks, ref_stats = tc.oracle_forward(seed=7, use_audio=use_audio)
     model, _ = common.product_models(precision=precision)
     fwd = training.TrainForward(model)
+    fwd.h2_forward = bool(h2f)
     with fake_ops.installed(), torch.no_grad():
+        fake_ops.CALLS.clear()
         out, stats = fwd(audio, spk, motion, mask, masks, use_audio=use_audio)
         assert "bn_stats" in fake_ops.CALLS and "attention_dropout" in fake_ops.CALLS and "attention" not in fake_ops.CALLS
+        assert (fake_ops.CALLS.count("h2_cast") > 50) == bool(h2f), fake_ops.CALLS.count("h2_cast")      # the operands that no LayerNorm wrote an image of
     for k in ref:
         err = float((out[k] - ref[k]).abs().max())
         assert err < 2e-4, (k, err)
