@@ -369,6 +369,27 @@ class _Packed:
         w2 = wcat * g[None, :]
         return w2, (bcat.double() + wcat.double() @ be.double()).float(), w2.double().sum(dim=1).float().contiguous()
 
+    @staticmethod
+    def _stack(ts):
+        """torch.cat(ts, 0) — or, when the pieces are consecutive row blocks of ONE contiguous tensor in memory order (the q / k / v blocks of an
+        in_proj weight, a single source), the view that covers them: the operand packing reads the parameter itself instead of a copy of it
+        (~170 concatenation launches per training step, which re-packs behind every update)."""
+        t0 = ts[0]
+        if len(ts) == 1:
+            return t0
+        if all(t.is_contiguous() and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:] and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in ts):
+            if all(b.storage_offset() == a.storage_offset() + a.numel() for a, b in zip(ts, ts[1:])):
+                return torch.as_strided(t0, (sum(t.shape[0] for t in ts),) + tuple(t0.shape[1:]), t0.stride(), t0.storage_offset())
+        return torch.cat(ts, 0)
+
+    def _bias(self, bs):
+        """The stacked bias vector of an entry.  A train-only set (re-packed behind every optimiser step, dropped with it) may read the parameter
+        in place; every other set keeps its own copy (an eval-mode set outlives in-place edits until the next stamp check)."""
+        if not self.train_only:
+            return torch.cat(bs).float().contiguous()
+        b = self._stack(bs).float()
+        return b if (b.is_contiguous() and b.data_ptr() % 16 == 0) else b.clone()      # the kernels read bias vectors 16 bytes at a time
+
     def linear(self, key, names, rows=None, fold=None):
         """Stack nn.Linear weights along N (optionally row-slices `rows[i]` of each) -> entry `key`.  fold: the name of the LayerNorm
         whose output is this Linear's operand — the entry then holds the FOLDED operands (`_fold_norm`) and `c`; eval only."""
@@ -380,8 +401,8 @@ class _Packed:
             ws.append(w)
             bs.append(b)
         k_real = ws[0].shape[1]
-        wcat = (torch.cat(ws, 0) if len(ws) > 1 else ws[0]).float()       # one source: the operand packing reads the parameter itself
-        bcat = torch.cat(bs).float().contiguous()
+        wcat = self._stack(ws).float()                                    # one source / adjacent blocks: the operand packing reads the parameter itself
+        bcat = self._bias(bs)
         extra = {}
         if fold is not None:
             wcat, bcat, c = self._fold_norm(wcat, bcat, fold)
@@ -405,8 +426,8 @@ class _Packed:
                 bs.append(self.p[nm + ".in_proj_bias"][sl[part]])
                 origin.append((nm + ".in_proj_weight", nm + ".in_proj_bias", sl[part]))
         k_real = ws[0].shape[1]
-        wcat = (torch.cat(ws, 0) if len(ws) > 1 else ws[0]).float()
-        bcat = torch.cat(bs).float().contiguous()
+        wcat = self._stack(ws).float()
+        bcat = self._bias(bs)
         extra = {}
         if fold is not None:
             wcat, bcat, c = self._fold_norm(wcat, bcat, fold)

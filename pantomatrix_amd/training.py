@@ -867,7 +867,14 @@ class TrainForward:
         """Apply the queued parameter-gradient contributions (call before anything reads or exchanges the accumulators)."""
         self._fin.flush()                 # the queued finalize steps of the column reductions (bias / affine gradients)
         if self._pg_dst:
-            torch._foreach_add_(self._pg_dst, self._pg_src)
+            # ONE pair that is not dense with equal strides (the convolutions' weight gradients arrive as permuted (Cout, taps, Cin) views) sends the
+            # WHOLE multi-tensor add down torch's one-launch-per-tensor path (~440 launches per step): those pairs go in a call of their own.  The
+            # queued destinations never overlap (`_grad_rows` flushes first), so the order between the two calls does not matter
+            plain = [d.stride() == g.stride() and d.is_contiguous() for d, g in zip(self._pg_dst, self._pg_src)]
+            for want in (True, False):
+                dst = [d for d, ok in zip(self._pg_dst, plain) if ok == want]
+                if dst:
+                    torch._foreach_add_(dst, [g for g, ok in zip(self._pg_src, plain) if ok == want])
         self._pg_dst, self._pg_src, self._pg_spans, self._pg_bytes = [], [], {}, 0
 
     def _add(self, cx, a, bb, mod_b=0, grad_b=True):

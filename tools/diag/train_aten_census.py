@@ -1,5 +1,6 @@
-"""Which ATen kernels does one EMAGE training step (training.Trainer.step, f16x3) issue besides the emage ops, and from where?  Runs on the CPU stand-ins
-(tests/fake_ops.py): the Python-level ATen calls of the host code are the same as on the device; what the stand-ins themselves do is left out.
+"""Which ATen kernels does one EMAGE training step (training.Trainer.step, f16x3) issue besides the emage ops, and from where?  On the MI355X: the real
+step (2 clips; the launch COUNT does not depend on the batch).  Without a GPU: the CPU stand-ins (tests/fake_ops.py) — the host code's own ATen calls
+only (the `ops` wrappers are replaced there, and what the stand-ins do is left out).
     python tools/diag/train_aten_census.py [--second]      # --second: count the SECOND step (packing caches warm)"""
 import collections, os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,8 +12,13 @@ from pantomatrix_amd import training
 VIEWS = {"view", "slice", "detach", "t", "permute", "expand", "select", "as_strided", "unsqueeze", "squeeze", "_unsafe_view", "alias", "empty", "empty_like",
          "empty_strided", "reshape", "transpose", "unbind", "split", "_reshape_alias", "narrow", "unfold", "lift_fresh", "new_empty", "view_as", "chunk", "split_with_sizes",
          "resize_", "set_", "record_stream", "_to_copy_noop", "is_same_size", "sym_size", "stride", "size", "numel", "_local_scalar_dense", "item"}
+import contextlib
+gpu = torch.cuda.is_available()
 batch, _ref, masks, random_mask, _ = tc.oracle_step(3, 0)
-model, vq = common.product_models(precision="f16x3")
+model, vq = common.product_models(precision="f16x3", **({"device": "cuda"} if gpu else {}))
+if gpu:
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    masks, random_mask = None, random_mask.cuda()
 trainer = training.Trainer(model, vq)
 sites = collections.Counter()
 class M(TorchDispatchMode):
@@ -31,7 +37,7 @@ class M(TorchDispatchMode):
         numel = max([a.numel() for a in list(args) + ([out] if torch.is_tensor(out) else []) if torch.is_tensor(a)] + [0])
         sites[(site, name)] += 1
         return out
-with fake_ops.installed(), torch.no_grad():
+with (contextlib.nullcontext() if gpu else fake_ops.installed()), torch.no_grad():
     if "--second" in sys.argv:
         trainer.step(batch, 0, masks, random_mask)
     with M():
