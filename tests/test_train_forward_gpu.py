@@ -235,7 +235,7 @@ def test_wav_encoder_gradients_block_by_block_on_device():
     assert res["clean_blocks"] >= 1 and res["params_checked"] >= 8, res
 
 
-def test_training_step_matches_the_reference(golden_dir):
+def test_training_step_matches_the_reference_in_losses_gradient_norms_and_parameter_sums(golden_dir):
     """One whole optimisation step on the GPU — targets, three forwards, three backwards, Adam, BatchNorm buffers — with the
     reference's draws: the seven losses, every gradient's norm and first entry, and every parameter's sum after the update
     against the REAL reference step (tests/golden/train_step_b2.npz)."""
@@ -564,7 +564,7 @@ def _check_step_against(g, losses, params, before, grads=None, what=""):
     return worst
 
 
-def test_baseline_batch_step_matches_the_reference(golden_dir):
+def test_baseline_batch_step_matches_the_reference_in_losses_gradient_norms_and_parameter_sums(golden_dir):
     """VERDICT round 3, next #1a: BASELINE configs[2] at its PER-GPU BATCH — 56 clips x 64 frames (BatchNorm couples the clips) — against
     the REAL reference's step (tests/golden/train_step_b56.npz, generated by tests/golden/make_golden_train.py 56): the eager f16x3 step
     (seven losses, every gradient norm, post-Adam parameter sums) and the step as ONE hipGraph replay, captured twice on fresh models.
