@@ -238,6 +238,7 @@ class TrainForward:
         self.grad_scale = 1024.0
         self.conv_backward_rows = 1 << 17                 # output rows per piece of a long convolution's backward (_conv_backward_h2)
         self._w_scale, self._wt_cache = {}, {}
+        self.direct_conv_dx = True      # stride-1 convolutions: the input gradient as ONE implicit-GEMM convolution of dY (A/B switch; False: dcol = dY W + col2im)
         self.accumulate_dw = True       # Linear weight gradients are added into the gradient rows by their contraction (A/B switch; False: a temporary + a queued add)
         self.defer_finalize = True      # bias / affine-gradient reductions end in batched finalize launches (`ops.FinalizeQueue`; A/B switch: False = one each)
         self._fin = ops.FinalizeQueue()
@@ -483,7 +484,20 @@ class TrainForward:
         pieces = [(s0, min(s0 + per, nseq)) for s0 in range(0, nseq, per)]
         w_t = wsc = None
         np_ = _rup(n)
-        if need_dx:
+        # stride-1 'same' convolutions (every conv2 of the WavEncoder blocks, the motion encoder): dX is itself a convolution of dY with the
+        # flipped, transposed filters — ONE implicit-GEMM launch per piece writing dX, instead of dcol = dY W (M x taps*Cin float32: 1.5 GB for
+        # the first block at 56 clips) + col2im
+        direct = need_dx and self.direct_conv_dx and stride == 1 and lin == lout and 2 * pad == taps - 1 and cin % 8 == 0
+        if direct:
+            key = ("conv^T",) + tuple(wn for wn, _ in origins)
+            hit = self._wt_cache.get(key)
+            if hit is None:
+                wcat = torch.cat(ws, 0) if len(ws) > 1 else ws[0]                                                      # (N, Cin, k)
+                wrev = torch.nn.functional.pad(wcat.flip(2).permute(1, 2, 0), (0, np_ - n)).reshape(cin, taps * np_).contiguous()   # [ci][k-1-tap][co], co padded
+                wsc = self._backward_scale(key, wcat)
+                hit = self._wt_cache[key] = (ops.h2_cast(wrev, taps * np_, scale=wsc / 16.0), wsc)
+            w_t, wsc = hit
+        elif need_dx:
             key = ("conv",) + tuple(wn for wn, _ in origins)
             hit = self._wt_cache.get(key)
             if hit is None:
@@ -504,7 +518,14 @@ class TrainForward:
             ops.gemm(H2, dy_t, col_t, None, None, None, None, dwp, None, n=kc, cp=mps, w_scale=16.0, a_scale=16.0 * gs, workspace=self._splitk_ws(cx.dev))
             del col_t, dy_t
             dw = dwp if dw is None else dw.add_(dwp)
-            if need_dx:
+            if direct:
+                dy_h = ops.h2_cast(dys, np_, scale=gs)
+                if dx is None:
+                    dx = torch.empty(nseq * lin, cin, dtype=torch.float32, device=cx.dev)
+                ops.gemm(H2, dy_h, w_t, None, None, None, None, dx if whole else dx[s0 * lin:s1 * lin], None, n=cin, cp=np_, taps=taps, stride=1, pad=taps - 1 - pad,
+                         lin=lout, lout=lin, m=(s1 - s0) * lin, w_scale=wsc, a_scale=16.0 * gs)
+                del dy_h
+            elif need_dx:
                 dy_h = ops.h2_cast(dys, np_, scale=gs)
                 dcol = torch.empty(ms, _rup(kc, 4), dtype=torch.float32, device=cx.dev)[:, :kc]
                 ops.gemm(H2, dy_h, w_t, None, None, None, None, dcol, None, n=kc, cp=np_, w_scale=wsc, a_scale=16.0 * gs, workspace=self._splitk_ws(cx.dev))

@@ -392,13 +392,19 @@ def test_long_convolution_backward_in_pieces():
     dy = torch.randn(nseq * lin, cout, generator=g) * 1e-2
     res = {}
     with fake_ops.installed(), torch.no_grad():
-        for rows in (1 << 17, 2 * lin):
+        for rows in (1 << 17, 2 * lin, "col2im"):
             fwd = training.TrainForward(model)
-            fwd.conv_backward_rows = rows
-            n0 = fake_ops.CALLS.count("im2col_t_h2")
+            assert fwd.direct_conv_dx                                # round 6: a stride-1 convolution's dX is ONE implicit-GEMM convolution of dY per piece
+            if rows == "col2im":                                     # ... the A/B switch's other arm: dcol = dY W, then col2im
+                fwd.direct_conv_dx = False
+            else:
+                fwd.conv_backward_rows = rows
+            n0, c0 = fake_ops.CALLS.count("im2col_t_h2"), fake_ops.CALLS.count("col2im")
             dx = fwd._conv_backward(types.SimpleNamespace(dev=torch.device("cpu")), x, cin, [(base + ".weight", base + ".bias")], dy, k, 1, k // 2, lin, lin, nseq, True)
+            assert (fake_ops.CALLS.count("col2im") - c0 > 0) == (rows == "col2im")
             res[rows] = (dx, fwd.param_grads[base + ".weight"].clone(), fwd.param_grads[base + ".bias"].clone(), fake_ops.CALLS.count("im2col_t_h2") - n0)
     (dx1, dw1, db1, n1), (dx4, dw4, db4, n4) = res[1 << 17], res[2 * lin]
+    assert torch.allclose(res["col2im"][0], dx1, rtol=1e-5, atol=2e-6 * float(dx1.abs().max())) and torch.equal(res["col2im"][1], dw1)
     assert n1 == 1 and n4 == 4                                      # 7 sequences in pieces of 2
     assert torch.allclose(dx4, dx1, rtol=1e-6, atol=1e-7 * float(dx1.abs().max())) and torch.equal(db4, db1)
     assert torch.allclose(dw4, dw1, rtol=1e-5, atol=1e-6 * float(dw1.abs().max()))
