@@ -583,7 +583,7 @@ def bench_exchange_single_rank(dev, data, random_mask, steps=3):
             tdist.destroy_process_group()
 
 
-def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw=None, defer_finalize=None, exchange=True, h2_forward=None, direct_conv_dx=None):
+def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw=None, defer_finalize=None, exchange=True, h2_forward=None, direct_conv_dx=None, fuse_grad_adds=None):
     """One EMAGE optimisation step at BASELINE configs[2]'s per-GPU batch (56 clips x 64 frames): targets through the frozen VQ-VAEs, three
     train-mode forwards (batch-statistics BatchNorm, dropout masks drawn on the device), six losses, three backward passes, multi-tensor
     Adam, BatchNorm buffers — `training.Trainer.capture` / `replay`: the whole step is ONE hipGraph.  `roofline`: the step's algorithmic
@@ -605,6 +605,8 @@ def bench_train_step(dev, steps=3, cpu=True, batch=56, eager=True, accumulate_dw
         trainer.fwd.h2_forward = bool(h2_forward)
     if direct_conv_dx is not None:
         trainer.fwd.direct_conv_dx = bool(direct_conv_dx)
+    if fuse_grad_adds is not None:
+        trainer.fwd.fuse_grad_adds = bool(fuse_grad_adds)
     trainer.capture(data, random_mask)
     losses = trainer.replay()
     torch.cuda.synchronize()

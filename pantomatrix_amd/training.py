@@ -154,6 +154,16 @@ class _Tape:
             _accumulate(e[0], g, out=s)
             e[0], e[1] = s, True
 
+    def add_through(self, t, make, cols=None):
+        """grad(t)[:, :cols] += c for a contribution that a contraction produces: `make(prev)` launches it and returns `c` (prev None) or
+        `prev + c` as a NEW tensor (prev: the gradient so far, handed to the launch as its float32 residual — the add rides in the
+        epilogue instead of being a launch of its own; the same bits: fl(prev + fl(c)))."""
+        e = None if id(t) in self.views or (cols is not None and cols != t.shape[1]) else self.g.get(id(t))
+        if e is None:
+            self.add(t, make(None), cols)
+        else:
+            e[0], e[1] = make(e[0]), True
+
     def get(self, t):
         if id(t) in self.views:                          # a column block of its parent's gradient
             parent, c0, n = self.views[id(t)]
@@ -238,6 +248,7 @@ class TrainForward:
         self.grad_scale = 1024.0
         self.conv_backward_rows = 1 << 17                 # output rows per piece of a long convolution's backward (_conv_backward_h2)
         self._w_scale, self._wt_cache = {}, {}
+        self.fuse_grad_adds = True      # a Linear's input gradient is added to what its input has collected so far by the contraction's own epilogue (A/B switch; same bits)
         self.direct_conv_dx = True      # stride-1 convolutions: the input gradient as ONE implicit-GEMM convolution of dY (A/B switch; False: dcol = dY W + col2im)
         self.accumulate_dw = True       # Linear weight gradients are added into the gradient rows by their contraction (A/B switch; False: a temporary + a queued add)
         self.defer_finalize = True      # bias / affine-gradient reductions end in batched finalize launches (`ops.FinalizeQueue`; A/B switch: False = one each)
@@ -824,9 +835,17 @@ class TrainForward:
                 r0 += rows
         if need_dx:
             w_t, ws = self._weight_t_h2(cx, key, n, k)
-            dx = torch.empty(m, k, dtype=torch.float32, device=cx.dev)
-            ops.gemm(H2, dpre_h, w_t, None, None, None, None, dx, None, n=k, cp=_rup(n), w_scale=ws, a_scale=16.0 * gs, workspace=self._splitk_ws(cx.dev))
-            self.tape.add(x, dx, cols=k)
+
+            def make(prev):                            # prev: the gradient x has collected so far (its residual path) — added by this launch's epilogue
+                dx = torch.empty(m, k, dtype=torch.float32, device=cx.dev)
+                if prev is not None and not (self.fuse_grad_adds and prev.shape == dx.shape and prev.stride(1) == 1 and prev.stride(0) % 4 == 0 and prev.data_ptr() % 16 == 0):
+                    ops.gemm(H2, dpre_h, w_t, None, None, None, None, dx, None, n=k, cp=_rup(n), w_scale=ws, a_scale=16.0 * gs, workspace=self._splitk_ws(cx.dev))
+                    out = torch.empty_like(dx)
+                    _accumulate(prev, dx, out=out)
+                    return out
+                ops.gemm(H2, dpre_h, w_t, None, None, prev, None, dx, None, n=k, cp=_rup(n), w_scale=ws, a_scale=16.0 * gs, workspace=self._splitk_ws(cx.dev))
+                return dx
+            self.tape.add_through(x, make, cols=k)
 
     def _params(self):
         """name -> detached parameter / buffer view, built once per forward (walking the module tree per lookup costs more than

@@ -17,6 +17,7 @@ ln_fused = None if "--ln-fused" not in sys.argv else int(sys.argv[sys.argv.index
 defer = None if "--defer-finalize" not in sys.argv else int(sys.argv[sys.argv.index("--defer-finalize") + 1])
 h2f = None if "--h2-forward" not in sys.argv else int(sys.argv[sys.argv.index("--h2-forward") + 1])
 dcx = None if "--direct-conv-dx" not in sys.argv else int(sys.argv[sys.argv.index("--direct-conv-dx") + 1])
+fga = None if "--fuse-grad-adds" not in sys.argv else int(sys.argv[sys.argv.index("--fuse-grad-adds") + 1])
 sys.argv = ["bench.py"]
 import bench  # noqa: E402
 
@@ -27,6 +28,6 @@ if variant:                                     # tools library: emage_set_tunin
 if ln_fused is not None:
     from pantomatrix_amd import ops
     ops.FUSED_LAYERNORM_BACKWARD = {0: False, 1: 16}.get(ln_fused, ln_fused)
-line = bench.bench_train_step(torch.device("cuda", 0), cpu=cpu, eager=not quick, accumulate_dw=acc, defer_finalize=defer, exchange=not quick, h2_forward=h2f, direct_conv_dx=dcx)
-line["ab"] = {"accumulate_dw": acc, "h2_variant": variant, "ln_fused": ln_fused, "defer_finalize": defer, "h2_forward": h2f, "direct_conv_dx": dcx}
+line = bench.bench_train_step(torch.device("cuda", 0), cpu=cpu, eager=not quick, accumulate_dw=acc, defer_finalize=defer, exchange=not quick, h2_forward=h2f, direct_conv_dx=dcx, fuse_grad_adds=fga)
+line["ab"] = {"accumulate_dw": acc, "h2_variant": variant, "ln_fused": ln_fused, "defer_finalize": defer, "h2_forward": h2f, "direct_conv_dx": dcx, "fuse_grad_adds": fga}
 print(json.dumps(line))
