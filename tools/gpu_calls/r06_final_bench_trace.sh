@@ -22,7 +22,7 @@ for t in ("trace", "trace2"):
     for f in glob.glob(os.path.join(O, t, "**", "*kernel_trace.csv"), recursive=True):
         os.remove(f)
     for f in glob.glob(os.path.join(O, t, "**", "*kernel_stats.csv"), recursive=True):
-        rows = [x for x in csv.DictReader(open(f)) if "gemm_h2" in x["Name"] or "gemm_pipe" in x["Name"]]
+        rows = [x for x in csv.DictReader(open(f)) if "gemm_h2" in x["Name"] or "gemm_pipe_kernel<float" in x["Name"]]      # not the bf16 8192^3 calibration GEMM of the roofline object
         c = sum(int(x["Calls"]) for x in rows); ns = sum(float(x["TotalDurationNs"]) for x in rows)
         print(t, "rocprof gemm launches", c, "avg us", ns / c / 1e3)
         for l in open(os.path.join(O, t + ".log")):
